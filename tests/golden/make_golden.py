@@ -1,0 +1,505 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container).
+
+Imports the upstream reference read-only from /root/reference under the
+build-owned `gymshim` package, drives `MultiAgentTracking.reset()/step()` with
+recorded actions and *recorded random draws*, and dumps small `.npz` fixtures
+into this directory.  Nothing from the reference is copied: the fixtures are
+data (inputs and expected outputs).
+
+    python tests/golden/make_golden.py            # regenerate everything
+
+Fixture families:
+  trace_<cfg>_<policy>_s<seed>.npz   F1 reset snapshot + F4 LUT knots + F2 step trace
+  kat_obstruct.npz                   F3 ray/circle known answers (entities.py:158-184)
+  kat_scalar.npz                     F3 normalize_angle / polar clamp (utils.py:155,223-229)
+  kat_perceive.npz                   F3 Camera.perceive on crafted geometry (entities.py:491-511)
+
+Random draws are captured by replacing each RandomState with a recording proxy
+(the reference source is not modified): every in-sector `binomial(1, tau)` draw
+becomes a logged uniform U (result = U > 1 - tau for tau <= 0.5, identical to
+numpy's legacy inversion sampler, asserted below), and every goal `choice`
+becomes a logged (k candidates, picked j).
+"""
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFERENCE = os.environ.get('MATE_REFERENCE', '/root/reference')
+sys.path.insert(0, os.path.join(HERE, 'gymshim'))
+sys.path.insert(0, REFERENCE)
+
+import gym  # noqa: E402,F401  (the shim)
+import mate  # noqa: E402  (the reference, read-only)
+from mate.agents import GreedyCameraAgent, GreedyTargetAgent  # noqa: E402
+from mate.entities import Camera, Obstacle, Target  # noqa: E402
+from mate.utils import Vector2D, normalize_angle  # noqa: E402
+
+
+class RecordingRNG:
+    """Pass-through proxy for a numpy RandomState that logs the draws the step
+    path makes (`binomial` in Camera.perceive, `choice` in _assign_goals)."""
+
+    def __init__(self, real, log, owner):
+        self._real = real
+        self._log = log
+        self._owner = owner
+
+    def binomial(self, n, p, size=None):
+        assert n == 1 and size is None
+        frame = sys._getframe(1)
+        other = frame.f_locals.get('other', None)
+        u = float(self._real.random_sample())
+        out = int(u > 1.0 - p) if p <= 0.5 else int(u <= p)
+        self._log.append(('binomial', self._owner, other, float(p), u, out))
+        return out
+
+    def choice(self, a, size=None, replace=True, p=None):
+        if size is not None or p is not None or np.isscalar(a):
+            return self._real.choice(a, size=size, replace=replace, p=p)
+        a = np.asarray(a)
+        frame = sys._getframe(1)
+        t = frame.f_locals.get('t', None)
+        j = int(self._real.randint(0, len(a)))
+        self._log.append(('choice', self._owner, t, len(a), j, int(a[j])))
+        return a[j]
+
+    def __getattr__(self, name):
+        return getattr(self._real, name)
+
+
+def check_binomial_model():
+    """numpy legacy binomial(1,p) == (U > 1-p) on the same stream, p <= 0.5."""
+    a = np.random.RandomState(1234)
+    b = np.random.RandomState(1234)
+    for p in (0.1, 0.25, 0.5):
+        for _ in range(2000):
+            assert a.binomial(1, p) == int(b.random_sample() > 1.0 - p)
+
+
+def install_proxies(env, log):
+    for c, camera in enumerate(env.cameras):
+        box = camera.location_random_range
+        if not isinstance(box._np_random, RecordingRNG):
+            box._np_random = RecordingRNG(box.np_random, log, camera)
+    if not isinstance(env._np_random, RecordingRNG):
+        env._np_random = RecordingRNG(env.np_random, log, 'env')
+
+
+def pad_knots(funcs, width):
+    n = len(funcs)
+    phis = np.full((n, width), np.nan)
+    rhos = np.full((n, width), np.nan)
+    counts = np.zeros(n, dtype=np.int64)
+    for i, f in enumerate(funcs):
+        k = len(f.x)
+        counts[i] = k
+        phis[i, :k] = f.x
+        rhos[i, :k] = f.y
+    return phis, rhos, counts
+
+
+def snapshot_static(env):
+    out = {}
+    Nc, Nt, No = env.num_cameras, env.num_targets, env.num_obstacles
+    out['cam_xy'] = np.array([c.location for c in env.cameras]).reshape(Nc, 2)
+    out['cam_radius'] = np.array([c.radius for c in env.cameras], dtype=np.float64)
+    out['cam_min_viewing_angle'] = np.array([c.min_viewing_angle for c in env.cameras], dtype=np.float64)
+    out['cam_max_sight_range'] = np.array([c.max_sight_range for c in env.cameras], dtype=np.float64)
+    out['cam_rotation_step'] = np.array([c.rotation_step for c in env.cameras], dtype=np.float64)
+    out['cam_zooming_step'] = np.array([c.zooming_step for c in env.cameras], dtype=np.float64)
+    out['obs_xyr'] = np.array([np.append(o.location, o.radius) for o in env.obstacles]).reshape(No, 3)
+    out['tgt_capacity'] = np.array(env.target_capacities, dtype=np.int64)
+    out['tgt_step_size'] = np.array([t.step_size for t in env.targets], dtype=np.float64)
+    out['tgt_sight_range'] = np.array([t.sight_range for t in env.targets], dtype=np.float64)
+    out['camera_obstacle_view_mask'] = env.camera_obstacle_view_mask.copy()
+    if Nc > 0:
+        width = max(max(len(c.sight_range_func.x), len(c.sight_range_outer_func.x)) for c in env.cameras)
+        p, r, k = pad_knots([c.sight_range_func for c in env.cameras], width)
+        out['lut_phis'], out['lut_rhos'], out['lut_count'] = p, r, k
+        p, r, k = pad_knots([c.sight_range_outer_func for c in env.cameras], width)
+        out['lut_outer_phis'], out['lut_outer_rhos'], out['lut_outer_count'] = p, r, k
+    return out
+
+
+def snapshot_dynamic(env):
+    Nc, Nt = env.num_cameras, env.num_targets
+    d = {}
+    d['cam_phi'] = np.array([c.orientation for c in env.cameras], dtype=np.float64)
+    d['cam_theta'] = np.array([c.viewing_angle for c in env.cameras], dtype=np.float64)
+    d['cam_sight'] = np.array([c.sight_range for c in env.cameras], dtype=np.float64)
+    d['tgt_xy'] = np.array([t.location for t in env.targets]).reshape(Nt, 2)
+    d['tgt_colliding'] = np.array([bool(t.is_colliding) for t in env.targets])
+    d['tgt_empty_bits'] = np.array([t.empty_bits for t in env.targets]).astype(bool).reshape(Nt, 4)
+    d['tgt_goal_bits'] = env.target_goal_bits.astype(np.int64).copy()
+    d['tgt_goals'] = env.target_goals.astype(np.int64).copy()
+    d['freights'] = env.freights.astype(np.int64).copy()
+    d['bounties'] = env.bounties.astype(np.int64).copy()
+    d['target_steps'] = env.target_steps.astype(np.int64).copy()
+    d['tracked_steps'] = env.tracked_steps.astype(np.int64).copy()
+    d['remaining_cargoes'] = env.remaining_cargoes.astype(np.int64).copy()
+    d['awaiting_cargo_counts'] = env.awaiting_cargo_counts.astype(np.int64).copy()
+    d['num_delivered_cargoes'] = np.int64(env.num_delivered_cargoes)
+    d['episode_reward'] = np.float64(env.target_team_episode_reward)
+    d['delayed_episode_reward'] = np.float64(env.delayed_target_team_episode_reward)
+    d['episode_step'] = np.int64(env.episode_step)
+    d['camera_target_view_mask'] = env.camera_target_view_mask.copy()
+    d['target_camera_view_mask'] = env.target_camera_view_mask.copy()
+    d['target_obstacle_view_mask'] = env.target_obstacle_view_mask.copy()
+    d['target_target_view_mask'] = env.target_target_view_mask.copy()
+    d['camera_camera_view_mask'] = env.camera_camera_view_mask.copy()
+    d['tracked_bits'] = np.asarray(env.tracked_bits).astype(bool).copy()
+    d['target_dones'] = np.asarray(env.target_dones).astype(bool).copy()
+    d['target_warehouse_distances'] = env.target_warehouse_distances.copy()
+    d['coverage_rate'] = np.float64(env.coverage_rate)
+    d['real_coverage_rate'] = np.float64(env.real_coverage_rate)
+    d['mean_transport_rate'] = np.float64(env.mean_transport_rate)
+    d['state'] = env.state()
+    return d
+
+
+def drain_log(env, log):
+    """Turn the draw log of one step into dense tapes."""
+    Nc, Nt = env.num_cameras, env.num_targets
+    tape_ct = np.full((Nc, Nt), np.nan)
+    tape_cc = np.full((Nc, Nc), np.nan)
+    goal_u = np.full(Nt, np.nan)
+    goal_k = np.zeros(Nt, dtype=np.int64)
+    goal_j = np.full(Nt, -1, dtype=np.int64)
+    for item in log:
+        if item[0] == 'binomial':
+            _, cam, other, p, u, out = item
+            c = env.cameras.index(cam)
+            if isinstance(other, Camera):
+                tape_cc[c, env.cameras.index(other)] = u
+            else:
+                t = env.targets.index(other)
+                assert np.isnan(tape_ct[c, t])
+                tape_ct[c, t] = u
+        else:
+            _, _, t, k, j, value = item
+            assert t is not None and goal_j[t] < 0
+            goal_k[t], goal_j[t] = k, j
+            goal_u[t] = (j + 0.5) / k
+    log.clear()
+    return tape_ct, tape_cc, goal_u, goal_k, goal_j
+
+
+def random_actions(env, rng, step):
+    Nc, Nt = env.num_cameras, env.num_targets
+    cam = rng.uniform(-1.5, 1.5, size=(Nc, 2)) * np.array([env.camera_rotation_step, env.camera_zooming_step]) if Nc else np.zeros((0, 2))
+    tgt = rng.uniform(-1.5, 1.5, size=(Nt, 2)) * env.target_step_size
+    if step % 7 == 3:  # exact zero actions exercise the zero-length ray branch
+        tgt[step % Nt] = 0.0
+        if Nc:
+            cam[step % Nc] = 0.0
+    if step % 11 == 5:  # axis-aligned full-speed moves
+        tgt[(step // 11) % Nt] = [env.target_step_size, 0.0]
+    return cam, tgt
+
+
+def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f64_obs_steps=None):
+    env = mate.make('MultiAgentTracking-v0', config=config, **(overrides or {}))
+    env.seed(seed)
+    cam_obs, tgt_obs = env.reset()
+    if tweak is not None:
+        tweak(env)
+        cam_obs, tgt_obs = env.joint_observation()
+    log = []
+    install_proxies(env, log)
+
+    Nc, Nt, No = env.num_cameras, env.num_targets, env.num_obstacles
+    out = {
+        'config_file': np.str_(config),
+        'seed': np.int64(seed),
+        'policy': np.str_(policy),
+        'num_cameras': np.int64(Nc),
+        'num_targets': np.int64(Nt),
+        'num_obstacles': np.int64(No),
+        'transmittance': np.float64(env.obstacle_transmittance),
+        'max_episode_steps': np.int64(env.max_episode_steps),
+        'sparse_reward': np.bool_(env._sparse_reward),
+        'freight_scale': np.float64(env.freight_scale),
+        'bounty_scale': np.float64(env.bounty_scale),
+        'reward_scale': np.float64(env.reward_scale),
+        'max_target_team_episode_reward': np.float64(env.max_target_team_episode_reward),
+        'target_step_size': np.float64(env.target_step_size),
+    }
+    for k, v in snapshot_static(env).items():
+        out['static/' + k] = v
+    for k, v in snapshot_dynamic(env).items():
+        out['reset/' + k] = v
+    out['reset/cam_obs'] = cam_obs
+    out['reset/tgt_obs'] = tgt_obs
+
+    rng = np.random.RandomState(seed + 1000)
+    if policy == 'greedy':
+        cam_agents = GreedyCameraAgent(seed=seed + 1).spawn(Nc) if Nc else []
+        tgt_agents = GreedyTargetAgent(seed=seed + 2).spawn(Nt)
+        mate.group_reset(cam_agents, cam_obs)
+        mate.group_reset(tgt_agents, tgt_obs)
+        cam_infos = tgt_infos = None
+
+    per_step = {}
+
+    def push(key, value):
+        per_step.setdefault(key, []).append(np.asarray(value))
+
+    n_done = 0
+    for step in range(steps):
+        if policy == 'greedy':
+            cam_act = np.asarray(mate.group_step(env, cam_agents, cam_obs, cam_infos), dtype=np.float64).reshape(Nc, 2)
+            tgt_act = np.asarray(mate.group_step(env, tgt_agents, tgt_obs, tgt_infos), dtype=np.float64).reshape(Nt, 2)
+        else:
+            cam_act, tgt_act = random_actions(env, rng, step)
+        log.clear()
+        (cam_obs, tgt_obs), (r_cam, r_tgt), done, (cam_infos, tgt_infos) = env.step((cam_act, tgt_act))
+        tape_ct, tape_cc, goal_u, goal_k, goal_j = drain_log(env, log)
+
+        push('cam_act', cam_act)
+        push('tgt_act', tgt_act)
+        push('tape_ct', tape_ct)
+        push('goal_u', goal_u)
+        push('goal_k', goal_k)
+        push('goal_j', goal_j)
+        push('cam_obs', cam_obs)
+        push('tgt_obs', tgt_obs)
+        push('reward_cam', r_cam)
+        push('reward_tgt', r_tgt)
+        push('normalized_reward_tgt', tgt_infos[0]['normalized_raw_reward'])
+        push('done', done)
+        for k, v in snapshot_dynamic(env).items():
+            push(k, v)
+        if done:
+            n_done += 1
+            if n_done >= 2:  # keep one extra step after done, then stop
+                break
+
+    for k, v in per_step.items():
+        arr = np.stack(v)
+        out['step/' + k] = arr
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    nsteps = len(per_step['done'])
+    ndel = int(out['step/num_delivered_cargoes'][-1])
+    ncol = int(out['step/tgt_colliding'].sum())
+    nsee = int(np.isfinite(out['step/tape_ct']).sum()) if Nc else 0
+    print(f'{name}: {nsteps} steps, delivered={ndel}, collisions={ncol}, in-sector draws={nsee}, '
+          f'done={bool(out["step/done"][-1])}, {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+def tweak_few_cargoes(env):
+    """Leave only the cargoes in transit so the episode ends within the trace
+    (state injection on the reference object; reference code untouched)."""
+    env.remaining_cargoes.fill(0)
+    env.awaiting_cargo_counts[:] = 0
+    for t in range(env.num_targets):
+        g = env.target_goals[t]
+        if g >= 0:
+            env.awaiting_cargo_counts[g] += env.target_goal_bits[t, g]
+    env._state = None
+
+
+# --------------------------------------------------------------------------- KATs
+def kat_obstruct():
+    rng = np.random.RandomState(7)
+    rows = []
+
+    def run(origin, vec, center, radius, keep_tangential, outer):
+        ray = Vector2D(vector=np.array(vec, dtype=np.float64), origin=np.array(origin, dtype=np.float64))
+        obstacle = Obstacle(location=np.array(center, dtype=np.float64), radius=float(radius))
+        obstacle.location = np.array(center, dtype=np.float64)  # undo the terrain clip of Entity.reset
+        res = obstacle.obstruct(ray, keep_tangential=keep_tangential, outer=outer)
+        v = np.array(res.vector, dtype=np.float64)
+        rows.append(list(origin) + list(vec) + list(center) + [radius, float(keep_tangential), float(outer)] + list(v))
+
+    for _ in range(1500):
+        origin = rng.uniform(-300, 300, 2)
+        center = origin + rng.uniform(-150, 150, 2)
+        radius = rng.uniform(5, 100)
+        vec = rng.uniform(-60, 60, 2)
+        for kt in (False, True):
+            for outer in (False, True):
+                run(origin, vec, center, radius, kt, outer)
+    # crafted edge cases
+    for kt in (False, True):
+        for outer in (False, True):
+            run([0, 0], [0, 0], [10, 0], 5, kt, outer)            # zero-length ray
+            run([0, 0], [10, 0], [3, 0], 5, kt, outer)            # origin inside the circle
+            run([0, 0], [10, 0], [20, 0], 5, kt, outer)           # far: norm + r <= dist
+            run([0, 0], [15, 0], [20, 0], 5, kt, outer)           # exact touch: dist == norm + r
+            run([0, 0], [30, 0], [20, 5], 5, kt, outer)           # tangent: perpendicular == r
+            run([0, 0], [30, 0], [20, 0], 5, kt, outer)           # head-on
+            run([0, 0], [-30, 0], [20, 0], 5, kt, outer)          # pointing away (inner < 0)
+            run([0, 0], [30, 0], [20, 4.999], 5, kt, outer)       # grazing
+            run([0, 0], [0, 25], [0, 20], 5, kt, outer)           # vertical
+            run([5, 5], [20, 20], [25, 25], 10, kt, outer)        # diagonal through centre
+            run([0, 0], [100, 0], [20, 0], 5, kt, outer)          # passes fully through
+    np.savez_compressed(os.path.join(HERE, 'kat_obstruct.npz'), rows=np.array(rows, dtype=np.float64),
+                        columns=np.str_('ox oy vx vy cx cy r keep_tangential outer outx outy'))
+    print(f'kat_obstruct: {len(rows)} rows')
+
+
+def kat_scalar():
+    rng = np.random.RandomState(11)
+    angles = np.concatenate([
+        np.array([-540.0, -360.0, -180.0, -179.99999999999997, -0.0, 0.0, 1e-300, -1e-300, 179.99999999999997,
+                  180.0, 180.00000000000003, 360.0, 539.9999, 540.0, 720.0, 1e6 + 0.5, -1e6 - 0.5]),
+        rng.uniform(-1000, 1000, 500),
+    ])
+    normalized = np.array([normalize_angle(float(a)) for a in angles])
+
+    # target step clamp: Vector2D(vector=a); if norm > v: norm = v   (entities.py:648-650)
+    acts = np.concatenate([rng.uniform(-40, 40, (600, 2)),
+                           np.array([[0, 0], [20, 0], [0, 20], [-20, 0], [0, -20], [20, 20], [1e-12, 0], [14.142135623730951, 14.142135623730951]])])
+    vs = np.concatenate([np.full(304, 20.0), np.full(304, 10.0)])
+    clamped = []
+    for a, v in zip(acts, vs):
+        step = Vector2D(vector=np.array(a, dtype=np.float64), origin=np.zeros(2))
+        if step.norm > v:
+            step.norm = v
+        clamped.append(np.array(step.vector, dtype=np.float64))
+
+    # Camera.simulate clamps (entities.py:347-360)
+    cam_rows = []
+    for _ in range(600):
+        cam = Camera(location=np.array([0.0, 0.0]), min_viewing_angle=30.0, max_sight_range=1500.0,
+                     rotation_step=5.0, zooming_step=2.5, radius=40.0)
+        phi0 = float(rng.choice([rng.uniform(-180, 180), -180.0, 177.5, -177.5, 179.0]))
+        th0 = float(rng.choice([rng.uniform(30, 180), 30.0, 180.0, 31.0, 179.0]))
+        cam.orientation = phi0
+        cam.viewing_angle = th0
+        act = rng.uniform(-8, 8, 2)
+        phi0n = cam.orientation
+        cam.simulate(act)
+        cam_rows.append([phi0n, th0, act[0], act[1], cam.orientation, cam.viewing_angle, cam.sight_range])
+    np.savez_compressed(os.path.join(HERE, 'kat_scalar.npz'), angles=angles, normalized=normalized,
+                        clamp_action=acts, clamp_step=vs, clamp_out=np.array(clamped),
+                        cam_sim=np.array(cam_rows), cam_sim_columns=np.str_('phi0 theta0 dphi dtheta phi1 theta1 sight1'))
+    print(f'kat_scalar: {len(angles)} angles, {len(acts)} clamps, {len(cam_rows)} camera steps')
+
+
+class TapeRNG:
+    """Feeds a prescribed uniform to Camera.perceive's binomial draw."""
+
+    def __init__(self):
+        self.u = 0.0
+
+    def binomial(self, n, p):
+        return int(self.u > 1.0 - p) if p <= 0.5 else int(self.u <= p)
+
+
+def kat_perceive():
+    rng = np.random.RandomState(21)
+    cases = []
+    luts = []
+    for case in range(12):
+        cam = Camera(location=np.array([0.0, 0.0]), min_viewing_angle=30.0, max_sight_range=1500.0 if case % 2 == 0 else 700.0,
+                     rotation_step=5.0, zooming_step=2.5, radius=40.0)
+        cam.location = rng.uniform(-600, 600, 2)
+        cam.reset.__func__  # noqa: B018  (documenting that reset() is what builds the 360-ray boundary)
+        loc = cam.location.copy()
+        cam.location_random_range = gym.spaces.Box(low=loc, high=loc, dtype=np.float64)
+        cam.reset()
+        nobs = [0, 1, 3, 6, 9, 9, 2, 4, 9, 5, 7, 1][case]
+        obstacles = []
+        for _ in range(nobs):
+            while True:
+                c = cam.location + rng.uniform(-900, 900, 2)
+                r = rng.uniform(25, 100)
+                if np.linalg.norm(c - cam.location) > r + 60:
+                    break
+            ob = Obstacle(location=c, radius=float(r))
+            ob.location = np.asarray(c, dtype=np.float64)
+            ob.radius = float(r)
+            obstacles.append(ob)
+        cam.clear_obstacles()
+        cam.add_obstacles(*obstacles)
+        tape = TapeRNG()
+        cam.location_random_range._np_random = tape
+        obs_arr = np.array([np.append(o.location, o.radius) for o in obstacles]).reshape(nobs, 3)
+        luts.append((cam.sight_range_func.x.copy(), cam.sight_range_func.y.copy(), obs_arr, cam.location.copy(), cam.max_sight_range))
+        for _ in range(400):
+            cam.orientation = float(rng.choice([rng.uniform(-180, 180), -180.0, 179.5, 0.0]))
+            cam.viewing_angle = float(rng.uniform(30, 180))
+            cam.sight_range = np.sqrt(cam.area_product / cam.viewing_angle)
+            mode = rng.randint(0, 5)
+            if mode == 0 and nobs > 0:      # just behind / beside an obstacle
+                ob = obstacles[rng.randint(nobs)]
+                d = ob.location - cam.location
+                p = cam.location + d * rng.uniform(0.8, 1.6) + rng.uniform(-1, 1, 2) * ob.radius * 1.3
+            elif mode == 1:                 # exactly on a knot angle
+                k = rng.randint(len(cam.sight_range_func.x) - 1)
+                ang = np.deg2rad(cam.sight_range_func.x[k])
+                p = cam.location + rng.uniform(10, cam.sight_range * 1.1) * np.array([np.cos(ang), np.sin(ang)])
+            elif mode == 2:                 # near the sector edge
+                edge = cam.orientation + rng.choice([-0.5, 0.5]) * cam.viewing_angle + rng.uniform(-0.2, 0.2)
+                ang = np.deg2rad(edge)
+                p = cam.location + rng.uniform(10, cam.sight_range) * np.array([np.cos(ang), np.sin(ang)])
+            elif mode == 3:                 # near the range limit, centre of the sector
+                ang = np.deg2rad(cam.orientation + rng.uniform(-0.4, 0.4) * cam.viewing_angle)
+                p = cam.location + cam.sight_range * rng.uniform(0.98, 1.02) * np.array([np.cos(ang), np.sin(ang)])
+            else:
+                p = cam.location + rng.uniform(-1, 1, 2) * cam.sight_range
+            tgt = Target(location=np.array([0.0, 0.0]))
+            tgt.location = np.asarray(p, dtype=np.float64)
+            tape.u = float(rng.uniform(0, 1))
+            tau = float(rng.choice([0.0, 0.1, 0.1]))
+            seen = bool(cam.perceive(tgt, transmittance=tau))
+            cases.append([case, cam.orientation, cam.viewing_angle, cam.sight_range, p[0], p[1], tape.u, tau, float(seen)])
+    width = max(len(l[0]) for l in luts)
+    phis = np.full((len(luts), width), np.nan)
+    rhos = np.full((len(luts), width), np.nan)
+    counts = np.zeros(len(luts), dtype=np.int64)
+    obs = np.full((len(luts), 9, 3), np.nan)
+    nobs = np.zeros(len(luts), dtype=np.int64)
+    cam_xy = np.zeros((len(luts), 2))
+    rmax = np.zeros(len(luts))
+    for i, (x, y, o, loc, rm) in enumerate(luts):
+        counts[i] = len(x)
+        phis[i, :len(x)] = x
+        rhos[i, :len(x)] = y
+        nobs[i] = len(o)
+        obs[i, :len(o)] = o
+        cam_xy[i] = loc
+        rmax[i] = rm
+    np.savez_compressed(os.path.join(HERE, 'kat_perceive.npz'), cases=np.array(cases),
+                        columns=np.str_('case phi theta sight px py u tau seen'),
+                        lut_phis=phis, lut_rhos=rhos, lut_count=counts, obstacles=obs, num_obstacles=nobs,
+                        cam_xy=cam_xy, cam_max_sight_range=rmax)
+    print(f'kat_perceive: {len(cases)} cases, seen={int(np.array(cases)[:, -1].sum())}')
+
+
+def main():
+    check_binomial_model()
+    kat_obstruct()
+    kat_scalar()
+    kat_perceive()
+    plan = [
+        # name,                      config,                 seed, policy,  steps, overrides, tweak
+        ('trace_4v2-9_random_s0',    'MATE-4v2-9.yaml',        0, 'random',   96, None, None),
+        ('trace_4v2-9_greedy_s1',    'MATE-4v2-9.yaml',        1, 'greedy',  192, None, None),
+        ('trace_4v8-9_random_s0',    'MATE-4v8-9.yaml',        0, 'random',   96, None, None),
+        ('trace_4v8-9_random_s1',    'MATE-4v8-9.yaml',        1, 'random',   64, None, None),
+        ('trace_4v8-9_greedy_s2',    'MATE-4v8-9.yaml',        2, 'greedy',  256, None, None),
+        ('trace_4v8-9_greedy_done',  'MATE-4v8-9.yaml',        3, 'greedy',  400, None, tweak_few_cargoes),
+        ('trace_4v8-9_timelimit',    'MATE-4v8-9.yaml',        4, 'random',   16, {'max_episode_steps': 8}, None),
+        ('trace_8v8-9_random_s0',    'MATE-8v8-9.yaml',        0, 'random',   64, None, None),
+        ('trace_8v8-9_greedy_s1',    'MATE-8v8-9.yaml',        1, 'greedy',  256, None, None),
+        ('trace_4v8-0_random_s0',    'MATE-4v8-0.yaml',        0, 'random',   64, None, None),
+        ('trace_4v8-0_greedy_s1',    'MATE-4v8-0.yaml',        1, 'greedy',  192, None, None),
+        ('trace_nav_random_s0',      'MATE-Navigation.yaml',   0, 'random',   96, None, None),
+        ('trace_nav_greedy_s1',      'MATE-Navigation.yaml',   1, 'greedy',  256, None, None),
+    ]
+    only = sys.argv[1:]
+    for name, config, seed, policy, steps, overrides, tweak in plan:
+        if only and not any(o in name for o in only):
+            continue
+        make_trace(name, config, seed, policy, steps, overrides, tweak)
+
+
+if __name__ == '__main__':
+    main()

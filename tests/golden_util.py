@@ -1,0 +1,99 @@
+"""Helpers shared by the parity tests: load golden fixtures into an oracle env."""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+# (fixture key under reset/ or step/, oracle field)
+DYNAMIC_FIELDS = [
+    ('cam_phi', 'cam_phi'), ('cam_theta', 'cam_theta'), ('cam_sight', 'cam_sight'),
+    ('tgt_colliding', 'tgt_colliding'), ('tgt_empty_bits', 'tgt_empty_bits'), ('tgt_goal_bits', 'tgt_goal_bits'),
+    ('tgt_goals', 'tgt_goals'), ('freights', 'freights'), ('bounties', 'bounties'),
+    ('target_steps', 'target_steps'), ('tracked_steps', 'tracked_steps'),
+    ('remaining_cargoes', 'remaining_cargoes'), ('awaiting_cargo_counts', 'awaiting_cargo_counts'),
+    ('num_delivered_cargoes', 'num_delivered_cargoes'), ('episode_reward', 'episode_reward'),
+    ('delayed_episode_reward', 'delayed_episode_reward'), ('episode_step', 'episode_step'),
+]
+MASK_FIELDS = ['camera_target_view_mask', 'target_camera_view_mask', 'target_obstacle_view_mask',
+               'target_target_view_mask', 'camera_camera_view_mask', 'tracked_bits']
+
+
+def trace_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, 'trace_*.npz')))
+
+
+def load(name):
+    path = name if os.path.isabs(name) else os.path.join(GOLDEN_DIR, name)
+    return dict(np.load(path))
+
+
+def static_of(fx):
+    """Static per-episode geometry of a trace fixture as plain arrays."""
+    Nc, Nt, No = int(fx['num_cameras']), int(fx['num_targets']), int(fx['num_obstacles'])
+    st = {
+        'Nc': Nc, 'Nt': Nt, 'No': No,
+        'transmittance': float(fx['transmittance']), 'max_episode_steps': int(fx['max_episode_steps']),
+        'sparse_reward': int(bool(fx['sparse_reward'])), 'freight_scale': float(fx['freight_scale']),
+        'bounty_scale': float(fx['bounty_scale']), 'reward_scale': float(fx['reward_scale']),
+        'max_target_team_episode_reward': float(fx['max_target_team_episode_reward']),
+        'target_step_size': float(fx['target_step_size']),
+        'cam_x': fx['static/cam_xy'][:, 0], 'cam_y': fx['static/cam_xy'][:, 1], 'cam_radius': fx['static/cam_radius'],
+        'cam_min_viewing_angle': fx['static/cam_min_viewing_angle'], 'cam_max_sight_range': fx['static/cam_max_sight_range'],
+        'cam_rotation_step': fx['static/cam_rotation_step'], 'cam_zooming_step': fx['static/cam_zooming_step'],
+        'obs_x': fx['static/obs_xyr'][:, 0], 'obs_y': fx['static/obs_xyr'][:, 1], 'obs_radius': fx['static/obs_xyr'][:, 2],
+        'tgt_capacity': fx['static/tgt_capacity'], 'tgt_step_size': fx['static/tgt_step_size'],
+        'tgt_sight_range': fx['static/tgt_sight_range'],
+        'camera_obstacle_view_mask': fx['static/camera_obstacle_view_mask'],
+    }
+    return st
+
+
+def dynamic_of(fx, prefix='reset/', index=None):
+    def pick(key):
+        v = fx[prefix + key]
+        return v if index is None else v[index]
+    dyn = {field: pick(key) for key, field in DYNAMIC_FIELDS}
+    xy = pick('tgt_xy')
+    dyn['tgt_x'], dyn['tgt_y'] = xy[:, 0], xy[:, 1]
+    for m in MASK_FIELDS + ['target_dones', 'target_warehouse_distances']:
+        dyn[m] = pick(m)
+    return dyn
+
+
+def luts_of(fx, outer=False):
+    Nc = int(fx['num_cameras'])
+    tag = 'lut_outer_' if outer else 'lut_'
+    out = []
+    for c in range(Nc):
+        n = int(fx['static/' + tag + 'count'][c])
+        out.append((fx['static/' + tag + 'phis'][c, :n].copy(), fx['static/' + tag + 'rhos'][c, :n].copy()))
+    return out
+
+
+SCALARS = ['transmittance', 'max_episode_steps', 'sparse_reward', 'freight_scale', 'bounty_scale', 'reward_scale',
+           'max_target_team_episode_reward', 'target_step_size']
+
+
+def oracle_from_fixture(fx, use_golden_lut=True):
+    from oracle import oracle as O
+    st = static_of(fx)
+    env = O.OracleEnv(st['Nc'], st['Nt'], st['No'])
+    for k in SCALARS:
+        env.set(k, st[k])
+    for k, v in st.items():
+        if k in ('Nc', 'Nt', 'No') or k in SCALARS:
+            continue
+        env.set(k, v)
+    if use_golden_lut:
+        for c, (phis, rhos) in enumerate(luts_of(fx)):
+            env.set_lut(c, phis, rhos)
+        if 'static/lut_outer_count' in fx:
+            for c, (phis, rhos) in enumerate(luts_of(fx, outer=True)):
+                env.set_lut(c, phis, rhos, outer=True)
+    else:
+        env.build_luts()
+    for k, v in dynamic_of(fx).items():
+        env.set(k, v)
+    return env

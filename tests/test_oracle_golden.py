@@ -1,0 +1,110 @@
+"""Pins the CPU oracle (oracle/mate_oracle.c) to golden vectors recorded from the
+upstream Python reference (tests/golden/make_golden.py).  CPU only.
+
+Tolerances: integer state, masks, rewards, done: exact.  f64 quantities: 1e-9
+absolute on O(1e3) coordinates (observed <= 3e-12; the residue is libm vs numpy
+SIMD sin/cos/atan2 last-place differences accumulated along a trace).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as G
+from oracle import oracle as O
+
+F64_TOL = 1e-9
+
+
+def test_kat_obstruct():
+    rows = G.load('kat_obstruct.npz')['rows']
+    exact = 0
+    for r in rows:
+        out = O.obstruct(r[0:2], r[2:4], r[4:6], r[6], bool(r[7]), bool(r[8]))
+        np.testing.assert_allclose(out, r[9:11], rtol=0, atol=1e-12)
+        exact += np.array_equal(out, r[9:11])
+    assert exact >= 0.99 * len(rows)  # the rest differ in the last place through atan2/sincos
+
+
+def test_kat_scalar():
+    k = G.load('kat_scalar.npz')
+    got = np.array([O.normalize_angle(a) for a in k['angles']])
+    assert np.array_equal(got, k['normalized'])  # utils.py:155-158, pure arithmetic: bit exact
+    cl = np.array([O.clamp_step(a[0], a[1], v) for a, v in zip(k['clamp_action'], k['clamp_step'])])
+    np.testing.assert_allclose(cl, k['clamp_out'], rtol=0, atol=1e-12)
+    cs = np.array([O.camera_simulate(r[0], r[1], r[2], r[3], 30.0, 1500.0, 5.0, 2.5) for r in k['cam_sim']])
+    assert np.array_equal(cs, k['cam_sim'][:, 4:7])  # entities.py:347-360: bit exact
+
+
+def test_kat_lut_builder_and_perceive():
+    k = G.load('kat_perceive.npz')
+    luts = []
+    for i in range(len(k['lut_count'])):
+        n, no = int(k['lut_count'][i]), int(k['num_obstacles'][i])
+        phis, rhos = O.build_lut(k['cam_xy'][i], k['cam_max_sight_range'][i], k['obstacles'][i, :no], tau=0.0)
+        assert len(phis) == n
+        np.testing.assert_allclose(phis, k['lut_phis'][i, :n], rtol=0, atol=1e-10)
+        # A ray exactly tangent to an obstacle is clipped or not depending on the last
+        # bit of asin/atan2 (entities.py:170: `radius > perpendicular`): at most the two
+        # tangent knots per obstacle may land on the other side of that coin flip.
+        bad = np.abs(rhos - k['lut_rhos'][i, :n]) > 1e-8
+        assert bad.sum() <= 2 * no, (i, bad.sum())
+        luts.append((phis, rhos))
+    for r in k['cases']:
+        i = int(r[0])
+        n = int(k['lut_count'][i])
+        seen = O.camera_perceive(k['cam_xy'][i], r[1], r[2], r[3], r[4:6], r[6], r[7], k['lut_phis'][i, :n], k['lut_rhos'][i, :n])
+        assert seen == bool(r[8])
+
+
+@pytest.mark.parametrize('path', G.trace_files(), ids=lambda p: os.path.basename(p)[6:-4])
+def test_trace_parity(path):
+    fx = G.load(path)
+    env = G.oracle_from_fixture(fx)
+    co, to = env.observe()
+    if co.size:
+        np.testing.assert_allclose(co, fx['reset/cam_obs'], rtol=0, atol=F64_TOL)
+    np.testing.assert_allclose(to, fx['reset/tgt_obs'], rtol=0, atol=F64_TOL)
+    np.testing.assert_allclose(env.state(), fx['reset/state'], rtol=0, atol=F64_TOL)
+    exact_keys = ['tgt_colliding', 'tgt_empty_bits', 'tgt_goal_bits', 'tgt_goals', 'freights', 'bounties', 'target_steps',
+                  'tracked_steps', 'remaining_cargoes', 'awaiting_cargo_counts', 'num_delivered_cargoes', 'episode_step']
+    fields = dict(G.DYNAMIC_FIELDS)
+    for s in range(len(fx['step/done'])):
+        env.step(fx['step/cam_act'][s], fx['step/tgt_act'][s], fx['step/tape_ct'][s], fx['step/goal_u'][s])
+        for m in G.MASK_FIELDS + ['target_dones']:
+            got = np.asarray(env.get(m)) != 0
+            assert np.array_equal(got, fx['step/' + m][s].astype(bool)), (m, s)
+        for key in exact_keys:
+            got = np.asarray(env.get(fields[key]), dtype=np.float64)
+            assert np.array_equal(got, np.asarray(fx['step/' + key][s], dtype=np.float64)), (key, s)
+        assert env.get('reward_cam') == fx['step/reward_cam'][s]
+        assert env.get('reward_tgt') == fx['step/reward_tgt'][s]
+        assert env.get('normalized_reward_tgt') == fx['step/normalized_reward_tgt'][s]
+        assert bool(env.get('done')) == bool(fx['step/done'][s])
+        assert env.get('episode_reward') == fx['step/episode_reward'][s]
+        assert env.get('delayed_episode_reward') == fx['step/delayed_episode_reward'][s]
+        for k in ('coverage_rate', 'real_coverage_rate', 'mean_transport_rate'):
+            assert env.get(k) == fx['step/' + k][s], (k, s)
+        co, to = env.observe()
+        if co.size:
+            np.testing.assert_allclose(co, fx['step/cam_obs'][s], rtol=0, atol=F64_TOL)
+        np.testing.assert_allclose(to, fx['step/tgt_obs'][s], rtol=0, atol=F64_TOL)
+        np.testing.assert_allclose(env.state(), fx['step/state'][s], rtol=0, atol=F64_TOL)
+        np.testing.assert_allclose(env.get('target_warehouse_distances'), fx['step/target_warehouse_distances'][s], rtol=0, atol=F64_TOL)
+        for key in ('cam_phi', 'cam_theta', 'cam_sight'):
+            np.testing.assert_allclose(env.get(key), fx['step/' + key][s], rtol=0, atol=F64_TOL)
+
+
+def test_trace_parity_with_own_lut():
+    """Same replay, but the occlusion LUT comes from the oracle's own builder (a10)."""
+    fx = G.load('trace_4v8-9_greedy_s2.npz')
+    env = G.oracle_from_fixture(fx, use_golden_lut=False)
+    for c, (phis, rhos) in enumerate(G.luts_of(fx)):
+        p2, r2 = env.get_lut(c)
+        assert len(p2) == len(phis)
+        assert (np.abs(r2 - rhos) > 1e-8).sum() <= 2 * int(fx['num_obstacles'])
+    mism = 0
+    for s in range(len(fx['step/done'])):
+        env.step(fx['step/cam_act'][s], fx['step/tgt_act'][s], fx['step/tape_ct'][s], fx['step/goal_u'][s])
+        mism += int(not np.array_equal(env.get('camera_target_view_mask') != 0, fx['step/camera_target_view_mask'][s]))
+    assert mism == 0
