@@ -1,0 +1,140 @@
+/* mate_engine.h -- C ABI of the MI355X-native batched MultiAgentTracking step engine.
+ *
+ * The upstream reference (XuehaiPan/mate) has no FFI: the boundary its callers use is the
+ * Python class mate.environment.MultiAgentTracking (mate/environment.py:288) reached through
+ * mate.make (mate/__init__.py:24-46).  This header is the C-ABI a binding for that class
+ * sits on; every entry point names the reference method it stands in for.  Plain pointers
+ * and sizes only: all `*_dev` pointers are DEVICE pointers (e.g. torch `.data_ptr()`),
+ * caller-owned, never freed by the engine.  `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream); calls on one handle must be serialised by the caller.
+ * Every function returns 0 on success or a negative MATE_E* code; the message is available
+ * from mate_engine_last_error().  One handle drives N independent environments on one GPU.
+ */
+#ifndef MATE_ENGINE_H
+#define MATE_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MATE_ABI_VERSION 1
+
+enum {
+    MATE_OK = 0,
+    MATE_EINVAL = -1,   /* bad argument / configuration (reference: ValueError / AssertionError) */
+    MATE_EHIP = -2,     /* a HIP runtime call failed */
+    MATE_ENOMEM = -3,
+    MATE_ESTATE = -4    /* call sequence error (e.g. step before reset) */
+};
+
+enum { MATE_OBS_F32 = 0, MATE_OBS_F64 = 1 };
+enum { MATE_ACT_F32 = 0, MATE_ACT_F64 = 1 };
+
+/* Scenario description = the validated YAML/JSON/dict configuration of the reference
+ * (mate/environment.py:113-269: read_config + validate_config), flattened. */
+typedef struct mate_config {
+    int32_t num_cameras, num_targets, num_obstacles;
+    int32_t max_episode_steps;            /* environment.py:199-203 */
+    int32_t sparse_reward;                /* reward_type == 'sparse', environment.py:526 */
+    int32_t num_cargoes_per_target;       /* environment.py:223-229 */
+    int32_t shuffle_entities;             /* environment.py:253-256 */
+    int32_t targets_start_with_cargoes;   /* environment.py:240-243 */
+    double high_capacity_target_split;    /* environment.py:231-238 */
+    double bounty_factor;                 /* environment.py:245-251 */
+    double transmittance;                 /* obstacle/transmittance, environment.py:1470-1476 */
+    double camera_radius, camera_min_viewing_angle, camera_max_sight_range;
+    double camera_rotation_step, camera_zooming_step;   /* entities.py:248-254 */
+    double target_step_size, target_sight_range;        /* entities.py:563-566 */
+    double obstacle_radius_range[2];      /* radius_random_range (lo, hi) */
+    const double *camera_location_ranges;   /* [num_cameras][4]  = x_lo, x_hi, y_lo, y_hi (host memory) */
+    const double *target_location_ranges;   /* [num_targets][4] */
+    const double *obstacle_location_ranges; /* [num_obstacles][4] */
+    int32_t obs_dtype;                    /* MATE_OBS_F32 (default product path) or MATE_OBS_F64 */
+} mate_config;
+
+/* Sizes and the bit layout of the packed visibility masks, for the binding. */
+typedef struct mate_layout {
+    int32_t camera_obs_dim, target_obs_dim, state_dim;   /* constants.py:267-300, environment.py:450-466 */
+    int32_t mask_words;          /* u32 words per environment in the packed mask export */
+    int32_t bit_camera_target;   /* bit(c,t)  = bit_camera_target + c*Nt + t       (environment.py:1364-1367) */
+    int32_t bit_camera_camera;   /* bit(c,c') = bit_camera_camera + c*Nc + c'      (environment.py:1381-1386) */
+    int32_t bit_target_row;      /* bit(t,j)  = bit_target_row + t*(Nc+No+Nt) + j, j: cameras, obstacles, targets */
+    int32_t bit_camera_obstacle; /* bit(c,o)  = bit_camera_obstacle + c*64 + o      (environment.py:752-755) */
+    int32_t export_width;        /* doubles per environment in mate_engine_export_state */
+    int32_t lut_capacity;        /* max knots per camera occlusion table */
+    int32_t scalars_per_env;     /* floats per environment in the step scalar record (8) */
+} mate_layout;
+
+/* Per-step outputs (any pointer may be NULL to skip that output).
+ *   scalars_dev: [N][8] f32 = camera_team_reward, target_team_reward, done, coverage_rate,
+ *                real_coverage_rate, mean_transport_rate, num_delivered_cargoes,
+ *                normalized target_team_reward   (environment.py:618-661)
+ *   masks_dev:   [N][mask_words] u32 packed view masks + tracked bits (environment.py:1356-1388) */
+typedef struct mate_step_io {
+    const void *camera_actions_dev;   /* [N][Nc][2]  f32 or f64 (act_dtype) */
+    const void *target_actions_dev;   /* [N][Nt][2] */
+    int32_t act_dtype;
+    const double *tape_camera_target_dev; /* [N][Nc][Nt] uniforms for the see-through draw, or NULL = Philox */
+    const double *tape_goal_dev;          /* [N][Nt] uniforms for the goal choice, or NULL = Philox */
+    void *camera_obs_dev;             /* [N][Nc][Dc] f32/f64 (obs_dtype) */
+    void *target_obs_dev;             /* [N][Nt][Dt] */
+    float *scalars_dev;
+    uint32_t *masks_dev;
+} mate_step_io;
+
+typedef struct mate_engine mate_engine;
+
+const char *mate_engine_last_error(void);
+int mate_engine_abi_version(void);
+
+/* MultiAgentTracking.__init__ (environment.py:330-562) for N environments on HIP device `device`.
+ * RNG streams are keyed by (seed, first_env_index + i), so results do not depend on how a
+ * global batch is sharded over GPUs. */
+int mate_engine_create(const mate_config *config, int64_t num_envs, int32_t device, uint64_t seed,
+                       uint64_t first_env_index, mate_engine **out);
+int mate_engine_destroy(mate_engine *engine);                               /* close(), environment.py:1192 */
+int mate_engine_get_layout(const mate_engine *engine, mate_layout *out);
+int mate_engine_seed(mate_engine *engine, uint64_t seed);                   /* seed(), environment.py:1203-1227 */
+
+/* reset() (environment.py:679-834) of every environment (env_mask_dev == NULL) or of those with a
+ * non-zero byte in env_mask_dev[N].  Writes the initial observations/masks like a step does. */
+int mate_engine_reset(mate_engine *engine, const uint8_t *env_mask_dev, const mate_step_io *io, void *stream);
+
+/* step() (environment.py:590-676).  With auto_reset != 0, environments whose episode ended
+ * are reset in the same call and their observation rows hold the first observation of the
+ * new episode (rewards/done in `scalars_dev` still describe the finished step). */
+int mate_engine_step(mate_engine *engine, const mate_step_io *io, int32_t auto_reset, void *stream);
+
+/* step() with the uniform random policy of SURVEY.md section 8d generated on-device
+ * (camera U[-rot,rot] x U[-zoom,zoom], target U[-v,v]^2, Philox keyed by seed/env/tick);
+ * io->*_actions_dev are ignored. */
+int mate_engine_step_random(mate_engine *engine, const mate_step_io *io, int32_t auto_reset, void *stream);
+
+/* joint_observation() (environment.py:908-983) without advancing the simulation: recomputes
+ * the view masks from the current state (see-through draws from io tape or Philox) and packs. */
+int mate_engine_observe(mate_engine *engine, const mate_step_io *io, void *stream);
+
+/* Canonical f64 export / import of the whole simulation state, [N][export_width] doubles
+ * (layout documented in DESIGN.md; used by state(), the attribute views and the parity tests). */
+int mate_engine_export_state(mate_engine *engine, double *dst_dev, void *stream);
+int mate_engine_import_state(mate_engine *engine, const double *src_dev, void *stream);
+
+/* Occlusion table of one camera (Camera.sight_range_func, entities.py:457-479): host buffers. */
+int mate_engine_lut_read(mate_engine *engine, int64_t env, int32_t camera, double *phis_host,
+                         double *rhos_host, int32_t capacity, int32_t *count);
+int mate_engine_lut_write(mate_engine *engine, int64_t env, int32_t camera, const double *phis_host,
+                          const double *rhos_host, int32_t count);
+/* Rebuild the occlusion tables of all environments from the current static geometry
+ * (Camera.add_obstacles, entities.py:362-479) -- used after mate_engine_import_state. */
+int mate_engine_rebuild_luts(mate_engine *engine, void *stream);
+
+/* Average duration (ms) of the dominant kernel over the launches recorded since the last
+ * call with reset != 0, measured with HIP events on the launch stream (bench.py roofline). */
+int mate_engine_kernel_time(mate_engine *engine, int32_t enable, double *avg_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MATE_ENGINE_H */

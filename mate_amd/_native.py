@@ -1,0 +1,106 @@
+"""ctypes binding of ``mate_amd/lib/libmate_engine.so`` (C ABI: ``include/mate_engine.h``).
+
+There is no CPU fallback: if the HIP library is missing or fails to load this
+module raises, and every engine call that returns a non-zero status raises
+``EngineError`` carrying ``mate_engine_last_error()``.
+"""
+import ctypes
+import os
+
+__all__ = ['lib', 'load', 'EngineError', 'MateConfig', 'MateLayout', 'MateStepIO', 'LIB_PATH', 'check', 'EXPORTED_SYMBOLS']
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libmate_engine.so')
+
+EXPORTED_SYMBOLS = (
+    'mate_engine_last_error', 'mate_engine_abi_version', 'mate_engine_create', 'mate_engine_destroy',
+    'mate_engine_get_layout', 'mate_engine_seed', 'mate_engine_reset', 'mate_engine_step', 'mate_engine_step_random',
+    'mate_engine_observe', 'mate_engine_export_state', 'mate_engine_import_state', 'mate_engine_lut_read',
+    'mate_engine_lut_write', 'mate_engine_rebuild_luts', 'mate_engine_kernel_time',
+)
+
+
+class EngineError(RuntimeError):
+    """A C-ABI call failed (status code + message from the engine)."""
+
+    def __init__(self, code, message):
+        super().__init__(f'mate_engine error {code}: {message}')
+        self.code = code
+
+
+class MateConfig(ctypes.Structure):
+    _fields_ = [
+        ('num_cameras', ctypes.c_int32), ('num_targets', ctypes.c_int32), ('num_obstacles', ctypes.c_int32),
+        ('max_episode_steps', ctypes.c_int32), ('sparse_reward', ctypes.c_int32),
+        ('num_cargoes_per_target', ctypes.c_int32), ('shuffle_entities', ctypes.c_int32),
+        ('targets_start_with_cargoes', ctypes.c_int32),
+        ('high_capacity_target_split', ctypes.c_double), ('bounty_factor', ctypes.c_double),
+        ('transmittance', ctypes.c_double),
+        ('camera_radius', ctypes.c_double), ('camera_min_viewing_angle', ctypes.c_double),
+        ('camera_max_sight_range', ctypes.c_double), ('camera_rotation_step', ctypes.c_double),
+        ('camera_zooming_step', ctypes.c_double),
+        ('target_step_size', ctypes.c_double), ('target_sight_range', ctypes.c_double),
+        ('obstacle_radius_range', ctypes.c_double * 2),
+        ('camera_location_ranges', ctypes.POINTER(ctypes.c_double)),
+        ('target_location_ranges', ctypes.POINTER(ctypes.c_double)),
+        ('obstacle_location_ranges', ctypes.POINTER(ctypes.c_double)),
+        ('obs_dtype', ctypes.c_int32),
+    ]
+
+
+class MateLayout(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_int32) for name in (
+        'camera_obs_dim', 'target_obs_dim', 'state_dim', 'mask_words', 'bit_camera_target', 'bit_camera_camera',
+        'bit_target_row', 'bit_camera_obstacle', 'export_width', 'lut_capacity', 'scalars_per_env')]
+
+
+class MateStepIO(ctypes.Structure):
+    _fields_ = [
+        ('camera_actions_dev', ctypes.c_void_p), ('target_actions_dev', ctypes.c_void_p), ('act_dtype', ctypes.c_int32),
+        ('tape_camera_target_dev', ctypes.c_void_p), ('tape_goal_dev', ctypes.c_void_p),
+        ('camera_obs_dev', ctypes.c_void_p), ('target_obs_dev', ctypes.c_void_p),
+        ('scalars_dev', ctypes.c_void_p), ('masks_dev', ctypes.c_void_p),
+    ]
+
+
+lib = None
+
+
+def load():
+    """Load the HIP engine; raises if it has not been built (python -m mate_amd.build)."""
+    global lib
+    if lib is not None:
+        return lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} is missing: build the HIP engine first (python -m mate_amd.build or '
+            f'__graft_entry__.build()).  mate_amd has no CPU fallback.')
+    handle = ctypes.CDLL(LIB_PATH)
+    P, I32, I64, U64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
+    handle.mate_engine_last_error.restype = ctypes.c_char_p
+    handle.mate_engine_last_error.argtypes = []
+    handle.mate_engine_abi_version.restype = ctypes.c_int
+    handle.mate_engine_create.argtypes = [ctypes.POINTER(MateConfig), I64, I32, U64, U64, ctypes.POINTER(P)]
+    handle.mate_engine_destroy.argtypes = [P]
+    handle.mate_engine_get_layout.argtypes = [P, ctypes.POINTER(MateLayout)]
+    handle.mate_engine_seed.argtypes = [P, U64]
+    handle.mate_engine_reset.argtypes = [P, P, ctypes.POINTER(MateStepIO), P]
+    handle.mate_engine_step.argtypes = [P, ctypes.POINTER(MateStepIO), I32, P]
+    handle.mate_engine_step_random.argtypes = [P, ctypes.POINTER(MateStepIO), I32, P]
+    handle.mate_engine_observe.argtypes = [P, ctypes.POINTER(MateStepIO), P]
+    handle.mate_engine_export_state.argtypes = [P, P, P]
+    handle.mate_engine_import_state.argtypes = [P, P, P]
+    handle.mate_engine_lut_read.argtypes = [P, I64, I32, P, P, I32, ctypes.POINTER(I32)]
+    handle.mate_engine_lut_write.argtypes = [P, I64, I32, P, P, I32]
+    handle.mate_engine_rebuild_luts.argtypes = [P, P]
+    handle.mate_engine_kernel_time.argtypes = [P, I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I64)]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(handle, name)
+        if name not in ('mate_engine_last_error',):
+            fn.restype = ctypes.c_int
+    lib = handle
+    return lib
+
+
+def check(status):
+    if status != 0:
+        raise EngineError(status, load().mate_engine_last_error().decode())

@@ -1,0 +1,609 @@
+// engine_kernels.hpp -- gfx950 kernels of the batched MultiAgentTracking step engine.
+//
+// Mapping: ONE WAVE (64 lanes) PER ENVIRONMENT, four environments per 256-thread
+// workgroup.  An environment's state is two small contiguous records (static geometry,
+// dynamic state) that the wave loads with one coalesced 8-byte-per-lane read, stages in LDS,
+// and then works on with lanes mapped to (entity, entity) pairs; wave ballots produce the
+// visibility masks; the observation rows are gathered from an LDS scratch through a
+// per-scenario descriptor table and stored as contiguous 16-byte-per-lane rows.
+#pragma once
+#include "device_math.hpp"
+
+namespace mate {
+
+enum Mode : int32_t { MODE_STEP = 0, MODE_STEP_RANDOM = 1, MODE_OBSERVE = 2 };
+
+// dynamic int record, per target (5 ints) then per environment
+enum { TI_BOUNTY = 0, TI_FREIGHT = 1, TI_GW = 2, TI_TSTEPS = 3, TI_TRSTEPS = 4, TI_STRIDE = 5 };
+enum { EI_REMAINING = 0, EI_AWAITING = 16, EI_DELIVERED = 20, EI_EPSTEP = 21, EI_TICK = 22, EI_EPISODE = 23, EI_DONE = 24, EI_PAD = 25, EI_COUNT = 26 };
+// TI_GW packing: bits 0-7 goal+1 (0 = no goal), 8-15 cargo weight, 16-19 empty bits, 24 colliding
+
+struct Params {
+    int32_t Nc, Nt, No, NK, NJ;
+    int32_t Dc, Dt, cam_elems, tgt_elems;
+    int32_t SW, DF, NI, DW;
+    int32_t n_sector, n_range, sector_rounds, range_rounds;
+    int32_t bit_cc, bit_range, bit_camobs, bit_always, MW;
+    int32_t nscratch, sc_cam, sc_tgt, sc_obs;
+    int32_t tgt_table_off;   // first target descriptor (cam_elems rounded up to 4)
+    int32_t kmax, nbucket;
+    int32_t max_episode_steps, sparse_reward, num_cargoes_per_target, shuffle, start_with_cargoes, n_high;
+    int32_t obs_f64;
+    float inv_Nt, inv_NK, inv_NJ, inv_Nc;
+    double tau, cam_radius, theta_min, rmax, rot, zoom, area, tgt_step, tgt_sight;
+    double freight_scale, bounty_scale, reward_scale, max_team_reward;
+    double obs_r_lo, obs_r_hi;
+    uint32_t seed_lo, seed_hi, first_env;
+    int32_t lds_table_bytes, lds_wave_bytes, off_st, off_dy, off_tmp, off_scratch, off_mask, off_misc;
+    int32_t export_width;
+};
+
+struct Ptrs {
+    double *stat;                 // [N][SW]
+    double *dyn;                  // [N][DW] (8-byte words: DF doubles then NI ints)
+    double2 *lut_knots;           // [N][Nc][kmax]  (phi, rho)
+    uint16_t *lut_bucket;         // [N][Nc][nbucket]
+    int32_t *lut_count;           // [N][Nc]
+    const uint32_t *desc;         // [cam_elems + tgt_elems]  src | bit << 16
+    const void *scratch_init;     // [nscratch] ObsT
+    const double *reset_ranges;   // [Nc+No+Nt][4] cameras, obstacles, targets
+    const void *cam_act, *tgt_act;
+    const double *tape_ct, *tape_goal;
+    void *cam_obs, *tgt_obs;
+    float *scalars;
+    uint32_t *masks;
+    int32_t *done_count;          // [2] ping-pong counters
+    int32_t *done_list;           // [2][N]
+    const uint8_t *reset_mask;    // optional
+    int64_t N;
+    int32_t mode, act_f64, parity, reset_kind;
+};
+
+// Wave-level LDS hand-off: all 64 lanes run in lockstep, so draining this wave's LDS queue and
+// pinning the compiler's order is a complete producer->consumer fence inside the wave.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <typename ObsT>
+struct Ctx {
+    const Params &p;
+    const Ptrs &g;
+    int lane;
+    int64_t env;
+    double *st, *dy, *tmp;
+    int32_t *di;
+    ObsT *scratch;
+    uint32_t *mask;
+    int32_t *misc;
+    const uint32_t *table;
+
+    __device__ Ctx(const Params &p_, const Ptrs &g_, unsigned char *wave_base, const unsigned char *table_base, int lane_, int64_t env_)
+        : p(p_), g(g_), lane(lane_), env(env_) {
+        st = reinterpret_cast<double *>(wave_base + p.off_st);
+        dy = reinterpret_cast<double *>(wave_base + p.off_dy);
+        di = reinterpret_cast<int32_t *>(dy + p.DF);
+        tmp = reinterpret_cast<double *>(wave_base + p.off_tmp);
+        scratch = reinterpret_cast<ObsT *>(wave_base + p.off_scratch);
+        mask = reinterpret_cast<uint32_t *>(wave_base + p.off_mask);
+        misc = reinterpret_cast<int32_t *>(wave_base + p.off_misc);
+        table = reinterpret_cast<const uint32_t *>(table_base);
+    }
+    // static record
+    __device__ double cam_x(int c) const { return st[c]; }
+    __device__ double cam_y(int c) const { return st[p.Nc + c]; }
+    __device__ double obs_x(int o) const { return st[2 * p.Nc + o]; }
+    __device__ double obs_y(int o) const { return st[2 * p.Nc + p.No + o]; }
+    __device__ double obs_r(int o) const { return st[2 * p.Nc + 2 * p.No + o]; }
+    __device__ uint64_t camobs(int c) const { return reinterpret_cast<const uint64_t *>(st)[2 * p.Nc + 3 * p.No + c]; }
+    __device__ uint64_t capword() const { return reinterpret_cast<const uint64_t *>(st)[3 * p.Nc + 3 * p.No]; }
+    __device__ void circle(int k, double &x, double &y, double &r) const {  // obstacles, then cameras (Target.add_obstacles, environment.py:743)
+        if (k < p.No) { x = obs_x(k); y = obs_y(k); r = obs_r(k); }
+        else { x = cam_x(k - p.No); y = cam_y(k - p.No); r = p.cam_radius; }
+    }
+    // dynamic record
+    __device__ double &phi(int c) { return dy[c]; }
+    __device__ double &theta(int c) { return dy[p.Nc + c]; }
+    __device__ double &tx(int t) { return dy[2 * p.Nc + t]; }
+    __device__ double &ty(int t) { return dy[2 * p.Nc + p.Nt + t]; }
+    __device__ double &ep_reward() { return dy[2 * p.Nc + 2 * p.Nt]; }
+    __device__ double &ep_delayed() { return dy[2 * p.Nc + 2 * p.Nt + 1]; }
+    __device__ int32_t &ti(int t, int f) { return di[t * TI_STRIDE + f]; }
+    __device__ int32_t &ei(int f) { return di[p.Nt * TI_STRIDE + f]; }
+    // temporaries
+    __device__ double &sight(int c) { return tmp[c]; }
+    __device__ double &svx(int t) { return tmp[p.Nc + t]; }
+    __device__ double &svy(int t) { return tmp[p.Nc + p.Nt + t]; }
+    __device__ double &snorm(int t) { return tmp[p.Nc + 2 * p.Nt + t]; }
+    __device__ int32_t &near(int t) { return misc[t]; }
+    __device__ int32_t &inside(int t) { return misc[p.Nt + t]; }
+    __device__ int32_t &tracked(int t) { return misc[2 * p.Nt + t]; }
+    __device__ int32_t &xch(int i) { return misc[3 * p.Nt + i]; }
+    __device__ bool mask_bit(int b) const { return (mask[b >> 5] >> (b & 31)) & 1u; }
+    __device__ uint32_t env_global() const { return p.first_env + (uint32_t)env; }
+    __device__ double draw(uint32_t tick, uint32_t stream, uint32_t sub) const {
+        const U4 r = philox(p.seed_lo, p.seed_hi, env_global(), tick, stream, sub);
+        return u53(r.x, r.y);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// record <-> LDS
+template <typename ObsT>
+__device__ void load_records(Ctx<ObsT> &c) {
+    const double *s = c.g.stat + c.env * c.p.SW;
+    const double *d = c.g.dyn + c.env * c.p.DW;
+    for (int i = c.lane; i < c.p.SW; i += 64) c.st[i] = s[i];
+    for (int i = c.lane; i < c.p.DW; i += 64) c.dy[i] = d[i];
+    if (c.g.scratch_init) {
+        const ObsT *si = reinterpret_cast<const ObsT *>(c.g.scratch_init);
+        for (int i = c.lane; i < c.p.nscratch; i += 64) c.scratch[i] = si[i];
+    }
+    for (int i = c.lane; i < c.p.MW; i += 64) c.mask[i] = 0u;
+}
+
+template <typename ObsT>
+__device__ void store_dynamic(Ctx<ObsT> &c) {
+    double *d = c.g.dyn + c.env * c.p.DW;
+    for (int i = c.lane; i < c.p.DW; i += 64) d[i] = c.dy[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase A: kinematics.  Camera.simulate (entities.py:347-360), Target.simulate (entities.py:645-668).
+template <typename ObsT>
+__device__ void simulate(Ctx<ObsT> &c, uint32_t tick) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    const bool advance = c.g.mode != MODE_OBSERVE;
+    // ---- cameras: lanes [0, Nc)
+    if (lane < p.Nc) {
+        double ph = c.phi(lane), th = c.theta(lane);
+        if (advance) {
+            double da, dz;
+            if (c.g.mode == MODE_STEP_RANDOM) {
+                const U4 r = philox(p.seed_lo, p.seed_hi, c.env_global(), tick, S_ACT_CAM, (uint32_t)lane);
+                da = action_component(r.x, p.rot); dz = action_component(r.y, p.zoom);
+            } else if (c.g.act_f64) {
+                const double *a = reinterpret_cast<const double *>(c.g.cam_act) + (c.env * p.Nc + lane) * 2;
+                da = a[0]; dz = a[1];
+            } else {
+                const float2 a = reinterpret_cast<const float2 *>(c.g.cam_act)[c.env * p.Nc + lane];
+                da = (double)a.x; dz = (double)a.y;
+            }
+            da = clipd(da, -p.rot, p.rot);
+            dz = clipd(dz, -p.zoom, p.zoom);
+            ph = normalize_angle(ph + da);
+            th = clipd(th + dz, p.theta_min, kMaxViewingAngle);
+            c.phi(lane) = ph; c.theta(lane) = th;
+        }
+        const double sr = sqrt(p.area / th);      // entities.py:360
+        c.sight(lane) = sr;
+        double sn, cs;
+        sincos(ph * kDeg2Rad, &sn, &cs);           // Camera.state: polar2cartesian(sight_range, orientation), entities.py:318
+        ObsT *sc = c.scratch + p.sc_cam + lane * 10;
+        sc[0] = (ObsT)c.cam_x(lane); sc[1] = (ObsT)c.cam_y(lane);
+        sc[3] = (ObsT)(sr * cs); sc[4] = (ObsT)(sr * sn); sc[5] = (ObsT)th;
+    }
+    if (!advance) { wave_sync(); return; }
+
+    // ---- targets: lanes [0, Nt): clamp the step through the polar form (entities.py:648-650, utils.py:223-229)
+    Ray step;
+    double desx = 0.0, desy = 0.0, step_size = 0.0;
+    if (lane < p.Nt) {
+        double ax, ay;
+        if (c.g.mode == MODE_STEP_RANDOM) {
+            const U4 r = philox(p.seed_lo, p.seed_hi, c.env_global(), tick, S_ACT_TGT, (uint32_t)lane);
+            ax = action_component(r.x, p.tgt_step); ay = action_component(r.y, p.tgt_step);
+        } else if (c.g.act_f64) {
+            const double *a = reinterpret_cast<const double *>(c.g.tgt_act) + (c.env * p.Nt + lane) * 2;
+            ax = a[0]; ay = a[1];
+        } else {
+            const float2 a = reinterpret_cast<const float2 *>(c.g.tgt_act)[c.env * p.Nt + lane];
+            ax = (double)a.x; ay = (double)a.y;
+        }
+        const int cap = 1 + (int)((c.capword() >> lane) & 1ull);
+        step_size = p.tgt_step / (double)cap;      // entities.py:612-615
+        step.ox = c.tx(lane); step.oy = c.ty(lane);
+        step.vx = ax; step.vy = ay; step.hv = true; step.hn = false; step.ha = false; step.n = 0.0; step.a = 0.0;
+        if (ray_norm(step) > step_size) { ray_set_norm(step, step_size); ray_materialize(step); }
+        desx = step.ox + step.vx; desy = step.oy + step.vy;
+        c.svx(lane) = step.vx; c.svy(lane) = step.vy; c.snorm(lane) = step.n;
+        c.near(lane) = 0;
+    }
+    wave_sync();
+    // ---- which (target, circle) pairs can interact at all?  (entities.py:161-164 early-outs)
+    const int npairs = p.Nt * p.NK;
+    for (int base = 0; base < npairs; base += 64) {
+        const int q = base + lane;
+        if (q < npairs) {
+            const int t = (int)(((float)q + 0.5f) * p.inv_NK);
+            const int k = q - t * p.NK;
+            double cx, cy, cr;
+            c.circle(k, cx, cy, cr);
+            const double rel_norm = norm2(cx - c.tx(t), cy - c.ty(t));
+            const double n = c.snorm(t);
+            const bool is_near = (n != 0.0) && (rel_norm < cr || !(rel_norm >= n + cr));
+            if (is_near) atomicOr(&c.near(t), 1);
+        }
+    }
+    wave_sync();
+    // ---- rare path: walk every circle in order with the full Vector2D semantics
+    if (lane < p.Nt) {
+        if (c.near(lane)) {
+            for (int k = 0; k < p.NK; ++k) {
+                double cx, cy, cr;
+                c.circle(k, cx, cy, cr);
+                obstruct_tangential(step, cx, cy, cr);
+            }
+            ray_materialize(step);
+        }
+        const double nx = clipd(step.ox + step.vx, -kTerrain, kTerrain);   // entities.py:664-666
+        const double ny = clipd(step.oy + step.vy, -kTerrain, kTerrain);
+        const bool colliding = (fabs(nx - desx) > 1e-6) || (fabs(ny - desy) > 1e-6);  // entities.py:668
+        c.tx(lane) = nx; c.ty(lane) = ny;
+        int gw = c.ti(lane, TI_GW) & ~(1 << 24);
+        c.ti(lane, TI_GW) = gw | ((int)colliding << 24);
+    }
+    wave_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Occlusion-table lookup: Camera.sight_range_at (entities.py:507-511) == np.interp on the knots.
+__device__ __forceinline__ double lut_lookup(const double2 *knots, const uint16_t *bucket, int n, double x) {
+    if (x > knots[n - 1].x) return knots[n - 1].y;
+    if (x < knots[0].x) return knots[0].y;
+    int d = (int)floor(x + 180.0);
+    d = d < 0 ? 0 : (d > 359 ? 359 : d);
+    int lo = bucket[d > 0 ? d - 1 : 0];
+    int hi = bucket[d + 2 > 360 ? 360 : d + 2];      // knots[hi].x > x, knots[lo].x <= x
+    if (hi > n - 1) hi = n - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (knots[mid].x <= x) lo = mid; else hi = mid;
+    }
+    if (knots[hi].x <= x) lo = hi;
+    const int j = lo;
+    const double2 k0 = knots[j];
+    if (j == n - 1 || k0.x == x) return k0.y;
+    const double2 k1 = knots[j + 1];
+    const double slope = (k1.y - k0.y) / (k1.x - k0.x);
+    double res = slope * (x - k0.x) + k0.y;
+    if (res != res) {
+        res = slope * (x - k1.x) + k1.y;
+        if (res != res && k0.y == k1.y) res = k0.y;
+    }
+    return res;
+}
+
+// Phase B: _update_view (environment.py:1356-1388).
+template <typename ObsT>
+__device__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    // ---- sector tests: Camera.perceive (entities.py:491-505) for camera->target and camera->camera
+    for (int round = 0; round < p.sector_rounds; ++round) {
+        const int q = round * 64 + lane;
+        bool seen = false;
+        if (q < p.n_sector) {
+            int cam, other; bool is_target;
+            if (q < p.bit_cc) { cam = (int)(((float)q + 0.5f) * p.inv_Nt); other = q - cam * p.Nt; is_target = true; }
+            else { const int r = q - p.bit_cc; cam = (int)(((float)r + 0.5f) * p.inv_Nc); other = r - cam * p.Nc; is_target = false; }
+            if (!is_target && cam == other) {
+                seen = true;                                         // environment.py:1383-1384
+            } else {
+                const double px = is_target ? c.tx(other) : c.cam_x(other);
+                const double py = is_target ? c.ty(other) : c.cam_y(other);
+                const double rx = px - c.cam_x(cam), ry = py - c.cam_y(cam);
+                const double rn = norm2(rx, ry);
+                if (!(rn > c.sight(cam))) {
+                    const double ang = atan2_deg(ry, rx);
+                    double ra = fabs(c.phi(cam) - ang);
+                    const double alt = 360.0 - ra;
+                    if (alt < ra) ra = alt;
+                    if (!(ra * 2.0 > c.theta(cam))) {
+                        bool see_through = false;
+                        if (is_target) {                             // np_random.binomial(1, tau), entities.py:503
+                            const double u = c.g.tape_ct ? c.g.tape_ct[(c.env * p.Nc + cam) * p.Nt + other]
+                                                         : c.draw(tick, stream, (uint32_t)(cam * p.Nt + other));
+                            see_through = (p.tau <= 0.5) ? (u > 1.0 - p.tau) : (u <= p.tau);
+                        }
+                        if (see_through) {
+                            seen = true;
+                        } else {
+                            const int64_t lc = c.env * p.Nc + cam;
+                            const double limit = lut_lookup(c.g.lut_knots + lc * p.kmax, c.g.lut_bucket + lc * p.nbucket,
+                                                            c.g.lut_count[lc], normalize_angle(ang));
+                            seen = rn <= limit * (1.0 + 1e-6);       // entities.py:505
+                        }
+                    }
+                }
+            }
+        }
+        const unsigned long long b = __ballot(seen);
+        if (lane == 0) { c.mask[2 * round] = (uint32_t)b; c.mask[2 * round + 1] = (uint32_t)(b >> 32); }
+    }
+    // ---- range tests: Sensor.perceive (entities.py:229-232) target -> camera / obstacle / target
+    const int rbase = p.bit_range >> 5;
+    for (int round = 0; round < p.range_rounds; ++round) {
+        const int q = round * 64 + lane;
+        bool seen = false;
+        if (q < p.n_range) {
+            const int t = (int)(((float)q + 0.5f) * p.inv_NJ);
+            const int j = q - t * p.NJ;
+            double ox, oy, orad;
+            bool diag = false;
+            if (j < p.Nc) { ox = c.cam_x(j); oy = c.cam_y(j); orad = p.cam_radius; }
+            else if (j < p.Nc + p.No) { const int o = j - p.Nc; ox = c.obs_x(o); oy = c.obs_y(o); orad = c.obs_r(o); }
+            else { const int t2 = j - p.Nc - p.No; ox = c.tx(t2); oy = c.ty(t2); orad = 0.0; diag = (t2 == t); }
+            seen = diag || (norm2(c.tx(t) - ox, c.ty(t) - oy) <= p.tgt_sight + orad);
+        }
+        const unsigned long long b = __ballot(seen);
+        if (lane == 0) { c.mask[rbase + 2 * round] = (uint32_t)b; c.mask[rbase + 2 * round + 1] = (uint32_t)(b >> 32); }
+    }
+    // ---- static camera->obstacle bits (environment.py:752-755) and the always-true bit
+    if (lane < p.Nc) {
+        const uint64_t m = c.camobs(lane);
+        c.mask[(p.bit_camobs >> 5) + 2 * lane] = (uint32_t)m;
+        c.mask[(p.bit_camobs >> 5) + 2 * lane + 1] = (uint32_t)(m >> 32);
+    }
+    if (lane == 0) c.mask[p.bit_always >> 5] = 1u;
+    wave_sync();
+    // ---- tracked_bits = camera_target_view_mask.any(axis=0) (environment.py:1388); which warehouse holds the target
+    if (lane < p.Nt) {
+        int any = 0;
+        for (int cam = 0; cam < p.Nc; ++cam) any |= (int)c.mask_bit(cam * p.Nt + lane);
+        c.tracked(lane) = any;
+        int w_in = -1;
+        const double x = c.tx(lane), y = c.ty(lane);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {   // constants.py:70-72: (+,+), (-,+), (-,-), (+,-)
+            const double wx = (w == 0 || w == 3) ? kWarehouseCenter : -kWarehouseCenter;
+            const double wy = (w < 2) ? kWarehouseCenter : -kWarehouseCenter;
+            const double sup = fmax(fabs(x - wx), fabs(y - wy));    // environment.py:1283
+            if (sup <= kWarehouseRadius && w_in < 0) w_in = w;
+        }
+        c.inside(lane) = w_in;
+    }
+    wave_sync();
+}
+
+// Phase C: _assign_goals + the bookkeeping of step() (environment.py:1271-1324, 613-632).
+template <typename ObsT>
+__device__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    bool penal = false;
+    if (lane < p.Nt) {
+        const int b = c.ti(lane, TI_BOUNTY);
+        const int tr = c.tracked(lane);
+        penal = tr && b > 0;                                  // environment.py:1275
+        const int nb = b - tr;
+        c.ti(lane, TI_BOUNTY) = nb > 0 ? nb : 0;               // environment.py:1276
+    }
+    const int n_penal = __popcll(__ballot(penal));
+    const bool any_inside = __ballot(lane < p.Nt && c.inside(lane) >= 0) != 0ull;
+    wave_sync();
+    double reward = -(double)n_penal, delayed = 0.0;
+    if (any_inside) {
+        if (lane == 0) {
+            for (int t = 0; t < p.Nt; ++t) {
+                const int w = c.inside(t);
+                if (w < 0) continue;
+                int gw = c.ti(t, TI_GW);
+                const int goal = (gw & 0xff) - 1;
+                const int weight0 = (gw >> 8) & 0xff;
+                bool proceed = true;
+                if (goal >= 0) {
+                    if (goal == w) {                            // delivery, environment.py:1286-1293
+                        const double total_bounty = (double)weight0 * p.bounty_scale;
+                        const double r = (double)(c.ti(t, TI_FREIGHT) + c.ti(t, TI_BOUNTY));
+                        reward += r;
+                        delayed += r - (total_bounty - (double)c.ti(t, TI_BOUNTY));
+                        c.ei(EI_DELIVERED) += weight0;
+                        c.ei(EI_AWAITING + goal) -= weight0;
+                    } else {
+                        proceed = false;                        // environment.py:1294-1295
+                    }
+                }
+                if (proceed) {
+                    c.ti(t, TI_FREIGHT) = 0; c.ti(t, TI_BOUNTY) = 0;
+                    c.ti(t, TI_TSTEPS) = 0; c.ti(t, TI_TRSTEPS) = 0;
+                    gw &= ~0xffff;                              // goal := none, weight := 0
+                    int *row = &c.ei(EI_REMAINING + 4 * w);
+                    int k = 0;
+                    for (int gq = 0; gq < 4; ++gq) k += row[gq] > 0;
+                    if (k > 0) {                                // environment.py:1302-1315
+                        const double u = c.g.tape_goal ? c.g.tape_goal[c.env * p.Nt + t] : c.draw(tick, S_GOAL, (uint32_t)t);
+                        int j = (int)(u * (double)k);
+                        if (j >= k) j = k - 1;
+                        int new_goal = 0;
+                        for (int gq = 0, seen = 0; gq < 4; ++gq) if (row[gq] > 0) { if (seen == j) new_goal = gq; ++seen; }
+                        const int cap = 1 + (int)((c.capword() >> t) & 1ull);
+                        const int rem = row[new_goal];
+                        const int weight = cap < rem ? cap : rem;
+                        row[new_goal] -= weight;
+                        c.ti(t, TI_FREIGHT) = (int)((double)weight * p.freight_scale);
+                        c.ti(t, TI_BOUNTY) = (int)((double)weight * p.bounty_scale);
+                        gw |= (new_goal + 1) | (weight << 8);
+                    }
+                }
+                // empty bits of the warehouse the target stands in (environment.py:1317-1318)
+                const int *row = &c.ei(EI_REMAINING + 4 * w);
+                const bool empty = !(row[0] || row[1] || row[2] || row[3]);
+                gw = (gw & ~(1 << (16 + w))) | ((int)empty << (16 + w));
+                c.ti(t, TI_GW) = gw;
+            }
+            c.xch(0) = __double2hiint(reward); c.xch(1) = __double2loint(reward);
+            c.xch(2) = __double2hiint(delayed); c.xch(3) = __double2loint(delayed);
+        }
+        wave_sync();
+        reward = __hiloint2double(c.xch(0), c.xch(1));
+        delayed = __hiloint2double(c.xch(2), c.xch(3));
+    }
+    // metrics (environment.py:966-979), counters (environment.py:626-632)
+    bool with_bounty = false, tr = false;
+    if (lane < p.Nt) {
+        with_bounty = c.ti(lane, TI_BOUNTY) > 0;
+        tr = c.tracked(lane) != 0;
+        c.ti(lane, TI_TSTEPS) += 1;
+        c.ti(lane, TI_TRSTEPS) += (int)tr;
+    }
+    const int n_tracked = __popcll(__ballot(tr));
+    const int n_bounty = __popcll(__ballot(with_bounty));
+    const int n_both = __popcll(__ballot(tr && with_bounty));
+    if (lane == 0) {
+        const double epr = c.ep_reward() + reward;
+        const double epd = c.ep_delayed() + delayed;
+        c.ep_reward() = epr; c.ep_delayed() = epd;
+        const int delivered = c.ei(EI_DELIVERED);
+        const double coverage = (double)n_tracked / (double)p.Nt;
+        const double real_cov = n_bounty > 0 ? (double)n_both / (double)n_bounty : 0.0;
+        const double transport = delivered > 0 ? epd / (p.reward_scale * (double)delivered) : 0.0;
+        const double r = p.sparse_reward ? delayed : reward;
+        const int ep_step = c.ei(EI_EPSTEP) + 1;
+        c.ei(EI_EPSTEP) = ep_step;
+        const bool awaiting = c.ei(EI_AWAITING) || c.ei(EI_AWAITING + 1) || c.ei(EI_AWAITING + 2) || c.ei(EI_AWAITING + 3);
+        const int done = !(ep_step <= p.max_episode_steps && awaiting);
+        c.ei(EI_DONE) = done;
+        c.ei(EI_TICK) = (int)(tick + 1u);
+        if (scalars_out) {
+            float *o = scalars_out + c.env * 8;
+            o[0] = (float)(-r); o[1] = (float)r; o[2] = (float)done; o[3] = (float)coverage;
+            o[4] = (float)real_cov; o[5] = (float)transport; o[6] = (float)delivered; o[7] = (float)(r / p.max_team_reward);
+        }
+        if (done && c.g.done_count) {
+            const int slot = atomicAdd(c.g.done_count + c.g.parity, 1);
+            c.g.done_list[(int64_t)c.g.parity * c.g.N + slot] = (int32_t)c.env;
+        }
+    }
+    wave_sync();
+}
+
+// metrics only (after reset / observe): no counters advance
+template <typename ObsT>
+__device__ void score_only(Ctx<ObsT> &c, float *scalars_out) {
+    const Params &p = c.p;
+    bool with_bounty = false, tr = false;
+    if (c.lane < p.Nt) { with_bounty = c.ti(c.lane, TI_BOUNTY) > 0; tr = c.tracked(c.lane) != 0; }
+    const int n_tracked = __popcll(__ballot(tr));
+    const int n_bounty = __popcll(__ballot(with_bounty));
+    const int n_both = __popcll(__ballot(tr && with_bounty));
+    if (c.lane == 0 && scalars_out) {
+        float *o = scalars_out + c.env * 8;
+        const int delivered = c.ei(EI_DELIVERED);
+        o[0] = 0.f; o[1] = 0.f; o[2] = (float)c.ei(EI_DONE); o[3] = (float)((double)n_tracked / (double)p.Nt);
+        o[4] = n_bounty > 0 ? (float)((double)n_both / (double)n_bounty) : 0.f;
+        o[5] = delivered > 0 ? (float)(c.ep_delayed() / (p.reward_scale * (double)delivered)) : 0.f;
+        o[6] = (float)delivered; o[7] = 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Phase D: joint_observation (environment.py:908-964): fill the per-environment scratch, then gather.
+template <typename ObsT>
+__device__ void fill_scratch(Ctx<ObsT> &c) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    if (lane < p.Nt) {                        // Target.state(private=True), entities.py:631-637
+        ObsT *sc = c.scratch + p.sc_tgt + lane * 14;
+        const int gw = c.ti(lane, TI_GW);
+        const int goal = (gw & 0xff) - 1, weight = (gw >> 8) & 0xff;
+        const int cap = 1 + (int)((c.capword() >> lane) & 1ull);
+        sc[0] = (ObsT)c.tx(lane); sc[1] = (ObsT)c.ty(lane);
+        sc[3] = (ObsT)(goal >= 0 && weight > 0 ? 1.0 : 0.0);
+        sc[4] = (ObsT)(p.tgt_step / (double)cap); sc[5] = (ObsT)cap;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            sc[6 + w] = (ObsT)(goal == w ? weight : 0);
+            sc[10 + w] = (ObsT)((gw >> (16 + w)) & 1);
+        }
+    }
+    for (int o = lane; o < p.No; o += 64) {   // Obstacle.state, entities.py:147-148
+        ObsT *sc = c.scratch + p.sc_obs + o * 3;
+        sc[0] = (ObsT)c.obs_x(o); sc[1] = (ObsT)c.obs_y(o); sc[2] = (ObsT)c.obs_r(o);
+    }
+    wave_sync();
+}
+
+template <typename ObsT> struct Vec;
+template <> struct Vec<float> { using type = float4; static constexpr int W = 4; };
+template <> struct Vec<double> { using type = double2; static constexpr int W = 2; };
+
+template <typename ObsT>
+__device__ __forceinline__ ObsT gather_one(const Ctx<ObsT> &c, uint32_t d) {
+    const ObsT v = c.scratch[d & 0xffffu];
+    return c.mask_bit((int)(d >> 16)) ? v : (ObsT)0;
+}
+
+template <typename ObsT>
+__device__ void pack_block(const Ctx<ObsT> &c, ObsT *dst, const uint32_t *table, int elems) {
+    constexpr int W = Vec<ObsT>::W;
+    using V = typename Vec<ObsT>::type;
+    if ((elems % W) == 0) {                       // row block is 16-byte aligned for every environment
+        V *out = reinterpret_cast<V *>(dst);
+        const int nvec = elems / W;
+        for (int i = c.lane; i < nvec; i += 64) {
+            if constexpr (W == 4) {
+                const uint4 d = reinterpret_cast<const uint4 *>(table)[i];
+                float4 v;
+                v.x = gather_one(c, d.x); v.y = gather_one(c, d.y); v.z = gather_one(c, d.z); v.w = gather_one(c, d.w);
+                out[i] = v;
+            } else {
+                const uint2 d = reinterpret_cast<const uint2 *>(table)[i];
+                double2 v;
+                v.x = gather_one(c, d.x); v.y = gather_one(c, d.y);
+                out[i] = v;
+            }
+        }
+    } else {
+        for (int i = c.lane; i < elems; i += 64) dst[i] = gather_one(c, table[i]);
+    }
+}
+
+template <typename ObsT>
+__device__ void pack_observations(Ctx<ObsT> &c) {
+    const Params &p = c.p;
+    if (c.g.cam_obs && p.cam_elems > 0)
+        pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.cam_obs) + c.env * p.cam_elems, c.table, p.cam_elems);
+    if (c.g.tgt_obs)
+        pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.tgt_obs) + c.env * p.tgt_elems, c.table + p.tgt_table_off, p.tgt_elems);
+    if (c.g.masks) {
+        uint32_t *m = c.g.masks + c.env * p.MW;
+        for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
+    }
+}
+
+__device__ __forceinline__ void stage_table(const Params &p, const Ptrs &g, unsigned char *smem) {
+    const int n16 = p.lds_table_bytes >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(g.desc);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+}
+
+// =============================================================================================
+// The step kernel: one wave per environment, 4 environments per workgroup.
+template <typename ObsT>
+__global__ __launch_bounds__(256) void step_kernel(const Params p, const Ptrs g) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    stage_table(p, g, smem);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;  // next step's counter
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t env = (int64_t)blockIdx.x * 4 + wave;
+    if (env >= g.N) return;
+    Ctx<ObsT> c(p, g, smem + p.lds_table_bytes + wave * p.lds_wave_bytes, smem, lane, env);
+    load_records(c);
+    wave_sync();
+    const uint32_t tick = (uint32_t)c.ei(EI_TICK);
+    simulate(c, tick);
+    update_view(c, tick, S_TRANSMIT);
+    if (g.mode == MODE_OBSERVE) score_only(c, g.scalars);
+    else assign_and_score(c, tick, g.scalars);
+    fill_scratch(c);
+    pack_observations(c);
+    if (g.mode != MODE_OBSERVE) store_dynamic(c);
+}
+
+}  // namespace mate

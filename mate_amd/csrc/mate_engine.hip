@@ -1,0 +1,469 @@
+// mate_engine.hip -- host side of the C ABI declared in include/mate_engine.h.
+// Plain HIP runtime: no torch types cross this boundary (device pointers + sizes only).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mate_engine.h"
+#include "reset_kernels.hpp"
+
+using namespace mate;
+
+static thread_local std::string g_error;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(MATE_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+struct mate_engine {
+    Params p{};
+    Ptrs g{};
+    ResetLds rl{};
+    mate_config cfg{};
+    int device = 0;
+    int64_t N = 0;
+    int parity = 0;
+    bool was_reset = false;
+    size_t step_lds = 0, reset_lds = 0;
+    std::vector<void *> allocs;
+    // kernel timing (HIP events on the launch stream)
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+};
+
+extern "C" const char *mate_engine_last_error(void) { return g_error.c_str(); }
+extern "C" int mate_engine_abi_version(void) { return MATE_ABI_VERSION; }
+
+static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <typename T>
+static int dev_alloc(mate_engine *e, T **out, size_t count, bool zero = true) {
+    void *ptr = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    hipError_t err = hipMalloc(&ptr, bytes);
+    if (err != hipSuccess) return fail(MATE_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(err));
+    if (zero) HIP_TRY(hipMemset(ptr, 0, bytes));
+    e->allocs.push_back(ptr);
+    *out = reinterpret_cast<T *>(ptr);
+    return MATE_OK;
+}
+
+// Observation descriptors: for every element of a camera / target row block, which scratch slot
+// it copies and which visibility bit gates it (joint_observation, environment.py:908-964).
+static void build_descriptors(const Params &p, std::vector<uint32_t> &desc) {
+    const int Nc = p.Nc, Nt = p.Nt, No = p.No;
+    auto D = [](int src, int bit) { return (uint32_t)src | ((uint32_t)bit << 16); };
+    const int ALWAYS = p.bit_always;
+    const int SC_ZERO = 0, SC_ONE = 1, SC_CONST = 2, SC_IDX = 14;
+    (void)SC_ZERO;
+    desc.assign((size_t)p.tgt_table_off + round_up(p.tgt_elems, 4), D(0, ALWAYS));
+    auto preserved = [&](uint32_t *row, int index) {   // environment.py:499-501, 941
+        row[0] = D(SC_CONST + 0, ALWAYS); row[1] = D(SC_CONST + 1, ALWAYS); row[2] = D(SC_CONST + 2, ALWAYS);
+        row[3] = D(SC_IDX + index, ALWAYS);
+        for (int i = 0; i < 9; ++i) row[4 + i] = D(SC_CONST + 3 + i, ALWAYS);
+    };
+    auto cam_pub = [&](uint32_t *dst, int c, int bit) {   // Camera.state + flag, entities.py:313-321
+        for (int i = 0; i < 6; ++i) dst[i] = D(p.sc_cam + c * 10 + i, bit);
+        dst[6] = D(SC_ONE, bit);
+    };
+    auto tgt_pub = [&](uint32_t *dst, int t, int bit) {   // Target.state + flag, entities.py:631-632
+        for (int i = 0; i < 4; ++i) dst[i] = D(p.sc_tgt + t * 14 + i, bit);
+        dst[4] = D(SC_ONE, bit);
+    };
+    auto obs_pub = [&](uint32_t *dst, int o, int bit) {   // Obstacle.state + flag
+        for (int i = 0; i < 3; ++i) dst[i] = D(p.sc_obs + o * 3 + i, bit);
+        dst[3] = D(SC_ONE, bit);
+    };
+    for (int c = 0; c < Nc; ++c) {
+        uint32_t *row = desc.data() + (size_t)c * p.Dc;
+        preserved(row, c);
+        for (int i = 0; i < 9; ++i) row[13 + i] = D(p.sc_cam + c * 10 + i, ALWAYS);
+        uint32_t *q = row + 22;
+        for (int t = 0; t < Nt; ++t, q += 5) tgt_pub(q, t, c * Nt + t);
+        for (int o = 0; o < No; ++o, q += 4) obs_pub(q, o, p.bit_camobs + c * 64 + o);
+        for (int c2 = 0; c2 < Nc; ++c2, q += 7) cam_pub(q, c2, p.bit_cc + c * Nc + c2);
+    }
+    for (int t = 0; t < Nt; ++t) {
+        uint32_t *row = desc.data() + p.tgt_table_off + (size_t)t * p.Dt;
+        preserved(row, t);
+        for (int i = 0; i < 14; ++i) row[13 + i] = D(p.sc_tgt + t * 14 + i, ALWAYS);
+        uint32_t *q = row + 27;
+        const int rb = p.bit_range + t * p.NJ;
+        for (int c = 0; c < Nc; ++c, q += 7) cam_pub(q, c, rb + c);
+        for (int o = 0; o < No; ++o, q += 4) obs_pub(q, o, rb + Nc + o);
+        for (int t2 = 0; t2 < Nt; ++t2, q += 5) tgt_pub(q, t2, rb + Nc + No + t2);
+    }
+}
+
+template <typename T>
+static void build_scratch_init(const Params &p, const mate_config &cfg, std::vector<T> &s) {
+    s.assign((size_t)p.nscratch, (T)0);
+    s[1] = (T)1;
+    s[2] = (T)p.Nc; s[3] = (T)p.Nt; s[4] = (T)p.No;
+    const double wh[8] = {925, 925, -925, 925, -925, -925, 925, -925};   // constants.py:70-72
+    for (int i = 0; i < 8; ++i) s[5 + i] = (T)wh[i];
+    s[13] = (T)75.0;                                                      // constants.py:67
+    for (int i = 0; i < 16; ++i) s[14 + i] = (T)i;
+    for (int c = 0; c < p.Nc; ++c) {
+        T *q = s.data() + p.sc_cam + c * 10;
+        q[2] = (T)cfg.camera_radius; q[6] = (T)cfg.camera_max_sight_range;
+        q[7] = (T)cfg.camera_rotation_step; q[8] = (T)cfg.camera_zooming_step;
+    }
+    for (int t = 0; t < p.Nt; ++t) s[p.sc_tgt + t * 14 + 2] = (T)cfg.target_sight_range;
+}
+
+extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int32_t device, uint64_t seed,
+                                  uint64_t first_env_index, mate_engine **out) {
+    if (!cfg || !out) return fail(MATE_EINVAL, "null argument");
+    const int Nc = cfg->num_cameras, Nt = cfg->num_targets, No = cfg->num_obstacles;
+    if (Nt < 1) return fail(MATE_EINVAL, "There must be at least one target in the environment.");   // environment.py:220-221
+    if (Nc < 0 || Nc > 16 || Nt > 16 || No < 0 || No > 64) return fail(MATE_EINVAL, "unsupported entity counts (%d cameras, %d targets, %d obstacles)", Nc, Nt, No);
+    if (num_envs < 1) return fail(MATE_EINVAL, "num_envs must be positive");
+    if (cfg->max_episode_steps <= 0) return fail(MATE_EINVAL, "`max_episode_steps` must be a positive integer.");   // environment.py:202-203
+    if (cfg->num_cargoes_per_target < 4) return fail(MATE_EINVAL, "`num_cargoes_per_target` should be no less than 4. Got %d.", cfg->num_cargoes_per_target);
+    if (!(cfg->high_capacity_target_split >= 0.0 && cfg->high_capacity_target_split <= 1.0)) return fail(MATE_EINVAL, "`high_capacity_target_split` must be between 0 and 1.");
+    if (!(cfg->bounty_factor >= 0.0)) return fail(MATE_EINVAL, "`bounty_factor` must be a non-negative number.");
+    if (!(cfg->target_step_size > 0.0) || !(cfg->target_sight_range > 0.0)) return fail(MATE_EINVAL, "`target/step_size` and `target/sight_range` must be positive numbers.");
+    if (Nc > 0 && (!(cfg->camera_min_viewing_angle > 0.0 && cfg->camera_min_viewing_angle <= 180.0) || !(cfg->camera_rotation_step > 0.0) ||
+                   !(cfg->camera_zooming_step > 0.0) || !(cfg->camera_max_sight_range > 0.0) || !(cfg->camera_radius >= 0.0)))
+        return fail(MATE_EINVAL, "invalid camera parameters");
+    if (!(cfg->transmittance >= 0.0 && cfg->transmittance <= 1.0)) return fail(MATE_EINVAL, "`transmittance` must be within [0, 1]");
+    if ((Nc > 0 && !cfg->camera_location_ranges) || !cfg->target_location_ranges || (No > 0 && !cfg->obstacle_location_ranges))
+        return fail(MATE_EINVAL, "missing location ranges");
+    if (Nc * Nt + Nc * Nc > 0xfff0 || Nt * (Nc + No + Nt) > 0xfff0) return fail(MATE_EINVAL, "mask too large");
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(MATE_EHIP, "no HIP device available: the MI355X engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(MATE_EINVAL, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    mate_engine *e = new mate_engine();
+    e->cfg = *cfg;
+    e->device = device;
+    e->N = num_envs;
+    Params &p = e->p;
+    p.Nc = Nc; p.Nt = Nt; p.No = No; p.NK = No + Nc; p.NJ = Nc + No + Nt;
+    p.Dc = 13 + 9 + 5 * Nt + 4 * No + 7 * Nc;    // constants.py:267-282
+    p.Dt = 13 + 14 + 7 * Nc + 4 * No + 5 * Nt;   // constants.py:285-300
+    p.cam_elems = Nc * p.Dc; p.tgt_elems = Nt * p.Dt;
+    p.tgt_table_off = round_up(p.cam_elems, 4);
+    p.SW = 3 * Nc + 3 * No + 1;
+    p.DF = 2 * Nc + 2 * Nt + 2;
+    p.NI = Nt * TI_STRIDE + EI_COUNT; if (p.NI & 1) p.NI += 1;
+    p.DW = p.DF + p.NI / 2;
+    p.n_sector = Nc * Nt + Nc * Nc; p.n_range = Nt * p.NJ;
+    p.sector_rounds = (p.n_sector + 63) / 64; p.range_rounds = (p.n_range + 63) / 64;
+    p.bit_cc = Nc * Nt;
+    p.bit_range = p.sector_rounds * 64;
+    p.bit_camobs = p.bit_range + p.range_rounds * 64;
+    p.bit_always = p.bit_camobs + Nc * 64;
+    p.MW = p.bit_always / 32 + 1;
+    p.sc_cam = 30; p.sc_tgt = p.sc_cam + 10 * Nc; p.sc_obs = p.sc_tgt + 14 * Nt; p.nscratch = round_up(p.sc_obs + 3 * No, 4);
+    p.kmax = round_up(360 + No * 185 + 2, 8);
+    p.nbucket = 368;
+    p.max_episode_steps = cfg->max_episode_steps; p.sparse_reward = cfg->sparse_reward != 0;
+    p.num_cargoes_per_target = cfg->num_cargoes_per_target; p.shuffle = cfg->shuffle_entities != 0;
+    p.start_with_cargoes = cfg->targets_start_with_cargoes != 0;
+    p.n_high = (int)((double)Nt * std::min(std::max(cfg->high_capacity_target_split, 0.0), 1.0));   // environment.py:1530-1533
+    p.obs_f64 = cfg->obs_dtype == MATE_OBS_F64;
+    p.inv_Nt = 1.0f / (float)Nt; p.inv_NK = p.NK > 0 ? 1.0f / (float)p.NK : 0.f; p.inv_NJ = 1.0f / (float)p.NJ; p.inv_Nc = Nc > 0 ? 1.0f / (float)Nc : 0.f;
+    p.tau = std::min(std::max(cfg->transmittance, 0.0), 1.0);
+    p.cam_radius = cfg->camera_radius; p.theta_min = cfg->camera_min_viewing_angle; p.rmax = cfg->camera_max_sight_range;
+    p.rot = cfg->camera_rotation_step; p.zoom = cfg->camera_zooming_step;
+    p.area = cfg->camera_min_viewing_angle * (cfg->camera_max_sight_range * cfg->camera_max_sight_range);   // entities.py:285
+    p.tgt_step = cfg->target_step_size; p.tgt_sight = cfg->target_sight_range;
+    p.freight_scale = std::ceil(2000.0 / cfg->target_step_size);                 // environment.py:521
+    p.bounty_scale = std::ceil(p.freight_scale * std::max(0.0, cfg->bounty_factor));   // environment.py:522
+    p.reward_scale = p.freight_scale + p.bounty_scale;
+    p.max_team_reward = p.reward_scale * cfg->num_cargoes_per_target * Nt;       // environment.py:527-529
+    p.obs_r_lo = cfg->obstacle_radius_range[0]; p.obs_r_hi = cfg->obstacle_radius_range[1];
+    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.first_env = (uint32_t)first_env_index;
+    p.export_width = 2 * Nc + 3 * No + Nt + Nc * No + 2 * Nc + 2 * Nt + Nt + 4 * Nt + 4 * Nt + 5 * Nt + 20 + 7;
+    // LDS carve: [descriptor table][per-wave context] (x4 for the step kernel)
+    const int obs_size = p.obs_f64 ? 8 : 4;
+    p.lds_table_bytes = round_up((p.tgt_table_off + round_up(p.tgt_elems, 4)) * 4, 16);
+    int off = 0;
+    p.off_st = off; off += round_up(p.SW * 8, 16);
+    p.off_dy = off; off += round_up(p.DW * 8, 16);
+    p.off_tmp = off; off += round_up((Nc + 3 * Nt) * 8, 16);
+    p.off_scratch = off; off += round_up(p.nscratch * obs_size, 16);
+    p.off_mask = off; off += round_up(p.MW * 4, 16);
+    p.off_misc = off; off += round_up((3 * Nt + 8) * 4, 16);
+    p.lds_wave_bytes = off;
+    e->step_lds = (size_t)p.lds_table_bytes + 4 * (size_t)p.lds_wave_bytes;
+    ResetLds &rl = e->rl;
+    rl.sort_cap = std::max(512, next_pow2(Nc > 0 ? 360 + No * 185 + 1 : 1));
+    int roff = p.lds_table_bytes + p.lds_wave_bytes;
+    rl.off_keys = roff; roff += rl.sort_cap * 8;
+    rl.off_vals = roff; roff += rl.sort_cap * 8;
+    rl.off_meta = roff; roff += round_up(8 * No * 8 + (2 * No + 4) * 4, 16);
+    rl.off_scan = roff; roff += 256 * 4;
+    rl.total_bytes = roff;
+    e->reset_lds = (size_t)roff;
+    if (e->step_lds > 160 * 1024 || e->reset_lds > 160 * 1024) {
+        const size_t a = e->step_lds, b = e->reset_lds;
+        delete e;
+        return fail(MATE_EINVAL, "scenario too large for the 160 KiB LDS (%zu / %zu bytes)", a, b);
+    }
+
+    int rc = MATE_OK;
+    const size_t N = (size_t)num_envs;
+    Ptrs &g = e->g;
+    g.N = num_envs;
+    do {
+        if ((rc = dev_alloc(e, &g.stat, N * p.SW))) break;
+        if ((rc = dev_alloc(e, &g.dyn, N * p.DW))) break;
+        if ((rc = dev_alloc(e, &g.lut_knots, N * std::max(Nc, 1) * (size_t)p.kmax, false))) break;
+        if ((rc = dev_alloc(e, &g.lut_bucket, N * std::max(Nc, 1) * (size_t)p.nbucket))) break;
+        if ((rc = dev_alloc(e, &g.lut_count, N * std::max(Nc, 1)))) break;
+        if ((rc = dev_alloc(e, &g.done_count, (size_t)2))) break;
+        if ((rc = dev_alloc(e, &g.done_list, 2 * N))) break;
+        std::vector<uint32_t> desc;
+        build_descriptors(p, desc);
+        uint32_t *d_desc = nullptr;
+        if ((rc = dev_alloc(e, &d_desc, (size_t)p.lds_table_bytes / 4))) break;
+        if (hipMemcpy(d_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(MATE_EHIP, "descriptor upload failed"); break; }
+        g.desc = d_desc;
+        if (p.obs_f64) {
+            std::vector<double> s; build_scratch_init(p, *cfg, s);
+            double *d = nullptr;
+            if ((rc = dev_alloc(e, &d, s.size()))) break;
+            if (hipMemcpy(d, s.data(), s.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(MATE_EHIP, "scratch upload failed"); break; }
+            g.scratch_init = d;
+        } else {
+            std::vector<float> s; build_scratch_init(p, *cfg, s);
+            float *d = nullptr;
+            if ((rc = dev_alloc(e, &d, s.size()))) break;
+            if (hipMemcpy(d, s.data(), s.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(MATE_EHIP, "scratch upload failed"); break; }
+            g.scratch_init = d;
+        }
+        std::vector<double> ranges((size_t)(Nc + No + Nt) * 4, 0.0);
+        if (Nc) std::memcpy(ranges.data(), cfg->camera_location_ranges, sizeof(double) * 4 * Nc);
+        if (No) std::memcpy(ranges.data() + 4 * Nc, cfg->obstacle_location_ranges, sizeof(double) * 4 * No);
+        std::memcpy(ranges.data() + 4 * (Nc + No), cfg->target_location_ranges, sizeof(double) * 4 * Nt);
+        double *d_ranges = nullptr;
+        if ((rc = dev_alloc(e, &d_ranges, ranges.size()))) break;
+        if (hipMemcpy(d_ranges, ranges.data(), ranges.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(MATE_EHIP, "range upload failed"); break; }
+        g.reset_ranges = d_ranges;
+    } while (0);
+    if (rc == MATE_OK) {
+        // opt in to large dynamic LDS
+        hipError_t err = hipSuccess;
+        if (p.obs_f64) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+            if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
+        } else {
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+            if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
+        }
+        if (err != hipSuccess) rc = fail(MATE_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
+    }
+    if (rc != MATE_OK) { mate_engine_destroy(e); return rc; }
+    *out = e;
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_destroy(mate_engine *e) {
+    if (!e) return MATE_OK;
+    (void)hipSetDevice(e->device);
+    for (auto &ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (void *ptr : e->allocs) (void)hipFree(ptr);
+    delete e;
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_get_layout(const mate_engine *e, mate_layout *out) {
+    if (!e || !out) return fail(MATE_EINVAL, "null argument");
+    const Params &p = e->p;
+    out->camera_obs_dim = p.Dc; out->target_obs_dim = p.Dt;
+    out->state_dim = 13 + 9 * p.Nc + 14 * p.Nt + 3 * p.No + 2 * p.Nt + 16;   // environment.py:450-466
+    out->mask_words = p.MW;
+    out->bit_camera_target = 0; out->bit_camera_camera = p.bit_cc; out->bit_target_row = p.bit_range;
+    out->bit_camera_obstacle = p.bit_camobs;
+    out->export_width = p.export_width; out->lut_capacity = p.kmax; out->scalars_per_env = 8;
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_seed(mate_engine *e, uint64_t seed) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    e->p.seed_lo = (uint32_t)seed; e->p.seed_hi = (uint32_t)(seed >> 32);
+    return MATE_OK;
+}
+
+static void apply_io(Ptrs &g, const mate_step_io *io) {
+    g.cam_act = g.tgt_act = nullptr; g.tape_ct = g.tape_goal = nullptr;
+    g.cam_obs = g.tgt_obs = nullptr; g.scalars = nullptr; g.masks = nullptr; g.act_f64 = 0;
+    if (!io) return;
+    g.cam_act = io->camera_actions_dev; g.tgt_act = io->target_actions_dev; g.act_f64 = io->act_dtype == MATE_ACT_F64;
+    g.tape_ct = io->tape_camera_target_dev; g.tape_goal = io->tape_goal_dev;
+    g.cam_obs = io->camera_obs_dev; g.tgt_obs = io->target_obs_dev; g.scalars = io->scalars_dev; g.masks = io->masks_dev;
+}
+
+static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream) {
+    g.mode = MODE_OBSERVE; g.reset_kind = kind; g.parity = e->parity;
+    const int64_t blocks = kind == RESET_DONE ? std::min<int64_t>(e->N, 512) : e->N;
+    if (e->p.obs_f64) hipLaunchKernelGGL(reset_kernel<double>, dim3((unsigned)blocks), dim3(256), e->reset_lds, stream, e->p, g, e->rl, phases);
+    else hipLaunchKernelGGL(reset_kernel<float>, dim3((unsigned)blocks), dim3(256), e->reset_lds, stream, e->p, g, e->rl, phases);
+    HIP_TRY(hipGetLastError());
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_reset(mate_engine *e, const uint8_t *env_mask_dev, const mate_step_io *io, void *stream) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    Ptrs g = e->g;
+    apply_io(g, io);
+    g.tape_ct = nullptr; g.tape_goal = nullptr;
+    g.reset_mask = env_mask_dev;
+    int rc = launch_reset(e, g, env_mask_dev ? RESET_MASK : RESET_ALL, PH_PLACE | PH_LUT | PH_VIEW, (hipStream_t)stream);
+    if (rc == MATE_OK && !env_mask_dev) e->was_reset = true;
+    return rc;
+}
+
+extern "C" int mate_engine_rebuild_luts(mate_engine *e, void *stream) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    Ptrs g = e->g;
+    apply_io(g, nullptr);
+    return launch_reset(e, g, RESET_ALL, PH_LUT, (hipStream_t)stream);
+}
+
+static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int auto_reset, hipStream_t stream) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    if (!e->was_reset) return fail(MATE_ESTATE, "step()/observe() called before reset() (or import_state)");
+    HIP_TRY(hipSetDevice(e->device));
+    Ptrs g = e->g;
+    apply_io(g, io);
+    if (mode == MODE_STEP && ((e->p.Nc > 0 && !g.cam_act) || !g.tgt_act)) return fail(MATE_EINVAL, "step() needs camera and target joint actions");
+    g.mode = mode; g.parity = e->parity; g.reset_kind = -1;
+    if (mode == MODE_OBSERVE || !auto_reset) g.done_count = nullptr;
+    const unsigned blocks = (unsigned)((e->N + 3) / 4);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (e->timing && mode != MODE_OBSERVE) {
+        if (e->events_used == e->events.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+            e->events.emplace_back(a, b);
+        }
+        ev0 = e->events[e->events_used].first; ev1 = e->events[e->events_used].second; ++e->events_used;
+        HIP_TRY(hipEventRecord(ev0, stream));
+    }
+    if (e->p.obs_f64) hipLaunchKernelGGL(step_kernel<double>, dim3(blocks), dim3(256), e->step_lds, stream, e->p, g);
+    else hipLaunchKernelGGL(step_kernel<float>, dim3(blocks), dim3(256), e->step_lds, stream, e->p, g);
+    HIP_TRY(hipGetLastError());
+    if (ev1) HIP_TRY(hipEventRecord(ev1, stream));
+    if (mode != MODE_OBSERVE && auto_reset) {
+        Ptrs r = e->g;
+        apply_io(r, io);
+        r.scalars = nullptr; r.tape_ct = nullptr; r.tape_goal = nullptr;   // keep the finished step's reward/done
+        int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream);
+        if (rc != MATE_OK) return rc;
+        e->parity ^= 1;
+    }
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_step(mate_engine *e, const mate_step_io *io, int32_t auto_reset, void *stream) {
+    return launch_step(e, io, MODE_STEP, auto_reset, (hipStream_t)stream);
+}
+extern "C" int mate_engine_step_random(mate_engine *e, const mate_step_io *io, int32_t auto_reset, void *stream) {
+    return launch_step(e, io, MODE_STEP_RANDOM, auto_reset, (hipStream_t)stream);
+}
+extern "C" int mate_engine_observe(mate_engine *e, const mate_step_io *io, void *stream) {
+    return launch_step(e, io, MODE_OBSERVE, 0, (hipStream_t)stream);
+}
+
+extern "C" int mate_engine_export_state(mate_engine *e, double *dst_dev, void *stream) {
+    if (!e || !dst_dev) return fail(MATE_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(export_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->p, e->g, dst_dev);
+    HIP_TRY(hipGetLastError());
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_import_state(mate_engine *e, const double *src_dev, void *stream) {
+    if (!e || !src_dev) return fail(MATE_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(import_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->p, e->g, src_dev);
+    HIP_TRY(hipGetLastError());
+    e->was_reset = true;
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_lut_read(mate_engine *e, int64_t env, int32_t camera, double *phis, double *rhos, int32_t capacity, int32_t *count) {
+    if (!e || !phis || !rhos || !count) return fail(MATE_EINVAL, "null argument");
+    if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_read: index out of range");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t lc = env * e->p.Nc + camera;
+    int32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, e->g.lut_count + lc, sizeof(n), hipMemcpyDeviceToHost));
+    *count = n;
+    if (n > capacity) return fail(MATE_EINVAL, "lut_read: capacity %d < %d knots", capacity, n);
+    std::vector<double2> knots((size_t)n);
+    HIP_TRY(hipMemcpy(knots.data(), e->g.lut_knots + lc * e->p.kmax, sizeof(double2) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) { phis[i] = knots[i].x; rhos[i] = knots[i].y; }
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_lut_write(mate_engine *e, int64_t env, int32_t camera, const double *phis, const double *rhos, int32_t n) {
+    if (!e || !phis || !rhos) return fail(MATE_EINVAL, "null argument");
+    if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_write: index out of range");
+    if (n < 2 || n > e->p.kmax) return fail(MATE_EINVAL, "lut_write: %d knots do not fit (capacity %d)", n, e->p.kmax);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<double2> knots((size_t)n);
+    std::vector<uint16_t> bucket((size_t)e->p.nbucket, 0);
+    for (int i = 0; i < n; ++i) { knots[i].x = phis[i]; knots[i].y = rhos[i]; }
+    // per-degree index: bucket[d] = last knot with angle <= d - 180 (exact integer knots exist in real tables)
+    int j = 0;
+    for (int d = 0; d <= 361; ++d) {
+        const double a = (double)(d > 360 ? 360 : d) - 180.0;
+        while (j + 1 < n && phis[j + 1] <= a) ++j;
+        bucket[d] = (uint16_t)j;
+    }
+    const int64_t lc = env * e->p.Nc + camera;
+    HIP_TRY(hipMemcpy(e->g.lut_knots + lc * e->p.kmax, knots.data(), sizeof(double2) * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->g.lut_bucket + lc * e->p.nbucket, bucket.data(), sizeof(uint16_t) * bucket.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->g.lut_count + lc, &n, sizeof(n), hipMemcpyHostToDevice));
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_kernel_time(mate_engine *e, int32_t enable, double *avg_ms, int64_t *launches) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    double total = 0.0;
+    int64_t n = 0;
+    if (e->events_used) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (size_t i = 0; i < e->events_used; ++i) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e->events[i].first, e->events[i].second));
+            total += ms; ++n;
+        }
+    }
+    if (avg_ms) *avg_ms = n ? total / (double)n : 0.0;
+    if (launches) *launches = n;
+    e->events_used = 0;
+    e->timing = enable != 0;
+    return MATE_OK;
+}

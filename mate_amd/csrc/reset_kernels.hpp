@@ -1,0 +1,437 @@
+// reset_kernels.hpp -- episode boundary on the GPU: MultiAgentTracking.reset (environment.py:679-834).
+//
+// One 256-thread workgroup per environment that needs a reset:
+//   R1 (thread 0)      placement by rejection sampling + cargo matrix + initial goals; consumes the
+//                      Philox reset stream in exactly the order of oracle/mate_oracle.c::mo_reset
+//   R2 (256 threads)   Camera.add_obstacles (entities.py:362-479): build every camera's occlusion
+//                      table -- generate rays, clip them by every obstacle, bitonic-sort by angle in
+//                      LDS, dedupe, compact to HBM together with a per-degree bucket index
+//   R3 (wave 0)        first _update_view + joint_observation of the new episode
+#pragma once
+#include "engine_kernels.hpp"
+
+namespace mate {
+
+enum ResetKind : int32_t { RESET_ALL = 0, RESET_MASK = 1, RESET_DONE = 2 };
+enum ResetPhase : int32_t { PH_PLACE = 1, PH_LUT = 2, PH_VIEW = 4 };
+
+struct ResetLds {   // byte offsets inside the workgroup's dynamic LDS, after the wave-0 context
+    int32_t off_keys, off_vals, off_meta, off_scan, sort_cap, total_bytes;
+};
+
+struct ResetRng {
+    uint32_t k0, k1, env, episode, n;
+    __device__ double draw() {
+        const uint32_t idx = n++;
+        const U4 r = philox(k0, k1, env, episode, S_RESET, idx >> 1);
+        return (idx & 1u) ? u53(r.z, r.w) : u53(r.x, r.y);
+    }
+    __device__ int randint(int m) { int j = (int)(draw() * (double)m); return j >= m ? m - 1 : j; }
+};
+
+__device__ __forceinline__ bool row_any(const int32_t *row) { return row[0] || row[1] || row[2] || row[3]; }
+__device__ __forceinline__ int pick_goal(const int32_t *row, double u) {  // np_random.choice(flatnonzero(row > 0))
+    int k = 0;
+    for (int g = 0; g < 4; ++g) k += row[g] > 0;
+    int j = (int)(u * (double)k);
+    if (j >= k) j = k - 1;
+    int pick = 0;
+    for (int g = 0, seen = 0; g < 4; ++g) if (row[g] > 0) { if (seen == j) pick = g; ++seen; }
+    return pick;
+}
+
+// R1: runs on ONE lane; all state lives in the wave context's LDS records.
+template <typename ObsT>
+__device__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][cap] x y r sight iscam */, int placed_cap) {
+    const Params &p = c.p;
+    const int Nc = p.Nc, Nt = p.Nt, No = p.No;
+    const uint32_t episode = (uint32_t)c.ei(EI_EPISODE) + 1u;
+    c.ei(EI_EPISODE) = (int32_t)episode;
+    ResetRng rng{p.seed_lo, p.seed_hi, c.env_global(), episode, 0u};
+    double *px = placed, *py = placed + placed_cap, *pr = placed + 2 * placed_cap, *ps = placed + 3 * placed_cap, *pk = placed + 4 * placed_cap;
+    int32_t *perm = reinterpret_cast<int32_t *>(placed + 5 * placed_cap);   // [Nc + Nt + No]
+    int32_t *perm_c = perm, *perm_t = perm + Nc, *perm_o = perm + Nc + Nt;
+    // shuffles (environment.py:707-710): Fisher-Yates on the range indices
+    for (int which = 0; which < 3; ++which) {
+        int32_t *pp = which == 0 ? perm_c : (which == 1 ? perm_t : perm_o);
+        const int n = which == 0 ? Nc : (which == 1 ? Nt : No);
+        for (int i = 0; i < n; ++i) pp[i] = i;
+        if (p.shuffle) for (int i = n - 1; i >= 1; --i) { const int j = rng.randint(i + 1); const int tmp = pp[i]; pp[i] = pp[j]; pp[j] = tmp; }
+    }
+    // capacities (environment.py:712-722)
+    uint64_t capword = 0;
+    if (p.n_high > 0) {
+        if (p.shuffle) {
+            int32_t *idx = perm + Nc + Nt + No;   // scratch [Nt]
+            for (int i = 0; i < Nt; ++i) idx[i] = i;
+            for (int i = 0; i < p.n_high; ++i) { const int j = i + rng.randint(Nt - i); const int tmp = idx[i]; idx[i] = idx[j]; idx[j] = tmp; capword |= 1ull << idx[i]; }
+        } else {
+            for (int i = 0; i < p.n_high; ++i) capword |= 1ull << i;
+        }
+    }
+    reinterpret_cast<uint64_t *>(c.st)[3 * Nc + 3 * No] = capword;
+    // placement (environment.py:724-737)
+    int np = 0;
+    for (int w = 0; w < 4; ++w) {
+        px[np] = (w == 0 || w == 3) ? kWarehouseCenter : -kWarehouseCenter;
+        py[np] = (w < 2) ? kWarehouseCenter : -kWarehouseCenter;
+        pr[np] = 0.75 * kWarehouseRadius; ps[np] = 0.0; pk[np] = 0.0; ++np;
+    }
+    const int total = Nc + No + Nt;
+    for (int k = 0; k < total; ++k) {
+        const int kind = k < Nc ? 0 : (k < Nc + No ? 1 : 2);
+        const int i = kind == 0 ? k : (kind == 1 ? k - Nc : k - Nc - No);
+        const int ridx = kind == 0 ? perm_c[i] : (kind == 1 ? Nc + perm_o[i] : Nc + No + perm_t[i]);
+        const double *range = c.g.reset_ranges + 4 * ridx;
+        const double xlo = range[0], xhi = range[1], ylo = range[2], yhi = range[3];
+        const double min_distance = kind == 2 ? 0.0 : p.tgt_step;
+        double x = 0, y = 0, rad = 0, sight = 0, phi = 0, theta = 0;
+        bool ok = false;
+        for (int attempt = 0; attempt < 500 && !ok; ++attempt) {
+            rad = kind == 0 ? p.cam_radius : 0.0;
+            if (kind == 1) rad = p.obs_r_lo + (p.obs_r_hi - p.obs_r_lo) * rng.draw();   // entities.py:151
+            const double sx = xlo + (xhi - xlo) * rng.draw();                               // entities.py:61
+            const double sy = ylo + (yhi - ylo) * rng.draw();
+            const double lim = kTerrain - 1.2 * rad;                                        // entities.py:62-65
+            x = clipd(sx, -lim, lim); y = clipd(sy, -lim, lim);
+            sight = 0.0;
+            if (kind == 0) {                                                                // entities.py:326-334
+                const int nsteps = (int)(360.0 / p.rot);
+                phi = normalize_angle(p.rot * (double)rng.randint(nsteps));
+                theta = p.theta_min + (kMaxViewingAngle - p.theta_min) * rng.draw();
+                sight = sqrt(p.area / theta);
+            }
+            ok = true;
+            for (int q = 0; q < np && ok; ++q) {                                            // entities.py:96-100, 484-489
+                const double d = norm2(x - px[q], y - py[q]);
+                if (d * (1.0 + 1e-6) < rad + pr[q] + min_distance) ok = false;
+                else if (kind == 0 && pk[q] != 0.0) { const double m = sight < ps[q] ? sight : ps[q]; if (d < 0.1 * m) ok = false; }
+            }
+        }
+        if (!ok && kind == 1) rad = 0.0;                                                    // environment.py:735-736
+        px[np] = x; py[np] = y; pr[np] = rad; ps[np] = sight; pk[np] = kind == 0 ? 1.0 : 0.0; ++np;
+        if (kind == 0) { c.st[i] = x; c.st[Nc + i] = y; c.phi(i) = phi; c.theta(i) = theta; }
+        else if (kind == 1) { c.st[2 * Nc + i] = x; c.st[2 * Nc + No + i] = y; c.st[2 * Nc + 2 * No + i] = rad; }
+        else { c.tx(i) = x; c.ty(i) = y; }
+    }
+    // cargo matrix (environment.py:768-775)
+    int32_t *remaining = &c.ei(EI_REMAINING);
+    for (int i = 0; i < 16; ++i) remaining[i] = 0;
+    for (;;) {
+        for (int k = 0; k < p.num_cargoes_per_target * Nt; ++k) {
+            const int s = rng.randint(4);
+            int r = rng.randint(3);
+            if (r >= s) r += 1;
+            remaining[4 * s + r] += 1;
+        }
+        bool all = true;
+        for (int s = 0; s < 4; ++s) all = all && row_any(remaining + 4 * s);
+        for (int g = 0; g < 4; ++g) c.ei(EI_AWAITING + g) = remaining[g] + remaining[4 + g] + remaining[8 + g] + remaining[12 + g];
+        if (all) break;
+    }
+    for (int t = 0; t < Nt; ++t) {                                                          // environment.py:777-783
+        c.ti(t, TI_BOUNTY) = 0; c.ti(t, TI_FREIGHT) = 0; c.ti(t, TI_GW) = 0; c.ti(t, TI_TSTEPS) = 0; c.ti(t, TI_TRSTEPS) = 0;
+    }
+    // _assign_goals at reset (environment.py:784): only targets that spawn inside a warehouse pick up here
+    for (int t = 0; t < Nt; ++t) {
+        const double x = c.tx(t), y = c.ty(t);
+        for (int w = 0; w < 4; ++w) {
+            const double wx = (w == 0 || w == 3) ? kWarehouseCenter : -kWarehouseCenter;
+            const double wy = (w < 2) ? kWarehouseCenter : -kWarehouseCenter;
+            if (!(fmax(fabs(x - wx), fabs(y - wy)) <= kWarehouseRadius)) continue;
+            int gw = c.ti(t, TI_GW);
+            bool picked = false;
+            if ((gw & 0xff) == 0) {   // no goal yet (a goal-carrying target cannot exist here)
+                int32_t *row = remaining + 4 * w;
+                if (row_any(row)) {
+                    const int goal = pick_goal(row, rng.draw());
+                    const int cap = 1 + (int)((capword >> t) & 1ull);
+                    const int weight = cap < row[goal] ? cap : row[goal];
+                    row[goal] -= weight;
+                    c.ti(t, TI_FREIGHT) = (int)((double)weight * p.freight_scale);
+                    c.ti(t, TI_BOUNTY) = (int)((double)weight * p.bounty_scale);
+                    gw = (goal + 1) | (weight << 8);
+                    picked = true;
+                }
+            }
+            const bool empty = !row_any(remaining + 4 * w);
+            gw = (gw & ~(1 << (16 + w))) | ((int)empty << (16 + w));
+            c.ti(t, TI_GW) = gw;
+            if (picked) break;
+        }
+    }
+    c.ei(EI_DELIVERED) = 0; c.ep_reward() = 0.0; c.ep_delayed() = 0.0;
+    if (p.start_with_cargoes) {                                                             // environment.py:789-807
+        for (int t = 0; t < Nt; ++t) {
+            if ((c.ti(t, TI_GW) & 0xff) != 0) continue;
+            int wp[4] = {0, 1, 2, 3};
+            for (int i = 3; i >= 1; --i) { const int j = rng.randint(i + 1); const int tmp = wp[i]; wp[i] = wp[j]; wp[j] = tmp; }
+            for (int q = 0; q < 4; ++q) {
+                int32_t *row = remaining + 4 * wp[q];
+                if (!row_any(row)) continue;
+                const int goal = pick_goal(row, rng.draw());
+                const int cap = 1 + (int)((capword >> t) & 1ull);
+                const int weight = cap < row[goal] ? cap : row[goal];
+                row[goal] -= weight;
+                c.ti(t, TI_FREIGHT) = (int)((double)weight * p.freight_scale);
+                c.ti(t, TI_BOUNTY) = (int)((double)weight * p.bounty_scale);
+                c.ti(t, TI_GW) = (c.ti(t, TI_GW) & ~0xffff) | (goal + 1) | (weight << 8);
+                break;
+            }
+        }
+    }
+    c.ei(EI_EPSTEP) = 0; c.ei(EI_DONE) = 0;
+}
+
+// R2: occlusion table of camera `cam` by the whole workgroup.
+template <typename ObsT>
+__device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, double *meta, int32_t *scan, int sort_cap) {
+    const Params &p = c.p;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int No = p.No;
+    // meta rows (stride = No): 0 relx 1 rely 2 rel_norm 3 rad 4 a_left 5 a_right 6 step 7 max_rho ; ints: num, offset
+    double *m_relx = meta, *m_rely = meta + No, *m_rn = meta + 2 * No, *m_rad = meta + 3 * No;
+    double *m_al = meta + 4 * No, *m_ar = meta + 5 * No, *m_step = meta + 6 * No, *m_rho = meta + 7 * No;
+    int32_t *m_num = reinterpret_cast<int32_t *>(meta + 8 * No);
+    int32_t *m_off = m_num + No;
+    int32_t *hdr = m_off + No;    // [0] nrays [1] degenerate [2] kept count
+    const double cx = c.cam_x(cam), cy = c.cam_y(cam);
+    for (int o = tid; o < No; o += nthreads) {
+        const double relx = c.obs_x(o) - cx, rely = c.obs_y(o) - cy, rad = c.obs_r(o);
+        const double rn = norm2(relx, rely);
+        const bool in_range = rn < p.rmax + rad;                 // entities.py:365 (strict)
+        int num = 0;
+        m_relx[o] = relx; m_rely[o] = rely; m_rn[o] = rn; m_rad[o] = rad;
+        if (in_range && p.tau != 1.0) {
+            if (rad > rn) { num = -1; }                          // entities.py:378: camera inside the obstacle
+            else {
+                const double half = asin(rad / rn) * kRad2Deg;   // entities.py:389
+                const double far = rn + rad;
+                m_rho[o] = far < p.rmax ? far : p.rmax;          // entities.py:390
+                const double ra = atan2_deg(rely, relx);
+                const double al = ra - half, ar = ra + half;
+                int n = (int)(2.0 * half);
+                if (n < 16) n = 16;
+                num = n + 1;                                     // entities.py:413
+                m_al[o] = al; m_ar[o] = ar; m_step[o] = (ar - al) / (double)(num - 1);
+            }
+        }
+        m_num[o] = in_range ? (num == 0 ? -2 : num) : 0;         // -2: in range but transparent (tau == 1)
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int off = 360, degenerate = 0;
+        uint64_t bits = 0;
+        for (int o = 0; o < No; ++o) {
+            const int num = m_num[o];
+            if (num != 0) bits |= 1ull << o;
+            m_off[o] = off;
+            if (num > 0) off += 4 + num;
+            if (num == -1) degenerate = 1;
+        }
+        hdr[0] = off; hdr[1] = degenerate;
+        reinterpret_cast<uint64_t *>(c.st)[2 * p.Nc + 3 * No + cam] = bits;   // camera_obstacle_view_mask row
+    }
+    __syncthreads();
+    const int nr = hdr[0];
+    const int64_t lc = c.env * p.Nc + cam;
+    double2 *knots = c.g.lut_knots + lc * p.kmax;
+    uint16_t *bucket = c.g.lut_bucket + lc * p.nbucket;
+    if (hdr[1]) {   // fully blocked view
+        if (tid == 0) { knots[0] = make_double2(-180.0, 0.0); knots[1] = make_double2(180.0, 0.0); c.g.lut_count[lc] = 2; }
+        for (int d = tid; d < p.nbucket; d += nthreads) bucket[d] = d >= 360 ? 1 : 0;
+        __syncthreads();
+        return;
+    }
+    int P = 512;
+    while (P < nr) P <<= 1;          // nr <= sort_cap by construction
+    (void)sort_cap;
+    for (int i = tid; i < P; i += nthreads) {
+        double key = __longlong_as_double(0x7ff0000000000000ll), val = 0.0;
+        if (i < nr) {
+            double a, n0;
+            if (i < 360) { a = -180.0 + (double)i; n0 = p.rmax; }                // entities.py:336-339
+            else {
+                int o = 0;
+                for (int q = 0; q < No; ++q) if (m_num[q] > 0 && i >= m_off[q]) o = q;
+                const int j = i - m_off[o];
+                const double al = m_al[o], ar = m_ar[o];
+                if (j < 4) { a = (j < 2 ? al : ar) + ((j & 1) ? 0.01 : -0.01); n0 = p.rmax; }   // entities.py:395-406
+                else { const int m = j - 4; a = (m == m_num[o] - 1) ? ar : ((double)m * m_step[o] + al); n0 = m_rho[o]; }  // :409-415
+                a = normalize_angle(a);
+            }
+            double sn, cs;
+            sincos(a * kDeg2Rad, &sn, &cs);
+            for (int q = 0; q < No; ++q)                                          // entities.py:450-454
+                if (m_num[q] > 0) n0 = clip_polar(n0, cs, sn, m_relx[q], m_rely[q], m_rn[q], m_rad[q]);
+            key = a; val = n0;
+        }
+        keys[i] = key; vals[i] = val;
+    }
+    __syncthreads();
+    // bitonic sort by angle (entities.py:458); equal angles are merged below, so stability is moot
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += nthreads) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const double ki = keys[i], kl = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((ki > kl) == up && ki != kl) {
+                        keys[i] = kl; keys[l] = ki;
+                        const double vi = vals[i]; vals[i] = vals[l]; vals[l] = vi;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // dedupe equal angles keeping the smaller norm (entities.py:460-466) + compaction
+    const int per = (P + nthreads - 1) / nthreads;
+    const int lo = tid * per, hi = (lo + per < nr) ? lo + per : nr;
+    int local = 0;
+    for (int i = lo; i < hi; ++i) local += (i == 0 || keys[i] != keys[i - 1]);
+    scan[tid] = local;
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int q = 0; q < nthreads; ++q) { const int v = scan[q]; scan[q] = acc; acc += v; } hdr[2] = acc; }
+    __syncthreads();
+    int pos = scan[tid];
+    for (int i = lo; i < hi; ++i) {
+        if (i == 0 || keys[i] != keys[i - 1]) {
+            const double a = keys[i];
+            double rho = vals[i];
+            for (int q = i + 1; q < nr && keys[q] == a; ++q) rho = vals[q] < rho ? vals[q] : rho;
+            knots[pos] = make_double2(a, rho);
+            if (a == floor(a)) bucket[(int)a + 180] = (uint16_t)pos;     // per-degree index
+            if (i == 0) { const int m = hdr[2]; knots[m] = make_double2(a + 360.0, rho); }   // entities.py:470-471
+            ++pos;
+        }
+    }
+    if (tid == 0) { const int m = hdr[2]; c.g.lut_count[lc] = m + 1; bucket[360] = (uint16_t)m; bucket[361] = (uint16_t)m; }
+    __syncthreads();
+}
+
+template <typename ObsT>
+__global__ __launch_bounds__(256) void reset_kernel(const Params p, const Ptrs g, const ResetLds rl, const int32_t phases) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    stage_table(p, g, smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char *wave_base = smem + p.lds_table_bytes;
+    double *keys = reinterpret_cast<double *>(smem + rl.off_keys);
+    double *vals = reinterpret_cast<double *>(smem + rl.off_vals);
+    double *meta = reinterpret_cast<double *>(smem + rl.off_meta);
+    int32_t *scan = reinterpret_cast<int32_t *>(smem + rl.off_scan);
+    int64_t count = g.N;
+    if (g.reset_kind == RESET_DONE) count = g.done_count[g.parity];
+    for (int64_t item = blockIdx.x; item < count; item += gridDim.x) {
+        const int64_t env = g.reset_kind == RESET_DONE ? (int64_t)g.done_list[(int64_t)g.parity * g.N + item] : item;
+        if (g.reset_kind == RESET_MASK && !g.reset_mask[env]) continue;
+        __syncthreads();
+        Ctx<ObsT> c(p, g, wave_base, smem, lane, env);
+        if (wave == 0) {
+            load_records(c);
+            wave_sync();
+            if ((phases & PH_PLACE) && lane == 0) reset_place(c, keys, 4 + p.Nc + p.No + p.Nt);
+            wave_sync();
+        }
+        __syncthreads();
+        if (phases & PH_LUT)
+            for (int cam = 0; cam < p.Nc; ++cam) build_lut(c, cam, keys, vals, meta, scan, rl.sort_cap);
+        __syncthreads();
+        if (wave == 0) {
+            // static record back to HBM
+            double *s = g.stat + env * p.SW;
+            for (int i = lane; i < p.SW; i += 64) s[i] = c.st[i];
+            if (phases & PH_VIEW) {
+                __threadfence();   // this wave reads the tables other waves of the workgroup just wrote
+                simulate(c, 0u);   // MODE_OBSERVE: camera sight + scratch only
+                update_view(c, (uint32_t)c.ei(EI_EPISODE), S_RESET_VIEW);
+                score_only(c, g.scalars);
+                fill_scratch(c);
+                pack_observations(c);
+            }
+            store_dynamic(c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// canonical f64 export / import (one lane per environment; not on the hot path)
+struct Exporter {
+    const Params &p;
+    __device__ int width() const { return p.export_width; }
+};
+
+__global__ void export_kernel(const Params p, const Ptrs g, double *dst) {
+    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= g.N) return;
+    const double *st = g.stat + env * p.SW;
+    const double *dy = g.dyn + env * p.DW;
+    const int32_t *di = reinterpret_cast<const int32_t *>(dy + p.DF);
+    const uint64_t *stw = reinterpret_cast<const uint64_t *>(st);
+    double *o = dst + env * p.export_width;
+    const int Nc = p.Nc, Nt = p.Nt, No = p.No;
+    for (int i = 0; i < 2 * Nc + 3 * No; ++i) *o++ = st[i];                       // cam_x cam_y obs_x obs_y obs_r
+    const uint64_t capword = stw[3 * Nc + 3 * No];
+    for (int t = 0; t < Nt; ++t) *o++ = (double)(1 + (int)((capword >> t) & 1ull));
+    for (int c = 0; c < Nc; ++c) for (int q = 0; q < No; ++q) *o++ = (double)((stw[2 * Nc + 3 * No + c] >> q) & 1ull);
+    for (int i = 0; i < 2 * Nc + 2 * Nt; ++i) *o++ = dy[i];                       // cam_phi cam_theta tgt_x tgt_y
+    for (int t = 0; t < Nt; ++t) *o++ = (double)((di[t * TI_STRIDE + TI_GW] >> 24) & 1);
+    for (int t = 0; t < Nt; ++t) for (int w = 0; w < 4; ++w) *o++ = (double)((di[t * TI_STRIDE + TI_GW] >> (16 + w)) & 1);
+    for (int t = 0; t < Nt; ++t) {
+        const int gw = di[t * TI_STRIDE + TI_GW];
+        const int goal = (gw & 0xff) - 1, weight = (gw >> 8) & 0xff;
+        for (int w = 0; w < 4; ++w) *o++ = (double)(goal == w ? weight : 0);
+    }
+    for (int t = 0; t < Nt; ++t) *o++ = (double)((di[t * TI_STRIDE + TI_GW] & 0xff) - 1);
+    for (int t = 0; t < Nt; ++t) *o++ = (double)di[t * TI_STRIDE + TI_FREIGHT];
+    for (int t = 0; t < Nt; ++t) *o++ = (double)di[t * TI_STRIDE + TI_BOUNTY];
+    for (int t = 0; t < Nt; ++t) *o++ = (double)di[t * TI_STRIDE + TI_TSTEPS];
+    for (int t = 0; t < Nt; ++t) *o++ = (double)di[t * TI_STRIDE + TI_TRSTEPS];
+    const int32_t *e = di + Nt * TI_STRIDE;
+    for (int i = 0; i < 20; ++i) *o++ = (double)e[i];                             // remaining[16], awaiting[4]
+    *o++ = (double)e[EI_DELIVERED];
+    *o++ = dy[2 * Nc + 2 * Nt]; *o++ = dy[2 * Nc + 2 * Nt + 1];
+    *o++ = (double)e[EI_EPSTEP]; *o++ = (double)(uint32_t)e[EI_TICK]; *o++ = (double)(uint32_t)e[EI_EPISODE]; *o++ = (double)e[EI_DONE];
+}
+
+__global__ void import_kernel(const Params p, const Ptrs g, const double *src) {
+    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= g.N) return;
+    double *st = g.stat + env * p.SW;
+    double *dy = g.dyn + env * p.DW;
+    int32_t *di = reinterpret_cast<int32_t *>(dy + p.DF);
+    uint64_t *stw = reinterpret_cast<uint64_t *>(st);
+    const double *o = src + env * p.export_width;
+    const int Nc = p.Nc, Nt = p.Nt, No = p.No;
+    for (int i = 0; i < 2 * Nc + 3 * No; ++i) st[i] = *o++;
+    uint64_t capword = 0;
+    for (int t = 0; t < Nt; ++t) capword |= (uint64_t)((*o++) >= 2.0) << t;
+    stw[3 * Nc + 3 * No] = capword;
+    for (int c = 0; c < Nc; ++c) { uint64_t bits = 0; for (int q = 0; q < No; ++q) bits |= (uint64_t)((*o++) != 0.0) << q; stw[2 * Nc + 3 * No + c] = bits; }
+    for (int i = 0; i < 2 * Nc + 2 * Nt; ++i) dy[i] = *o++;
+    const double *colliding = o; o += Nt;
+    const double *empty = o; o += 4 * Nt;
+    const double *goal_bits = o; o += 4 * Nt;
+    const double *goals = o; o += Nt;
+    for (int t = 0; t < Nt; ++t) {
+        const int goal = (int)goals[t];
+        int weight = 0;
+        for (int w = 0; w < 4; ++w) if (goal_bits[4 * t + w] != 0.0) weight = (int)goal_bits[4 * t + w];
+        int gw = (goal + 1) | (weight << 8) | ((int)(colliding[t] != 0.0) << 24);
+        for (int w = 0; w < 4; ++w) gw |= (int)(empty[4 * t + w] != 0.0) << (16 + w);
+        di[t * TI_STRIDE + TI_GW] = gw;
+    }
+    for (int t = 0; t < Nt; ++t) di[t * TI_STRIDE + TI_FREIGHT] = (int)*o++;
+    for (int t = 0; t < Nt; ++t) di[t * TI_STRIDE + TI_BOUNTY] = (int)*o++;
+    for (int t = 0; t < Nt; ++t) di[t * TI_STRIDE + TI_TSTEPS] = (int)*o++;
+    for (int t = 0; t < Nt; ++t) di[t * TI_STRIDE + TI_TRSTEPS] = (int)*o++;
+    int32_t *e = di + Nt * TI_STRIDE;
+    for (int i = 0; i < 20; ++i) e[i] = (int)*o++;
+    e[EI_DELIVERED] = (int)*o++;
+    dy[2 * Nc + 2 * Nt] = *o++; dy[2 * Nc + 2 * Nt + 1] = *o++;
+    e[EI_EPSTEP] = (int)*o++; e[EI_TICK] = (int)(uint32_t)*o++; e[EI_EPISODE] = (int)(uint32_t)*o++; e[EI_DONE] = (int)*o++;
+    e[EI_PAD] = 0;
+}
+
+}  // namespace mate

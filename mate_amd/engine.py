@@ -1,0 +1,243 @@
+"""`Engine`: the batched step engine as torch tensors over the C ABI.
+
+PyTorch is plumbing here (device memory, streams); all simulation work happens
+in the HIP kernels behind ``include/mate_engine.h``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from mate_amd import _native
+from mate_amd._native import MateConfig, MateLayout, MateStepIO, check
+
+__all__ = ['Engine', 'export_layout', 'SCALAR_NAMES']
+
+SCALAR_NAMES = ('camera_team_reward', 'target_team_reward', 'done', 'coverage_rate', 'real_coverage_rate',
+                'mean_transport_rate', 'num_delivered_cargoes', 'normalized_target_team_reward')
+
+
+def export_layout(Nc, Nt, No):
+    """name -> (offset, shape) inside one row of `Engine.export_state()` ("state export")."""
+    fields = [
+        ('cam_x', (Nc,)), ('cam_y', (Nc,)), ('obs_x', (No,)), ('obs_y', (No,)), ('obs_radius', (No,)),
+        ('tgt_capacity', (Nt,)), ('camera_obstacle_view_mask', (Nc, No)),
+        ('cam_phi', (Nc,)), ('cam_theta', (Nc,)), ('tgt_x', (Nt,)), ('tgt_y', (Nt,)),
+        ('tgt_colliding', (Nt,)), ('tgt_empty_bits', (Nt, 4)), ('tgt_goal_bits', (Nt, 4)), ('tgt_goals', (Nt,)),
+        ('freights', (Nt,)), ('bounties', (Nt,)), ('target_steps', (Nt,)), ('tracked_steps', (Nt,)),
+        ('remaining_cargoes', (4, 4)), ('awaiting_cargo_counts', (4,)), ('num_delivered_cargoes', ()),
+        ('episode_reward', ()), ('delayed_episode_reward', ()), ('episode_step', ()), ('tick', ()), ('episode', ()),
+        ('done', ()),
+    ]
+    layout, off = {}, 0
+    for name, shape in fields:
+        layout[name] = (off, shape)
+        off += int(np.prod(shape)) if shape else 1
+    return layout, off
+
+
+class Engine:
+    """N environments of one scenario on one GPU."""
+
+    def __init__(self, config, num_envs, device=0, seed=0, first_env_index=0, obs_dtype=torch.float32):
+        """`config` is a validated scenario mapping (mate_amd.config.read_config)."""
+        self.lib = _native.load()
+        self.config = config
+        self.num_envs = int(num_envs)
+        self.device_index = int(device)
+        self.device = torch.device('cuda', self.device_index)
+        self.obs_dtype = obs_dtype
+        cam, tgt, obs = config.get('camera', {}), config['target'], config.get('obstacle', {})
+
+        def ranges(sub):
+            rows = [[x, x, y, y] for x, y in sub.get('location', [])] + [list(r) for r in sub.get('location_random_range', [])]
+            return np.ascontiguousarray(np.asarray(rows, dtype=np.float64).reshape(-1, 4))
+
+        self._ranges = (ranges(cam), ranges(tgt), ranges(obs))
+        self.num_cameras, self.num_targets, self.num_obstacles = (len(r) for r in self._ranges)
+        c = MateConfig()
+        c.num_cameras, c.num_targets, c.num_obstacles = self.num_cameras, self.num_targets, self.num_obstacles
+        c.max_episode_steps = int(config['max_episode_steps'])
+        c.sparse_reward = int(config['reward_type'] == 'sparse')
+        c.num_cargoes_per_target = int(config['num_cargoes_per_target'])
+        c.shuffle_entities = int(bool(config['shuffle_entities']))
+        c.targets_start_with_cargoes = int(bool(config['targets_start_with_cargoes']))
+        c.high_capacity_target_split = float(config['high_capacity_target_split'])
+        c.bounty_factor = float(config['bounty_factor'])
+        c.transmittance = float(obs.get('transmittance', 0.0))
+        c.camera_radius = float(cam.get('radius', 40.0))
+        c.camera_min_viewing_angle = float(cam.get('min_viewing_angle', 90.0))
+        c.camera_max_sight_range = float(cam.get('max_sight_range', 500.0))
+        c.camera_rotation_step = float(cam.get('rotation_step', 5.0))
+        c.camera_zooming_step = float(cam.get('zooming_step', 2.5))
+        c.target_step_size = float(tgt['step_size'])
+        c.target_sight_range = float(tgt['sight_range'])
+        if 'radius_random_range' in obs:
+            rr = list(obs['radius_random_range'])
+        else:
+            rr = [float(obs.get('radius', 0.0))] * 2
+        c.obstacle_radius_range[0], c.obstacle_radius_range[1] = float(rr[0]), float(rr[1])
+        dp = ctypes.POINTER(ctypes.c_double)
+        c.camera_location_ranges = self._ranges[0].ctypes.data_as(dp)
+        c.target_location_ranges = self._ranges[1].ctypes.data_as(dp)
+        c.obstacle_location_ranges = self._ranges[2].ctypes.data_as(dp)
+        c.obs_dtype = 1 if obs_dtype == torch.float64 else 0
+        self._cfg = c
+        handle = ctypes.c_void_p()
+        check(self.lib.mate_engine_create(ctypes.byref(c), self.num_envs, self.device_index, int(seed), int(first_env_index), ctypes.byref(handle)))
+        self._h = handle
+        layout = MateLayout()
+        check(self.lib.mate_engine_get_layout(self._h, ctypes.byref(layout)))
+        self.layout = layout
+        self.camera_obs_dim, self.target_obs_dim = layout.camera_obs_dim, layout.target_obs_dim
+        self.export_fields, width = export_layout(self.num_cameras, self.num_targets, self.num_obstacles)
+        assert width == layout.export_width, (width, layout.export_width)
+        N, Nc, Nt = self.num_envs, self.num_cameras, self.num_targets
+        with torch.cuda.device(self.device):
+            self.camera_obs = torch.zeros((N, Nc, layout.camera_obs_dim), dtype=obs_dtype, device=self.device)
+            self.target_obs = torch.zeros((N, Nt, layout.target_obs_dim), dtype=obs_dtype, device=self.device)
+            self.scalars = torch.zeros((N, 8), dtype=torch.float32, device=self.device)
+            self.masks = torch.zeros((N, layout.mask_words), dtype=torch.int32, device=self.device)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.mate_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _io(self, cam_act=None, tgt_act=None, tape_ct=None, tape_goal=None, want_masks=True):
+        io = MateStepIO()
+        keep = []
+        if tgt_act is not None:
+            act_dtype = tgt_act.dtype
+            assert act_dtype in (torch.float32, torch.float64)
+            tgt_act = tgt_act.contiguous()
+            assert tgt_act.numel() == self.num_envs * self.num_targets * 2 and tgt_act.device == self.device
+            io.target_actions_dev = tgt_act.data_ptr()
+            io.act_dtype = 1 if act_dtype == torch.float64 else 0
+            keep.append(tgt_act)
+            if self.num_cameras:
+                cam_act = cam_act.to(act_dtype).contiguous()
+                assert cam_act.numel() == self.num_envs * self.num_cameras * 2 and cam_act.device == self.device
+                io.camera_actions_dev = cam_act.data_ptr()
+                keep.append(cam_act)
+        if tape_ct is not None and self.num_cameras:
+            tape_ct = tape_ct.to(torch.float64).contiguous()
+            assert tape_ct.numel() == self.num_envs * self.num_cameras * self.num_targets
+            io.tape_camera_target_dev = tape_ct.data_ptr()
+            keep.append(tape_ct)
+        if tape_goal is not None:
+            tape_goal = tape_goal.to(torch.float64).contiguous()
+            assert tape_goal.numel() == self.num_envs * self.num_targets
+            io.tape_goal_dev = tape_goal.data_ptr()
+            keep.append(tape_goal)
+        io.camera_obs_dev = self.camera_obs.data_ptr() if self.num_cameras else None
+        io.target_obs_dev = self.target_obs.data_ptr()
+        io.scalars_dev = self.scalars.data_ptr()
+        io.masks_dev = self.masks.data_ptr() if want_masks else None
+        return io, keep
+
+    # ---------------------------------------------------------------------- API
+    def seed(self, seed):
+        check(self.lib.mate_engine_seed(self._h, int(seed)))
+
+    def reset(self, env_mask=None):
+        io, keep = self._io()
+        mask_ptr = None
+        if env_mask is not None:
+            env_mask = env_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            mask_ptr = ctypes.c_void_p(env_mask.data_ptr())
+        check(self.lib.mate_engine_reset(self._h, mask_ptr, ctypes.byref(io), self._stream()))
+        return self.camera_obs, self.target_obs
+
+    def step(self, cam_act, tgt_act, tape_ct=None, tape_goal=None, auto_reset=False):
+        io, keep = self._io(cam_act, tgt_act, tape_ct, tape_goal)
+        check(self.lib.mate_engine_step(self._h, ctypes.byref(io), int(auto_reset), self._stream()))
+        return self.camera_obs, self.target_obs, self.scalars
+
+    def step_random(self, auto_reset=True, want_masks=False):
+        io, keep = self._io(want_masks=want_masks)
+        check(self.lib.mate_engine_step_random(self._h, ctypes.byref(io), int(auto_reset), self._stream()))
+        return self.camera_obs, self.target_obs, self.scalars
+
+    def observe(self, tape_ct=None):
+        io, keep = self._io(tape_ct=tape_ct)
+        check(self.lib.mate_engine_observe(self._h, ctypes.byref(io), self._stream()))
+        return self.camera_obs, self.target_obs
+
+    def export_state(self):
+        out = torch.empty((self.num_envs, self.layout.export_width), dtype=torch.float64, device=self.device)
+        check(self.lib.mate_engine_export_state(self._h, ctypes.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def import_state(self, flat):
+        flat = flat.to(device=self.device, dtype=torch.float64).contiguous()
+        assert flat.shape == (self.num_envs, self.layout.export_width)
+        check(self.lib.mate_engine_import_state(self._h, ctypes.c_void_p(flat.data_ptr()), self._stream()))
+        torch.cuda.synchronize(self.device)
+
+    def state_dict(self):
+        """All state fields as numpy arrays [N, ...] (host copy)."""
+        flat = self.export_state().cpu().numpy()
+        out = {}
+        for name, (off, shape) in self.export_fields.items():
+            n = int(np.prod(shape)) if shape else 1
+            out[name] = flat[:, off:off + n].reshape((self.num_envs,) + tuple(shape))
+        return out
+
+    def load_state_dict(self, fields):
+        flat = self.export_state().cpu().numpy()
+        for name, value in fields.items():
+            off, shape = self.export_fields[name]
+            n = int(np.prod(shape)) if shape else 1
+            flat[:, off:off + n] = np.asarray(value, dtype=np.float64).reshape(self.num_envs, n)
+        self.import_state(torch.from_numpy(flat))
+
+    def rebuild_luts(self):
+        check(self.lib.mate_engine_rebuild_luts(self._h, self._stream()))
+
+    def lut_read(self, env, camera):
+        cap = self.layout.lut_capacity
+        phis, rhos = np.zeros(cap), np.zeros(cap)
+        n = ctypes.c_int32()
+        check(self.lib.mate_engine_lut_read(self._h, int(env), int(camera), phis.ctypes.data_as(ctypes.c_void_p),
+                                            rhos.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n)))
+        return phis[:n.value].copy(), rhos[:n.value].copy()
+
+    def lut_write(self, env, camera, phis, rhos):
+        phis = np.ascontiguousarray(phis, dtype=np.float64)
+        rhos = np.ascontiguousarray(rhos, dtype=np.float64)
+        check(self.lib.mate_engine_lut_write(self._h, int(env), int(camera), phis.ctypes.data_as(ctypes.c_void_p),
+                                             rhos.ctypes.data_as(ctypes.c_void_p), len(phis)))
+
+    def kernel_time(self, enable=True):
+        """(avg ms, launches) of the step kernel since the last call; (re)arms the HIP-event timer."""
+        avg, n = ctypes.c_double(), ctypes.c_int64()
+        check(self.lib.mate_engine_kernel_time(self._h, int(enable), ctypes.byref(avg), ctypes.byref(n)))
+        return avg.value, n.value
+
+    # decoded masks ------------------------------------------------------------
+    def unpack_masks(self, masks=None):
+        """Packed u32 words -> dict of boolean numpy arrays [N, ...] (environment.py:475-494 names)."""
+        words = (self.masks if masks is None else masks).cpu().numpy().astype(np.uint32)
+        N, Nc, Nt, No = self.num_envs, self.num_cameras, self.num_targets, self.num_obstacles
+        bits = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool).reshape(N, -1)
+        L = self.layout
+        NJ = Nc + No + Nt
+        ct = bits[:, L.bit_camera_target:L.bit_camera_target + Nc * Nt].reshape(N, Nc, Nt)
+        cc = bits[:, L.bit_camera_camera:L.bit_camera_camera + Nc * Nc].reshape(N, Nc, Nc)
+        rows = bits[:, L.bit_target_row:L.bit_target_row + Nt * NJ].reshape(N, Nt, NJ)
+        co = np.zeros((N, Nc, No), dtype=bool)
+        for c in range(Nc):
+            co[:, c] = bits[:, L.bit_camera_obstacle + 64 * c:L.bit_camera_obstacle + 64 * c + No]
+        return {
+            'camera_target_view_mask': ct, 'camera_camera_view_mask': cc,
+            'target_camera_view_mask': rows[:, :, :Nc], 'target_obstacle_view_mask': rows[:, :, Nc:Nc + No],
+            'target_target_view_mask': rows[:, :, Nc + No:], 'camera_obstacle_view_mask': co,
+            'tracked_bits': ct.any(axis=1),
+        }
