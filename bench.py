@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the HIP step engine on MATE-4v8-9, batch 4096 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one `step()` of every environment of the batch (BASELINE.json config[1]:
+MATE-4v8-9.yaml, 4096 environments per GPU, uniform random policy generated on-device by the
+engine's Philox streams, auto-reset of finished episodes inside the timed loop).  State,
+actions and observations are resident in HBM for the whole timed region.  For N > 1 the
+batch is sharded (4096 environments per rank, env index = rank * 4096 + i; no data-path
+collective); RCCL only all-gathers the episode statistics after the timed region.
+
+Rank 0 prints ONE JSON line (see the driver contract).  Extra objects:
+  roofline      HBM roofline of the dominant kernel (step_kernel): algorithmic bytes per launch
+                (7504 B/env-step x 4096) / average launch duration measured with
+                HIP events on the launch stream over the timed region.
+  cpu_baseline  the CPU oracle (oracle/, a parity-checked port of the reference's step path)
+                stepping + packing f32 observations for the same workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOAD = 'MATE-4v8-9.yaml'
+BATCH_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); measured copy peak ~6290 GB/s
+
+
+def algorithmic_bytes(Nc, Nt, No):
+    """B_alg per env-step."""
+    Dc = 13 + 9 + 5 * Nt + 4 * No + 7 * Nc
+    Dt = 13 + 14 + 7 * Nc + 4 * No + 5 * Nt
+    return 4 * (Nc * Dc + Nt * Dt) + 8 * (Nc + Nt) + 2 * (16 * Nc + 35 * Nt + 72) + (24 * Nc + 24 * No + Nt) + 48
+
+
+def cpu_baseline(seconds=10.0):
+    """Oracle (CPU port of the reference step path) on the host cores: step + f32 observation pack."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle import oracle as O
+    import gpu_util as U
+    from mate_amd.config import read_config
+    cfg = read_config(WORKLOAD)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    proto = U.oracle_proto_from_config(cfg, O)
+    batch = O.OracleBatch(proto, BATCH_PER_GPU, seed=0, first_env_index=0)
+    batch.reset(threads=min(cores, 32))
+    # pick the thread count that is fastest on this box (containers often expose more CPUs than they may use)
+    best = (0.0, 1)
+    for threads in sorted({1, 8, 16, 32, 64, 128, cores}):
+        if threads > cores:
+            continue
+        batch.step(auto_reset=True, threads=threads)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            batch.step(auto_reset=True, threads=threads)
+            batch.observe(threads=threads)
+        rate = 2 * BATCH_PER_GPU / (time.perf_counter() - t0)
+        if rate > best[0]:
+            best = (rate, threads)
+    cores = best[1]
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        batch.step(auto_reset=True, threads=cores)
+        batch.observe(threads=cores)
+        steps += 1
+        if steps >= 20 and time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        'value': BATCH_PER_GPU * steps / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+        'sample': f'{WORKLOAD} batch={BATCH_PER_GPU} x {steps} steps (random policy, f32 observation pack), '
+                  f'{dt:.1f} s, OpenMP over environments',
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='environments per GPU')
+    ap.add_argument('--workload', default=WORKLOAD)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=10.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    cfg = read_config(args.workload)
+    eng = Engine(cfg, args.batch, device=local_rank, seed=0, first_env_index=rank * args.batch)
+    eng.reset()
+    for _ in range(args.warmup):
+        eng.step_random(auto_reset=True)
+    eng.kernel_time(enable=16)            # HIP-event pair around every 16th step_kernel launch of the timed region
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step_random(auto_reset=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = eng.kernel_time(enable=False)
+
+    stats = eng.scalars[:, [1, 3, 6]].mean(dim=0)    # reward, coverage, delivered: logging only
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)              # the only collective of the path: episode statistics
+        stats = torch.stack(gathered).mean(dim=0)
+
+    if rank == 0:
+        total_envs = args.batch * world
+        value = total_envs * args.steps / elapsed
+        b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
+        achieved = b_alg * args.batch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        line = {
+            'metric': 'env-steps/sec MATE-4v8-9 batch=4096 per GPU (random policy, auto-reset)',
+            'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'{args.workload} batch={args.batch} envs per GPU, uniform random policy (on-device Philox), '
+                                   f'auto-reset', 'global_batch': total_envs, 'parallelism': f'env-shard x{world}'},
+            'roofline': {
+                'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'kernel': 'step_kernel<float>', 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches,
+                'algorithmic_bytes_per_launch': b_alg * args.batch,
+            },
+            'episode_stats': {'mean_target_reward': float(stats[0]), 'mean_coverage_rate': float(stats[1]),
+                              'mean_delivered': float(stats[2])},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

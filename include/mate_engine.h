@@ -130,8 +130,9 @@ int mate_engine_lut_write(mate_engine *engine, int64_t env, int32_t camera, cons
  * (Camera.add_obstacles, entities.py:362-479) -- used after mate_engine_import_state. */
 int mate_engine_rebuild_luts(mate_engine *engine, void *stream);
 
-/* Average duration (ms) of the dominant kernel over the launches recorded since the last
- * call with reset != 0, measured with HIP events on the launch stream (bench.py roofline). */
+/* Average duration (ms) of the dominant kernel (step_kernel) over the launches timed since the
+ * previous call, measured with HIP event pairs on the launch stream (bench.py roofline).
+ * `enable` = k > 0 arms the timer for every k-th step launch from now on, 0 disarms it. */
 int mate_engine_kernel_time(mate_engine *engine, int32_t enable, double *avg_ms, int64_t *launches);
 
 #ifdef __cplusplus

@@ -9,7 +9,7 @@ import os
 
 __all__ = ['lib', 'load', 'EngineError', 'MateConfig', 'MateLayout', 'MateStepIO', 'LIB_PATH', 'check', 'EXPORTED_SYMBOLS']
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libmate_engine.so')
+LIB_PATH = os.environ.get('MATE_ENGINE_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libmate_engine.so')
 
 EXPORTED_SYMBOLS = (
     'mate_engine_last_error', 'mate_engine_abi_version', 'mate_engine_create', 'mate_engine_destroy',
@@ -74,6 +74,9 @@ def load():
         raise ImportError(
             f'{LIB_PATH} is missing: build the HIP engine first (python -m mate_amd.build or '
             f'__graft_entry__.build()).  mate_amd has no CPU fallback.')
+    # torch first: the engine must bind to the HIP runtime torch already loaded (one runtime per
+    # process; loading ROCm's copy before torch's leaves the later one without a device).
+    import torch  # noqa: F401
     handle = ctypes.CDLL(LIB_PATH)
     P, I32, I64, U64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
     handle.mate_engine_last_error.restype = ctypes.c_char_p

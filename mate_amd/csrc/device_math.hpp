@@ -60,57 +60,77 @@ __device__ __forceinline__ double pymod_pos(double a, double b) {
     if (r < 0.0) r += b;               // sign follows the divisor
     return r == 0.0 ? 0.0 : r;
 }
-__device__ __forceinline__ double normalize_angle(double a) { return pymod_pos(a + 180.0, 360.0) - 180.0; }  // utils.py:155-158
+__device__ __forceinline__ double normalize_angle(double a) {   // utils.py:155-158: (a + 180) % 360 - 180
+    const double x = a + 180.0;
+    double r;
+    if (x >= 0.0 && x < 360.0) r = x;                 // fmod is the identity here
+    else if (x >= 360.0 && x < 720.0) r = x - 360.0;  // exact (Sterbenz)
+    else if (x < 0.0 && x >= -360.0) r = x + 360.0;   // Python: fmod keeps x, then adds the divisor once
+    else r = pymod_pos(x, 360.0);
+    return r - 180.0;
+}
 __device__ __forceinline__ double atan2_deg(double y, double x) { return atan2(y, x) * kRad2Deg; }           // utils.py:124-131
 
-// Vector2D with its lazy polar <-> cartesian caches (utils.py:161-271).
-struct Ray {
-    double ox, oy, vx, vy, n, a;
-    bool hv, hn, ha;
-};
-__device__ __forceinline__ void ray_materialize(Ray &r) {  // utils.py:177-181,144-152
-    if (!r.hv) {
-        double s, c;
-        sincos(r.a * kDeg2Rad, &s, &c);
-        r.vx = r.n * c; r.vy = r.n * s; r.hv = true;
-    }
+// sin and cos of an angle given in DEGREES, |deg| <= 720.  polar2cartesian (utils.py:144-152) converts
+// with phi * (pi/180) first, and so does this.  Two-term Cody-Waite reduction to [-pi/4, pi/4] plus
+// Taylor polynomials evaluated with fma: ~1 ulp, a third of the instructions of the general-range
+// libm sincos (which carries a Payne-Hanek path these bounded angles never need).
+__device__ __forceinline__ void sincos_deg(double deg, double &sn, double &cs) {
+    const double x = deg * kDeg2Rad;
+    const double k = rint(x * 0.63661977236758134308);            // 2/pi
+    double r = fma(-k, 1.57079632679489655800e+00, x);            // pi/2 high
+    r = fma(-k, 6.12323399573676603587e-17, r);                   // pi/2 low
+    const double z = r * r;
+    double ps = 2.81145725434552075980e-15;                       // 1/17!
+    ps = fma(ps, z, -7.64716373181981647590e-13);                 // -1/15!
+    ps = fma(ps, z, 1.60590438368216145994e-10);                  // 1/13!
+    ps = fma(ps, z, -2.50521083854417187751e-08);                 // -1/11!
+    ps = fma(ps, z, 2.75573192239858906526e-06);                  // 1/9!
+    ps = fma(ps, z, -1.98412698412698412698e-04);                 // -1/7!
+    ps = fma(ps, z, 8.33333333333333333333e-03);                  // 1/5!
+    ps = fma(ps, z, -1.66666666666666666667e-01);                 // -1/3!
+    const double s0 = fma(r * z, ps, r);
+    double pc = -1.56192069685862264622e-16;                      // -1/18!
+    pc = fma(pc, z, 4.77947733238738529744e-14);                  // 1/16!
+    pc = fma(pc, z, -1.14707455977297247139e-11);                 // -1/14!
+    pc = fma(pc, z, 2.08767569878680989792e-09);                  // 1/12!
+    pc = fma(pc, z, -2.75573192239858906526e-07);                 // -1/10!
+    pc = fma(pc, z, 2.48015873015873015873e-05);                  // 1/8!
+    pc = fma(pc, z, -1.38888888888888888889e-03);                 // -1/6!
+    pc = fma(pc, z, 4.16666666666666666667e-02);                  // 1/4!
+    const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
+    sn = (q & 2) ? -sa : sa;
+    cs = ((q + 1) & 2) ? -ca : ca;
 }
-__device__ __forceinline__ double ray_angle(Ray &r) { if (!r.ha) { r.a = atan2_deg(r.vy, r.vx); r.ha = true; } return r.a; }
-__device__ __forceinline__ double ray_norm(Ray &r) { if (!r.hn) { r.n = norm2(r.vx, r.vy); r.hn = true; } return r.n; }
-__device__ __forceinline__ void ray_set_norm(Ray &r, double value) {  // utils.py:223-229 (value >= 0 on this path)
-    (void)ray_angle(r);
-    r.n = fabs(value); r.hn = true; r.hv = false;
-}
-__device__ __forceinline__ void ray_set_vector(Ray &r, double vx, double vy) { r.vx = vx; r.vy = vy; r.hv = true; r.hn = false; r.ha = false; }
 
-// Obstacle.obstruct(ray, keep_tangential=True) (entities.py:158-184): clip the step by one circle.
-__device__ __noinline__ void obstruct_tangential(Ray &ray, double cx, double cy, double rad) {
-    const double relx = cx - ray.ox, rely = cy - ray.oy;
+// Obstacle.obstruct(ray, keep_tangential=True) (entities.py:158-184) on a step kept in cartesian form.
+// The reference shortens the ray through its polar form (new_norm * (cos a, sin a), a = atan2(v)); that
+// is v * (new_norm / |v|) up to last-place rounding, which is how it is done here (no atan2/sincos).
+// (vx, vy) step vector from origin (ox, oy); n = |v| (recomputed when n_known is false).
+__device__ __forceinline__ void obstruct_tangential(double ox, double oy, double &vx, double &vy, double &n, bool &n_known,
+                                                    double cx, double cy, double rad) {
+    const double relx = cx - ox, rely = cy - oy;
     const double rel_norm = norm2(relx, rely);
-    const double norm = ray_norm(ray);
-    if (norm == 0.0 || rel_norm < rad) {  // return -ray
-        ray_materialize(ray);
-        ray_set_vector(ray, -ray.vx, -ray.vy);
-        return;
-    }
-    if (rel_norm >= norm + rad) return;
-    ray_materialize(ray);
-    const double inner = dot2(relx, rely, ray.vx, ray.vy);
+    if (!n_known) { n = norm2(vx, vy); n_known = true; }
+    if (n == 0.0 || rel_norm < rad) { vx = -vx; vy = -vy; return; }   // return -ray
+    if (rel_norm >= n + rad) return;
+    const double inner = dot2(relx, rely, vx, vy);
     if (inner >= 0.0) {
-        const double c0 = inner / (rel_norm * norm);
+        const double c0 = inner / (rel_norm * n);
         const double cosv = c0 < 1.0 ? c0 : 1.0;
         const double perpendicular = rel_norm * sqrt(1.0 - cosv * cosv);
         if (rad > perpendicular) {
             const double half_chord = sqrt(rad * rad - perpendicular * perpendicular);
             const double cand = rel_norm * cosv - half_chord;
             const double new_norm = cand > 0.0 ? cand : 0.0;
-            if (new_norm < norm) {
-                const double oldx = ray.vx, oldy = ray.vy;
-                ray_set_norm(ray, new_norm);
-                ray_materialize(ray);
-                const double rx = (ray.ox + ray.vx) - cx, ry = (ray.oy + ray.vy) - cy;
-                const double s = (norm - new_norm) * half_chord / (rad * rad);
-                ray_set_vector(ray, oldx + rx * s, oldy + ry * s);
+            if (new_norm < n) {
+                const double scale = new_norm / n;
+                const double rx = (ox + vx * scale) - cx, ry = (oy + vy * scale) - cy;
+                const double s = (n - new_norm) * half_chord / (rad * rad);
+                vx = vx + rx * s; vy = vy + ry * s;
+                n_known = false;
             }
         }
     }

@@ -43,6 +43,7 @@ struct Ptrs {
     double *dyn;                  // [N][DW] (8-byte words: DF doubles then NI ints)
     double2 *lut_knots;           // [N][Nc][kmax]  (phi, rho)
     uint16_t *lut_bucket;         // [N][Nc][nbucket]
+    double2 *lut_deg;             // [N][Nc][360][kDegSlots] per-degree records (fast lookup path)
     int32_t *lut_count;           // [N][Nc]
     const uint32_t *desc;         // [cam_elems + tgt_elems]  src | bit << 16
     const void *scratch_init;     // [nscratch] ObsT
@@ -55,9 +56,18 @@ struct Ptrs {
     int32_t *done_count;          // [2] ping-pong counters
     int32_t *done_list;           // [2][N]
     const uint8_t *reset_mask;    // optional
+    long long *phase_clocks;      // [N][16] s_memtime stamps (debug builds with -DMATE_PHASE_CLOCKS)
     int64_t N;
     int32_t mode, act_f64, parity, reset_kind;
 };
+
+#ifdef MATE_PHASE_CLOCKS
+#define PHASE_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define SUB_STAMP(c, i) do { if ((c).lane == 0 && (c).g.phase_clocks) (c).g.phase_clocks[(c).env * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PHASE_STAMP(i) do { } while (0)
+#define SUB_STAMP(c, i) do { } while (0)
+#endif
 
 // Wave-level LDS hand-off: all 64 lanes run in lockstep, so draining this wave's LDS queue and
 // pinning the compiler's order is a complete producer->consumer fence inside the wave.
@@ -80,7 +90,7 @@ struct Ctx {
     int32_t *misc;
     const uint32_t *table;
 
-    __device__ Ctx(const Params &p_, const Ptrs &g_, unsigned char *wave_base, const unsigned char *table_base, int lane_, int64_t env_)
+    __device__ Ctx(const Params &p_, const Ptrs &g_, unsigned char *wave_base, int lane_, int64_t env_)
         : p(p_), g(g_), lane(lane_), env(env_) {
         st = reinterpret_cast<double *>(wave_base + p.off_st);
         dy = reinterpret_cast<double *>(wave_base + p.off_dy);
@@ -89,7 +99,7 @@ struct Ctx {
         scratch = reinterpret_cast<ObsT *>(wave_base + p.off_scratch);
         mask = reinterpret_cast<uint32_t *>(wave_base + p.off_mask);
         misc = reinterpret_cast<int32_t *>(wave_base + p.off_misc);
-        table = reinterpret_cast<const uint32_t *>(table_base);
+        table = g_.desc;   // read through L1: every wave on the CU gathers through the same 6 KB table
     }
     // static record
     __device__ double cam_x(int c) const { return st[c]; }
@@ -117,10 +127,11 @@ struct Ctx {
     __device__ double &svx(int t) { return tmp[p.Nc + t]; }
     __device__ double &svy(int t) { return tmp[p.Nc + p.Nt + t]; }
     __device__ double &snorm(int t) { return tmp[p.Nc + 2 * p.Nt + t]; }
+    __device__ double &udraw(int pair) { return tmp[p.Nc + 3 * p.Nt + pair]; }
     __device__ int32_t &near(int t) { return misc[t]; }
-    __device__ int32_t &inside(int t) { return misc[p.Nt + t]; }
-    __device__ int32_t &tracked(int t) { return misc[2 * p.Nt + t]; }
-    __device__ int32_t &xch(int i) { return misc[3 * p.Nt + i]; }
+    __device__ int32_t &inside(int t) { return misc[2 * p.Nt + t]; }
+    __device__ int32_t &tracked(int t) { return misc[3 * p.Nt + t]; }
+    __device__ int32_t &xch(int i) { return misc[4 * p.Nt + i]; }
     __device__ bool mask_bit(int b) const { return (mask[b >> 5] >> (b & 31)) & 1u; }
     __device__ uint32_t env_global() const { return p.first_env + (uint32_t)env; }
     __device__ double draw(uint32_t tick, uint32_t stream, uint32_t sub) const {
@@ -151,21 +162,43 @@ __device__ void store_dynamic(Ctx<ObsT> &c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Phase A: kinematics.  Camera.simulate (entities.py:347-360), Target.simulate (entities.py:645-668).
+// Random numbers of one step, one Philox call per lane, all lanes at once: lanes [0, Nc) camera
+// actions, [Nc, Nc+Nt) target actions, the remaining lanes pre-draw the see-through uniforms of the
+// first camera->target pairs (cheaper than a second divergent Philox in the visibility phase).
+struct StepDraws { double a0, a1; };
 template <typename ObsT>
-__device__ void simulate(Ctx<ObsT> &c, uint32_t tick) {
+__device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick) {
     const Params &p = c.p;
     const int lane = c.lane;
-    const bool advance = c.g.mode != MODE_OBSERVE;
-    // ---- cameras: lanes [0, Nc)
+    StepDraws d{0.0, 0.0};
+    const int nact = p.Nc + p.Nt;
+    const bool random_policy = c.g.mode == MODE_STEP_RANDOM;
+    const bool need_draws = !c.g.tape_ct && p.Nc > 0;
+    uint32_t stream = 0, sub = 0;
+    bool active = false;
+    if (lane < p.Nc) { stream = S_ACT_CAM; sub = (uint32_t)lane; active = random_policy; }
+    else if (lane < nact) { stream = S_ACT_TGT; sub = (uint32_t)(lane - p.Nc); active = random_policy; }
+    else if (lane - nact < p.Nc * p.Nt) { stream = S_TRANSMIT; sub = (uint32_t)(lane - nact); active = need_draws; }
+    if (active) {
+        const U4 r = philox(p.seed_lo, p.seed_hi, c.env_global(), tick, stream, sub);
+        if (lane < p.Nc) { d.a0 = action_component(r.x, p.rot); d.a1 = action_component(r.y, p.zoom); }
+        else if (lane < nact) { d.a0 = action_component(r.x, p.tgt_step); d.a1 = action_component(r.y, p.tgt_step); }
+        else c.udraw(lane - nact) = u53(r.x, r.y);
+    }
+    return d;
+}
+
+// Phase A: kinematics.  Camera.simulate (entities.py:347-360), Target.simulate (entities.py:645-668).
+template <typename ObsT>
+__device__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &draws, bool advance) {
+    const Params &p = c.p;
+    const int lane = c.lane;
     if (lane < p.Nc) {
         double ph = c.phi(lane), th = c.theta(lane);
         if (advance) {
             double da, dz;
-            if (c.g.mode == MODE_STEP_RANDOM) {
-                const U4 r = philox(p.seed_lo, p.seed_hi, c.env_global(), tick, S_ACT_CAM, (uint32_t)lane);
-                da = action_component(r.x, p.rot); dz = action_component(r.y, p.zoom);
-            } else if (c.g.act_f64) {
+            if (c.g.mode == MODE_STEP_RANDOM) { da = draws.a0; dz = draws.a1; }
+            else if (c.g.act_f64) {
                 const double *a = reinterpret_cast<const double *>(c.g.cam_act) + (c.env * p.Nc + lane) * 2;
                 da = a[0]; dz = a[1];
             } else {
@@ -181,92 +214,111 @@ __device__ void simulate(Ctx<ObsT> &c, uint32_t tick) {
         const double sr = sqrt(p.area / th);      // entities.py:360
         c.sight(lane) = sr;
         double sn, cs;
-        sincos(ph * kDeg2Rad, &sn, &cs);           // Camera.state: polar2cartesian(sight_range, orientation), entities.py:318
+        sincos_deg(ph, sn, cs);                    // Camera.state: polar2cartesian(sight_range, orientation), entities.py:318
         ObsT *sc = c.scratch + p.sc_cam + lane * 10;
         sc[0] = (ObsT)c.cam_x(lane); sc[1] = (ObsT)c.cam_y(lane);
         sc[3] = (ObsT)(sr * cs); sc[4] = (ObsT)(sr * sn); sc[5] = (ObsT)th;
     }
-    if (!advance) { wave_sync(); return; }
+}
 
-    // ---- targets: lanes [0, Nt): clamp the step through the polar form (entities.py:648-650, utils.py:223-229)
-    Ray step;
-    double desx = 0.0, desy = 0.0, step_size = 0.0;
-    if (lane < p.Nt) {
+// Target.simulate on lanes [Nc, Nc+Nt).  Fast path: a (target, circle) pair whose circle provably
+// cannot touch the step (entities.py:163: `relative.norm >= norm + radius`) is a no-op, so all pairs are
+// screened in parallel with a sqrt-free conservative test; only flagged circles are walked, in index
+// order.  A hit never lengthens the step (|v'|^2 = |v|^2 - a s^2 (2|v| - a) <= |v|^2 for penetration a and
+// s = half_chord/r), so a circle out of reach of the original step stays out of reach.
+template <typename ObsT>
+__device__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    const int t = lane - p.Nc;
+    const bool is_target = t >= 0 && t < p.Nt;
+    double ox = 0.0, oy = 0.0, vx = 0.0, vy = 0.0, n = 0.0, desx = 0.0, desy = 0.0;
+    if (is_target) {
         double ax, ay;
-        if (c.g.mode == MODE_STEP_RANDOM) {
-            const U4 r = philox(p.seed_lo, p.seed_hi, c.env_global(), tick, S_ACT_TGT, (uint32_t)lane);
-            ax = action_component(r.x, p.tgt_step); ay = action_component(r.y, p.tgt_step);
-        } else if (c.g.act_f64) {
-            const double *a = reinterpret_cast<const double *>(c.g.tgt_act) + (c.env * p.Nt + lane) * 2;
+        if (c.g.mode == MODE_STEP_RANDOM) { ax = draws.a0; ay = draws.a1; }
+        else if (c.g.act_f64) {
+            const double *a = reinterpret_cast<const double *>(c.g.tgt_act) + (c.env * p.Nt + t) * 2;
             ax = a[0]; ay = a[1];
         } else {
-            const float2 a = reinterpret_cast<const float2 *>(c.g.tgt_act)[c.env * p.Nt + lane];
+            const float2 a = reinterpret_cast<const float2 *>(c.g.tgt_act)[c.env * p.Nt + t];
             ax = (double)a.x; ay = (double)a.y;
         }
-        const int cap = 1 + (int)((c.capword() >> lane) & 1ull);
-        step_size = p.tgt_step / (double)cap;      // entities.py:612-615
-        step.ox = c.tx(lane); step.oy = c.ty(lane);
-        step.vx = ax; step.vy = ay; step.hv = true; step.hn = false; step.ha = false; step.n = 0.0; step.a = 0.0;
-        if (ray_norm(step) > step_size) { ray_set_norm(step, step_size); ray_materialize(step); }
-        desx = step.ox + step.vx; desy = step.oy + step.vy;
-        c.svx(lane) = step.vx; c.svy(lane) = step.vy; c.snorm(lane) = step.n;
-        c.near(lane) = 0;
+        const double step_size = ((c.capword() >> t) & 1ull) ? p.tgt_step * 0.5 : p.tgt_step;   // entities.py:612-615
+        ox = c.tx(t); oy = c.ty(t);
+        vx = ax; vy = ay;
+        n = norm2(ax, ay);
+        if (n > step_size) {
+            // `step.norm = step_size` (entities.py:649-650) goes through the polar form in the reference
+            // (s*(cos, sin) of atan2(a)); rescaling the vector is the same quantity to within the
+            // last-place noise a device atan2/sincos would add anyway, at a tenth of the instructions.
+            const double k = step_size / n;
+            vx = ax * k; vy = ay * k; n = step_size;
+        }
+        desx = ox + vx; desy = oy + vy;
+        c.snorm(t) = n;
+        c.near(t) = 0; c.near(p.Nt + t) = 0;
     }
     wave_sync();
-    // ---- which (target, circle) pairs can interact at all?  (entities.py:161-164 early-outs)
+    SUB_STAMP(c, 10);
     const int npairs = p.Nt * p.NK;
     for (int base = 0; base < npairs; base += 64) {
         const int q = base + lane;
         if (q < npairs) {
-            const int t = (int)(((float)q + 0.5f) * p.inv_NK);
-            const int k = q - t * p.NK;
+            const int tt = (int)(((float)q + 0.5f) * p.inv_NK);
+            const int k = q - tt * p.NK;
             double cx, cy, cr;
             c.circle(k, cx, cy, cr);
-            const double rel_norm = norm2(cx - c.tx(t), cy - c.ty(t));
-            const double n = c.snorm(t);
-            const bool is_near = (n != 0.0) && (rel_norm < cr || !(rel_norm >= n + cr));
-            if (is_near) atomicOr(&c.near(t), 1);
+            const double dx = cx - c.tx(tt), dy = cy - c.ty(tt);
+            const double d2 = fma(dy, dy, dx * dx);
+            const double nn = c.snorm(tt);
+            const double reach = nn + cr;
+            // far for sure  <=>  d2 comfortably above reach^2 (d >= reach then also holds after rounding)
+            const bool far = d2 > reach * reach * (1.0 + 1e-12);
+            if (nn != 0.0 && !far) atomicOr(&c.near(k < 32 ? tt : p.Nt + tt), 1 << (k & 31));
         }
     }
     wave_sync();
-    // ---- rare path: walk every circle in order with the full Vector2D semantics
-    if (lane < p.Nt) {
-        if (c.near(lane)) {
-            for (int k = 0; k < p.NK; ++k) {
-                double cx, cy, cr;
-                c.circle(k, cx, cy, cr);
-                obstruct_tangential(step, cx, cy, cr);
-            }
-            ray_materialize(step);
+    SUB_STAMP(c, 11);
+    if (is_target) {
+        uint64_t todo = (uint64_t)(uint32_t)c.near(t) | ((uint64_t)(uint32_t)c.near(p.Nt + t) << 32);
+        bool n_known = true;
+        while (todo) {
+            const int k = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            double cx, cy, cr;
+            c.circle(k, cx, cy, cr);
+            if (!n_known) { n = norm2(vx, vy); n_known = true; }
+            // sqrt-free screen against the current step: definitely out of reach -> Obstacle.obstruct returns the ray as is
+            const double dx = cx - ox, dy = cy - oy;
+            const double reach = n + cr;
+            if (n != 0.0 && fma(dy, dy, dx * dx) > reach * reach * (1.0 + 1e-12)) continue;
+            obstruct_tangential(ox, oy, vx, vy, n, n_known, cx, cy, cr);
         }
-        const double nx = clipd(step.ox + step.vx, -kTerrain, kTerrain);   // entities.py:664-666
-        const double ny = clipd(step.oy + step.vy, -kTerrain, kTerrain);
+        const double nx = clipd(ox + vx, -kTerrain, kTerrain);   // entities.py:664-666
+        const double ny = clipd(oy + vy, -kTerrain, kTerrain);
         const bool colliding = (fabs(nx - desx) > 1e-6) || (fabs(ny - desy) > 1e-6);  // entities.py:668
-        c.tx(lane) = nx; c.ty(lane) = ny;
-        int gw = c.ti(lane, TI_GW) & ~(1 << 24);
-        c.ti(lane, TI_GW) = gw | ((int)colliding << 24);
+        c.tx(t) = nx; c.ty(t) = ny;
+        int gw = c.ti(t, TI_GW) & ~(1 << 24);
+        c.ti(t, TI_GW) = gw | ((int)colliding << 24);
     }
     wave_sync();
 }
 
 // ---------------------------------------------------------------------------------------------
 // Occlusion-table lookup: Camera.sight_range_at (entities.py:507-511) == np.interp on the knots.
-__device__ __forceinline__ double lut_lookup(const double2 *knots, const uint16_t *bucket, int n, double x) {
-    if (x > knots[n - 1].x) return knots[n - 1].y;
-    if (x < knots[0].x) return knots[0].y;
+// General path: bucket[d] = index of the last knot with angle <= d - 180 (every integer degree is a
+// knot), then a short search.
+__device__ __noinline__ double lut_lookup(const double2 *knots, const uint16_t *bucket, int n, double x) {
     int d = (int)floor(x + 180.0);
-    d = d < 0 ? 0 : (d > 359 ? 359 : d);
-    int lo = bucket[d > 0 ? d - 1 : 0];
-    int hi = bucket[d + 2 > 360 ? 360 : d + 2];      // knots[hi].x > x, knots[lo].x <= x
+    d = d < 1 ? 1 : (d > 359 ? 359 : d);
+    int lo = bucket[d - 1];                           // knots[lo].x <= d-1-180 <= x  (x >= -180)
+    int hi = bucket[d + 2 > 360 ? 360 : d + 2];       // knots[hi].x = d+2-180 > x
     if (hi > n - 1) hi = n - 1;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (knots[mid].x <= x) lo = mid; else hi = mid;
-    }
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (knots[mid].x <= x) lo = mid; else hi = mid; }
     if (knots[hi].x <= x) lo = hi;
     const int j = lo;
     const double2 k0 = knots[j];
-    if (j == n - 1 || k0.x == x) return k0.y;
+    if (j >= n - 1 || k0.x == x) return k0.y;
     const double2 k1 = knots[j + 1];
     const double slope = (k1.y - k0.y) / (k1.x - k0.x);
     double res = slope * (x - k0.x) + k0.y;
@@ -277,53 +329,106 @@ __device__ __forceinline__ double lut_lookup(const double2 *knots, const uint16_
     return res;
 }
 
+// Fast path: one 96-byte record per (camera, degree) holding the knots of that degree, the next
+// integer-degree knot and +inf padding (kDegSlots entries); a NaN first angle marks a degree with more
+// knots than fit, which falls back to the general path.  One dependent memory round trip.
+constexpr int kDegSlots = 6;
+__device__ __forceinline__ int degree_of(double x) {
+    int d = (int)floor(x + 180.0);
+    d = d < 0 ? 0 : (d > 359 ? 359 : d);
+    if (x < (double)(d - 180)) d -= 1;                // x + 180 rounded up across an integer
+    return d < 0 ? 0 : d;
+}
+__device__ __forceinline__ double degree_interp(const double2 (&w)[kDegSlots], double x, bool &overflow) {
+    overflow = w[0].x != w[0].x;
+    double2 k0 = w[0], k1 = w[1];
+#pragma unroll
+    for (int i = 1; i < kDegSlots - 1; ++i)
+        if (w[i].x <= x) { k0 = w[i]; k1 = w[i + 1]; }
+    if (k0.x == x) return k0.y;
+    const double slope = (k1.y - k0.y) / (k1.x - k0.x);
+    double res = slope * (x - k0.x) + k0.y;
+    if (res != res) {
+        res = slope * (x - k1.x) + k1.y;
+        if (res != res && k0.y == k1.y) res = k0.y;
+    }
+    return res;
+}
+
 // Phase B: _update_view (environment.py:1356-1388).
+struct SectorEval { bool seen, need; double rn, x; int64_t lc; };
+
+// Camera.perceive (entities.py:491-505) up to the occlusion lookup.
 template <typename ObsT>
-__device__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream) {
+__device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t tick, uint32_t stream, bool predrawn) {
+    const Params &p = c.p;
+    SectorEval e{false, false, 0.0, 0.0, 0};
+    if (q >= p.n_sector) return e;
+    int cam, other; bool is_target;
+    if (q < p.bit_cc) { cam = (int)(((float)q + 0.5f) * p.inv_Nt); other = q - cam * p.Nt; is_target = true; }
+    else { const int r = q - p.bit_cc; cam = (int)(((float)r + 0.5f) * p.inv_Nc); other = r - cam * p.Nc; is_target = false; }
+    if (!is_target && cam == other) { e.seen = true; return e; }                   // environment.py:1383-1384
+    const double px = is_target ? c.tx(other) : c.cam_x(other);
+    const double py = is_target ? c.ty(other) : c.cam_y(other);
+    const double rx = px - c.cam_x(cam), ry = py - c.cam_y(cam);
+    const double rn = norm2(rx, ry);
+    if (rn > c.sight(cam)) return e;
+    const double ang = atan2_deg(ry, rx);
+    double ra = fabs(c.phi(cam) - ang);
+    const double alt = 360.0 - ra;
+    if (alt < ra) ra = alt;
+    if (ra * 2.0 > c.theta(cam)) return e;
+    if (is_target) {                                                               // np_random.binomial(1, tau), entities.py:503
+        const int pair = cam * p.Nt + other;
+        double u;
+        if (c.g.tape_ct) u = c.g.tape_ct[c.env * p.Nc * p.Nt + pair];
+        else if (predrawn && pair < 64 - p.Nc - p.Nt) u = c.udraw(pair);
+        else u = c.draw(tick, stream, (uint32_t)pair);
+        if ((p.tau <= 0.5) ? (u > 1.0 - p.tau) : (u <= p.tau)) { e.seen = true; return e; }
+    }
+    e.need = true; e.rn = rn; e.x = normalize_angle(ang); e.lc = c.env * p.Nc + cam;
+    return e;
+}
+
+template <typename ObsT>
+__device__ __forceinline__ void sector_fetch(const Ctx<ObsT> &c, const SectorEval &e, double2 (&w)[kDegSlots]) {
+    if (e.need) {
+        const double2 *rec = c.g.lut_deg + (e.lc * 360 + degree_of(e.x)) * kDegSlots;
+#pragma unroll
+        for (int i = 0; i < kDegSlots; ++i) w[i] = rec[i];
+    }
+}
+
+template <typename ObsT>
+__device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorEval &e, const double2 (&w)[kDegSlots]) {
+    if (!e.need) return e.seen;
+    bool overflow;
+    double limit = degree_interp(w, e.x, overflow);
+    if (overflow)
+        limit = lut_lookup(c.g.lut_knots + e.lc * c.p.kmax, c.g.lut_bucket + e.lc * c.p.nbucket, c.g.lut_count[e.lc], e.x);
+    return e.rn <= limit * (1.0 + 1e-6);                                           // entities.py:505
+}
+
+template <typename ObsT>
+__device__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn) {
     const Params &p = c.p;
     const int lane = c.lane;
-    // ---- sector tests: Camera.perceive (entities.py:491-505) for camera->target and camera->camera
-    for (int round = 0; round < p.sector_rounds; ++round) {
-        const int q = round * 64 + lane;
-        bool seen = false;
-        if (q < p.n_sector) {
-            int cam, other; bool is_target;
-            if (q < p.bit_cc) { cam = (int)(((float)q + 0.5f) * p.inv_Nt); other = q - cam * p.Nt; is_target = true; }
-            else { const int r = q - p.bit_cc; cam = (int)(((float)r + 0.5f) * p.inv_Nc); other = r - cam * p.Nc; is_target = false; }
-            if (!is_target && cam == other) {
-                seen = true;                                         // environment.py:1383-1384
-            } else {
-                const double px = is_target ? c.tx(other) : c.cam_x(other);
-                const double py = is_target ? c.ty(other) : c.cam_y(other);
-                const double rx = px - c.cam_x(cam), ry = py - c.cam_y(cam);
-                const double rn = norm2(rx, ry);
-                if (!(rn > c.sight(cam))) {
-                    const double ang = atan2_deg(ry, rx);
-                    double ra = fabs(c.phi(cam) - ang);
-                    const double alt = 360.0 - ra;
-                    if (alt < ra) ra = alt;
-                    if (!(ra * 2.0 > c.theta(cam))) {
-                        bool see_through = false;
-                        if (is_target) {                             // np_random.binomial(1, tau), entities.py:503
-                            const double u = c.g.tape_ct ? c.g.tape_ct[(c.env * p.Nc + cam) * p.Nt + other]
-                                                         : c.draw(tick, stream, (uint32_t)(cam * p.Nt + other));
-                            see_through = (p.tau <= 0.5) ? (u > 1.0 - p.tau) : (u <= p.tau);
-                        }
-                        if (see_through) {
-                            seen = true;
-                        } else {
-                            const int64_t lc = c.env * p.Nc + cam;
-                            const double limit = lut_lookup(c.g.lut_knots + lc * p.kmax, c.g.lut_bucket + lc * p.nbucket,
-                                                            c.g.lut_count[lc], normalize_angle(ang));
-                            seen = rn <= limit * (1.0 + 1e-6);       // entities.py:505
-                        }
-                    }
-                }
-            }
-        }
-        const unsigned long long b = __ballot(seen);
+    double2 w[kDegSlots];
+    // ---- sector tests for camera->target and camera->camera; all rounds but the last resolve at once
+    for (int round = 0; round + 1 < p.sector_rounds; ++round) {
+        const SectorEval e = sector_eval(c, round * 64 + lane, tick, stream, predrawn);
+        sector_fetch(c, e, w);
+        const unsigned long long b = __ballot(sector_resolve(c, e, w));
         if (lane == 0) { c.mask[2 * round] = (uint32_t)b; c.mask[2 * round + 1] = (uint32_t)(b >> 32); }
     }
+    // the last round's occlusion records travel while the range tests run
+    const int last = p.sector_rounds - 1;
+    SectorEval pending{false, false, 0.0, 0.0, 0};
+    if (last >= 0) {
+        pending = sector_eval(c, last * 64 + lane, tick, stream, predrawn);
+        sector_fetch(c, pending, w);
+    }
+    SUB_STAMP(c, 13);
     // ---- range tests: Sensor.perceive (entities.py:229-232) target -> camera / obstacle / target
     const int rbase = p.bit_range >> 5;
     for (int round = 0; round < p.range_rounds; ++round) {
@@ -337,11 +442,22 @@ __device__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream) {
             if (j < p.Nc) { ox = c.cam_x(j); oy = c.cam_y(j); orad = p.cam_radius; }
             else if (j < p.Nc + p.No) { const int o = j - p.Nc; ox = c.obs_x(o); oy = c.obs_y(o); orad = c.obs_r(o); }
             else { const int t2 = j - p.Nc - p.No; ox = c.tx(t2); oy = c.ty(t2); orad = 0.0; diag = (t2 == t); }
-            seen = diag || (norm2(c.tx(t) - ox, c.ty(t) - oy) <= p.tgt_sight + orad);
+            // distance <= sight + radius (entities.py:232): decided on squares unless within rounding of the rim
+            const double dx = c.tx(t) - ox, dy = c.ty(t) - oy;
+            const double d2 = fma(dy, dy, dx * dx);
+            const double lim = p.tgt_sight + orad, lim2 = lim * lim;
+            if (d2 < lim2 * (1.0 - 1e-14)) seen = true;
+            else if (d2 > lim2 * (1.0 + 1e-14)) seen = diag;
+            else seen = diag || (sqrt(d2) <= lim);
         }
         const unsigned long long b = __ballot(seen);
         if (lane == 0) { c.mask[rbase + 2 * round] = (uint32_t)b; c.mask[rbase + 2 * round + 1] = (uint32_t)(b >> 32); }
     }
+    if (last >= 0) {
+        const unsigned long long b = __ballot(sector_resolve(c, pending, w));
+        if (lane == 0) { c.mask[2 * last] = (uint32_t)b; c.mask[2 * last + 1] = (uint32_t)(b >> 32); }
+    }
+    SUB_STAMP(c, 14);
     // ---- static camera->obstacle bits (environment.py:752-755) and the always-true bit
     if (lane < p.Nc) {
         const uint64_t m = c.camobs(lane);
@@ -575,35 +691,47 @@ __device__ void pack_observations(Ctx<ObsT> &c) {
     }
 }
 
-__device__ __forceinline__ void stage_table(const Params &p, const Ptrs &g, unsigned char *smem) {
-    const int n16 = p.lds_table_bytes >> 4;
-    const uint4 *src = reinterpret_cast<const uint4 *>(g.desc);
-    uint4 *dst = reinterpret_cast<uint4 *>(smem);
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
-}
 
 // =============================================================================================
 // The step kernel: one wave per environment, 4 environments per workgroup.
 template <typename ObsT>
-__global__ __launch_bounds__(256) void step_kernel(const Params p, const Ptrs g) {
+__global__ __launch_bounds__(256, 4) void step_kernel(const Params p, const Ptrs g) {
     extern __shared__ __align__(16) unsigned char smem[];
-    stage_table(p, g, smem);
+#ifdef MATE_PHASE_CLOCKS
+    const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
+#endif
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;  // next step's counter
-    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t env = (int64_t)blockIdx.x * 4 + wave;
     if (env >= g.N) return;
-    Ctx<ObsT> c(p, g, smem + p.lds_table_bytes + wave * p.lds_wave_bytes, smem, lane, env);
+    // the four waves of a workgroup never synchronise: each owns one environment and its LDS slice
+    Ctx<ObsT> c(p, g, smem + wave * p.lds_wave_bytes, lane, env);
+#ifdef MATE_PHASE_CLOCKS
+    if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + 0] = t_begin;
+#endif
+    PHASE_STAMP(1);
     load_records(c);
     wave_sync();
+    PHASE_STAMP(2);
     const uint32_t tick = (uint32_t)c.ei(EI_TICK);
-    simulate(c, tick);
-    update_view(c, tick, S_TRANSMIT);
+    const StepDraws draws = step_draws(c, tick);
+    SUB_STAMP(c, 9);
+    simulate_cameras(c, draws, g.mode != MODE_OBSERVE);
+    SUB_STAMP(c, 12);
+    if (g.mode != MODE_OBSERVE) simulate_targets(c, draws);
+    else wave_sync();
+    PHASE_STAMP(3);
+    update_view(c, tick, S_TRANSMIT, true);
+    PHASE_STAMP(4);
     if (g.mode == MODE_OBSERVE) score_only(c, g.scalars);
     else assign_and_score(c, tick, g.scalars);
+    PHASE_STAMP(5);
     fill_scratch(c);
+    PHASE_STAMP(6);
     pack_observations(c);
+    PHASE_STAMP(7);
     if (g.mode != MODE_OBSERVE) store_dynamic(c);
+    PHASE_STAMP(8);
 }
 
 }  // namespace mate

@@ -1,6 +1,7 @@
 // mate_engine.hip -- host side of the C ABI declared in include/mate_engine.h.
 // Plain HIP runtime: no torch types cross this boundary (device pointers + sizes only).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -43,7 +44,8 @@ struct mate_engine {
     size_t step_lds = 0, reset_lds = 0;
     std::vector<void *> allocs;
     // kernel timing (HIP events on the launch stream)
-    bool timing = false;
+    int timing = 0;            // 0 = off, k = time every k-th step launch
+    int64_t timing_tick = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
 };
@@ -204,17 +206,20 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     int off = 0;
     p.off_st = off; off += round_up(p.SW * 8, 16);
     p.off_dy = off; off += round_up(p.DW * 8, 16);
-    p.off_tmp = off; off += round_up((Nc + 3 * Nt) * 8, 16);
+    p.off_tmp = off; off += round_up((Nc + 3 * Nt + 64) * 8, 16);
     p.off_scratch = off; off += round_up(p.nscratch * obs_size, 16);
     p.off_mask = off; off += round_up(p.MW * 4, 16);
-    p.off_misc = off; off += round_up((3 * Nt + 8) * 4, 16);
+    p.off_misc = off; off += round_up((4 * Nt + 8) * 4, 16);
     p.lds_wave_bytes = off;
-    e->step_lds = (size_t)p.lds_table_bytes + 4 * (size_t)p.lds_wave_bytes;
+    e->step_lds = 4 * (size_t)p.lds_wave_bytes;
     ResetLds &rl = e->rl;
     rl.sort_cap = std::max(512, next_pow2(Nc > 0 ? 360 + No * 185 + 1 : 1));
-    int roff = p.lds_table_bytes + p.lds_wave_bytes;
+    int roff = p.lds_wave_bytes;
     rl.off_keys = roff; roff += rl.sort_cap * 8;
     rl.off_vals = roff; roff += rl.sort_cap * 8;
+    rl.off_okeys = roff; roff += rl.sort_cap * 8;
+    rl.off_ovals = roff; roff += rl.sort_cap * 8;
+    rl.off_bucket = roff; roff += 368 * 2;
     rl.off_meta = roff; roff += round_up(8 * No * 8 + (2 * No + 4) * 4, 16);
     rl.off_scan = roff; roff += 256 * 4;
     rl.total_bytes = roff;
@@ -235,6 +240,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         if ((rc = dev_alloc(e, &g.lut_knots, N * std::max(Nc, 1) * (size_t)p.kmax, false))) break;
         if ((rc = dev_alloc(e, &g.lut_bucket, N * std::max(Nc, 1) * (size_t)p.nbucket))) break;
         if ((rc = dev_alloc(e, &g.lut_count, N * std::max(Nc, 1)))) break;
+        if ((rc = dev_alloc(e, &g.lut_deg, N * std::max(Nc, 1) * (size_t)360 * kDegSlots, false))) break;
         if ((rc = dev_alloc(e, &g.done_count, (size_t)2))) break;
         if ((rc = dev_alloc(e, &g.done_list, 2 * N))) break;
         std::vector<uint32_t> desc;
@@ -320,7 +326,7 @@ static void apply_io(Ptrs &g, const mate_step_io *io) {
 
 static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream) {
     g.mode = MODE_OBSERVE; g.reset_kind = kind; g.parity = e->parity;
-    const int64_t blocks = kind == RESET_DONE ? std::min<int64_t>(e->N, 512) : e->N;
+    const int64_t blocks = kind == RESET_DONE ? std::min<int64_t>(e->N, 256) : e->N;
     if (e->p.obs_f64) hipLaunchKernelGGL(reset_kernel<double>, dim3((unsigned)blocks), dim3(256), e->reset_lds, stream, e->p, g, e->rl, phases);
     else hipLaunchKernelGGL(reset_kernel<float>, dim3((unsigned)blocks), dim3(256), e->reset_lds, stream, e->p, g, e->rl, phases);
     HIP_TRY(hipGetLastError());
@@ -358,19 +364,19 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     if (mode == MODE_OBSERVE || !auto_reset) g.done_count = nullptr;
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (e->timing && mode != MODE_OBSERVE) {
+    if (e->timing > 0 && mode != MODE_OBSERVE && (e->timing_tick++ % e->timing) == 0) {
         if (e->events_used == e->events.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
             e->events.emplace_back(a, b);
         }
         ev0 = e->events[e->events_used].first; ev1 = e->events[e->events_used].second; ++e->events_used;
-        HIP_TRY(hipEventRecord(ev0, stream));
     }
-    if (e->p.obs_f64) hipLaunchKernelGGL(step_kernel<double>, dim3(blocks), dim3(256), e->step_lds, stream, e->p, g);
-    else hipLaunchKernelGGL(step_kernel<float>, dim3(blocks), dim3(256), e->step_lds, stream, e->p, g);
+    // start/stop events attached to the dispatch itself (hipExtLaunchKernelGGL): the elapsed time is the
+    // kernel's own begin->end, without the marker-packet latency separate hipEventRecord calls would add
+    if (e->p.obs_f64) hipExtLaunchKernelGGL(step_kernel<double>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->p, g);
+    else hipExtLaunchKernelGGL(step_kernel<float>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->p, g);
     HIP_TRY(hipGetLastError());
-    if (ev1) HIP_TRY(hipEventRecord(ev1, stream));
     if (mode != MODE_OBSERVE && auto_reset) {
         Ptrs r = e->g;
         apply_io(r, io);
@@ -442,9 +448,34 @@ extern "C" int mate_engine_lut_write(mate_engine *e, int64_t env, int32_t camera
         bucket[d] = (uint16_t)j;
     }
     const int64_t lc = env * e->p.Nc + camera;
+    // per-degree records (same rule as the device builder in reset_kernels.hpp)
+    std::vector<double2> deg((size_t)360 * kDegSlots);
+    const double inf = INFINITY;
+    for (int d = 0; d < 360; ++d) {
+        const int start = bucket[d], endk = bucket[d + 1];
+        double2 *rec = deg.data() + (size_t)d * kDegSlots;
+        if (endk - start + 1 <= kDegSlots && phis[start] == (double)(d - 180)) {
+            for (int i = 0; i < kDegSlots; ++i) {
+                const int idx = start + i;
+                rec[i].x = idx <= endk ? phis[idx] : inf;
+                rec[i].y = idx <= endk ? rhos[idx] : 0.0;
+            }
+        } else {
+            for (int i = 0; i < kDegSlots; ++i) { rec[i].x = NAN; rec[i].y = 0.0; }
+        }
+    }
+    HIP_TRY(hipMemcpy(e->g.lut_deg + lc * 360 * kDegSlots, deg.data(), sizeof(double2) * deg.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->g.lut_knots + lc * e->p.kmax, knots.data(), sizeof(double2) * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->g.lut_bucket + lc * e->p.nbucket, bucket.data(), sizeof(uint16_t) * bucket.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->g.lut_count + lc, &n, sizeof(n), hipMemcpyHostToDevice));
+    return MATE_OK;
+}
+
+// Debug hook (not part of the stable ABI): per-environment s_memtime stamps at the phase boundaries of
+// the step kernel; only filled by builds with -DMATE_PHASE_CLOCKS.
+extern "C" int mate_engine_debug_phase_clocks(mate_engine *e, long long *buf_dev) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    e->g.phase_clocks = buf_dev;
     return MATE_OK;
 }
 
@@ -464,6 +495,7 @@ extern "C" int mate_engine_kernel_time(mate_engine *e, int32_t enable, double *a
     if (avg_ms) *avg_ms = n ? total / (double)n : 0.0;
     if (launches) *launches = n;
     e->events_used = 0;
-    e->timing = enable != 0;
+    e->timing = enable > 0 ? enable : 0;
+    e->timing_tick = 0;
     return MATE_OK;
 }

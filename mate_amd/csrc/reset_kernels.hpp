@@ -16,7 +16,7 @@ enum ResetKind : int32_t { RESET_ALL = 0, RESET_MASK = 1, RESET_DONE = 2 };
 enum ResetPhase : int32_t { PH_PLACE = 1, PH_LUT = 2, PH_VIEW = 4 };
 
 struct ResetLds {   // byte offsets inside the workgroup's dynamic LDS, after the wave-0 context
-    int32_t off_keys, off_vals, off_meta, off_scan, sort_cap, total_bytes;
+    int32_t off_keys, off_vals, off_okeys, off_ovals, off_bucket, off_meta, off_scan, sort_cap, total_bytes;
 };
 
 struct ResetRng {
@@ -164,7 +164,8 @@ __device__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][cap] x y r sight
     if (p.start_with_cargoes) {                                                             // environment.py:789-807
         for (int t = 0; t < Nt; ++t) {
             if ((c.ti(t, TI_GW) & 0xff) != 0) continue;
-            int wp[4] = {0, 1, 2, 3};
+            int32_t *wp = perm + Nc + Nt + No;   // LDS scratch [4]
+            for (int i = 0; i < 4; ++i) wp[i] = i;
             for (int i = 3; i >= 1; --i) { const int j = rng.randint(i + 1); const int tmp = wp[i]; wp[i] = wp[j]; wp[j] = tmp; }
             for (int q = 0; q < 4; ++q) {
                 int32_t *row = remaining + 4 * wp[q];
@@ -185,7 +186,8 @@ __device__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][cap] x y r sight
 
 // R2: occlusion table of camera `cam` by the whole workgroup.
 template <typename ObsT>
-__device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, double *meta, int32_t *scan, int sort_cap) {
+__device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, double *okeys, double *ovals, uint16_t *lbucket,
+                          double *meta, int32_t *scan, int sort_cap) {
     const Params &p = c.p;
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int No = p.No;
@@ -240,6 +242,11 @@ __device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, dou
     if (hdr[1]) {   // fully blocked view
         if (tid == 0) { knots[0] = make_double2(-180.0, 0.0); knots[1] = make_double2(180.0, 0.0); c.g.lut_count[lc] = 2; }
         for (int d = tid; d < p.nbucket; d += nthreads) bucket[d] = d >= 360 ? 1 : 0;
+        for (int d = tid; d < 360; d += nthreads) {
+            double2 *rec = c.g.lut_deg + (lc * 360 + d) * kDegSlots;
+            rec[0] = make_double2(-180.0, 0.0); rec[1] = make_double2(180.0, 0.0);
+            for (int i = 2; i < kDegSlots; ++i) rec[i] = make_double2(__longlong_as_double(0x7ff0000000000000ll), 0.0);
+        }
         __syncthreads();
         return;
     }
@@ -261,7 +268,7 @@ __device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, dou
                 a = normalize_angle(a);
             }
             double sn, cs;
-            sincos(a * kDeg2Rad, &sn, &cs);
+            sincos_deg(a, sn, cs);
             for (int q = 0; q < No; ++q)                                          // entities.py:450-454
                 if (m_num[q] > 0) n0 = clip_polar(n0, cs, sn, m_relx[q], m_rely[q], m_rn[q], m_rad[q]);
             key = a; val = n0;
@@ -301,24 +308,48 @@ __device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, dou
             const double a = keys[i];
             double rho = vals[i];
             for (int q = i + 1; q < nr && keys[q] == a; ++q) rho = vals[q] < rho ? vals[q] : rho;
-            knots[pos] = make_double2(a, rho);
-            if (a == floor(a)) bucket[(int)a + 180] = (uint16_t)pos;     // per-degree index
-            if (i == 0) { const int m = hdr[2]; knots[m] = make_double2(a + 360.0, rho); }   // entities.py:470-471
+            okeys[pos] = a; ovals[pos] = rho;
+            if (a == floor(a)) lbucket[(int)a + 180] = (uint16_t)pos;     // per-degree index
             ++pos;
         }
     }
-    if (tid == 0) { const int m = hdr[2]; c.g.lut_count[lc] = m + 1; bucket[360] = (uint16_t)m; bucket[361] = (uint16_t)m; }
+    __syncthreads();
+    const int m = hdr[2];
+    if (tid == 0) {
+        okeys[m] = okeys[0] + 360.0; ovals[m] = ovals[0];                 // entities.py:470-471
+        lbucket[360] = (uint16_t)m; lbucket[361] = (uint16_t)m;
+        c.g.lut_count[lc] = m + 1;
+    }
+    __syncthreads();
+    for (int i = tid; i <= m; i += nthreads) knots[i] = make_double2(okeys[i], ovals[i]);
+    for (int d = tid; d < p.nbucket; d += nthreads) bucket[d] = d <= 361 ? lbucket[d] : (uint16_t)m;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    for (int d = tid; d < 360; d += nthreads) {       // per-degree records of the fast lookup path
+        const int start = lbucket[d], endk = lbucket[d + 1];
+        double2 *rec = c.g.lut_deg + (lc * 360 + d) * kDegSlots;
+        if (endk - start + 1 <= kDegSlots) {
+            for (int i = 0; i < kDegSlots; ++i) {
+                const int idx = start + i;
+                rec[i] = idx <= endk ? make_double2(okeys[idx], ovals[idx]) : make_double2(inf, 0.0);
+            }
+        } else {
+            rec[0] = make_double2(__longlong_as_double(0x7ff8000000000000ll), 0.0);
+        }
+    }
     __syncthreads();
 }
 
 template <typename ObsT>
 __global__ __launch_bounds__(256) void reset_kernel(const Params p, const Ptrs g, const ResetLds rl, const int32_t phases) {
     extern __shared__ __align__(16) unsigned char smem[];
-    stage_table(p, g, smem);
+    if (g.reset_kind == RESET_DONE && (int64_t)blockIdx.x >= (int64_t)g.done_count[g.parity]) return;   // idle: nothing finished
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned char *wave_base = smem + p.lds_table_bytes;
+    unsigned char *wave_base = smem;
     double *keys = reinterpret_cast<double *>(smem + rl.off_keys);
     double *vals = reinterpret_cast<double *>(smem + rl.off_vals);
+    double *okeys = reinterpret_cast<double *>(smem + rl.off_okeys);
+    double *ovals = reinterpret_cast<double *>(smem + rl.off_ovals);
+    uint16_t *lbucket = reinterpret_cast<uint16_t *>(smem + rl.off_bucket);
     double *meta = reinterpret_cast<double *>(smem + rl.off_meta);
     int32_t *scan = reinterpret_cast<int32_t *>(smem + rl.off_scan);
     int64_t count = g.N;
@@ -327,7 +358,7 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params p, const Ptrs g
         const int64_t env = g.reset_kind == RESET_DONE ? (int64_t)g.done_list[(int64_t)g.parity * g.N + item] : item;
         if (g.reset_kind == RESET_MASK && !g.reset_mask[env]) continue;
         __syncthreads();
-        Ctx<ObsT> c(p, g, wave_base, smem, lane, env);
+        Ctx<ObsT> c(p, g, wave_base, lane, env);
         if (wave == 0) {
             load_records(c);
             wave_sync();
@@ -336,7 +367,7 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params p, const Ptrs g
         }
         __syncthreads();
         if (phases & PH_LUT)
-            for (int cam = 0; cam < p.Nc; ++cam) build_lut(c, cam, keys, vals, meta, scan, rl.sort_cap);
+            for (int cam = 0; cam < p.Nc; ++cam) build_lut(c, cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap);
         __syncthreads();
         if (wave == 0) {
             // static record back to HBM
@@ -344,8 +375,9 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params p, const Ptrs g
             for (int i = lane; i < p.SW; i += 64) s[i] = c.st[i];
             if (phases & PH_VIEW) {
                 __threadfence();   // this wave reads the tables other waves of the workgroup just wrote
-                simulate(c, 0u);   // MODE_OBSERVE: camera sight + scratch only
-                update_view(c, (uint32_t)c.ei(EI_EPISODE), S_RESET_VIEW);
+                simulate_cameras(c, StepDraws{0.0, 0.0}, false);   // camera sight + scratch only
+                wave_sync();
+                update_view(c, (uint32_t)c.ei(EI_EPISODE), S_RESET_VIEW, false);
                 score_only(c, g.scalars);
                 fill_scratch(c);
                 pack_observations(c);

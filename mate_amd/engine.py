@@ -215,8 +215,9 @@ class Engine:
         check(self.lib.mate_engine_lut_write(self._h, int(env), int(camera), phis.ctypes.data_as(ctypes.c_void_p),
                                              rhos.ctypes.data_as(ctypes.c_void_p), len(phis)))
 
-    def kernel_time(self, enable=True):
-        """(avg ms, launches) of the step kernel since the last call; (re)arms the HIP-event timer."""
+    def kernel_time(self, enable=1):
+        """(avg ms, launches) of the step kernel since the last call; `enable` = k arms the HIP-event timer
+        for every k-th launch (0 disarms)."""
         avg, n = ctypes.c_double(), ctypes.c_int64()
         check(self.lib.mate_engine_kernel_time(self._h, int(enable), ctypes.byref(avg), ctypes.byref(n)))
         return avg.value, n.value
