@@ -1,0 +1,563 @@
+"""The environment boundary: `MultiAgentTracking` (one environment, NumPy in/out -- the drop-in for
+the reference class mate/environment.py:288) and `BatchedMultiAgentTracking` (N environments,
+torch tensors resident in HBM).  Both are thin hosts over the HIP engine (`mate_amd.engine.Engine`);
+there is no CPU simulation path in this package.
+"""
+import copy
+from collections import OrderedDict, defaultdict, deque
+
+import numpy as np
+import torch
+
+from mate_amd import constants as consts
+from mate_amd import spaces
+from mate_amd.config import DEFAULT_CONFIG_FILE, read_config
+from mate_amd.engine import Engine
+from mate_amd.utils import Message, Team, polar2cartesian
+
+__all__ = ['MultiAgentTracking', 'BatchedMultiAgentTracking', 'EnvMeta']
+
+try:  # reference wrappers are gym.Wrapper subclasses; inherit from gym.Env when gym exists
+    import gym as _gym
+    _EnvBase = _gym.Env
+except Exception:  # pragma: no cover
+    _gym = None
+
+    class _EnvBase:
+        metadata = {'render.modes': []}
+        reward_range = (-float('inf'), float('inf'))
+        spec = None
+
+        @property
+        def unwrapped(self):
+            return self
+
+        def __str__(self):
+            return f'<{type(self).__name__}<{getattr(self.spec, "id", "MultiAgentTracking-v0")}>>'
+
+
+class EnvMeta(type(_EnvBase)):
+    """isinstance(wrapped_env, MultiAgentTracking) looks through wrapper chains (environment.py:272-284)."""
+
+    def __instancecheck__(cls, instance):
+        if super().__instancecheck__(instance):
+            return True
+        while hasattr(instance, 'env') and not super().__instancecheck__(instance):
+            instance = instance.env
+        return super().__instancecheck__(instance)
+
+
+# --------------------------------------------------------------------------------------------- entity views
+class _EntityView:
+    """Read-only window onto one entity of one environment (the reference exposes live objects)."""
+
+    def __init__(self, env, index):
+        self._env, self.index = env, index
+
+    def _f(self, name):
+        return self._env._fields()[name]
+
+    @property
+    def x(self):
+        return self.location[0]
+
+    @property
+    def y(self):
+        return self.location[1]
+
+    def distance(self, other):
+        other = other.location if isinstance(other, _EntityView) else np.asarray(other, dtype=np.float64)
+        return float(np.linalg.norm(self.location - other))
+
+    def __sub__(self, other):
+        return self.location - other.location
+
+
+class ObstacleView(_EntityView):
+    @property
+    def location(self):
+        return np.array([self._f('obs_x')[self.index], self._f('obs_y')[self.index]])
+
+    @property
+    def radius(self):
+        return float(self._f('obs_radius')[self.index])
+
+    @property
+    def transmittance(self):
+        return self._env.obstacle_transmittance
+
+    def state(self, private=False):
+        return np.append(self.location, self.radius).astype(np.float64)
+
+
+class CameraView(_EntityView):
+    @property
+    def location(self):
+        return np.array([self._f('cam_x')[self.index], self._f('cam_y')[self.index]])
+
+    @property
+    def radius(self):
+        return float(self._env.config['camera']['radius'])
+
+    @property
+    def orientation(self):
+        return float(self._f('cam_phi')[self.index])
+
+    @property
+    def viewing_angle(self):
+        return float(self._f('cam_theta')[self.index])
+
+    @property
+    def min_viewing_angle(self):
+        return float(self._env.camera_min_viewing_angle)
+
+    @property
+    def max_sight_range(self):
+        return float(self._env.camera_max_sight_range)
+
+    @property
+    def rotation_step(self):
+        return float(self._env.camera_rotation_step)
+
+    @property
+    def zooming_step(self):
+        return float(self._env.camera_zooming_step)
+
+    @property
+    def area_product(self):
+        return self.min_viewing_angle * self.max_sight_range ** 2
+
+    @property
+    def sight_range(self):
+        return float(np.sqrt(self.area_product / self.viewing_angle))
+
+    def state(self, private=False):
+        out = np.concatenate([self.location, [self.radius], polar2cartesian(self.sight_range, self.orientation), [self.viewing_angle]])
+        if private:
+            out = np.append(out, [self.max_sight_range, self.rotation_step, self.zooming_step])
+        return out.astype(np.float64)
+
+    def _table(self):
+        return self._env.engine.lut_read(0, self.index)
+
+    def sight_range_at(self, angle, outer=False):
+        if outer:
+            raise NotImplementedError('the outer occlusion boundary is not built on the device yet (DESIGN.md, next rows)')
+        phis, rhos = self._table()
+        return float(np.interp((angle + 180.0) % 360.0 - 180.0, phis, rhos))
+
+    def boundary_between(self, angle_left, angle_right, outer=False):
+        """Knots of the occlusion boundary inside a sector (entities.py:513-543)."""
+        assert 0.0 < angle_right - angle_left <= 360.0
+        if outer:
+            raise NotImplementedError('the outer occlusion boundary is not built on the device yet (DESIGN.md, next rows)')
+        phis_all, rhos_all = self._table()
+        left = (angle_left + 180.0) % 360.0 - 180.0
+        right = left + (angle_right - angle_left)
+        if right <= 180.0:
+            pick = (left < phis_all) & (phis_all < right)
+            phis, rhos = phis_all[pick], rhos_all[pick]
+        else:
+            a = (left < phis_all) & (phis_all <= 180.0)
+            b = (phis_all > -180.0) & (phis_all < right - 360.0)
+            phis, rhos = np.concatenate([phis_all[a], phis_all[b]]), np.concatenate([rhos_all[a], rhos_all[b]])
+        phis = np.concatenate([[left], phis, [right]])
+        rhos = np.concatenate([[self.sight_range_at(left)], rhos, [self.sight_range_at(right)]])
+        return phis.astype(np.float64), rhos.astype(np.float64)
+
+
+class TargetView(_EntityView):
+    @property
+    def location(self):
+        return np.array([self._f('tgt_x')[self.index], self._f('tgt_y')[self.index]])
+
+    radius = consts.TARGET_RADIUS
+
+    @property
+    def capacity(self):
+        return int(self._f('tgt_capacity')[self.index])
+
+    @property
+    def step_size(self):
+        return self._env.target_step_size / self.capacity
+
+    @property
+    def sight_range(self):
+        return float(self._env.target_sight_range)
+
+    @property
+    def is_colliding(self):
+        return bool(self._f('tgt_colliding')[self.index])
+
+    @property
+    def goal_bits(self):
+        return self._f('tgt_goal_bits')[self.index].astype(np.int64)
+
+    @property
+    def empty_bits(self):
+        return self._f('tgt_empty_bits')[self.index].astype(bool)
+
+    @property
+    def is_loaded(self):
+        return bool(self.goal_bits.any())
+
+    def state(self, private=False):
+        out = np.append(self.location, [self.sight_range, self.is_loaded])
+        if private:
+            out = np.concatenate([out, [self.step_size, self.capacity], self.goal_bits, self.empty_bits])
+        return out.astype(np.float64)
+
+
+# --------------------------------------------------------------------------------------------- shared host logic
+class _ScenarioMixin:
+    """Configuration-derived attributes shared by the single and the batched environment."""
+
+    def _setup_scenario(self, config, kwargs):
+        if config is None:
+            config = {} if len(kwargs) > 0 else DEFAULT_CONFIG_FILE
+        self.config = read_config(config, **kwargs)
+
+    # properties with the reference's names (environment.py:1396-1560)
+    name = property(lambda self: self.config['name'])
+    max_episode_steps = property(lambda self: self.config['max_episode_steps'])
+    camera_min_viewing_angle = property(lambda self: self.config['camera']['min_viewing_angle'])
+    camera_max_sight_range = property(lambda self: self.config['camera']['max_sight_range'])
+    camera_rotation_step = property(lambda self: self.config['camera']['rotation_step'])
+    camera_zooming_step = property(lambda self: self.config['camera']['zooming_step'])
+    target_step_size = property(lambda self: self.config['target']['step_size'])
+    target_sight_range = property(lambda self: self.config['target']['sight_range'])
+    num_cargoes_per_target = property(lambda self: self.config['num_cargoes_per_target'])
+    targets_start_with_cargoes = property(lambda self: self.config.get('targets_start_with_cargoes', True))
+    bounty_factor = property(lambda self: max(0.0, self.config.get('bounty_factor', 1.0)))
+    obstacle_transmittance = property(lambda self: min(max(0.0, self.config.get('obstacle', {}).get('transmittance', 0.0)), 1.0))
+    shuffle_entities = property(lambda self: self.config.get('shuffle_entities', True))
+    num_warehouses = property(lambda self: consts.NUM_WAREHOUSES)
+    high_capacity_target_split = property(lambda self: min(max(0.0, self.config.get('high_capacity_target_split', 0.5)), 1.0))
+    num_high_capacity_targets = property(lambda self: int(self.num_targets * self.high_capacity_target_split))
+    num_low_capacity_targets = property(lambda self: self.num_targets - self.num_high_capacity_targets)
+    camera_observation_dim = property(lambda self: self.camera_observation_space.shape[-1])
+    target_observation_dim = property(lambda self: self.target_observation_space.shape[-1])
+
+    def _setup_spaces(self):
+        Nc, Nt, No = self.num_cameras, self.num_targets, self.num_obstacles
+
+        def box(lo, hi):
+            return spaces.Box(low=np.asarray(lo, dtype=np.float64), high=np.asarray(hi, dtype=np.float64), dtype=np.float64)
+
+        if Nc > 0:
+            rot, zoom = self.camera_rotation_step, self.camera_zooming_step
+            self.camera_action_space = box([-rot, -zoom], [rot, zoom])
+        else:
+            self.camera_action_space = box([0.0, 0.0], [0.0, 0.0])
+        # the reference merges per-target boxes with an element-wise min (environment.py:369-378):
+        # with mixed capacities the joint bound is the full step size of a capacity-1 target
+        step = self.target_step_size
+        self.target_action_space = box([-step, -step], [step, step])
+        self.camera_joint_action_space = spaces.Tuple((self.camera_action_space,) * Nc)
+        self.target_joint_action_space = spaces.Tuple((self.target_action_space,) * Nt)
+        self.action_space = spaces.Tuple((self.camera_joint_action_space, self.target_joint_action_space))
+        self.camera_observation_space = consts.camera_observation_space_of(Nc, Nt, No)
+        self.target_observation_space = consts.target_observation_space_of(Nc, Nt, No)
+        self.camera_joint_observation_space = spaces.Tuple((self.camera_observation_space,) * Nc)
+        self.target_joint_observation_space = spaces.Tuple((self.target_observation_space,) * Nt)
+        self.observation_space = spaces.Tuple((self.camera_joint_observation_space, self.target_joint_observation_space))
+        self.camera_state_space_public, self.camera_state_space_private = consts.CAMERA_STATE_SPACE_PUBLIC, consts.CAMERA_STATE_SPACE_PRIVATE
+        self.target_state_space_public, self.target_state_space_private = consts.TARGET_STATE_SPACE_PUBLIC, consts.TARGET_STATE_SPACE_PRIVATE
+        self.obstacle_state_space = consts.OBSTACLE_STATE_SPACE
+        tail = 2 * Nt + consts.NUM_WAREHOUSES ** 2
+        low = np.concatenate([consts.PRESERVED_SPACE.low] + [consts.CAMERA_STATE_SPACE_PRIVATE.low] * Nc + [consts.TARGET_STATE_SPACE_PRIVATE.low] * Nt
+                             + [consts.OBSTACLE_STATE_SPACE.low] * No + [np.zeros(tail)])
+        high = np.concatenate([consts.PRESERVED_SPACE.high] + [consts.CAMERA_STATE_SPACE_PRIVATE.high] * Nc + [consts.TARGET_STATE_SPACE_PRIVATE.high] * Nt
+                              + [consts.OBSTACLE_STATE_SPACE.high] * No + [np.full(tail, np.inf)])
+        self.state_space = box(low, high)
+        self.freight_scale = float(np.ceil(consts.TERRAIN_WIDTH / self.target_step_size))
+        self.bounty_scale = float(np.ceil(self.freight_scale * self.bounty_factor))
+        self.reward_scale = self.freight_scale + self.bounty_scale
+        self.max_target_team_episode_reward = self.reward_scale * self.num_cargoes_per_target * Nt
+
+
+class MultiAgentTracking(_ScenarioMixin, _EnvBase, metaclass=EnvMeta):
+    """One Multi-Agent Tracking environment on the MI355X engine, with the reference's Python API:
+    `seed / reset / step / state / joint_observation / send_messages / receive_messages / load_config /
+    close` and the attribute set its wrappers and harnesses read."""
+
+    metadata = {'render.modes': ['human', 'rgb_array'], 'video.frames_per_second': 60, 'video.output_frames_per_second': 60}
+    DEFAULT_CONFIG_FILE = DEFAULT_CONFIG_FILE
+
+    def __init__(self, config=None, device=0, obs_dtype=torch.float64, **kwargs):
+        self._setup_scenario(config, kwargs)
+        self._device_index, self._obs_dtype = device, obs_dtype
+        self._seed_value = 0
+        self.engine = Engine(self.config, 1, device=device, seed=0, obs_dtype=obs_dtype)
+        self.num_cameras, self.num_targets, self.num_obstacles = self.engine.num_cameras, self.engine.num_targets, self.engine.num_obstacles
+        self._setup_spaces()
+        Nc, Nt, No = self.num_cameras, self.num_targets, self.num_obstacles
+        self.cameras = [CameraView(self, c) for c in range(Nc)]
+        self.targets = [TargetView(self, t) for t in range(Nt)]
+        self.obstacles = [ObstacleView(self, o) for o in range(No)]
+        self.cameras_ordered, self.targets_ordered, self.obstacles_ordered = list(self.cameras), list(self.targets), list(self.obstacles)
+        self.preserved_data = np.concatenate([[Nc, Nt, No], [0], consts.WAREHOUSES.ravel(), [consts.WAREHOUSE_RADIUS]]).astype(np.float64)
+        self._sparse_reward = self.config['reward_type'] == 'sparse'
+        self.viewer = None
+        self.render_callbacks = OrderedDict()
+        self.camera_message_buffer, self.target_message_buffer = defaultdict(list), defaultdict(list)
+        self.message_buffers = (self.camera_message_buffer, self.target_message_buffer)
+        self.camera_message_queue, self.target_message_queue = defaultdict(deque), defaultdict(deque)
+        self.message_queues = (self.camera_message_queue, self.target_message_queue)
+        self.camera_communication_edges = np.zeros((Nc, Nc), dtype=np.int64)
+        self.target_communication_edges = np.zeros((Nt, Nt), dtype=np.int64)
+        self.camera_total_communication_edges = self.camera_communication_edges.copy()
+        self.target_total_communication_edges = self.target_communication_edges.copy()
+        self.communication_edges = (self.camera_communication_edges, self.target_communication_edges)
+        self.coverage_rate = self.real_coverage_rate = self.mean_transport_rate = 0.0
+        self.num_delivered_cargoes = 0
+        self.episode_step = 0
+        self._cache = None
+        self._masks = None
+        self._np_random = None
+        self.seed(0)
+
+    # ------------------------------------------------------------------ state access
+    def _fields(self):
+        if self._cache is None:
+            self._cache = {k: v[0] for k, v in self.engine.state_dict().items()}
+        return self._cache
+
+    def _mask(self, name):
+        if self._masks is None:
+            self._masks = {k: v[0] for k, v in self.engine.unpack_masks().items()}
+        return self._masks[name]
+
+    camera_target_view_mask = property(lambda self: self._mask('camera_target_view_mask'))
+    target_camera_view_mask = property(lambda self: self._mask('target_camera_view_mask'))
+    target_obstacle_view_mask = property(lambda self: self._mask('target_obstacle_view_mask'))
+    target_target_view_mask = property(lambda self: self._mask('target_target_view_mask'))
+    camera_camera_view_mask = property(lambda self: self._mask('camera_camera_view_mask'))
+    camera_obstacle_view_mask = property(lambda self: self._mask('camera_obstacle_view_mask'))
+    tracked_bits = property(lambda self: self._mask('tracked_bits'))
+    remaining_cargoes = property(lambda self: self._fields()['remaining_cargoes'].astype(np.int64))
+    awaiting_cargo_counts = property(lambda self: self._fields()['awaiting_cargo_counts'].astype(np.int64))
+    target_goals = property(lambda self: self._fields()['tgt_goals'].astype(np.int64))
+    target_goal_bits = property(lambda self: self._fields()['tgt_goal_bits'].astype(np.int64))
+    target_capacities = property(lambda self: self._fields()['tgt_capacity'].astype(np.int64))
+    target_steps = property(lambda self: self._fields()['target_steps'].astype(np.int64))
+    tracked_steps = property(lambda self: self._fields()['tracked_steps'].astype(np.int64))
+    freights = property(lambda self: self._fields()['freights'].astype(np.int64))
+    bounties = property(lambda self: self._fields()['bounties'].astype(np.int64))
+    target_team_episode_reward = property(lambda self: float(self._fields()['episode_reward']))
+    delayed_target_team_episode_reward = property(lambda self: float(self._fields()['delayed_episode_reward']))
+
+    @property
+    def obstacle_states(self):
+        f = self._fields()
+        return np.stack([f['obs_x'], f['obs_y'], f['obs_radius']], axis=-1).reshape(self.num_obstacles, 3)
+
+    @property
+    def obstacle_states_flagged(self):
+        return np.hstack([self.obstacle_states, np.ones((self.num_obstacles, 1))])
+
+    @property
+    def target_warehouse_distances(self):
+        f = self._fields()
+        xy = np.stack([f['tgt_x'], f['tgt_y']], axis=-1)
+        return np.linalg.norm(xy[:, None, :] - consts.WAREHOUSES[None], axis=-1)
+
+    @property
+    def np_random(self):
+        if self._np_random is None:
+            self.seed()
+        return self._np_random
+
+    # ------------------------------------------------------------------ gym API
+    def seed(self, seed=None):
+        """Seed the host RNG handed to callers and the engine's counter-based streams."""
+        if seed is None:
+            seed = int(np.random.SeedSequence().entropy % (2 ** 31))
+        if not (isinstance(seed, (int, np.integer)) and seed >= 0):
+            raise ValueError(f'Seed must be a non-negative integer or omitted, not {seed}')
+        self._seed_value = int(seed)
+        self._np_random = np.random.RandomState(self._seed_value % (2 ** 32))
+        self.engine.seed(self._seed_value)
+        return [self._seed_value]
+
+    def _collect(self):
+        self._cache = self._masks = None
+        cam = self.engine.camera_obs[0].to(torch.float64).cpu().numpy() if self.num_cameras else np.zeros((0, self.camera_observation_dim))
+        tgt = self.engine.target_obs[0].to(torch.float64).cpu().numpy()
+        scalars = self.engine.scalars[0].cpu().numpy()
+        self.coverage_rate, self.real_coverage_rate = float(scalars[3]), float(scalars[4])
+        self.mean_transport_rate, self.num_delivered_cargoes = float(scalars[5]), int(scalars[6])
+        return cam, tgt, scalars
+
+    def reset(self, *, seed=None):
+        self._clear_messages(totals=True)
+        if seed is not None:
+            self.seed(seed)
+        self.engine.reset()
+        cam, tgt, _ = self._collect()
+        self.target_dones = np.zeros(self.num_targets, dtype=bool)
+        self._last_goals = self.target_goals.copy()
+        self.episode_step = 0
+        return cam, tgt
+
+    def step(self, action):
+        camera_joint_action, target_joint_action = action
+        cam_act = np.asarray(camera_joint_action, dtype=np.float64).reshape(self.num_cameras, consts.CAMERA_ACTION_DIM)
+        tgt_act = np.asarray(target_joint_action, dtype=np.float64).reshape(self.num_targets, consts.TARGET_ACTION_DIM)
+        assert np.isfinite(cam_act).all(), f'Got unexpected joint action {cam_act}.'
+        assert np.isfinite(tgt_act).all(), f'Got unexpected joint action {tgt_act}.'
+        dev = self.engine.device
+        self.engine.step(torch.from_numpy(cam_act[None]).to(dev), torch.from_numpy(tgt_act[None]).to(dev), auto_reset=False)
+        cam, tgt, scalars = self._collect()
+        goals = self.target_goals
+        self.target_dones = (goals != self._last_goals) & (self._last_goals >= 0)
+        self._last_goals = goals.copy()
+        self.episode_step += 1
+        r_tgt = float(scalars[1])
+        r_cam = -r_tgt
+        done = bool(scalars[2])
+        norm = r_tgt / self.max_target_team_episode_reward
+        common = {'coverage_rate': self.coverage_rate, 'real_coverage_rate': self.real_coverage_rate,
+                  'mean_transport_rate': self.mean_transport_rate, 'num_delivered_cargoes': self.num_delivered_cargoes}
+        camera_infos = [dict(raw_reward=r_cam, normalized_raw_reward=-norm, messages=self.camera_message_buffer[c],
+                             out_communication_edges=self.camera_communication_edges[c, :].sum(),
+                             in_communication_edges=self.camera_communication_edges[:, c].sum(), **common)
+                        for c in range(self.num_cameras)]
+        target_infos = [dict(raw_reward=r_tgt, normalized_raw_reward=norm, messages=self.target_message_buffer[t],
+                             out_communication_edges=self.target_communication_edges[t, :].sum(),
+                             in_communication_edges=self.target_communication_edges[:, t].sum(), **common)
+                        for t in range(self.num_targets)]
+        self._clear_messages(totals=False)
+        return (cam, tgt), (r_cam, r_tgt), done, (camera_infos, target_infos)
+
+    def joint_observation(self):
+        self.engine.observe()
+        cam, tgt, _ = self._collect()
+        return cam, tgt
+
+    def state(self):
+        f = self._fields()
+        parts = [self.preserved_data] + [c.state(private=True) for c in self.cameras] + [t.state(private=True) for t in self.targets] \
+            + [o.state() for o in self.obstacles] + [f['freights'], f['bounties'], f['remaining_cargoes'].ravel()]
+        return np.concatenate(parts).astype(np.float64)
+
+    def load_config(self, config=None):
+        seed = self.np_random.randint(np.iinfo(np.int32).max)
+        self.engine.close()
+        self.__init__(config=config, device=self._device_index, obs_dtype=self._obs_dtype)
+        self.seed(seed)
+
+    def render(self, mode='human', **kwargs):
+        raise NotImplementedError('rendering is out of scope of the MI355X step engine (no display on the GPU box)')
+
+    def add_render_callback(self, name, callback):
+        self.render_callbacks[name] = callback
+
+    def close(self):
+        self.engine.close()
+
+    def __str__(self):
+        def plural(n, word):
+            return f'{n} {word}{"s" if n > 1 else ""}'
+        return f'{_EnvBase.__str__(self)}({plural(self.num_cameras, "camera")}, {plural(self.num_targets, "target")}, {plural(self.num_obstacles, "obstacle")})'
+
+    # ------------------------------------------------------------------ intra-team messaging (host-side mailbox)
+    def _clear_messages(self, totals):
+        if totals:
+            self.camera_total_communication_edges.fill(0)
+            self.target_total_communication_edges.fill(0)
+        else:
+            self.camera_total_communication_edges += self.camera_communication_edges
+            self.target_total_communication_edges += self.target_communication_edges
+        self.camera_communication_edges.fill(0)
+        self.target_communication_edges.fill(0)
+        for store in (self.camera_message_buffer, self.target_message_buffer, self.camera_message_queue, self.target_message_queue):
+            store.clear()
+
+    def route_messages(self, messages):
+        """Expand broadcasts into one message per teammate (environment.py:1249-1269)."""
+        routed = []
+        for message in messages:
+            if message.recipient is None:
+                for recipient in range((self.num_cameras, self.num_targets)[message.team.value]):
+                    routed.append(Message(sender=message.sender, recipient=recipient, content=copy.deepcopy(message.content),
+                                          team=message.team, broadcasting=True))
+            else:
+                routed.append(message)
+        return routed
+
+    def send_messages(self, messages):
+        if isinstance(messages, Message):
+            messages = (messages,)
+        messages = list(messages)
+        assert len({m.team for m in messages}) <= 1, f'All messages must be from the same team. Got messages = {messages}.'
+        for message in self.route_messages(messages):
+            team = message.team.value
+            self.message_queues[team][message.recipient].append(message)
+            self.message_buffers[team][message.recipient].append(message)
+            self.communication_edges[team][message.sender, message.recipient] += 1
+
+    def receive_messages(self, agent_id=None, agent=None):
+        if agent_id is None and agent is None:
+            out = ([list(self.camera_message_queue[c]) for c in range(self.num_cameras)],
+                   [list(self.target_message_queue[t]) for t in range(self.num_targets)])
+            self.camera_message_queue.clear()
+            self.target_message_queue.clear()
+            return out
+        if agent_id is not None and not isinstance(agent_id, tuple) and agent is None:
+            agent_id, agent = None, agent_id
+        team, index = (agent.TEAM, agent.index) if agent is not None else agent_id
+        out = list(self.message_queues[team.value][index])
+        del self.message_queues[team.value][index]
+        return out
+
+
+class BatchedMultiAgentTracking(_ScenarioMixin):
+    """N independent environments stepped by one kernel launch; every array is a torch tensor on the GPU.
+
+        env = BatchedMultiAgentTracking('MATE-4v8-9.yaml', num_envs=4096)
+        cam_obs, tgt_obs = env.reset()
+        (cam_obs, tgt_obs), (r_cam, r_tgt), done, info = env.step((cam_act, tgt_act))
+
+    `first_env_index` makes the RNG streams of a shard equal to those of the same environments in a
+    larger single-GPU batch (sharding invariance, DESIGN.md section "multi-GPU")."""
+
+    def __init__(self, config=None, num_envs=1, device=0, seed=0, first_env_index=0, obs_dtype=torch.float32, auto_reset=True, **kwargs):
+        self._setup_scenario(config, kwargs)
+        self.num_envs, self.auto_reset = int(num_envs), bool(auto_reset)
+        self.engine = Engine(self.config, self.num_envs, device=device, seed=seed, first_env_index=first_env_index, obs_dtype=obs_dtype)
+        self.num_cameras, self.num_targets, self.num_obstacles = self.engine.num_cameras, self.engine.num_targets, self.engine.num_obstacles
+        self._setup_spaces()
+        self.device = self.engine.device
+
+    def seed(self, seed):
+        self.engine.seed(int(seed))
+        return [int(seed)]
+
+    def reset(self, env_mask=None):
+        return self.engine.reset(env_mask)
+
+    def _result(self):
+        s = self.engine.scalars
+        info = {'coverage_rate': s[:, 3], 'real_coverage_rate': s[:, 4], 'mean_transport_rate': s[:, 5],
+                'num_delivered_cargoes': s[:, 6], 'normalized_raw_reward': s[:, 7]}
+        return (self.engine.camera_obs, self.engine.target_obs), (s[:, 0], s[:, 1]), s[:, 2] > 0, info
+
+    def step(self, action):
+        cam_act, tgt_act = action
+        self.engine.step(cam_act, tgt_act, auto_reset=self.auto_reset)
+        return self._result()
+
+    def step_random(self):
+        """One step under the on-device uniform random policy (no action tensors)."""
+        self.engine.step_random(auto_reset=self.auto_reset)
+        return self._result()
+
+    def masks(self):
+        return self.engine.unpack_masks()
+
+    def state_dict(self):
+        return self.engine.state_dict()
+
+    def close(self):
+        self.engine.close()

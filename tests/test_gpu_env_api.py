@@ -1,0 +1,106 @@
+"""GPU tests of the Python boundary: the single-environment NumPy API (drop-in for the reference
+class) and the batched torch API."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+import gpu_util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_env_reference_style_loop():
+    """config[0] plumbing: MATE-4v2-9, one environment, random actions, evaluate-style loop."""
+    import mate_amd
+    env = mate_amd.make('MATE-4v2-9-v0')
+    assert str(env).endswith('(4 cameras, 2 targets, 9 obstacles)')
+    assert env.seed(3) == [3]
+    cam_obs, tgt_obs = env.reset()
+    assert cam_obs.shape == (4, 96) and tgt_obs.shape == (2, 101) and cam_obs.dtype == np.float64
+    assert env.camera_observation_space.contains(cam_obs[0]) and env.target_observation_space.contains(tgt_obs[1])
+    assert env.state().shape == env.state_space.shape == (13 + 9 * 4 + 14 * 2 + 3 * 9 + 2 * 2 + 16,)
+    assert np.array_equal(cam_obs[:, 3], np.arange(4)) and np.array_equal(tgt_obs[:, 3], np.arange(2))
+    assert (env.target_goals >= 0).all() and env.awaiting_cargo_counts.sum() == 8 * 2
+    rng = np.random.RandomState(0)
+    total = 0.0
+    for step in range(60):
+        action = (rng.uniform(-1, 1, (4, 2)) * [5.0, 2.5], rng.uniform(-20, 20, (2, 2)))
+        (cam_obs, tgt_obs), (r_cam, r_tgt), done, (cam_infos, tgt_infos) = env.step(action)
+        assert r_cam == -r_tgt and isinstance(done, bool) and len(cam_infos) == 4 and len(tgt_infos) == 2
+        assert set(cam_infos[0]) >= {'raw_reward', 'normalized_raw_reward', 'messages', 'coverage_rate', 'real_coverage_rate',
+                                     'mean_transport_rate', 'num_delivered_cargoes', 'out_communication_edges', 'in_communication_edges'}
+        assert env.episode_step == step + 1
+        total += r_tgt
+        # the observation is the packed view of the state the attributes expose
+        t0 = env.targets[0]
+        assert np.allclose(tgt_obs[0, 13:15], t0.location) and tgt_obs[0, 16] == float(t0.is_loaded)
+        assert np.allclose(cam_obs[1, 13:22], env.cameras[1].state(private=True))
+        assert np.array_equal(env.camera_target_view_mask.any(axis=0), env.tracked_bits)
+        assert env.coverage_rate == pytest.approx(env.tracked_bits.mean())
+    assert env.target_team_episode_reward == pytest.approx(total)
+    with pytest.raises(AssertionError):
+        env.step((np.full((4, 2), np.nan), np.zeros((2, 2))))
+    env.close()
+
+
+def test_single_env_replays_golden_trace_without_obstacles():
+    """MATE-4v8-0 has no obstacles and transmittance 0: no random draw on the step path, so the plain
+    `env.step()` API must reproduce the reference trace from the injected reset state."""
+    import mate_amd
+    fx = G.load('trace_4v8-0_random_s0.npz')
+    env = mate_amd.make('MATE-4v8-0-v0')
+    env.reset()
+    state = {k: v[None] for k, v in U.fixture_state(fx).items()}
+    state.update(tick=np.zeros(1), episode=np.ones(1), done=np.zeros(1))
+    env.engine.load_state_dict(state)
+    env.engine.rebuild_luts()
+    env._cache = env._masks = None
+    env._last_goals = env.target_goals.copy()
+    for s in range(len(fx['step/done'])):
+        (cam_obs, tgt_obs), (r_cam, r_tgt), done, _ = env.step((fx['step/cam_act'][s], fx['step/tgt_act'][s]))
+        assert np.allclose(cam_obs, fx['step/cam_obs'][s], rtol=0, atol=1e-9)
+        assert np.allclose(tgt_obs, fx['step/tgt_obs'][s], rtol=0, atol=1e-9)
+        assert r_tgt == fx['step/reward_tgt'][s] and done == bool(fx['step/done'][s])
+        assert np.array_equal(env.camera_target_view_mask, fx['step/camera_target_view_mask'][s])
+        assert np.array_equal(env.target_dones, fx['step/target_dones'][s])
+        assert np.allclose(env.state(), fx['step/state'][s], rtol=0, atol=1e-9)
+        assert np.allclose(env.target_warehouse_distances, fx['step/target_warehouse_distances'][s], rtol=0, atol=1e-9)
+
+
+def test_messaging_is_a_host_side_mailbox():
+    import mate_amd
+    from mate_amd import Message, Team
+    env = mate_amd.make('MATE-4v2-9-v0')
+    env.reset()
+    env.send_messages(Message(sender=0, recipient=None, content={'k': 1}, team=Team.CAMERA))
+    env.send_messages([Message(sender=1, recipient=0, content='x', team=Team.TARGET)])
+    assert env.camera_communication_edges[0].sum() == 4 and env.target_communication_edges[1, 0] == 1
+    got = env.receive_messages(agent_id=(Team.CAMERA, 2))
+    assert len(got) == 1 and got[0].broadcasting and got[0].content == {'k': 1}
+    cams, tgts = env.receive_messages()
+    assert [len(q) for q in cams] == [1, 1, 0, 1] and [len(q) for q in tgts] == [1, 0]
+    _, _, _, (cam_infos, tgt_infos) = env.step((np.zeros((4, 2)), np.zeros((2, 2))))
+    assert len(cam_infos[3]['messages']) == 1 and cam_infos[0]['out_communication_edges'] == 4
+    assert env.camera_communication_edges.sum() == 0 and env.camera_total_communication_edges.sum() == 4
+
+
+def test_batched_env_and_sharding_invariance():
+    """A shard (first_env_index = k) reproduces environments k.. of the full batch bit for bit."""
+    from mate_amd.environment import BatchedMultiAgentTracking
+    full = BatchedMultiAgentTracking('MATE-4v8-9.yaml', num_envs=24, seed=5)
+    part = BatchedMultiAgentTracking('MATE-4v8-9.yaml', num_envs=8, seed=5, first_env_index=16)
+    full.reset(); part.reset()
+    for _ in range(12):
+        (co_f, to_f), (rc_f, rt_f), done_f, info_f = full.step_random()
+        (co_p, to_p), (rc_p, rt_p), done_p, info_p = part.step_random()
+    assert torch.equal(co_f[16:], co_p) and torch.equal(to_f[16:], to_p) and torch.equal(rt_f[16:], rt_p)
+    assert co_f.dtype == torch.float32 and co_f.shape == (24, 4, 126) and to_f.shape == (24, 8, 131)
+    # explicit actions: zero actions leave the targets where they are
+    before = full.state_dict()
+    cam_act = torch.zeros((24, 4, 2), device=full.device)
+    tgt_act = torch.zeros((24, 8, 2), device=full.device)
+    full.step((cam_act, tgt_act))
+    after = full.state_dict()
+    assert np.array_equal(before['tgt_x'], after['tgt_x']) and np.array_equal(before['cam_phi'], after['cam_phi'])
+    assert (after['episode_step'] == before['episode_step'] + 1).all()

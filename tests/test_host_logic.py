@@ -1,0 +1,141 @@
+"""CPU-only tests of the host side: scenario data, configuration reader, observation layout,
+C-ABI library symbols, sharding helper.  Comparisons against the upstream reference run only where
+/root/reference exists (the build container); they are skipped elsewhere."""
+import ctypes
+import glob
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = '/root/reference'
+HAVE_REF = os.path.isdir(os.path.join(REFERENCE, 'mate'))
+
+
+@pytest.fixture(scope='module')
+def ref_mate():
+    if not HAVE_REF:
+        pytest.skip('upstream reference not available here')
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden', 'gymshim'))
+    sys.path.insert(0, REFERENCE)
+    import gym  # noqa: F401  (the build-owned shim)
+    import mate
+    return mate
+
+
+def test_scenarios_match_reference_assets():
+    if not HAVE_REF:
+        pytest.skip('upstream reference not available here')
+    import yaml
+    from mate_amd import scenarios
+    files = sorted(glob.glob(os.path.join(REFERENCE, 'mate', 'assets', '*.yaml')))
+    assert len(files) == len(scenarios.SCENARIOS) == 18
+    for f in files:
+        with open(f) as fh:
+            assert yaml.safe_load(fh) == scenarios.scenario(os.path.basename(f)), f
+
+
+def test_read_config_defaults_and_errors():
+    from mate_amd.config import read_config
+    cfg = read_config('MATE-1v1-0.yaml')
+    assert cfg['shuffle_entities'] is True and cfg['high_capacity_target_split'] == 0.5
+    assert cfg['camera']['location'] == [[0.0, 0.0]]
+    cfg = read_config('MATE-Navigation.yaml')
+    assert cfg['bounty_factor'] == 1.0 and cfg['reward_type'] == 'sparse' and len(cfg['obstacle']['location_random_range']) == 32
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=12, camera={'radius': 30.0})
+    assert cfg['max_episode_steps'] == 12 and cfg['camera']['radius'] == 30.0 and cfg['camera']['max_sight_range'] == 1500.0
+    with pytest.raises(ValueError, match='Did you mean'):
+        read_config('MATE-4v8-8.yaml')
+    with pytest.raises(ValueError, match='num_cargoes_per_target'):
+        read_config('MATE-4v8-9.yaml', num_cargoes_per_target=3)
+    with pytest.raises(ValueError, match='at least one target'):
+        read_config({'num_cargoes_per_target': 8, 'target': {}})
+    with pytest.raises(ValueError, match='max_episode_steps'):
+        read_config('MATE-4v8-9.yaml', max_episode_steps=0)
+    with pytest.raises(ValueError, match='reward type'):
+        read_config('MATE-4v8-9.yaml', reward_type='shaped')
+
+
+def test_read_config_matches_reference(ref_mate):
+    from mate_amd.config import read_config
+    from mate.environment import read_config as ref_read
+    for name in ('MATE-4v2-9.yaml', 'MATE-4v8-9.yaml', 'MATE-8v8-9.yaml', 'MATE-4v8-0.yaml', 'MATE-Navigation.yaml', 'MATE-1v1-0.yaml'):
+        mine, ref = read_config(name), ref_read(name)
+        for key in ('max_episode_steps', 'reward_type', 'num_cargoes_per_target', 'high_capacity_target_split',
+                    'targets_start_with_cargoes', 'bounty_factor', 'shuffle_entities'):
+            assert mine[key] == ref[key], (name, key)
+        for ent in ('camera', 'target', 'obstacle'):
+            boxes = ref[ent].get('location_random_range', [])
+            got = mine[ent].get('location_random_range', [])
+            assert len(boxes) == len(got)
+            for b, g in zip(boxes, got):
+                assert [b.low[0], b.high[0], b.low[1], b.high[1]] == g
+            for k, v in ref[ent].items():
+                if k not in ('location', 'location_random_range', 'radius_random_range'):
+                    assert mine[ent][k] == v, (name, ent, k)
+
+
+def test_observation_layout_matches_reference(ref_mate):
+    from mate import constants as R
+    from mate_amd import constants as C
+    for nums in ((4, 2, 9), (4, 8, 9), (8, 8, 9), (4, 8, 0), (0, 8, 32), (1, 1, 0)):
+        for mine, ref in ((C.camera_observation_space_of(*nums), R.camera_observation_space_of(*nums)),
+                          (C.target_observation_space_of(*nums), R.target_observation_space_of(*nums))):
+            assert np.array_equal(mine.low, ref.low) and np.array_equal(mine.high, ref.high)
+        assert np.array_equal(C.camera_observation_indices_of(*nums), R.camera_observation_indices_of(*nums))
+        assert np.array_equal(C.target_observation_indices_of(*nums), R.target_observation_indices_of(*nums))
+        assert C.camera_observation_slices_of(*nums) == R.camera_observation_slices_of(*nums)
+        assert C.target_observation_slices_of(*nums) == R.target_observation_slices_of(*nums)
+        assert np.array_equal(C.camera_coordinate_mask_of(*nums), R.camera_coordinate_mask_of(*nums))
+        assert np.array_equal(C.target_coordinate_mask_of(*nums), R.target_coordinate_mask_of(*nums))
+    assert np.array_equal(C.WAREHOUSES, R.WAREHOUSES) and C.WAREHOUSE_RADIUS == R.WAREHOUSE_RADIUS
+    assert np.array_equal(C.PRESERVED_SPACE.high, R.PRESERVED_SPACE.high)
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """The in-tree HIP library loads without a GPU and exports exactly what include/mate_engine.h declares."""
+    from mate_amd import _native
+    assert os.path.exists(_native.LIB_PATH), 'run __graft_entry__.build() first'
+    with open(os.path.join(ROOT, 'include', 'mate_engine.h')) as fh:
+        header = fh.read()
+    declared = set(re.findall(r'\b(mate_engine_[a-z_]+)\s*\(', header))
+    assert declared == set(_native.EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.mate_engine_abi_version.restype = ctypes.c_int
+    assert lib.mate_engine_abi_version() == 1
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    from mate_amd import _native
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    with pytest.raises((_native.EngineError, RuntimeError, AssertionError)):
+        Engine(read_config('MATE-4v8-9.yaml'), 4)
+
+
+def test_shard_of_covers_the_batch():
+    from mate_amd.distributed import shard_of
+    for total, world in ((65536, 8), (32768, 8), (4096, 3), (10, 4), (7, 8)):
+        spans = [shard_of(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+            assert f0 + c0 == f1
+
+
+def test_export_layout_is_dense():
+    from mate_amd.engine import export_layout
+    layout, width = export_layout(4, 8, 9)
+    offs = sorted((off, int(np.prod(shape)) if shape else 1) for off, shape in layout.values())
+    pos = 0
+    for off, n in offs:
+        assert off == pos
+        pos += n
+    assert pos == width == 242
