@@ -40,6 +40,18 @@ def algorithmic_bytes(Nc, Nt, No):
     return 4 * (Nc * Dc + Nt * Dt) + 8 * (Nc + Nt) + 2 * (16 * Nc + 35 * Nt + 72) + (24 * Nc + 24 * No + Nt) + 48
 
 
+def measured_traffic():
+    """HBM bytes per step_kernel launch from the committed rocprofv3 PMC summary (FETCH_SIZE + WRITE_SIZE,
+    KiB, separate --pmc passes; see profiles/README.md).  None when no profile is present."""
+    path = os.path.join(ROOT, 'profiles', 'latest_pmc.json')
+    try:
+        with open(path) as fh:
+            k = json.load(fh)['step_kernel']
+        return (k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds=10.0):
     """Oracle (CPU port of the reference step path) on the host cores: step + f32 observation pack."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -151,7 +163,9 @@ def main():
                                    f'auto-reset', 'global_batch': total_envs, 'parallelism': f'env-shard x{world}'},
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                'frac': achieved / HBM_PEAK_GBS,
+                'traffic': measured_traffic() if args.batch == BATCH_PER_GPU and args.workload == WORKLOAD else None,
+                'traffic_unit': 'bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/latest_pmc.json)',
                 'kernel': 'step_kernel<float>', 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches,
                 'algorithmic_bytes_per_launch': b_alg * args.batch,
             },
