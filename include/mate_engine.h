@@ -112,6 +112,13 @@ int mate_engine_step(mate_engine *engine, const mate_step_io *io, int32_t auto_r
  * io->*_actions_dev are ignored. */
 int mate_engine_step_random(mate_engine *engine, const mate_step_io *io, int32_t auto_reset, void *stream);
 
+/* `steps` consecutive step() calls under the on-device random policy fused into ONE launch (rollout
+ * collection, the `for _ in range(T): env.step(...)` loop of examples/random.py).  Every io output
+ * buffer is rollout-shaped: [steps][N][...] (row r*N + i = step r of environment i).  An environment
+ * whose episode ends at step r stops there: its scalar rows of later steps carry done = 2 and its
+ * observation rows are left untouched; with auto_reset it starts a new episode before the next call. */
+int mate_engine_rollout_random(mate_engine *engine, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream);
+
 /* joint_observation() (environment.py:908-983) without advancing the simulation: recomputes
  * the view masks from the current state (see-through draws from io tape or Philox) and packs. */
 int mate_engine_observe(mate_engine *engine, const mate_step_io *io, void *stream);

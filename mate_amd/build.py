@@ -12,7 +12,10 @@ SRC = os.path.join(HERE, 'csrc', 'mate_engine.hip')
 DEPS = [SRC] + [os.path.join(HERE, 'csrc', f) for f in ('engine_kernels.hpp', 'reset_kernels.hpp', 'device_math.hpp')] + [
     os.path.join(os.path.dirname(HERE), 'include', 'mate_engine.h')]
 OUT = os.path.join(HERE, 'lib', 'libmate_engine.so')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+         # MachineLICM hoists every literal (polynomial coefficients, masks) out of the phase loops and pins
+         # ~50 VGPRs for the whole kernel; without it step_kernel needs 52 VGPRs instead of 100
+         '-mllvm', '-disable-machine-licm']
 
 
 def needs_build():

@@ -34,7 +34,8 @@ struct Params {
     double freight_scale, bounty_scale, reward_scale, max_team_reward;
     double obs_r_lo, obs_r_hi;
     uint32_t seed_lo, seed_hi, first_env;
-    int32_t lds_table_bytes, lds_wave_bytes, off_st, off_dy, off_tmp, off_scratch, off_mask, off_misc;
+    int32_t lds_table_bytes, lds_wave_bytes, off_st, off_dy, off_tmp, off_scratch, off_mask, off_misc, off_flags, off_ent;
+    float inv_No;
     int32_t export_width;
 };
 
@@ -57,8 +58,11 @@ struct Ptrs {
     int32_t *done_list;           // [2][N]
     const uint8_t *reset_mask;    // optional
     long long *phase_clocks;      // [N][16] s_memtime stamps (debug builds with -DMATE_PHASE_CLOCKS)
+    int32_t debug_skip;           // phase-ablation mask (debug builds only)
     int64_t N;
     int32_t mode, act_f64, parity, reset_kind;
+    int32_t rollout_steps;        // steps per launch of rollout_kernel
+    uint32_t tick;                // host step counter: Philox tick of this launch (all environments step together)
 };
 
 #ifdef MATE_PHASE_CLOCKS
@@ -83,15 +87,18 @@ struct Ctx {
     const Ptrs &g;
     int lane;
     int64_t env;
+    int64_t out;                  // row of this environment in the output buffers (env, or step*N + env in rollouts)
     double *st, *dy, *tmp;
     int32_t *di;
     ObsT *scratch;
     uint32_t *mask;
     int32_t *misc;
     const uint32_t *table;
+    unsigned char *base;
+    double *ex, *ey, *er;         // unified entity table [cameras | obstacles | targets]: x, y, radius
 
     __device__ Ctx(const Params &p_, const Ptrs &g_, unsigned char *wave_base, int lane_, int64_t env_)
-        : p(p_), g(g_), lane(lane_), env(env_) {
+        : p(p_), g(g_), lane(lane_), env(env_), out(env_) {
         st = reinterpret_cast<double *>(wave_base + p.off_st);
         dy = reinterpret_cast<double *>(wave_base + p.off_dy);
         di = reinterpret_cast<int32_t *>(dy + p.DF);
@@ -100,6 +107,8 @@ struct Ctx {
         mask = reinterpret_cast<uint32_t *>(wave_base + p.off_mask);
         misc = reinterpret_cast<int32_t *>(wave_base + p.off_misc);
         table = g_.desc;   // read through L1: every wave on the CU gathers through the same 6 KB table
+        base = wave_base;
+        ex = reinterpret_cast<double *>(wave_base + p.off_ent); ey = ex + p.NJ; er = ey + p.NJ;
     }
     // static record
     __device__ double cam_x(int c) const { return st[c]; }
@@ -110,9 +119,10 @@ struct Ctx {
     __device__ uint64_t camobs(int c) const { return reinterpret_cast<const uint64_t *>(st)[2 * p.Nc + 3 * p.No + c]; }
     __device__ uint64_t capword() const { return reinterpret_cast<const uint64_t *>(st)[3 * p.Nc + 3 * p.No]; }
     __device__ void circle(int k, double &x, double &y, double &r) const {  // obstacles, then cameras (Target.add_obstacles, environment.py:743)
-        if (k < p.No) { x = obs_x(k); y = obs_y(k); r = obs_r(k); }
-        else { x = cam_x(k - p.No); y = cam_y(k - p.No); r = p.cam_radius; }
+        const int j = k < p.No ? p.Nc + k : k - p.No;
+        x = ex[j]; y = ey[j]; r = er[j];
     }
+    __device__ int tgt_slot(int t) const { return p.Nc + p.No + t; }
     // dynamic record
     __device__ double &phi(int c) { return dy[c]; }
     __device__ double &theta(int c) { return dy[p.Nc + c]; }
@@ -140,6 +150,15 @@ struct Ctx {
     }
 };
 
+template <typename ObsT> struct Bits;
+template <> struct Bits<float> { using type = uint32_t; };
+template <> struct Bits<double> { using type = uint64_t; };
+template <typename ObsT>
+__device__ __forceinline__ void set_flag(const Ctx<ObsT> &c, int bit, bool on) {
+    using U = typename Bits<ObsT>::type;
+    reinterpret_cast<U *>(c.base + c.p.off_flags)[bit] = on ? ~(U)0 : (U)0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // record <-> LDS
 template <typename ObsT>
@@ -153,6 +172,19 @@ __device__ void load_records(Ctx<ObsT> &c) {
         for (int i = c.lane; i < c.p.nscratch; i += 64) c.scratch[i] = si[i];
     }
     for (int i = c.lane; i < c.p.MW; i += 64) c.mask[i] = 0u;
+}
+
+// unified entity table (after the records are visible in LDS)
+template <typename ObsT>
+__device__ void build_entities(Ctx<ObsT> &c) {
+    const Params &p = c.p;
+    for (int j = c.lane; j < p.NJ; j += 64) {
+        double x, y, r;
+        if (j < p.Nc) { x = c.cam_x(j); y = c.cam_y(j); r = p.cam_radius; }
+        else if (j < p.Nc + p.No) { const int o = j - p.Nc; x = c.obs_x(o); y = c.obs_y(o); r = c.obs_r(o); }
+        else { const int t = j - p.Nc - p.No; x = c.tx(t); y = c.ty(t); r = 0.0; }
+        c.ex[j] = x; c.ey[j] = y; c.er[j] = r;
+    }
 }
 
 template <typename ObsT>
@@ -268,7 +300,7 @@ __device__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws) {
             const int k = q - tt * p.NK;
             double cx, cy, cr;
             c.circle(k, cx, cy, cr);
-            const double dx = cx - c.tx(tt), dy = cy - c.ty(tt);
+            const double dx = cx - c.ex[c.tgt_slot(tt)], dy = cy - c.ey[c.tgt_slot(tt)];
             const double d2 = fma(dy, dy, dx * dx);
             const double nn = c.snorm(tt);
             const double reach = nn + cr;
@@ -298,6 +330,7 @@ __device__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws) {
         const double ny = clipd(oy + vy, -kTerrain, kTerrain);
         const bool colliding = (fabs(nx - desx) > 1e-6) || (fabs(ny - desy) > 1e-6);  // entities.py:668
         c.tx(t) = nx; c.ty(t) = ny;
+        c.ex[c.tgt_slot(t)] = nx; c.ey[c.tgt_slot(t)] = ny;
         int gw = c.ti(t, TI_GW) & ~(1 << 24);
         c.ti(t, TI_GW) = gw | ((int)colliding << 24);
     }
@@ -329,10 +362,10 @@ __device__ __noinline__ double lut_lookup(const double2 *knots, const uint16_t *
     return res;
 }
 
-// Fast path: one 96-byte record per (camera, degree) holding the knots of that degree, the next
+// Fast path: one 80-byte record per (camera, degree) holding the knots of that degree, the next
 // integer-degree knot and +inf padding (kDegSlots entries); a NaN first angle marks a degree with more
 // knots than fit, which falls back to the general path.  One dependent memory round trip.
-constexpr int kDegSlots = 6;
+constexpr int kDegSlots = 5;
 __device__ __forceinline__ int degree_of(double x) {
     int d = (int)floor(x + 180.0);
     d = d < 0 ? 0 : (d > 359 ? 359 : d);
@@ -368,9 +401,8 @@ __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t 
     if (q < p.bit_cc) { cam = (int)(((float)q + 0.5f) * p.inv_Nt); other = q - cam * p.Nt; is_target = true; }
     else { const int r = q - p.bit_cc; cam = (int)(((float)r + 0.5f) * p.inv_Nc); other = r - cam * p.Nc; is_target = false; }
     if (!is_target && cam == other) { e.seen = true; return e; }                   // environment.py:1383-1384
-    const double px = is_target ? c.tx(other) : c.cam_x(other);
-    const double py = is_target ? c.ty(other) : c.cam_y(other);
-    const double rx = px - c.cam_x(cam), ry = py - c.cam_y(cam);
+    const int oj = is_target ? c.tgt_slot(other) : other;
+    const double rx = c.ex[oj] - c.ex[cam], ry = c.ey[oj] - c.ey[cam];
     const double rn = norm2(rx, ry);
     if (rn > c.sight(cam)) return e;
     const double ang = atan2_deg(ry, rx);
@@ -418,7 +450,9 @@ __device__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool p
     for (int round = 0; round + 1 < p.sector_rounds; ++round) {
         const SectorEval e = sector_eval(c, round * 64 + lane, tick, stream, predrawn);
         sector_fetch(c, e, w);
-        const unsigned long long b = __ballot(sector_resolve(c, e, w));
+        const bool seen = sector_resolve(c, e, w);
+        if (round * 64 + lane < p.n_sector) set_flag(c, round * 64 + lane, seen);
+        const unsigned long long b = __ballot(seen);
         if (lane == 0) { c.mask[2 * round] = (uint32_t)b; c.mask[2 * round + 1] = (uint32_t)(b >> 32); }
     }
     // the last round's occlusion records travel while the range tests run
@@ -429,32 +463,41 @@ __device__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool p
         sector_fetch(c, pending, w);
     }
     SUB_STAMP(c, 13);
-    // ---- range tests: Sensor.perceive (entities.py:229-232) target -> camera / obstacle / target
+    // ---- range tests: Sensor.perceive (entities.py:229-232) target -> camera / obstacle / target.
+    // Two passes: (1) all rounds' LDS reads and arithmetic back to back (independent chains overlap their
+    // latency), results collected in a per-lane bit set; (2) flags, ballots and mask words.
     const int rbase = p.bit_range >> 5;
+    uint32_t seen_bits = 0;
+#pragma unroll 4
     for (int round = 0; round < p.range_rounds; ++round) {
         const int q = round * 64 + lane;
-        bool seen = false;
-        if (q < p.n_range) {
-            const int t = (int)(((float)q + 0.5f) * p.inv_NJ);
-            const int j = q - t * p.NJ;
-            double ox, oy, orad;
-            bool diag = false;
-            if (j < p.Nc) { ox = c.cam_x(j); oy = c.cam_y(j); orad = p.cam_radius; }
-            else if (j < p.Nc + p.No) { const int o = j - p.Nc; ox = c.obs_x(o); oy = c.obs_y(o); orad = c.obs_r(o); }
-            else { const int t2 = j - p.Nc - p.No; ox = c.tx(t2); oy = c.ty(t2); orad = 0.0; diag = (t2 == t); }
-            // distance <= sight + radius (entities.py:232): decided on squares unless within rounding of the rim
-            const double dx = c.tx(t) - ox, dy = c.ty(t) - oy;
-            const double d2 = fma(dy, dy, dx * dx);
-            const double lim = p.tgt_sight + orad, lim2 = lim * lim;
-            if (d2 < lim2 * (1.0 - 1e-14)) seen = true;
-            else if (d2 > lim2 * (1.0 + 1e-14)) seen = diag;
-            else seen = diag || (sqrt(d2) <= lim);
-        }
+        const int qq = q < p.n_range ? q : 0;
+        const int t = (int)(((float)qq + 0.5f) * p.inv_NJ);
+        const int j = qq - t * p.NJ;
+        const int tj = c.tgt_slot(t);
+        const bool diag = (j == tj);
+        const double orad = c.er[j];
+        // distance <= sight + radius (entities.py:232): decided on squares unless within rounding of the rim
+        const double dx = c.ex[tj] - c.ex[j], dy = c.ey[tj] - c.ey[j];
+        const double d2 = fma(dy, dy, dx * dx);
+        const double lim = p.tgt_sight + orad, lim2 = lim * lim;
+        bool seen;
+        if (d2 < lim2 * (1.0 - 1e-14)) seen = true;
+        else if (d2 > lim2 * (1.0 + 1e-14)) seen = diag;
+        else seen = diag || (sqrt(d2) <= lim);
+        seen_bits |= (uint32_t)(seen && q < p.n_range) << round;
+    }
+    for (int round = 0; round < p.range_rounds; ++round) {
+        const int q = round * 64 + lane;
+        const bool seen = (seen_bits >> round) & 1u;
+        if (q < p.n_range) set_flag(c, p.bit_range + q, seen);
         const unsigned long long b = __ballot(seen);
         if (lane == 0) { c.mask[rbase + 2 * round] = (uint32_t)b; c.mask[rbase + 2 * round + 1] = (uint32_t)(b >> 32); }
     }
     if (last >= 0) {
-        const unsigned long long b = __ballot(sector_resolve(c, pending, w));
+        const bool seen = sector_resolve(c, pending, w);
+        if (last * 64 + lane < p.n_sector) set_flag(c, last * 64 + lane, seen);
+        const unsigned long long b = __ballot(seen);
         if (lane == 0) { c.mask[2 * last] = (uint32_t)b; c.mask[2 * last + 1] = (uint32_t)(b >> 32); }
     }
     SUB_STAMP(c, 14);
@@ -464,7 +507,12 @@ __device__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool p
         c.mask[(p.bit_camobs >> 5) + 2 * lane] = (uint32_t)m;
         c.mask[(p.bit_camobs >> 5) + 2 * lane + 1] = (uint32_t)(m >> 32);
     }
-    if (lane == 0) c.mask[p.bit_always >> 5] = 1u;
+    if (lane == 0) { c.mask[p.bit_always >> 5] = 1u; set_flag(c, p.bit_always, true); }
+    for (int q = lane; q < p.Nc * p.No; q += 64) {
+        const int cam = (int)(((float)q + 0.5f) * p.inv_No);
+        const int o = q - cam * p.No;
+        set_flag(c, p.bit_camobs + cam * 64 + o, (c.camobs(cam) >> o) & 1ull);
+    }
     wave_sync();
     // ---- tracked_bits = camera_target_view_mask.any(axis=0) (environment.py:1388); which warehouse holds the target
     if (lane < p.Nt) {
@@ -585,7 +633,7 @@ __device__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out
         c.ei(EI_DONE) = done;
         c.ei(EI_TICK) = (int)(tick + 1u);
         if (scalars_out) {
-            float *o = scalars_out + c.env * 8;
+            float *o = scalars_out + c.out * 8;
             o[0] = (float)(-r); o[1] = (float)r; o[2] = (float)done; o[3] = (float)coverage;
             o[4] = (float)real_cov; o[5] = (float)transport; o[6] = (float)delivered; o[7] = (float)(r / p.max_team_reward);
         }
@@ -607,7 +655,7 @@ __device__ void score_only(Ctx<ObsT> &c, float *scalars_out) {
     const int n_bounty = __popcll(__ballot(with_bounty));
     const int n_both = __popcll(__ballot(tr && with_bounty));
     if (c.lane == 0 && scalars_out) {
-        float *o = scalars_out + c.env * 8;
+        float *o = scalars_out + c.out * 8;
         const int delivered = c.ei(EI_DELIVERED);
         o[0] = 0.f; o[1] = 0.f; o[2] = (float)c.ei(EI_DONE); o[3] = (float)((double)n_tracked / (double)p.Nt);
         o[4] = n_bounty > 0 ? (float)((double)n_both / (double)n_bounty) : 0.f;
@@ -647,10 +695,17 @@ template <typename ObsT> struct Vec;
 template <> struct Vec<float> { using type = float4; static constexpr int W = 4; };
 template <> struct Vec<double> { using type = double2; static constexpr int W = 2; };
 
+// descriptor = byte offset of the source slot | byte offset of the visibility word << 16 (both inside the
+// wave's LDS slice); the word is all-ones or zero, so a bitwise AND is the masked copy (exact +0.0 when hidden)
 template <typename ObsT>
 __device__ __forceinline__ ObsT gather_one(const Ctx<ObsT> &c, uint32_t d) {
-    const ObsT v = c.scratch[d & 0xffffu];
-    return c.mask_bit((int)(d >> 16)) ? v : (ObsT)0;
+    using U = typename Bits<ObsT>::type;
+    const U v = *reinterpret_cast<const U *>(c.base + (d & 0xffffu));
+    const U m = *reinterpret_cast<const U *>(c.base + (d >> 16));
+    const U r = v & m;
+    ObsT out;
+    __builtin_memcpy(&out, &r, sizeof(out));
+    return out;
 }
 
 template <typename ObsT>
@@ -682,11 +737,11 @@ template <typename ObsT>
 __device__ void pack_observations(Ctx<ObsT> &c) {
     const Params &p = c.p;
     if (c.g.cam_obs && p.cam_elems > 0)
-        pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.cam_obs) + c.env * p.cam_elems, c.table, p.cam_elems);
+        pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.cam_obs) + c.out * p.cam_elems, c.table, p.cam_elems);
     if (c.g.tgt_obs)
-        pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.tgt_obs) + c.env * p.tgt_elems, c.table + p.tgt_table_off, p.tgt_elems);
+        pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.tgt_obs) + c.out * p.tgt_elems, c.table + p.tgt_table_off, p.tgt_elems);
     if (c.g.masks) {
-        uint32_t *m = c.g.masks + c.env * p.MW;
+        uint32_t *m = c.g.masks + c.out * p.MW;
         for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
     }
 }
@@ -695,13 +750,15 @@ __device__ void pack_observations(Ctx<ObsT> &c) {
 // =============================================================================================
 // The step kernel: one wave per environment, 4 environments per workgroup.
 template <typename ObsT>
-__global__ __launch_bounds__(256, 4) void step_kernel(const Params p, const Ptrs g) {
+__global__ __launch_bounds__(256, 4) void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
+    const Params &p = *pp;   // scenario constants live in device memory: scalar loads on demand instead of ~80 pinned SGPRs
     extern __shared__ __align__(16) unsigned char smem[];
 #ifdef MATE_PHASE_CLOCKS
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
 #endif
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;  // next step's counter
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave-uniform by construction; readfirstlane lets the compiler keep everything derived from it in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t env = (int64_t)blockIdx.x * 4 + wave;
     if (env >= g.N) return;
     // the four waves of a workgroup never synchronise: each owns one environment and its LDS slice
@@ -710,28 +767,92 @@ __global__ __launch_bounds__(256, 4) void step_kernel(const Params p, const Ptrs
     if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + 0] = t_begin;
 #endif
     PHASE_STAMP(1);
+    const uint32_t tick = g.tick;
     load_records(c);
+#ifdef MATE_PHASE_CLOCKS
+#define SKIP(bit) (g.debug_skip & (bit))
+#else
+#define SKIP(bit) false
+#endif
+    StepDraws draws{0.0, 0.0};
+    if (!SKIP(1)) draws = step_draws(c, tick);   // independent of the records: overlaps their latency
+    wave_sync();
+    build_entities(c);
     wave_sync();
     PHASE_STAMP(2);
-    const uint32_t tick = (uint32_t)c.ei(EI_TICK);
-    const StepDraws draws = step_draws(c, tick);
     SUB_STAMP(c, 9);
-    simulate_cameras(c, draws, g.mode != MODE_OBSERVE);
+    if (!SKIP(2)) simulate_cameras(c, draws, g.mode != MODE_OBSERVE);
     SUB_STAMP(c, 12);
-    if (g.mode != MODE_OBSERVE) simulate_targets(c, draws);
+    if (g.mode != MODE_OBSERVE && !SKIP(4)) simulate_targets(c, draws);
     else wave_sync();
     PHASE_STAMP(3);
-    update_view(c, tick, S_TRANSMIT, true);
+    if (!SKIP(8)) update_view(c, tick, S_TRANSMIT, true);
     PHASE_STAMP(4);
     if (g.mode == MODE_OBSERVE) score_only(c, g.scalars);
-    else assign_and_score(c, tick, g.scalars);
+    else if (!SKIP(32)) assign_and_score(c, tick, g.scalars);
     PHASE_STAMP(5);
-    fill_scratch(c);
+    if (!SKIP(64)) fill_scratch(c);
     PHASE_STAMP(6);
-    pack_observations(c);
+    if (!SKIP(128)) pack_observations(c);
     PHASE_STAMP(7);
     if (g.mode != MODE_OBSERVE) store_dynamic(c);
     PHASE_STAMP(8);
+}
+
+// =============================================================================================
+// K-step fused rollout under the on-device random policy: the same phases as step_kernel in a loop, with
+// the environment's records resident in LDS for the whole launch.  Outputs of step r go to row r*N + env
+// of the (rollout-shaped) output buffers.  Waves drift apart freely, so the launch takes about the MEAN
+// wave time per step instead of the slowest wave's, and there is no kernel boundary between steps.
+// An environment whose episode ends stops stepping (rows of the remaining steps carry done = 2 in the
+// scalar record) and is reset by the host-launched reset kernel after the rollout.
+template <typename ObsT>
+__global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restrict__ pp, const Ptrs g) {
+    const Params &p = *pp;
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;
+    // wave-uniform by construction; readfirstlane lets the compiler keep everything derived from it in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int64_t env = (int64_t)blockIdx.x * 4 + wave;
+    if (env >= g.N) return;
+    {
+        Ctx<ObsT> c(p, g, smem + wave * p.lds_wave_bytes, lane, env);
+        load_records(c);
+        wave_sync();
+        build_entities(c);
+        wave_sync();
+    }
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < g.rollout_steps; ++r) {
+        // an opaque copy of the lane id per iteration keeps the compiler from hoisting every lane-role
+        // computation of the body out of the loop (which costs >100 VGPRs of spills)
+        int lane_r = lane, wave_r = wave;
+        asm volatile("" : "+v"(lane_r));
+        asm volatile("" : "+s"(wave_r));
+        const Params *pr = pp;
+        asm volatile("" : "+s"(pr));
+        const Params &p = *pr;
+        const int64_t env_r = (int64_t)blockIdx.x * 4 + wave_r;
+        Ctx<ObsT> c(p, g, smem + wave_r * p.lds_wave_bytes, lane_r, env_r);
+        c.out = (int64_t)r * g.N + env_r;
+        if (c.ei(EI_DONE) != 0) {
+            if (lane_r == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
+            continue;
+        }
+        const uint32_t tick = g.tick + (uint32_t)r;
+        const StepDraws draws = step_draws(c, tick);
+        simulate_cameras(c, draws, true);
+        simulate_targets(c, draws);
+        update_view(c, tick, S_TRANSMIT, true);
+        assign_and_score(c, tick, g.scalars);
+        fill_scratch(c);
+        pack_observations(c);
+        wave_sync();
+    }
+    {
+        Ctx<ObsT> c(p, g, smem + wave * p.lds_wave_bytes, lane, env);
+        store_dynamic(c);
+    }
 }
 
 }  // namespace mate

@@ -34,12 +34,14 @@ static int fail(int code, const char *fmt, ...) {
 
 struct mate_engine {
     Params p{};
+    Params *d_params = nullptr;   // device copy read by the kernels
     Ptrs g{};
     ResetLds rl{};
     mate_config cfg{};
     int device = 0;
     int64_t N = 0;
     int parity = 0;
+    uint32_t tick = 0;         // Philox tick of the next step launch
     bool was_reset = false;
     size_t step_lds = 0, reset_lds = 0;
     std::vector<void *> allocs;
@@ -72,7 +74,8 @@ static int dev_alloc(mate_engine *e, T **out, size_t count, bool zero = true) {
 // it copies and which visibility bit gates it (joint_observation, environment.py:908-964).
 static void build_descriptors(const Params &p, std::vector<uint32_t> &desc) {
     const int Nc = p.Nc, Nt = p.Nt, No = p.No;
-    auto D = [](int src, int bit) { return (uint32_t)src | ((uint32_t)bit << 16); };
+    const int sz = p.obs_f64 ? 8 : 4;
+    auto D = [&](int src, int bit) { return (uint32_t)(p.off_scratch + src * sz) | ((uint32_t)(p.off_flags + bit * sz) << 16); };
     const int ALWAYS = p.bit_always;
     const int SC_ZERO = 0, SC_ONE = 1, SC_CONST = 2, SC_IDX = 14;
     (void)SC_ZERO;
@@ -210,8 +213,12 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     p.off_scratch = off; off += round_up(p.nscratch * obs_size, 16);
     p.off_mask = off; off += round_up(p.MW * 4, 16);
     p.off_misc = off; off += round_up((4 * Nt + 8) * 4, 16);
+    p.off_flags = off; off += round_up(p.MW * 32 * obs_size, 16);
+    p.off_ent = off; off += round_up(3 * p.NJ * 8, 16);
+    p.inv_No = No > 0 ? 1.0f / (float)No : 0.f;
     p.lds_wave_bytes = off;
     e->step_lds = 4 * (size_t)p.lds_wave_bytes;
+    if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }
     ResetLds &rl = e->rl;
     rl.sort_cap = std::max(512, next_pow2(Nc > 0 ? 360 + No * 185 + 1 : 1));
     int roff = p.lds_wave_bytes;
@@ -271,15 +278,19 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         if (hipMemcpy(d_ranges, ranges.data(), ranges.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(MATE_EHIP, "range upload failed"); break; }
         g.reset_ranges = d_ranges;
     } while (0);
+    if (rc == MATE_OK) rc = dev_alloc(e, &e->d_params, (size_t)1);
+    if (rc == MATE_OK && hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice) != hipSuccess) rc = fail(MATE_EHIP, "params upload failed");
     if (rc == MATE_OK) {
         // opt in to large dynamic LDS
         hipError_t err = hipSuccess;
         if (p.obs_f64) {
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
             if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
+            if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
         } else {
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
             if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
+            if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
         }
         if (err != hipSuccess) rc = fail(MATE_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
     }
@@ -312,6 +323,9 @@ extern "C" int mate_engine_get_layout(const mate_engine *e, mate_layout *out) {
 extern "C" int mate_engine_seed(mate_engine *e, uint64_t seed) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     e->p.seed_lo = (uint32_t)seed; e->p.seed_hi = (uint32_t)(seed >> 32);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice));
     return MATE_OK;
 }
 
@@ -327,8 +341,8 @@ static void apply_io(Ptrs &g, const mate_step_io *io) {
 static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream) {
     g.mode = MODE_OBSERVE; g.reset_kind = kind; g.parity = e->parity;
     const int64_t blocks = kind == RESET_DONE ? std::min<int64_t>(e->N, 256) : e->N;
-    if (e->p.obs_f64) hipLaunchKernelGGL(reset_kernel<double>, dim3((unsigned)blocks), dim3(256), e->reset_lds, stream, e->p, g, e->rl, phases);
-    else hipLaunchKernelGGL(reset_kernel<float>, dim3((unsigned)blocks), dim3(256), e->reset_lds, stream, e->p, g, e->rl, phases);
+    if (e->p.obs_f64) hipLaunchKernelGGL(reset_kernel<double>, dim3((unsigned)blocks), dim3(256), e->reset_lds, stream, e->d_params, g, e->rl, phases);
+    else hipLaunchKernelGGL(reset_kernel<float>, dim3((unsigned)blocks), dim3(256), e->reset_lds, stream, e->d_params, g, e->rl, phases);
     HIP_TRY(hipGetLastError());
     return MATE_OK;
 }
@@ -360,7 +374,7 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     Ptrs g = e->g;
     apply_io(g, io);
     if (mode == MODE_STEP && ((e->p.Nc > 0 && !g.cam_act) || !g.tgt_act)) return fail(MATE_EINVAL, "step() needs camera and target joint actions");
-    g.mode = mode; g.parity = e->parity; g.reset_kind = -1;
+    g.mode = mode; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick;
     if (mode == MODE_OBSERVE || !auto_reset) g.done_count = nullptr;
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -374,9 +388,10 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     }
     // start/stop events attached to the dispatch itself (hipExtLaunchKernelGGL): the elapsed time is the
     // kernel's own begin->end, without the marker-packet latency separate hipEventRecord calls would add
-    if (e->p.obs_f64) hipExtLaunchKernelGGL(step_kernel<double>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->p, g);
-    else hipExtLaunchKernelGGL(step_kernel<float>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->p, g);
+    if (e->p.obs_f64) hipExtLaunchKernelGGL(step_kernel<double>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->d_params, g);
+    else hipExtLaunchKernelGGL(step_kernel<float>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->d_params, g);
     HIP_TRY(hipGetLastError());
+    if (mode != MODE_OBSERVE) e->tick += 1;
     if (mode != MODE_OBSERVE && auto_reset) {
         Ptrs r = e->g;
         apply_io(r, io);
@@ -394,6 +409,41 @@ extern "C" int mate_engine_step(mate_engine *e, const mate_step_io *io, int32_t 
 extern "C" int mate_engine_step_random(mate_engine *e, const mate_step_io *io, int32_t auto_reset, void *stream) {
     return launch_step(e, io, MODE_STEP_RANDOM, auto_reset, (hipStream_t)stream);
 }
+extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    if (!e->was_reset) return fail(MATE_ESTATE, "rollout called before reset() (or import_state)");
+    if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(e->device));
+    Ptrs g = e->g;
+    apply_io(g, io);
+    g.mode = MODE_STEP_RANDOM; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick; g.rollout_steps = steps;
+    g.tape_ct = nullptr; g.tape_goal = nullptr;
+    if (!auto_reset) g.done_count = nullptr;
+    const unsigned blocks = (unsigned)((e->N + 3) / 4);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (e->timing > 0 && (e->timing_tick++ % e->timing) == 0) {
+        if (e->events_used == e->events.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+            e->events.emplace_back(a, b);
+        }
+        ev0 = e->events[e->events_used].first; ev1 = e->events[e->events_used].second; ++e->events_used;
+    }
+    if (e->p.obs_f64) hipExtLaunchKernelGGL(rollout_kernel<double>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->d_params, g);
+    else hipExtLaunchKernelGGL(rollout_kernel<float>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->d_params, g);
+    HIP_TRY(hipGetLastError());
+    e->tick += (uint32_t)steps;
+    if (auto_reset) {
+        Ptrs r = e->g;
+        apply_io(r, nullptr);     // state only: the next rollout observes the fresh episode on its first step
+        int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT, stream);
+        if (rc != MATE_OK) return rc;
+        e->parity ^= 1;
+    }
+    return MATE_OK;
+}
+
 extern "C" int mate_engine_observe(mate_engine *e, const mate_step_io *io, void *stream) {
     return launch_step(e, io, MODE_OBSERVE, 0, (hipStream_t)stream);
 }
@@ -401,7 +451,7 @@ extern "C" int mate_engine_observe(mate_engine *e, const mate_step_io *io, void 
 extern "C" int mate_engine_export_state(mate_engine *e, double *dst_dev, void *stream) {
     if (!e || !dst_dev) return fail(MATE_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(e->device));
-    hipLaunchKernelGGL(export_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->p, e->g, dst_dev);
+    hipLaunchKernelGGL(export_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->d_params, e->g, dst_dev);
     HIP_TRY(hipGetLastError());
     return MATE_OK;
 }
@@ -409,8 +459,13 @@ extern "C" int mate_engine_export_state(mate_engine *e, double *dst_dev, void *s
 extern "C" int mate_engine_import_state(mate_engine *e, const double *src_dev, void *stream) {
     if (!e || !src_dev) return fail(MATE_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(e->device));
-    hipLaunchKernelGGL(import_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->p, e->g, src_dev);
+    hipLaunchKernelGGL(import_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->d_params, e->g, src_dev);
     HIP_TRY(hipGetLastError());
+    // all environments step together, so they share one tick: adopt the imported one
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    int32_t tick = 0;
+    HIP_TRY(hipMemcpy(&tick, reinterpret_cast<const int32_t *>(e->g.dyn + e->p.DF) + e->p.Nt * TI_STRIDE + EI_TICK, sizeof(tick), hipMemcpyDeviceToHost));
+    e->tick = (uint32_t)tick;
     e->was_reset = true;
     return MATE_OK;
 }
@@ -476,6 +531,11 @@ extern "C" int mate_engine_lut_write(mate_engine *e, int64_t env, int32_t camera
 extern "C" int mate_engine_debug_phase_clocks(mate_engine *e, long long *buf_dev) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     e->g.phase_clocks = buf_dev;
+    return MATE_OK;
+}
+extern "C" int mate_engine_debug_skip(mate_engine *e, int32_t mask) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    e->g.debug_skip = mask;
     return MATE_OK;
 }
 

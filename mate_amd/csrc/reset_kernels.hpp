@@ -340,7 +340,8 @@ __device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, dou
 }
 
 template <typename ObsT>
-__global__ __launch_bounds__(256) void reset_kernel(const Params p, const Ptrs g, const ResetLds rl, const int32_t phases) {
+__global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ pp, const Ptrs g, const ResetLds rl, const int32_t phases) {
+    const Params &p = *pp;
     extern __shared__ __align__(16) unsigned char smem[];
     if (g.reset_kind == RESET_DONE && (int64_t)blockIdx.x >= (int64_t)g.done_count[g.parity]) return;   // idle: nothing finished
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params p, const Ptrs g
             for (int i = lane; i < p.SW; i += 64) s[i] = c.st[i];
             if (phases & PH_VIEW) {
                 __threadfence();   // this wave reads the tables other waves of the workgroup just wrote
+                build_entities(c);
                 simulate_cameras(c, StepDraws{0.0, 0.0}, false);   // camera sight + scratch only
                 wave_sync();
                 update_view(c, (uint32_t)c.ei(EI_EPISODE), S_RESET_VIEW, false);
@@ -394,7 +396,8 @@ struct Exporter {
     __device__ int width() const { return p.export_width; }
 };
 
-__global__ void export_kernel(const Params p, const Ptrs g, double *dst) {
+__global__ void export_kernel(const Params *__restrict__ pp, const Ptrs g, double *dst) {
+    const Params &p = *pp;
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= g.N) return;
     const double *st = g.stat + env * p.SW;
@@ -427,7 +430,8 @@ __global__ void export_kernel(const Params p, const Ptrs g, double *dst) {
     *o++ = (double)e[EI_EPSTEP]; *o++ = (double)(uint32_t)e[EI_TICK]; *o++ = (double)(uint32_t)e[EI_EPISODE]; *o++ = (double)e[EI_DONE];
 }
 
-__global__ void import_kernel(const Params p, const Ptrs g, const double *src) {
+__global__ void import_kernel(const Params *__restrict__ pp, const Ptrs g, const double *src) {
+    const Params &p = *pp;
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= g.N) return;
     double *st = g.stat + env * p.SW;

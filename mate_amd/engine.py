@@ -165,6 +165,31 @@ class Engine:
         check(self.lib.mate_engine_step_random(self._h, ctypes.byref(io), int(auto_reset), self._stream()))
         return self.camera_obs, self.target_obs, self.scalars
 
+    def rollout_random(self, steps, auto_reset=True, want_masks=False):
+        """`steps` fused steps under the on-device random policy.  Returns rollout-shaped tensors
+        (camera_obs [T,N,Nc,Dc], target_obs [T,N,Nt,Dt], scalars [T,N,8]); scalars[..., 2] == 2 marks
+        steps skipped because the episode had already ended inside this rollout."""
+        steps = int(steps)
+        buf = getattr(self, '_rollout', None)
+        if buf is None or buf['steps'] != steps or (want_masks and buf['masks'] is None):
+            N, Nc, Nt, L = self.num_envs, self.num_cameras, self.num_targets, self.layout
+            with torch.cuda.device(self.device):
+                buf = {
+                    'steps': steps,
+                    'camera_obs': torch.zeros((steps, N, Nc, L.camera_obs_dim), dtype=self.obs_dtype, device=self.device),
+                    'target_obs': torch.zeros((steps, N, Nt, L.target_obs_dim), dtype=self.obs_dtype, device=self.device),
+                    'scalars': torch.zeros((steps, N, 8), dtype=torch.float32, device=self.device),
+                    'masks': torch.zeros((steps, N, L.mask_words), dtype=torch.int32, device=self.device) if want_masks else None,
+                }
+            self._rollout = buf
+        io = MateStepIO()
+        io.camera_obs_dev = buf['camera_obs'].data_ptr() if self.num_cameras else None
+        io.target_obs_dev = buf['target_obs'].data_ptr()
+        io.scalars_dev = buf['scalars'].data_ptr()
+        io.masks_dev = buf['masks'].data_ptr() if want_masks else None
+        check(self.lib.mate_engine_rollout_random(self._h, ctypes.byref(io), steps, int(auto_reset), self._stream()))
+        return buf['camera_obs'], buf['target_obs'], buf['scalars']
+
     def observe(self, tape_ct=None):
         io, keep = self._io(tape_ct=tape_ct)
         check(self.lib.mate_engine_observe(self._h, ctypes.byref(io), self._stream()))

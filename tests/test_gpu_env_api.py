@@ -104,3 +104,40 @@ def test_batched_env_and_sharding_invariance():
     after = full.state_dict()
     assert np.array_equal(before['tgt_x'], after['tgt_x']) and np.array_equal(before['cam_phi'], after['cam_phi'])
     assert (after['episode_step'] == before['episode_step'] + 1).all()
+
+
+def test_fused_rollout_equals_single_steps():
+    """rollout_random(T) == T x step_random(): same observations, scalars, masks and final state."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-4v8-9.yaml')
+    a = Engine(cfg, 37, seed=9)
+    b = Engine(cfg, 37, seed=9)
+    a.reset(); b.reset()
+    T = 12
+    cam_r, tgt_r, sc_r = a.rollout_random(T, auto_reset=False, want_masks=True)
+    for r in range(T):
+        b.step_random(auto_reset=False, want_masks=True)
+        assert torch.equal(cam_r[r], b.camera_obs) and torch.equal(tgt_r[r], b.target_obs), r
+        assert torch.equal(sc_r[r], b.scalars), r
+        assert torch.equal(a._rollout['masks'][r], b.masks), r
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    # continue stepping after a rollout: ticks line up
+    a.step_random(auto_reset=False); b.step_random(auto_reset=False)
+    assert torch.equal(a.target_obs, b.target_obs)
+
+
+def test_rollout_stops_at_episode_end_and_resets():
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    eng = Engine(read_config('MATE-4v8-9.yaml', max_episode_steps=5), 9, seed=2)
+    eng.reset()
+    _, _, sc = eng.rollout_random(10, auto_reset=True)
+    done = sc[:, :, 2].cpu().numpy()
+    assert (done[:5] == 0).all() and (done[5] == 1).all() and (done[6:] == 2).all()
+    sd = eng.state_dict()
+    assert (sd['episode'] == 2).all() and (sd['episode_step'] == 0).all() and (sd['done'] == 0).all()
+    _, _, sc = eng.rollout_random(3, auto_reset=True)
+    assert (sc[:, :, 2].cpu().numpy() == 0).all()
