@@ -720,12 +720,16 @@ __device__ void pack_block(const Ctx<ObsT> &c, ObsT *dst, const uint32_t *table,
                 const uint4 d = reinterpret_cast<const uint4 *>(table)[i];
                 float4 v;
                 v.x = gather_one(c, d.x); v.y = gather_one(c, d.y); v.z = gather_one(c, d.z); v.w = gather_one(c, d.w);
-                out[i] = v;
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 nv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(nv, reinterpret_cast<f32x4 *>(&out[i]));   // write-once stream: keep it out of the caches
             } else {
                 const uint2 d = reinterpret_cast<const uint2 *>(table)[i];
                 double2 v;
                 v.x = gather_one(c, d.x); v.y = gather_one(c, d.y);
-                out[i] = v;
+                typedef double f64x2 __attribute__((ext_vector_type(2)));
+                const f64x2 nv = {v.x, v.y};
+                __builtin_nontemporal_store(nv, reinterpret_cast<f64x2 *>(&out[i]));
             }
         }
     } else {
