@@ -123,6 +123,15 @@ int mate_engine_rollout_random(mate_engine *engine, const mate_step_io *io, int3
  * the view masks from the current state (see-through draws from io tape or Philox) and packs. */
 int mate_engine_observe(mate_engine *engine, const mate_step_io *io, void *stream);
 
+/* Fuse the reference's observation post-processing wrappers into the packer (no second pass over the
+ * observation bytes): relative != 0 = RelativeCoordinates (mate/agents/utils.py:40-94: coordinates of
+ * warehouses and of visible entities minus the observing agent's own location); scale/bias per column
+ * ([camera_obs_dim] / [target_obs_dim], host arrays, NULL = identity) = any affine per-column map, e.g.
+ * RescaledObservation (utils.py:97-137).  out = ((value - own) if visible else 0) * scale + bias.
+ * All NULL / 0 restores the plain observations. */
+int mate_engine_set_obs_transform(mate_engine *engine, int32_t relative, const double *camera_scale,
+                                  const double *camera_bias, const double *target_scale, const double *target_bias);
+
 /* Canonical f64 export / import of the whole simulation state, [N][export_width] doubles
  * (layout documented in DESIGN.md; used by state(), the attribute views and the parity tests). */
 int mate_engine_export_state(mate_engine *engine, double *dst_dev, void *stream);

@@ -47,6 +47,8 @@ struct Ptrs {
     double2 *lut_deg;             // [N][Nc][360][kDegSlots] per-degree records (fast lookup path)
     int32_t *lut_count;           // [N][Nc]
     const uint32_t *desc;         // [cam_elems + tgt_elems]  src | bit << 16
+    const uint2 *xdesc;           // optional fused post-processing: per element (descriptor, LDS offset of the row's own x or y)
+    const void *xab;              // ... and (scale, bias) as ObsT pairs; NULL = plain observations
     const void *scratch_init;     // [nscratch] ObsT
     const double *reset_ranges;   // [Nc+No+Nt][4] cameras, obstacles, targets
     const void *cam_act, *tgt_act;
@@ -737,13 +739,42 @@ __device__ void pack_block(const Ctx<ObsT> &c, ObsT *dst, const uint32_t *table,
     }
 }
 
+// Fused observation post-processing (RelativeCoordinates = agents/utils.py:40-94, RescaledObservation =
+// agents/utils.py:97-137 of the reference): out = ((value - own coordinate) if visible else 0) * scale + bias.
+template <typename ObsT>
+__device__ void pack_block_xf(const Ctx<ObsT> &c, ObsT *dst, const uint2 *xdesc, const ObsT *xab, int elems) {
+    using U = typename Bits<ObsT>::type;
+    for (int i = c.lane; i < elems; i += 64) {
+        const uint2 d = xdesc[i];
+        const ObsT v = *reinterpret_cast<const ObsT *>(c.base + (d.x & 0xffffu));
+        const ObsT o = *reinterpret_cast<const ObsT *>(c.base + d.y);
+        const U m = *reinterpret_cast<const U *>(c.base + (d.x >> 16));
+        const ObsT rel = v - o;
+        U bits;
+        __builtin_memcpy(&bits, &rel, sizeof(bits));
+        bits &= m;
+        ObsT gated;
+        __builtin_memcpy(&gated, &bits, sizeof(gated));
+        dst[i] = gated * xab[2 * i] + xab[2 * i + 1];
+    }
+}
+
 template <typename ObsT>
 __device__ void pack_observations(Ctx<ObsT> &c) {
     const Params &p = c.p;
+    if (c.g.xdesc) {
+        const ObsT *xab = reinterpret_cast<const ObsT *>(c.g.xab);
+        if (c.g.cam_obs && p.cam_elems > 0)
+            pack_block_xf<ObsT>(c, reinterpret_cast<ObsT *>(c.g.cam_obs) + c.out * p.cam_elems, c.g.xdesc, xab, p.cam_elems);
+        if (c.g.tgt_obs)
+            pack_block_xf<ObsT>(c, reinterpret_cast<ObsT *>(c.g.tgt_obs) + c.out * p.tgt_elems, c.g.xdesc + p.tgt_table_off,
+                                xab + 2 * p.tgt_table_off, p.tgt_elems);
+    } else {
     if (c.g.cam_obs && p.cam_elems > 0)
         pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.cam_obs) + c.out * p.cam_elems, c.table, p.cam_elems);
     if (c.g.tgt_obs)
         pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.tgt_obs) + c.out * p.tgt_elems, c.table + p.tgt_table_off, p.tgt_elems);
+    }
     if (c.g.masks) {
         uint32_t *m = c.g.masks + c.out * p.MW;
         for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];

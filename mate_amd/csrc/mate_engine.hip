@@ -308,6 +308,71 @@ extern "C" int mate_engine_destroy(mate_engine *e) {
     return MATE_OK;
 }
 
+// Fused observation post-processing tables: descriptor + LDS offset of the row owner's x / y for the
+// coordinate entries (coordinate_mask_of, constants.py:371-426) + (scale, bias) per column.
+extern "C" int mate_engine_set_obs_transform(mate_engine *e, int32_t relative, const double *cam_scale, const double *cam_bias,
+                                             const double *tgt_scale, const double *tgt_bias) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const Params &p = e->p;
+    if (!relative && !cam_scale && !tgt_scale) { e->g.xdesc = nullptr; e->g.xab = nullptr; return MATE_OK; }
+    std::vector<uint32_t> desc;
+    build_descriptors(p, desc);
+    const size_t n = desc.size();
+    const int sz = p.obs_f64 ? 8 : 4;
+    const uint32_t zero_slot = (uint32_t)p.off_scratch;   // scratch[0] == 0
+    std::vector<uint2> xd(n);
+    std::vector<double> a(n, 1.0), b(n, 0.0);
+    auto fill = [&](int base, int rows, int D, int self_dim, int own_base, int own_stride, const int (&block)[3], const int (&stride)[3],
+                    const double *scale, const double *bias) {
+        for (int r = 0; r < rows; ++r) {
+            const uint32_t ox = (uint32_t)(p.off_scratch + (own_base + r * own_stride) * sz), oy = ox + (uint32_t)sz;
+            for (int col = 0; col < D; ++col) {
+                const size_t i = (size_t)base + (size_t)r * D + col;
+                uint32_t org = zero_slot;
+                if (relative) {
+                    if (col >= 4 && col < 12) org = ((col - 4) & 1) ? oy : ox;             // warehouse centres in the preserved block
+                    int start = 13 + self_dim;
+                    for (int k = 0; k < 3; ++k) {
+                        const int width = block[k] * stride[k];
+                        if (col >= start && col < start + width) { const int q = (col - start) % stride[k]; if (q == 0) org = ox; else if (q == 1) org = oy; }
+                        start += width;
+                    }
+                }
+                xd[i] = make_uint2(desc[i], org);
+                if (scale) { a[i] = scale[col]; b[i] = bias[col]; }
+            }
+        }
+    };
+    const int cam_blocks[3] = {p.Nt, p.No, p.Nc}, cam_strides[3] = {5, 4, 7};
+    const int tgt_blocks[3] = {p.Nc, p.No, p.Nt}, tgt_strides[3] = {7, 4, 5};
+    for (size_t i = 0; i < n; ++i) xd[i] = make_uint2(desc[i], zero_slot);
+    fill(0, p.Nc, p.Dc, 9, p.sc_cam, 10, cam_blocks, cam_strides, cam_scale, cam_bias);
+    fill(p.tgt_table_off, p.Nt, p.Dt, 14, p.sc_tgt, 14, tgt_blocks, tgt_strides, tgt_scale, tgt_bias);
+    uint2 *d_xd = nullptr;
+    int rc = dev_alloc(e, &d_xd, n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(d_xd, xd.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
+    if (p.obs_f64) {
+        std::vector<double> ab(2 * n);
+        for (size_t i = 0; i < n; ++i) { ab[2 * i] = a[i]; ab[2 * i + 1] = b[i]; }
+        double *d = nullptr;
+        if ((rc = dev_alloc(e, &d, 2 * n))) return rc;
+        HIP_TRY(hipMemcpy(d, ab.data(), ab.size() * 8, hipMemcpyHostToDevice));
+        e->g.xab = d;
+    } else {
+        std::vector<float> ab(2 * n);
+        for (size_t i = 0; i < n; ++i) { ab[2 * i] = (float)a[i]; ab[2 * i + 1] = (float)b[i]; }
+        float *d = nullptr;
+        if ((rc = dev_alloc(e, &d, 2 * n))) return rc;
+        HIP_TRY(hipMemcpy(d, ab.data(), ab.size() * 4, hipMemcpyHostToDevice));
+        e->g.xab = d;
+    }
+    e->g.xdesc = d_xd;
+    return MATE_OK;
+}
+
 extern "C" int mate_engine_get_layout(const mate_engine *e, mate_layout *out) {
     if (!e || !out) return fail(MATE_EINVAL, "null argument");
     const Params &p = e->p;

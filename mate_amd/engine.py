@@ -143,6 +143,32 @@ class Engine:
         return io, keep
 
     # ---------------------------------------------------------------------- API
+    def set_obs_transform(self, relative_coordinates=False, rescaled_observation=False):
+        """Fuse RelativeCoordinates / RescaledObservation (the reference's observation wrappers) into the
+        kernel's packer.  The affine map of the rescale comes from the observation-space bounds
+        (mate_amd.constants), exactly as `rescale_observation` derives it."""
+        from mate_amd import constants as consts
+
+        def affine(space):
+            low, high = np.asarray(space.low, dtype=np.float64), np.asarray(space.high, dtype=np.float64)
+            scale, bias = np.ones_like(low), np.zeros_like(low)
+            below = np.isfinite(low)
+            both = below & np.isfinite(high) & (high > low)
+            bias[below] = -low[below]                      # rescaled[bounded_below] -= low
+            span = np.where(both, high - low, 1.0)
+            scale[both] = 2.0 / span[both]                 # rescaled[mask] = 2 * rescaled / (high - low) - 1
+            bias[both] = -2.0 * low[both] / span[both] - 1.0
+            return np.ascontiguousarray(scale), np.ascontiguousarray(bias)
+
+        nums = (self.num_cameras, self.num_targets, self.num_obstacles)
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        if rescaled_observation:
+            cs, cb = affine(consts.camera_observation_space_of(*nums))
+            ts, tb = affine(consts.target_observation_space_of(*nums))
+            check(self.lib.mate_engine_set_obs_transform(self._h, int(relative_coordinates), ptr(cs), ptr(cb), ptr(ts), ptr(tb)))
+        else:
+            check(self.lib.mate_engine_set_obs_transform(self._h, int(relative_coordinates), None, None, None, None))
+
     def seed(self, seed):
         check(self.lib.mate_engine_seed(self._h, int(seed)))
 

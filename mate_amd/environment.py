@@ -522,13 +522,16 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
     `first_env_index` makes the RNG streams of a shard equal to those of the same environments in a
     larger single-GPU batch (sharding invariance, DESIGN.md section "multi-GPU")."""
 
-    def __init__(self, config=None, num_envs=1, device=0, seed=0, first_env_index=0, obs_dtype=torch.float32, auto_reset=True, **kwargs):
+    def __init__(self, config=None, num_envs=1, device=0, seed=0, first_env_index=0, obs_dtype=torch.float32, auto_reset=True,
+                 relative_coordinates=False, rescaled_observation=False, **kwargs):
         self._setup_scenario(config, kwargs)
         self.num_envs, self.auto_reset = int(num_envs), bool(auto_reset)
         self.engine = Engine(self.config, self.num_envs, device=device, seed=seed, first_env_index=first_env_index, obs_dtype=obs_dtype)
         self.num_cameras, self.num_targets, self.num_obstacles = self.engine.num_cameras, self.engine.num_targets, self.engine.num_obstacles
         self._setup_spaces()
         self.device = self.engine.device
+        if relative_coordinates or rescaled_observation:   # the reference's RelativeCoordinates / RescaledObservation wrappers, fused
+            self.engine.set_obs_transform(relative_coordinates, rescaled_observation)
 
     def seed(self, seed):
         self.engine.seed(int(seed))

@@ -473,8 +473,36 @@ def kat_perceive():
     print(f'kat_perceive: {len(cases)} cases, seen={int(np.array(cases)[:, -1].sum())}')
 
 
+def xform_fixture(trace_name, steps):
+    """Reference outputs of the observation post-processing wrappers (RelativeCoordinates =
+    agents/utils.py:40-94 `convert_coordinates`, RescaledObservation = :97-137 `rescale_observation`) applied
+    to the observations already recorded in a trace fixture.  Stored as f32."""
+    from mate.agents.utils import convert_coordinates, rescale_observation
+    from mate.utils import Team
+    fx = np.load(os.path.join(HERE, trace_name + '.npz'))
+    Nc, Nt, No = int(fx['num_cameras']), int(fx['num_targets']), int(fx['num_obstacles'])
+    out = {'trace': np.str_(trace_name), 'steps': np.int64(steps)}
+    for team, key in ((Team.CAMERA, 'cam_obs'), (Team.TARGET, 'tgt_obs')):
+        if team is Team.CAMERA and Nc == 0:
+            continue
+        obs = fx['step/' + key][:steps]
+        rel = np.stack([convert_coordinates(o, team, Nc, Nt, No) for o in obs])
+        res = np.stack([rescale_observation(o, team, Nc, Nt, No) for o in obs])
+        relres = np.stack([rescale_observation(o, team, Nc, Nt, No) for o in rel])
+        out[key + '_relative'] = rel.astype(np.float32)
+        out[key + '_rescaled'] = res.astype(np.float32)
+        out[key + '_relative_rescaled'] = relres.astype(np.float32)
+    path = os.path.join(HERE, 'xform_' + trace_name[6:] + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'xform_{trace_name[6:]}: {steps} steps, {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def main():
     check_binomial_model()
+    if sys.argv[1:] == ['xform']:
+        xform_fixture('trace_4v8-9_greedy_s2', 48)
+        xform_fixture('trace_nav_greedy_s1', 32)
+        return
     kat_obstruct()
     kat_scalar()
     kat_perceive()

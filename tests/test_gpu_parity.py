@@ -199,3 +199,33 @@ def test_errors_are_loud():
         eng.step_random()      # before reset
     with pytest.raises(ValueError):
         read_config('MATE-4v8-9.yaml', num_cargoes_per_target=2)
+
+
+@pytest.mark.parametrize('name', ['4v8-9_greedy_s2', 'nav_greedy_s1'])
+@pytest.mark.parametrize('mode', ['relative', 'rescaled', 'relative_rescaled'])
+def test_fused_observation_transforms(name, mode):
+    """RelativeCoordinates / RescaledObservation fused into the packer == the reference's wrapper functions
+    applied to the reference's observations (fixtures xform_*.npz)."""
+    fx = G.load('trace_' + name + '.npz')
+    xf = G.load('xform_' + name + '.npz')
+    N = 2
+    eng = U.engine_from_fixture(fx, N, obs_dtype=torch.float32)
+    eng.set_obs_transform(relative_coordinates='relative' in mode, rescaled_observation='rescaled' in mode)
+    Nc, Nt = eng.num_cameras, eng.num_targets
+    dev = eng.device
+    for s in range(int(xf['steps'])):
+        ca = torch.from_numpy(np.broadcast_to(fx['step/cam_act'][s], (N, Nc, 2)).copy()).to(dev)
+        ta = torch.from_numpy(np.broadcast_to(fx['step/tgt_act'][s], (N, Nt, 2)).copy()).to(dev)
+        tape = torch.from_numpy(np.broadcast_to(np.nan_to_num(fx['step/tape_ct'][s], nan=0.0), (N, Nc, Nt)).copy()).to(dev)
+        goal = torch.from_numpy(np.broadcast_to(np.nan_to_num(fx['step/goal_u'][s], nan=0.0), (N, Nt)).copy()).to(dev)
+        co, to, _ = eng.step(ca, ta, tape_ct=tape, tape_goal=goal)
+        ref_t = xf['tgt_obs_' + mode][s].astype(np.float64)
+        got_t = to[1].double().cpu().numpy()
+        # bound: 1e-5 of the column scale (rescaled columns live in [-1, 1]; raw coordinates in +-2000)
+        tol = 1e-5 * np.maximum(1.0, np.abs(ref_t)) if 'rescaled' not in mode else 1e-5
+        assert np.all(np.abs(got_t - ref_t) <= tol + 1e-4 * ('rescaled' not in mode)), (s, np.abs(got_t - ref_t).max())
+        if Nc:
+            ref_c = xf['cam_obs_' + mode][s].astype(np.float64)
+            got_c = co[1].double().cpu().numpy()
+            tolc = 1e-5 * np.maximum(1.0, np.abs(ref_c)) if 'rescaled' not in mode else 1e-5
+            assert np.all(np.abs(got_c - ref_c) <= tolc + 1e-4 * ('rescaled' not in mode)), (s, np.abs(got_c - ref_c).max())
