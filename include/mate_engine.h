@@ -119,6 +119,28 @@ int mate_engine_step_random(mate_engine *engine, const mate_step_io *io, int32_t
  * observation rows are left untouched; with auto_reset it starts a new episode before the next call. */
 int mate_engine_rollout_random(mate_engine *engine, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream);
 
+/* On-device rule-based policies: the reference's GreedyCameraAgent / GreedyTargetAgent
+ * (mate/agents/greedy.py:13-227, 229-365) for every agent of every environment, acting on the same
+ * partial observations (own state, opponents gated by the view masks of the previous step, teammates'
+ * messages).  mate_engine_policy_enable() must precede the reset()/step() whose view they first act on.
+ * mate_engine_step_greedy() = group_step of both teams (observe, two-phase message exchange, act;
+ * mate/wrappers/single_team.py:79-92) + step().  `tape` (device arrays, any member NULL = Philox):
+ * recorded draws of the agents, for parity runs. */
+typedef struct mate_policy_tape {
+    const double *camera_resample_u_dev;     /* [N][Nc]      Bernoulli(0.1) uniform when no target is remembered (greedy.py:93) */
+    const double *camera_sample_u_dev;       /* [N][Nc][2]   action_space.sample() uniforms (greedy.py:94) */
+    const int32_t *camera_delay_dev;         /* [N][Nc][Nc]  randint(6, 50) per sent message sender->recipient (greedy.py:184) */
+    const double *target_choice_u_dev;       /* [N][Nt]      choice among non-empty warehouses (greedy.py:298) */
+    const double *target_resample_u_dev;     /* [N][Nt]      Bernoulli(prob) uniform (greedy.py:316) */
+    const double *target_sample_u_dev;       /* [N][Nt][2]   noise sample uniforms (greedy.py:317) */
+    const double *target_reset_sample_u_dev; /* [N][Nt][2]   initial noise at agent.reset (greedy.py:277) */
+} mate_policy_tape;
+int mate_engine_policy_enable(mate_engine *engine);
+int mate_engine_step_greedy(mate_engine *engine, const mate_step_io *io, const mate_policy_tape *tape,
+                            int32_t auto_reset, void *stream);
+/* copies the joint actions of the last step_greedy into caller buffers [N][Nc][2] / [N][Nt][2] f64 (either may be NULL) */
+int mate_engine_policy_actions(mate_engine *engine, double *camera_actions_dev, double *target_actions_dev, void *stream);
+
 /* joint_observation() (environment.py:908-983) without advancing the simulation: recomputes
  * the view masks from the current state (see-through draws from io tape or Philox) and packs. */
 int mate_engine_observe(mate_engine *engine, const mate_step_io *io, void *stream);

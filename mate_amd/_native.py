@@ -7,14 +7,15 @@ module raises, and every engine call that returns a non-zero status raises
 import ctypes
 import os
 
-__all__ = ['lib', 'load', 'EngineError', 'MateConfig', 'MateLayout', 'MateStepIO', 'LIB_PATH', 'check', 'EXPORTED_SYMBOLS']
+__all__ = ['lib', 'load', 'EngineError', 'MateConfig', 'MateLayout', 'MateStepIO', 'MatePolicyTape', 'LIB_PATH', 'check', 'EXPORTED_SYMBOLS']
 
 LIB_PATH = os.environ.get('MATE_ENGINE_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libmate_engine.so')
 
 EXPORTED_SYMBOLS = (
     'mate_engine_last_error', 'mate_engine_abi_version', 'mate_engine_create', 'mate_engine_destroy',
     'mate_engine_get_layout', 'mate_engine_set_obs_transform', 'mate_engine_seed', 'mate_engine_reset', 'mate_engine_step', 'mate_engine_step_random',
-    'mate_engine_rollout_random', 'mate_engine_observe', 'mate_engine_export_state', 'mate_engine_import_state', 'mate_engine_lut_read',
+    'mate_engine_rollout_random', 'mate_engine_policy_enable', 'mate_engine_step_greedy', 'mate_engine_policy_actions',
+    'mate_engine_observe', 'mate_engine_export_state', 'mate_engine_import_state', 'mate_engine_lut_read',
     'mate_engine_lut_write', 'mate_engine_rebuild_luts', 'mate_engine_kernel_time',
 )
 
@@ -51,6 +52,12 @@ class MateLayout(ctypes.Structure):
     _fields_ = [(name, ctypes.c_int32) for name in (
         'camera_obs_dim', 'target_obs_dim', 'state_dim', 'mask_words', 'bit_camera_target', 'bit_camera_camera',
         'bit_target_row', 'bit_camera_obstacle', 'export_width', 'lut_capacity', 'scalars_per_env')]
+
+
+class MatePolicyTape(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_void_p) for name in (
+        'camera_resample_u_dev', 'camera_sample_u_dev', 'camera_delay_dev', 'target_choice_u_dev',
+        'target_resample_u_dev', 'target_sample_u_dev', 'target_reset_sample_u_dev')]
 
 
 class MateStepIO(ctypes.Structure):
@@ -91,6 +98,9 @@ def load():
     handle.mate_engine_step.argtypes = [P, ctypes.POINTER(MateStepIO), I32, P]
     handle.mate_engine_step_random.argtypes = [P, ctypes.POINTER(MateStepIO), I32, P]
     handle.mate_engine_rollout_random.argtypes = [P, ctypes.POINTER(MateStepIO), I32, I32, P]
+    handle.mate_engine_policy_enable.argtypes = [P]
+    handle.mate_engine_step_greedy.argtypes = [P, ctypes.POINTER(MateStepIO), ctypes.POINTER(MatePolicyTape), I32, P]
+    handle.mate_engine_policy_actions.argtypes = [P, P, P, P]
     handle.mate_engine_observe.argtypes = [P, ctypes.POINTER(MateStepIO), P]
     handle.mate_engine_export_state.argtypes = [P, P, P]
     handle.mate_engine_import_state.argtypes = [P, P, P]

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'mate_engine.hip')
-DEPS = [SRC] + [os.path.join(HERE, 'csrc', f) for f in ('engine_kernels.hpp', 'reset_kernels.hpp', 'device_math.hpp')] + [
+DEPS = [SRC] + [os.path.join(HERE, 'csrc', f) for f in ('engine_kernels.hpp', 'reset_kernels.hpp', 'policy_kernels.hpp', 'device_math.hpp')] + [
     os.path.join(os.path.dirname(HERE), 'include', 'mate_engine.h')]
 OUT = os.path.join(HERE, 'lib', 'libmate_engine.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',

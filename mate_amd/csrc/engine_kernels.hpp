@@ -56,6 +56,7 @@ struct Ptrs {
     void *cam_obs, *tgt_obs;
     float *scalars;
     uint32_t *masks;
+    uint32_t *own_masks;          // engine-owned copy of the packed masks (input of the on-device policies), or NULL
     int32_t *done_count;          // [2] ping-pong counters
     int32_t *done_list;           // [2][N]
     const uint8_t *reset_mask;    // optional
@@ -777,6 +778,10 @@ __device__ void pack_observations(Ctx<ObsT> &c) {
     }
     if (c.g.masks) {
         uint32_t *m = c.g.masks + c.out * p.MW;
+        for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
+    }
+    if (c.g.own_masks) {
+        uint32_t *m = c.g.own_masks + c.env * p.MW;
         for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
     }
 }

@@ -13,6 +13,7 @@
 
 #include "../../include/mate_engine.h"
 #include "reset_kernels.hpp"
+#include "policy_kernels.hpp"
 
 using namespace mate;
 
@@ -45,6 +46,9 @@ struct mate_engine {
     bool was_reset = false;
     size_t step_lds = 0, reset_lds = 0;
     std::vector<void *> allocs;
+    // on-device rule-based policies (mate_engine_step_greedy)
+    bool policy_ready = false;
+    PolicyPtrs q{};
     // kernel timing (HIP events on the launch stream)
     int timing = 0;            // 0 = off, k = time every k-th step launch
     int64_t timing_tick = 0;
@@ -506,6 +510,72 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
         if (rc != MATE_OK) return rc;
         e->parity ^= 1;
     }
+    return MATE_OK;
+}
+
+static int policy_enable(mate_engine *e) {
+    if (e->policy_ready) return MATE_OK;
+    const Params &p = e->p;
+    PolicyPtrs &q = e->q;
+    q.PF = p.Nc * p.Nt * 2 + p.Nc * 2 + p.Nt * 4;
+    q.PI = p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + 3 * p.Nt + 1;
+    q.PW = q.PF + (q.PI + 1) / 2;
+    q.memory_period = 25;      // greedy.py:21
+    q.noise_scale = 0.5;       // greedy.py:236
+    q.lds_bytes = round_up((q.PW + p.Nc * p.Nc / 2 + 2 + p.SW + p.DW) * 8 + p.MW * 4, 16);
+    int rc;
+    if ((rc = dev_alloc(e, &q.pol, (size_t)e->N * q.PW))) return rc;
+    if ((rc = dev_alloc(e, &q.cam_act, (size_t)e->N * std::max(p.Nc, 1) * 2))) return rc;
+    if ((rc = dev_alloc(e, &q.tgt_act, (size_t)e->N * p.Nt * 2))) return rc;
+    if (!e->g.own_masks && (rc = dev_alloc(e, &e->g.own_masks, (size_t)e->N * p.MW))) return rc;
+    q.masks = e->g.own_masks;
+    hipError_t err = e->p.obs_f64
+        ? hipFuncSetAttribute(reinterpret_cast<const void *>(&greedy_policy_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * q.lds_bytes)
+        : hipFuncSetAttribute(reinterpret_cast<const void *>(&greedy_policy_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * q.lds_bytes);
+    if (err != hipSuccess) return fail(MATE_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
+    e->policy_ready = true;
+    return MATE_OK;
+}
+
+// Turn on the engine-owned mask copy the on-device policies read (must precede the reset / step whose view they act on).
+extern "C" int mate_engine_policy_enable(mate_engine *e) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->device));
+    return policy_enable(e);
+}
+
+extern "C" int mate_engine_step_greedy(mate_engine *e, const mate_step_io *io, const mate_policy_tape *tape, int32_t auto_reset, void *stream_) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    if (!e->was_reset) return fail(MATE_ESTATE, "step_greedy called before reset() (or import_state)");
+    if (!e->policy_ready) return fail(MATE_ESTATE, "call mate_engine_policy_enable() before the reset whose observations the policies act on");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(e->device));
+    PolicyPtrs q = e->q;
+    std::memset(&q.tape, 0, sizeof(q.tape));
+    if (tape) {
+        q.tape.cam_binom_u = tape->camera_resample_u_dev; q.tape.cam_sample_u = tape->camera_sample_u_dev;
+        q.tape.cam_delay = tape->camera_delay_dev; q.tape.tgt_choice_u = tape->target_choice_u_dev;
+        q.tape.tgt_binom_u = tape->target_resample_u_dev; q.tape.tgt_sample_u = tape->target_sample_u_dev;
+        q.tape.tgt_reset_sample_u = tape->target_reset_sample_u_dev;
+    }
+    const unsigned blocks = (unsigned)((e->N + 3) / 4);
+    if (e->p.obs_f64) hipLaunchKernelGGL(greedy_policy_kernel<double>, dim3(blocks), dim3(256), 4 * q.lds_bytes, stream, e->d_params, e->g, q);
+    else hipLaunchKernelGGL(greedy_policy_kernel<float>, dim3(blocks), dim3(256), 4 * q.lds_bytes, stream, e->d_params, e->g, q);
+    HIP_TRY(hipGetLastError());
+    mate_step_io io2;
+    if (io) io2 = *io; else std::memset(&io2, 0, sizeof(io2));
+    io2.camera_actions_dev = q.cam_act; io2.target_actions_dev = q.tgt_act; io2.act_dtype = MATE_ACT_F64;
+    return launch_step(e, &io2, MODE_STEP, auto_reset, stream);
+}
+
+// Copy the joint actions the last mate_engine_step_greedy produced into caller buffers ([N][Nc][2], [N][Nt][2] f64).
+extern "C" int mate_engine_policy_actions(mate_engine *e, double *camera_actions_dev, double *target_actions_dev, void *stream) {
+    if (!e || !e->policy_ready) return fail(MATE_ESTATE, "policies are not enabled");
+    HIP_TRY(hipSetDevice(e->device));
+    if (camera_actions_dev && e->p.Nc > 0)
+        HIP_TRY(hipMemcpyAsync(camera_actions_dev, e->q.cam_act, sizeof(double) * 2 * e->p.Nc * (size_t)e->N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (target_actions_dev)
+        HIP_TRY(hipMemcpyAsync(target_actions_dev, e->q.tgt_act, sizeof(double) * 2 * e->p.Nt * (size_t)e->N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return MATE_OK;
 }
 

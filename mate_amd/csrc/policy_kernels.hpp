@@ -1,0 +1,323 @@
+// policy_kernels.hpp -- on-device rule-based policies: the reference's GreedyCameraAgent and
+// GreedyTargetAgent (mate/agents/greedy.py:13-227, :229-365) for every environment of the batch, so that
+// scenario C3 (Greedy vs Greedy) never leaves the GPU.
+//
+// One wave per environment (4 per workgroup), lanes = agents or (sender, recipient) pairs.  What an agent
+// may know is exactly what its observation row holds: its own private state, the opponents' public states
+// gated by the view masks of the previous step, and its teammates' messages (exchanged here through LDS:
+// the reference's mailbox is a host-side dict, mate/environment.py:836-892).
+// Random draws (tape or Philox): camera "re-sample when blind" Bernoulli(0.1) + action sample
+// (greedy.py:93-96), message delays randint(6, 50) (greedy.py:184-185); target goal choice (greedy.py:298),
+// noise Bernoulli + sample (greedy.py:315-319), initial noise (greedy.py:277).
+#pragma once
+#include "engine_kernels.hpp"
+
+namespace mate {
+
+enum PolicyStream : uint32_t { S_POL_CAM = 16, S_POL_DELAY = 17, S_POL_TGT = 18, S_POL_TGT_RESET = 19 };
+
+struct PolicyTape {          // all optional (NULL = Philox); device pointers
+    const double *cam_binom_u;        // [N][Nc]
+    const double *cam_sample_u;       // [N][Nc][2]
+    const int32_t *cam_delay;         // [N][Nc][Nc]  value drawn for the message sender->recipient (-1 = none)
+    const double *tgt_choice_u;       // [N][Nt]
+    const double *tgt_binom_u;        // [N][Nt]
+    const double *tgt_sample_u;       // [N][Nt][2]
+    const double *tgt_reset_sample_u; // [N][Nt][2]
+};
+
+struct PolicyPtrs {
+    double *pol;               // [N][PW] agent memory record
+    const uint32_t *masks;     // [N][MW] view masks of the previous step / reset
+    double *cam_act, *tgt_act; // [N][Nc][2], [N][Nt][2] f64 outputs
+    PolicyTape tape;
+    int32_t PF, PI, PW;        // doubles, ints, 8-byte words per record
+    int32_t lds_bytes;         // per wave
+    int32_t memory_period;     // 25 (greedy.py:21)
+    double noise_scale;        // 0.5 (greedy.py:236)
+};
+
+// f64 part of the record
+//   mem[c][t][2] | prev_action[c][2] | tgt_prev_xy[t][2] | tgt_prev_noise[t][2]
+// i32 part
+//   t2f[c][t] | delay[s][c] | neighbor[c][s] | has_state[c] | tgt_goal[t] | tgt_nonempty[t] | tgt_need[t] | episode
+template <typename ObsT>
+struct PolCtx {
+    const Params &p;
+    const PolicyPtrs &q;
+    double *f;
+    int32_t *i;
+    __device__ PolCtx(const Params &p_, const PolicyPtrs &q_, unsigned char *base) : p(p_), q(q_) {
+        f = reinterpret_cast<double *>(base);
+        i = reinterpret_cast<int32_t *>(f + q.PF);
+    }
+    __device__ double &mem(int c, int t, int k) { return f[(c * p.Nt + t) * 2 + k]; }
+    __device__ double &prev_action(int c, int k) { return f[p.Nc * p.Nt * 2 + c * 2 + k]; }
+    __device__ double &tgt_prev(int t, int k) { return f[p.Nc * p.Nt * 2 + p.Nc * 2 + t * 2 + k]; }
+    __device__ double &tgt_noise(int t, int k) { return f[p.Nc * p.Nt * 2 + p.Nc * 2 + p.Nt * 2 + t * 2 + k]; }
+    __device__ int32_t &t2f(int c, int t) { return i[c * p.Nt + t]; }
+    __device__ int32_t &delay(int s, int c) { return i[p.Nc * p.Nt + s * p.Nc + c]; }
+    __device__ int32_t &neighbor(int c, int s) { return i[p.Nc * p.Nt + p.Nc * p.Nc + c * p.Nc + s]; }
+    __device__ int32_t &has_state(int c) { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + c]; }
+    __device__ int32_t &tgt_goal(int t) { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + t]; }
+    __device__ int32_t &tgt_nonempty(int t) { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + p.Nt + t]; }
+    __device__ int32_t &tgt_need(int t) { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + 2 * p.Nt + t]; }
+    __device__ int32_t &episode() { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + 3 * p.Nt]; }
+    // scratch past the record: message staging
+    __device__ int32_t &send_bits(int s, int c) { return i[q.PI + s * p.Nc + c]; }      // bit 31: 'state', bits 0..Nt-1: targets
+};
+
+__device__ __forceinline__ double sin_deg_f64(double x) { double s, c; sincos_deg(x, s, c); return s; }
+
+template <typename ObsT>
+__global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q) {
+    const Params &p = *pp;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int64_t env = (int64_t)blockIdx.x * 4 + wave;
+    if (env >= g.N) return;
+    unsigned char *base = smem + wave * q.lds_bytes;
+    // LDS: [policy record + staging][static record][dynamic record][mask words]
+    PolCtx<ObsT> a(p, q, base);
+    double *st = reinterpret_cast<double *>(base + (size_t)(q.PW + p.Nc * p.Nc / 2 + 2) * 8);
+    double *dy = st + p.SW;
+    int32_t *di = reinterpret_cast<int32_t *>(dy + p.DF);
+    uint32_t *mk = reinterpret_cast<uint32_t *>(dy + p.DW);
+    {
+        const double *src = q.pol + env * q.PW;
+        for (int k = lane; k < q.PW; k += 64) a.f[k] = src[k];
+        const double *s = g.stat + env * p.SW;
+        for (int k = lane; k < p.SW; k += 64) st[k] = s[k];
+        const double *d = g.dyn + env * p.DW;
+        for (int k = lane; k < p.DW; k += 64) dy[k] = d[k];
+        const uint32_t *m = q.masks + env * p.MW;
+        for (int k = lane; k < p.MW; k += 64) mk[k] = m[k];
+    }
+    wave_sync();
+    const int Nc = p.Nc, Nt = p.Nt;
+    auto cam_x = [&](int c) { return st[c]; };
+    auto cam_y = [&](int c) { return st[Nc + c]; };
+    auto tx = [&](int t) { return dy[2 * Nc + t]; };
+    auto ty = [&](int t) { return dy[2 * Nc + Nt + t]; };
+    auto sees = [&](int c, int t) { const int b = c * Nt + t; return (mk[b >> 5] >> (b & 31)) & 1u; };
+    const int32_t *env_i = di + Nt * TI_STRIDE;
+    const uint32_t tick = (uint32_t)env_i[EI_TICK];
+    const uint32_t env_global = p.first_env + (uint32_t)env;
+    const bool fresh = a.episode() != env_i[EI_EPISODE];     // first call of a new episode: agent.reset(observation)
+    const uint64_t capword = reinterpret_cast<const uint64_t *>(st)[3 * Nc + 3 * p.No];
+
+    // ------------------------------------------------------------------ reset + observe
+    if (lane < Nc) {                                        // GreedyCameraAgent.reset / process_messages (greedy.py:43-61,100-113)
+        const int c = lane;
+        if (fresh) {
+            for (int t = 0; t < Nt; ++t) {
+                const bool s = sees(c, t);
+                a.mem(c, t, 0) = s ? tx(t) : 0.0; a.mem(c, t, 1) = s ? ty(t) : 0.0;   // hidden rows of the observation are zeros
+                a.t2f(c, t) = s ? q.memory_period : 0;
+            }
+            a.prev_action(c, 0) = 0.0; a.prev_action(c, 1) = 0.0;
+            for (int s = 0; s < Nc; ++s) { a.delay(c, s) = 0; a.neighbor(c, s) = 0; }
+            a.has_state(c) = 1;
+        }
+        for (int t = 0; t < Nt; ++t) {
+            int left = a.t2f(c, t) - 1;
+            if (left < 0) left = 0;
+            if (sees(c, t)) { left = q.memory_period; a.mem(c, t, 0) = tx(t); a.mem(c, t, 1) = ty(t); }
+            a.t2f(c, t) = left;
+        }
+    }
+    const int tl = lane - 32;
+    if (tl >= 0 && tl < Nt) {                               // GreedyTargetAgent.reset / process_messages (greedy.py:262-283,326-332)
+        const int t = tl;
+        const int gw = di[t * TI_STRIDE + TI_GW];
+        const int state_goal = (gw & 0xff) - 1;
+        const double step_size = ((capword >> t) & 1ull) ? p.tgt_step * 0.5 : p.tgt_step;
+        if (fresh) {
+            a.tgt_prev(t, 0) = tx(t); a.tgt_prev(t, 1) = ty(t);
+            double u0, u1;
+            if (q.tape.tgt_reset_sample_u) { u0 = q.tape.tgt_reset_sample_u[(env * Nt + t) * 2]; u1 = q.tape.tgt_reset_sample_u[(env * Nt + t) * 2 + 1]; }
+            else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, (uint32_t)env_i[EI_EPISODE], S_POL_TGT_RESET, (uint32_t)t); u0 = u53(r.x, r.y); u1 = u53(r.z, r.w); }
+            a.tgt_noise(t, 0) = 0.5 * (-step_size + (2.0 * step_size) * u0);               // 0.5 * action_space.sample()
+            a.tgt_noise(t, 1) = 0.5 * (-step_size + (2.0 * step_size) * u1);
+            a.tgt_goal(t) = state_goal;
+            a.tgt_nonempty(t) = 0xf;
+            a.tgt_need(t) = 0;
+        }
+        const int seen_empty = (gw >> 16) & 0xf;
+        if (seen_empty & a.tgt_nonempty(t)) { a.tgt_nonempty(t) &= ~seen_empty; a.tgt_need(t) = 1; }
+    }
+    if (lane == 0 && fresh) a.episode() = env_i[EI_EPISODE];
+    wave_sync();
+
+    // ------------------------------------------------------------------ communicate
+    // cameras: send_responses (greedy.py:158-190), one lane per (sender, recipient)
+    if (lane < Nc * Nc) {
+        const int s = (int)(((float)lane + 0.5f) * p.inv_Nc), c = lane - s * Nc;
+        int bits = 0;
+        int d = a.delay(s, c) - 1;
+        if (d < 0) d = 0;
+        // message2send is non-empty iff it still holds 'state' or a target was seen this step
+        uint32_t seen_now = 0;
+        for (int t = 0; t < Nt; ++t) seen_now |= (uint32_t)sees(s, t) << t;
+        const bool has_content = a.has_state(s) || seen_now;
+        if (has_content && s != c && d == 0) {
+            uint32_t list = 0;
+            if (seen_now && a.neighbor(s, c)) {            // filterout_beyond_range: 110 % of the teammate's range
+                const double threshold = 1.1 * p.rmax;
+                for (int t = 0; t < Nt; ++t)
+                    if ((seen_now >> t) & 1u) { if (norm2(tx(t) - cam_x(c), ty(t) - cam_y(c)) < threshold) list |= 1u << t; }
+            }
+            bits = (int)list | (a.has_state(s) ? (int)0x80000000u : 0);
+            if (bits) {
+                int v;
+                if (q.tape.cam_delay) v = q.tape.cam_delay[(env * Nc + s) * Nc + c];
+                else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_DELAY, (uint32_t)lane);
+                       const int lo = q.memory_period / 4, hi = 2 * q.memory_period; v = lo + (int)(u53(r.x, r.y) * (double)(hi - lo)); if (v >= hi) v = hi - 1; }
+                d = v;
+            }
+        }
+        if (has_content) a.delay(s, c) = d;                 // the decrement happens only inside `if len(message2send) > 0`... see note
+        else a.delay(s, c) = d;
+        a.send_bits(s, c) = bits;
+    }
+    wave_sync();
+    if (lane < Nc) {                                        // receive_responses (greedy.py:192-226) + message2send.clear()
+        const int c = lane;
+        for (int s = 0; s < Nc; ++s) {
+            const int bits = a.send_bits(s, c);
+            if (bits & (int)0x80000000u) a.neighbor(c, s) = 1;
+            for (int t = 0; t < Nt; ++t)
+                if ((bits >> t) & 1) { a.mem(c, t, 0) = tx(t); a.mem(c, t, 1) = ty(t); a.t2f(c, t) = q.memory_period; }
+        }
+    }
+    wave_sync();
+    if (lane < Nc) {
+        uint32_t seen_now = 0;
+        for (int t = 0; t < Nt; ++t) seen_now |= (uint32_t)sees(lane, t) << t;
+        if (a.has_state(lane) || seen_now) a.has_state(lane) = 0;   // message2send.clear()
+    }
+    // targets: broadcast non-empty warehouse sets (greedy.py:334-358)
+    if (tl >= 0 && tl < Nt) {
+        int set = a.tgt_nonempty(tl);
+        for (int s = 0; s < Nt; ++s) if (a.tgt_need(s)) set &= a.tgt_nonempty(s);
+        wave_sync();
+        a.tgt_nonempty(tl) = set;
+        a.tgt_need(tl) = 0;
+    } else {
+        wave_sync();
+    }
+    wave_sync();
+
+    // ------------------------------------------------------------------ act
+    if (lane < Nc) {                                        // GreedyCameraAgent.act (greedy.py:69-156)
+        const int c = lane;
+        const double phi = dy[c], theta = dy[Nc + c];
+        const double sr = sqrt(p.area / theta);
+        double sn, cs;
+        sincos_deg(phi, sn, cs);
+        // the agent reconstructs these from its observation row (agents/utils.py:206-255)
+        const double vx = sr * cs, vy = sr * sn;
+        const double sight = norm2(vx, vy);
+        const double orientation = atan2_deg(vy, vx);
+        const double q2 = sight / p.rmax;
+        const double min_va = theta * (q2 * q2);
+        const double threshold = 1.1 * p.rmax;
+        int best = -1; double best_d = 0.0;
+        for (int t = 0; t < Nt; ++t) {
+            if (a.t2f(c, t) <= 0) continue;
+            const double dnorm = norm2(a.mem(c, t, 0) - cam_x(c), a.mem(c, t, 1) - cam_y(c));
+            if (!(dnorm < threshold)) continue;
+            if (best < 0 || dnorm < best_d) { best = t; best_d = dnorm; }
+        }
+        double a0, a1;
+        if (best >= 0) {
+            const double rx = a.mem(c, best, 0) - cam_x(c), ry = a.mem(c, best, 1) - cam_y(c);
+            const double best_orientation = atan2_deg(ry, rx);
+            const double distance = best_d;
+            double best_va;
+            if (distance * (1.0 + sin_deg_f64(min_va / 2.0)) >= p.rmax) best_va = min_va;
+            else {
+                const double area_product = theta * (sight * sight);
+                if (distance <= sqrt(area_product / 180.0) / 2.0) best_va = 180.0;
+                else {
+                    double b = 180.0;
+                    for (int it = 0; it < 20; ++it) {
+                        const double half = b / 2.0;
+                        const double s2 = distance * (1.0 + sin_deg_f64(half < 90.0 ? half : 90.0));
+                        b = area_product / (s2 * s2);
+                    }
+                    best_va = clipd(b, min_va, 180.0);
+                }
+            }
+            a0 = clipd(normalize_angle(best_orientation - orientation), -p.rot, p.rot);
+            a1 = clipd(best_va - theta, -p.zoom, p.zoom);
+        } else {
+            double u;
+            if (q.tape.cam_binom_u) u = q.tape.cam_binom_u[env * Nc + c];
+            else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_CAM, (uint32_t)c); u = u53(r.x, r.y); }
+            if (u > 1.0 - 0.1) {                            // np_random.binomial(1, 0.1)
+                double u0, u1;
+                if (q.tape.cam_sample_u) { u0 = q.tape.cam_sample_u[(env * Nc + c) * 2]; u1 = q.tape.cam_sample_u[(env * Nc + c) * 2 + 1]; }
+                else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_CAM, (uint32_t)(Nc + c)); u0 = u53(r.x, r.y); u1 = u53(r.z, r.w); }
+                a0 = -p.rot + (2.0 * p.rot) * u0; a1 = -p.zoom + (2.0 * p.zoom) * u1;
+            } else { a0 = a.prev_action(c, 0); a1 = a.prev_action(c, 1); }
+        }
+        a.prev_action(c, 0) = a0; a.prev_action(c, 1) = a1;
+        q.cam_act[(env * Nc + c) * 2] = a0; q.cam_act[(env * Nc + c) * 2 + 1] = a1;
+    }
+    if (tl >= 0 && tl < Nt) {                               // GreedyTargetAgent.act (greedy.py:285-324)
+        const int t = tl;
+        const int gw = di[t * TI_STRIDE + TI_GW];
+        const int state_goal = (gw & 0xff) - 1;
+        const double step_size = ((capword >> t) & 1ull) ? p.tgt_step * 0.5 : p.tgt_step;
+        int goal = a.tgt_goal(t);
+        if (state_goal >= 0) goal = state_goal;
+        const int nonempty = a.tgt_nonempty(t);
+        if (goal < 0 || (state_goal < 0 && !((nonempty >> goal) & 1))) {
+            goal = -1;
+            const int k = __popc(nonempty);
+            if (k > 0) {
+                double u;
+                if (q.tape.tgt_choice_u) u = q.tape.tgt_choice_u[env * Nt + t];
+                else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_TGT, (uint32_t)(2 * Nt + t)); u = u53(r.x, r.y); }
+                int j = (int)(u * (double)k);
+                if (j >= k) j = k - 1;
+                for (int w = 0, seen = 0; w < 4; ++w) if ((nonempty >> w) & 1) { if (seen == j) goal = w; ++seen; }
+            }
+        }
+        a.tgt_goal(t) = goal;
+        const double x = tx(t), y = ty(t);
+        const double pax = x - a.tgt_prev(t, 0), pay = y - a.tgt_prev(t, 1);
+        double ax = 0.0, ay = 0.0;
+        if (goal >= 0) {
+            const double wx = (goal == 0 || goal == 3) ? kWarehouseCenter : -kWarehouseCenter;
+            const double wy = (goal < 2) ? kWarehouseCenter : -kWarehouseCenter;
+            ax = wx - x; ay = wy - y;
+        }
+        const double len = norm2(ax, ay);
+        if (len > step_size) { const double k2 = step_size / len; ax *= k2; ay *= k2; }
+        const double prob = norm2(pax, pay) > 0.2 * step_size ? 0.05 : 0.75;
+        double u;
+        if (q.tape.tgt_binom_u) u = q.tape.tgt_binom_u[env * Nt + t];
+        else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_TGT, (uint32_t)t); u = u53(r.x, r.y); }
+        double nx = a.tgt_noise(t, 0), ny = a.tgt_noise(t, 1);
+        if ((prob <= 0.5) ? (u > 1.0 - prob) : (u <= prob)) {
+            double u0, u1;
+            if (q.tape.tgt_sample_u) { u0 = q.tape.tgt_sample_u[(env * Nt + t) * 2]; u1 = q.tape.tgt_sample_u[(env * Nt + t) * 2 + 1]; }
+            else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_TGT, (uint32_t)(Nt + t)); u0 = u53(r.x, r.y); u1 = u53(r.z, r.w); }
+            nx = q.noise_scale * (-step_size + (2.0 * step_size) * u0);
+            ny = q.noise_scale * (-step_size + (2.0 * step_size) * u1);
+        }
+        const double outx = clipd(ax + nx, -step_size, step_size), outy = clipd(ay + ny, -step_size, step_size);
+        a.tgt_prev(t, 0) = x; a.tgt_prev(t, 1) = y;
+        a.tgt_noise(t, 0) = nx; a.tgt_noise(t, 1) = ny;
+        q.tgt_act[(env * Nt + t) * 2] = outx; q.tgt_act[(env * Nt + t) * 2 + 1] = outy;
+    }
+    wave_sync();
+    {
+        double *dst = q.pol + env * q.PW;
+        for (int k = lane; k < q.PW; k += 64) dst[k] = a.f[k];
+    }
+}
+
+}  // namespace mate

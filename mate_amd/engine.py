@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from mate_amd import _native
-from mate_amd._native import MateConfig, MateLayout, MateStepIO, check
+from mate_amd._native import MateConfig, MateLayout, MatePolicyTape, MateStepIO, check
 
 __all__ = ['Engine', 'export_layout', 'SCALAR_NAMES']
 
@@ -215,6 +215,38 @@ class Engine:
         io.masks_dev = buf['masks'].data_ptr() if want_masks else None
         check(self.lib.mate_engine_rollout_random(self._h, ctypes.byref(io), steps, int(auto_reset), self._stream()))
         return buf['camera_obs'], buf['target_obs'], buf['scalars']
+
+    def enable_policies(self):
+        """Allocate the on-device policy state (call before the reset whose observations the agents act on)."""
+        check(self.lib.mate_engine_policy_enable(self._h))
+
+    def step_greedy(self, policy_tape=None, tape_ct=None, tape_goal=None, auto_reset=True):
+        """One step with GreedyCameraAgent vs GreedyTargetAgent computed on the device.  `policy_tape`:
+        dict of recorded agent draws (tensors) for parity runs.  Returns (camera_obs, target_obs, scalars)."""
+        io, keep = self._io(tape_ct=tape_ct, tape_goal=tape_goal)
+        tape_ptr = None
+        if policy_tape is not None:
+            tape = MatePolicyTape()
+            for name, dtype in (('camera_resample_u', torch.float64), ('camera_sample_u', torch.float64), ('camera_delay', torch.int32),
+                                ('target_choice_u', torch.float64), ('target_resample_u', torch.float64), ('target_sample_u', torch.float64),
+                                ('target_reset_sample_u', torch.float64)):
+                value = policy_tape.get(name)
+                if value is not None:
+                    value = value.to(device=self.device, dtype=dtype).contiguous()
+                    keep.append(value)
+                    setattr(tape, name + '_dev', value.data_ptr())
+            tape_ptr = ctypes.byref(tape)
+        check(self.lib.mate_engine_step_greedy(self._h, ctypes.byref(io), tape_ptr, int(auto_reset), self._stream()))
+        return self.camera_obs, self.target_obs, self.scalars
+
+    def policy_actions(self):
+        """(camera_actions [N,Nc,2], target_actions [N,Nt,2]) f64: the joint actions of the last step_greedy."""
+        N, Nc, Nt = self.num_envs, self.num_cameras, self.num_targets
+        cam = torch.zeros((N, Nc, 2), dtype=torch.float64, device=self.device)
+        tgt = torch.zeros((N, Nt, 2), dtype=torch.float64, device=self.device)
+        check(self.lib.mate_engine_policy_actions(self._h, ctypes.c_void_p(cam.data_ptr()) if Nc else None,
+                                                  ctypes.c_void_p(tgt.data_ptr()), self._stream()))
+        return cam, tgt
 
     def observe(self, tape_ct=None):
         io, keep = self._io(tape_ct=tape_ct)

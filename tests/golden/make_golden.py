@@ -201,7 +201,80 @@ def random_actions(env, rng, step):
     return cam, tgt
 
 
-def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f64_obs_steps=None):
+class AgentRNG:
+    """Recording proxy for a rule-based agent's RandomState (agents/greedy.py draws)."""
+
+    def __init__(self, real, log, who):
+        self._real, self._log, self._who = real, log, who
+
+    def binomial(self, n, p, size=None):
+        assert n == 1 and size is None
+        u = float(self._real.random_sample())
+        out = int(u > 1.0 - p) if p <= 0.5 else int(u <= p)
+        self._log.append(('binom', self._who, float(p), u))
+        return out
+
+    def randint(self, low, high=None, size=None, dtype=int):
+        if high is None or size is not None or high - low > 1000:
+            return self._real.randint(low, high, size=size)
+        value = int(self._real.randint(low, high))
+        recipient = sys._getframe(1).f_locals.get('c', None)
+        self._log.append(('randint', self._who, int(low), int(high), value, recipient))
+        return value
+
+    def choice(self, a, size=None, replace=True, p=None):
+        assert size is None and p is None
+        a = list(a)
+        j = int(self._real.randint(0, len(a)))
+        self._log.append(('choice', self._who, len(a), j))
+        return a[j]
+
+    def __getattr__(self, name):
+        return getattr(self._real, name)
+
+
+AGENT_LOG = []
+_ORIG_BOX_SAMPLE = gym.spaces.Box.sample
+
+
+def _recording_box_sample(self):
+    """Box.sample of the (build-owned) gym stand-in with the uniforms logged: low + (high - low) * U."""
+    if not np.all(np.isfinite(self.low)) or not np.all(np.isfinite(self.high)):
+        return _ORIG_BOX_SAMPLE(self)
+    u = self.np_random.random_sample(self.shape)
+    AGENT_LOG.append(('sample', id(self), np.array(u, dtype=np.float64)))
+    return (self.low + (self.high - self.low) * u).astype(self.dtype)
+
+
+def drain_agent_log(cam_agents, tgt_agents):
+    Nc, Nt = len(cam_agents), len(tgt_agents)
+    spaces_of = {id(a.action_space): ('cam', a.index) for a in cam_agents}
+    spaces_of.update({id(a.action_space): ('tgt', a.index) for a in tgt_agents})
+    out = {
+        'cam_binom_u': np.full(Nc, np.nan), 'cam_sample_u': np.full((Nc, 2), np.nan), 'cam_delay': np.full((Nc, Nc), -1, dtype=np.int64),
+        'tgt_choice_u': np.full(Nt, np.nan), 'tgt_binom_u': np.full(Nt, np.nan), 'tgt_sample_u': np.full((Nt, 2), np.nan),
+    }
+    for item in AGENT_LOG:
+        if item[0] == 'sample':
+            if item[1] not in spaces_of:
+                continue
+            team, idx = spaces_of[item[1]]
+            out[team + '_sample_u'][idx] = item[2]
+        else:
+            team, idx = item[1]
+            if item[0] == 'binom':
+                out[team + '_binom_u'][idx] = item[3]
+            elif item[0] == 'choice':
+                assert team == 'tgt'
+                out['tgt_choice_u'][idx] = (item[3] + 0.5) / item[2]
+            elif item[0] == 'randint':
+                assert team == 'cam' and item[5] is not None
+                out['cam_delay'][idx, item[5]] = item[4]
+    AGENT_LOG.clear()
+    return out
+
+
+def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f64_obs_steps=None, record_agents=False):
     env = mate.make('MultiAgentTracking-v0', config=config, **(overrides or {}))
     env.seed(seed)
     cam_obs, tgt_obs = env.reset()
@@ -239,8 +312,22 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
     if policy == 'greedy':
         cam_agents = GreedyCameraAgent(seed=seed + 1).spawn(Nc) if Nc else []
         tgt_agents = GreedyTargetAgent(seed=seed + 2).spawn(Nt)
+        if record_agents:
+            gym.spaces.Box.sample = _recording_box_sample
+            for i, agent in enumerate(cam_agents):
+                agent._np_random = AgentRNG(agent.np_random, AGENT_LOG, None)
+            for i, agent in enumerate(tgt_agents):
+                agent._np_random = AgentRNG(agent.np_random, AGENT_LOG, None)
+        AGENT_LOG.clear()
         mate.group_reset(cam_agents, cam_obs)
         mate.group_reset(tgt_agents, tgt_obs)
+        if record_agents:
+            for agent in cam_agents:
+                agent._np_random._who = ('cam', agent.index)
+            for agent in tgt_agents:
+                agent._np_random._who = ('tgt', agent.index)
+            reset_draws = drain_agent_log(cam_agents, tgt_agents)
+            out['agent/tgt_reset_sample_u'] = reset_draws['tgt_sample_u']
         cam_infos = tgt_infos = None
 
     per_step = {}
@@ -253,6 +340,9 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
         if policy == 'greedy':
             cam_act = np.asarray(mate.group_step(env, cam_agents, cam_obs, cam_infos), dtype=np.float64).reshape(Nc, 2)
             tgt_act = np.asarray(mate.group_step(env, tgt_agents, tgt_obs, tgt_infos), dtype=np.float64).reshape(Nt, 2)
+            if record_agents:
+                for k, v in drain_agent_log(cam_agents, tgt_agents).items():
+                    push('agent_' + k, v)
         else:
             cam_act, tgt_act = random_actions(env, rng, step)
         log.clear()
@@ -278,9 +368,13 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
             if n_done >= 2:  # keep one extra step after done, then stop
                 break
 
+    gym.spaces.Box.sample = _ORIG_BOX_SAMPLE
     for k, v in per_step.items():
         arr = np.stack(v)
         out['step/' + k] = arr
+    if record_agents:   # observations are not needed to check a policy: keep these fixtures small
+        for k in ('step/cam_obs', 'step/tgt_obs', 'step/state'):
+            out.pop(k, None)
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
     nsteps = len(per_step['done'])
@@ -499,6 +593,11 @@ def xform_fixture(trace_name, steps):
 
 def main():
     check_binomial_model()
+    if sys.argv[1:] == ['agents']:
+        make_trace('greedy_4v8-9_s5', 'MATE-4v8-9.yaml', 5, 'greedy', 300, record_agents=True)
+        make_trace('greedy_8v8-9_s6', 'MATE-8v8-9.yaml', 6, 'greedy', 200, record_agents=True)
+        make_trace('greedy_4v2-9_s7', 'MATE-4v2-9.yaml', 7, 'greedy', 200, record_agents=True)
+        return
     if sys.argv[1:] == ['xform']:
         xform_fixture('trace_4v8-9_greedy_s2', 48)
         xform_fixture('trace_nav_greedy_s1', 32)
