@@ -100,6 +100,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='environments per GPU')
     ap.add_argument('--workload', default=WORKLOAD)
+    ap.add_argument('--policy', choices=['random', 'greedy'], default='random',
+                    help='on-device policy: uniform random (headline) or GreedyCamera vs GreedyTarget (BASELINE config 3)')
+    ap.add_argument('--reset-interval', type=int, default=32, help='greedy policy: batched auto-reset every k steps (1 = immediate)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
     args = ap.parse_args()
@@ -121,9 +124,14 @@ def main():
 
     cfg = read_config(args.workload)
     eng = Engine(cfg, args.batch, device=local_rank, seed=0, first_env_index=rank * args.batch)
+    if args.policy == 'greedy':
+        eng.enable_policies()
+        step = lambda: eng.step_greedy(auto_reset=args.reset_interval)     # noqa: E731
+    else:
+        step = lambda: eng.step_random(auto_reset=True)     # noqa: E731
     eng.reset()
     for _ in range(args.warmup):
-        eng.step_random(auto_reset=True)
+        step()
     eng.kernel_time(enable=16)            # HIP-event pair around every 16th step_kernel launch of the timed region
 
     def barrier():
@@ -133,11 +141,13 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
+    idle0 = eng.idle_steps()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.step_random(auto_reset=True)
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
+    executed = args.batch * args.steps - (eng.idle_steps() - idle0)   # env-steps actually simulated by this rank
     kernel_ms, launches = eng.kernel_time(enable=False)
 
     stats = eng.scalars[:, [1, 3, 6]].mean(dim=0)    # reward, coverage, delivered: logging only
@@ -145,13 +155,16 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ex = torch.tensor([executed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(ex, op=dist.ReduceOp.SUM)
+        executed = float(ex.item())
         gathered = [torch.zeros_like(stats) for _ in range(world)]
         dist.all_gather(gathered, stats)              # the only collective of the path: episode statistics
         stats = torch.stack(gathered).mean(dim=0)
 
     if rank == 0:
         total_envs = args.batch * world
-        value = total_envs * args.steps / elapsed
+        value = executed / elapsed            # == total_envs * steps / elapsed unless environments idled for a batched reset
         b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
         achieved = b_alg * args.batch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         line = {
@@ -159,8 +172,9 @@ def main():
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'{args.workload} batch={args.batch} envs per GPU, uniform random policy (on-device Philox), '
-                                   f'auto-reset', 'global_batch': total_envs, 'parallelism': f'env-shard x{world}'},
+            'config': {'workload': f'{args.workload} batch={args.batch} envs per GPU, '
+                                   + ('uniform random policy (on-device Philox), ' if args.policy == 'random' else 'on-device GreedyCamera vs GreedyTarget policies, ')
+                                   + 'auto-reset', 'global_batch': total_envs, 'parallelism': f'env-shard x{world}'},
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
@@ -172,7 +186,7 @@ def main():
             'episode_stats': {'mean_target_reward': float(stats[0]), 'mean_coverage_rate': float(stats[1]),
                               'mean_delivered': float(stats[2])},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.policy == 'random' and args.workload == WORKLOAD:
             line['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if distributed:

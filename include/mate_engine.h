@@ -102,9 +102,12 @@ int mate_engine_seed(mate_engine *engine, uint64_t seed);                   /* s
  * non-zero byte in env_mask_dev[N].  Writes the initial observations/masks like a step does. */
 int mate_engine_reset(mate_engine *engine, const uint8_t *env_mask_dev, const mate_step_io *io, void *stream);
 
-/* step() (environment.py:590-676).  With auto_reset != 0, environments whose episode ended
- * are reset in the same call and their observation rows hold the first observation of the
- * new episode (rewards/done in `scalars_dev` still describe the finished step). */
+/* step() (environment.py:590-676).  auto_reset == 1: environments whose episode ended are reset in
+ * the same call and their observation rows hold the first observation of the new episode (rewards/done
+ * in `scalars_dev` still describe the finished step).  auto_reset == k > 1: batched resets -- a
+ * finished environment idles (its scalar record reads done = 2, no new observation) until every k-th
+ * call restarts all finished environments together, which amortises the reset latency (occlusion-table
+ * build) when episodes end every step somewhere in the batch.  auto_reset == 0: the caller resets. */
 int mate_engine_step(mate_engine *engine, const mate_step_io *io, int32_t auto_reset, void *stream);
 
 /* step() with the uniform random policy of SURVEY.md section 8d generated on-device
@@ -167,6 +170,10 @@ int mate_engine_lut_write(mate_engine *engine, int64_t env, int32_t camera, cons
 /* Rebuild the occlusion tables of all environments from the current static geometry
  * (Camera.add_obstacles, entities.py:362-479) -- used after mate_engine_import_state. */
 int mate_engine_rebuild_luts(mate_engine *engine, void *stream);
+
+/* Number of (environment, step) slots spent idle waiting for a batched reset (auto_reset > 1) since creation:
+ * executed env-steps = N * calls - idle. */
+int mate_engine_idle_steps(mate_engine *engine, int64_t *total);
 
 /* Average duration (ms) of the dominant kernel (step_kernel) over the launches timed since the
  * previous call, measured with HIP event pairs on the launch stream (bench.py roofline).

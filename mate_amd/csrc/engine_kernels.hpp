@@ -56,6 +56,7 @@ struct Ptrs {
     void *cam_obs, *tgt_obs;
     float *scalars;
     uint32_t *masks;
+    int32_t *idle_steps;          // [N] steps an environment spent idle waiting for a batched reset
     uint32_t *own_masks;          // engine-owned copy of the packed masks (input of the on-device policies), or NULL
     int32_t *done_count;          // [2] ping-pong counters
     int32_t *done_list;           // [2][N]
@@ -65,6 +66,7 @@ struct Ptrs {
     int64_t N;
     int32_t mode, act_f64, parity, reset_kind;
     int32_t rollout_steps;        // steps per launch of rollout_kernel
+    int32_t freeze_done;          // batched auto-reset: finished environments idle (scalar done = 2) until the next reset launch
     uint32_t tick;                // host step counter: Philox tick of this launch (all environments step together)
 };
 
@@ -809,6 +811,14 @@ __global__ __launch_bounds__(256, 4) void step_kernel(const Params *__restrict__
     PHASE_STAMP(1);
     const uint32_t tick = g.tick;
     load_records(c);
+    if (g.freeze_done && g.mode != MODE_OBSERVE) {
+        wave_sync();
+        if (c.ei(EI_DONE) != 0) {     // waiting for the next batched reset: no step, no new observation
+            if (lane == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; }
+            if (lane == 0 && g.idle_steps) g.idle_steps[env] += 1;
+            return;
+        }
+    }
 #ifdef MATE_PHASE_CLOCKS
 #define SKIP(bit) (g.debug_skip & (bit))
 #else

@@ -43,6 +43,7 @@ struct mate_engine {
     int64_t N = 0;
     int parity = 0;
     uint32_t tick = 0;         // Philox tick of the next step launch
+    int64_t steps_since_reset = 0;   // batched auto-reset bookkeeping
     bool was_reset = false;
     size_t step_lds = 0, reset_lds = 0;
     std::vector<void *> allocs;
@@ -254,6 +255,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         if ((rc = dev_alloc(e, &g.lut_deg, N * std::max(Nc, 1) * (size_t)360 * kDegSlots, false))) break;
         if ((rc = dev_alloc(e, &g.done_count, (size_t)2))) break;
         if ((rc = dev_alloc(e, &g.done_list, 2 * N))) break;
+        if ((rc = dev_alloc(e, &g.idle_steps, N))) break;
         std::vector<uint32_t> desc;
         build_descriptors(p, desc);
         uint32_t *d_desc = nullptr;
@@ -408,7 +410,7 @@ static void apply_io(Ptrs &g, const mate_step_io *io) {
 }
 
 static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream) {
-    g.mode = MODE_OBSERVE; g.reset_kind = kind; g.parity = e->parity;
+    g.mode = MODE_OBSERVE; g.reset_kind = kind; g.parity = e->parity; g.freeze_done = 0;
     const int64_t blocks = kind == RESET_DONE ? std::min<int64_t>(e->N, 256) : e->N;
     if (e->p.obs_f64) hipLaunchKernelGGL(reset_kernel<double>, dim3((unsigned)blocks), dim3(256), e->reset_lds, stream, e->d_params, g, e->rl, phases);
     else hipLaunchKernelGGL(reset_kernel<float>, dim3((unsigned)blocks), dim3(256), e->reset_lds, stream, e->d_params, g, e->rl, phases);
@@ -444,7 +446,9 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     apply_io(g, io);
     if (mode == MODE_STEP && ((e->p.Nc > 0 && !g.cam_act) || !g.tgt_act)) return fail(MATE_EINVAL, "step() needs camera and target joint actions");
     g.mode = mode; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick;
-    if (mode == MODE_OBSERVE || !auto_reset) g.done_count = nullptr;
+    // auto_reset = 1: finished environments restart inside this call; k > 1: they idle and restart together every k-th call
+    g.freeze_done = auto_reset > 1;
+    if (mode == MODE_OBSERVE || auto_reset != 1) g.done_count = nullptr;
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e->timing > 0 && mode != MODE_OBSERVE && (e->timing_tick++ % e->timing) == 0) {
@@ -461,13 +465,20 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     else hipExtLaunchKernelGGL(step_kernel<float>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->d_params, g);
     HIP_TRY(hipGetLastError());
     if (mode != MODE_OBSERVE) e->tick += 1;
-    if (mode != MODE_OBSERVE && auto_reset) {
+    if (mode != MODE_OBSERVE && auto_reset == 1) {
         Ptrs r = e->g;
         apply_io(r, io);
         r.scalars = nullptr; r.tape_ct = nullptr; r.tape_goal = nullptr;   // keep the finished step's reward/done
         int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream);
         if (rc != MATE_OK) return rc;
         e->parity ^= 1;
+    } else if (mode != MODE_OBSERVE && auto_reset > 1 && ++e->steps_since_reset >= auto_reset) {
+        e->steps_since_reset = 0;
+        Ptrs r = e->g;
+        apply_io(r, io);
+        r.scalars = nullptr; r.tape_ct = nullptr; r.tape_goal = nullptr;
+        int rc = launch_reset(e, r, RESET_FLAGGED, PH_PLACE | PH_LUT | PH_VIEW, stream);
+        if (rc != MATE_OK) return rc;
     }
     return MATE_OK;
 }
@@ -559,8 +570,10 @@ extern "C" int mate_engine_step_greedy(mate_engine *e, const mate_step_io *io, c
         q.tape.tgt_reset_sample_u = tape->target_reset_sample_u_dev;
     }
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
-    if (e->p.obs_f64) hipLaunchKernelGGL(greedy_policy_kernel<double>, dim3(blocks), dim3(256), 4 * q.lds_bytes, stream, e->d_params, e->g, q);
-    else hipLaunchKernelGGL(greedy_policy_kernel<float>, dim3(blocks), dim3(256), 4 * q.lds_bytes, stream, e->d_params, e->g, q);
+    Ptrs gp = e->g;
+    gp.freeze_done = auto_reset > 1;
+    if (e->p.obs_f64) hipLaunchKernelGGL(greedy_policy_kernel<double>, dim3(blocks), dim3(256), 4 * q.lds_bytes, stream, e->d_params, gp, q);
+    else hipLaunchKernelGGL(greedy_policy_kernel<float>, dim3(blocks), dim3(256), 4 * q.lds_bytes, stream, e->d_params, gp, q);
     HIP_TRY(hipGetLastError());
     mate_step_io io2;
     if (io) io2 = *io; else std::memset(&io2, 0, sizeof(io2));
@@ -671,6 +684,19 @@ extern "C" int mate_engine_debug_phase_clocks(mate_engine *e, long long *buf_dev
 extern "C" int mate_engine_debug_skip(mate_engine *e, int32_t mask) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     e->g.debug_skip = mask;
+    return MATE_OK;
+}
+
+// Total number of (environment, step) slots spent idle waiting for a batched reset (auto_reset > 1) since creation.
+extern "C" int mate_engine_idle_steps(mate_engine *e, int64_t *total) {
+    if (!e || !total) return fail(MATE_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<int32_t> host((size_t)e->N);
+    HIP_TRY(hipMemcpy(host.data(), e->g.idle_steps, sizeof(int32_t) * host.size(), hipMemcpyDeviceToHost));
+    int64_t sum = 0;
+    for (int32_t v : host) sum += v;
+    *total = sum;
     return MATE_OK;
 }
 

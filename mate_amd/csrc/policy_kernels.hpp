@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     const int32_t *env_i = di + Nt * TI_STRIDE;
     const uint32_t tick = (uint32_t)env_i[EI_TICK];
     const uint32_t env_global = p.first_env + (uint32_t)env;
+    if (g.freeze_done && env_i[EI_DONE] != 0) return;        // finished, waiting for the batched reset
     const bool fresh = a.episode() != env_i[EI_EPISODE];     // first call of a new episode: agent.reset(observation)
     const uint64_t capword = reinterpret_cast<const uint64_t *>(st)[3 * Nc + 3 * p.No];
 

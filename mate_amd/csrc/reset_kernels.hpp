@@ -12,7 +12,7 @@
 
 namespace mate {
 
-enum ResetKind : int32_t { RESET_ALL = 0, RESET_MASK = 1, RESET_DONE = 2 };
+enum ResetKind : int32_t { RESET_ALL = 0, RESET_MASK = 1, RESET_DONE = 2, RESET_FLAGGED = 3 };
 enum ResetPhase : int32_t { PH_PLACE = 1, PH_LUT = 2, PH_VIEW = 4 };
 
 struct ResetLds {   // byte offsets inside the workgroup's dynamic LDS, after the wave-0 context
@@ -358,6 +358,7 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
     for (int64_t item = blockIdx.x; item < count; item += gridDim.x) {
         const int64_t env = g.reset_kind == RESET_DONE ? (int64_t)g.done_list[(int64_t)g.parity * g.N + item] : item;
         if (g.reset_kind == RESET_MASK && !g.reset_mask[env]) continue;
+        if (g.reset_kind == RESET_FLAGGED && !reinterpret_cast<const int32_t *>(g.dyn + env * p.DW + p.DF)[p.Nt * TI_STRIDE + EI_DONE]) continue;
         __syncthreads();
         Ctx<ObsT> c(p, g, wave_base, lane, env);
         if (wave == 0) {

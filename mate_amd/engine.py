@@ -298,6 +298,12 @@ class Engine:
         check(self.lib.mate_engine_lut_write(self._h, int(env), int(camera), phis.ctypes.data_as(ctypes.c_void_p),
                                              rhos.ctypes.data_as(ctypes.c_void_p), len(phis)))
 
+    def idle_steps(self):
+        """(environment, step) slots spent idle waiting for a batched reset since creation."""
+        total = ctypes.c_int64()
+        check(self.lib.mate_engine_idle_steps(self._h, ctypes.byref(total)))
+        return total.value
+
     def kernel_time(self, enable=1):
         """(avg ms, launches) of the step kernel since the last call; `enable` = k arms the HIP-event timer
         for every k-th launch (0 disarms)."""
