@@ -1,6 +1,7 @@
 // mate_engine.hip -- host side of the C ABI declared in include/mate_engine.h.
 // Plain HIP runtime: no torch types cross this boundary (device pointers + sizes only).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -33,6 +34,23 @@ static int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(MATE_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
     } while (0)
 
+using StepFn = void (*)(const Params *, const Ptrs);
+
+// Scenario shapes (cameras, targets, obstacles) with a compiled specialisation of the step kernel: the
+// shapes of the reference's shipped scenarios (mate/assets/*.yaml); any other shape runs the generic kernel.
+#define MATE_SHAPES(X) X(4, 8, 9) X(4, 2, 9) X(8, 8, 9) X(4, 8, 0) X(0, 8, 32)
+
+static StepFn pick_step_kernel(int Nc, int Nt, int No, bool f64, int *specialised) {
+    const char *gen = getenv("MATE_GENERIC");
+    *specialised = 0;
+    if (!(gen && atoi(gen) != 0)) {
+#define X(C, T, O) if (Nc == C && Nt == T && No == O) { *specialised = 1; return f64 ? (StepFn)step_kernel<double, FixedShape<C, T, O, true>> : (StepFn)step_kernel<float, FixedShape<C, T, O, false>>; }
+        MATE_SHAPES(X)
+#undef X
+    }
+    return f64 ? (StepFn)step_kernel<double, AnyShape> : (StepFn)step_kernel<float, AnyShape>;
+}
+
 struct mate_engine {
     Params p{};
     Params *d_params = nullptr;   // device copy read by the kernels
@@ -46,6 +64,8 @@ struct mate_engine {
     int64_t steps_since_reset = 0;   // batched auto-reset bookkeeping
     bool was_reset = false;
     size_t step_lds = 0, reset_lds = 0;
+    StepFn step_fn = nullptr;     // step kernel chosen at create: shape-specialised when one was compiled for these counts
+    int specialised = 0;
     std::vector<void *> allocs;
     // on-device rule-based policies (mate_engine_step_greedy)
     bool policy_ready = false;
@@ -171,31 +191,11 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     e->device = device;
     e->N = num_envs;
     Params &p = e->p;
-    p.Nc = Nc; p.Nt = Nt; p.No = No; p.NK = No + Nc; p.NJ = Nc + No + Nt;
-    p.Dc = 13 + 9 + 5 * Nt + 4 * No + 7 * Nc;    // constants.py:267-282
-    p.Dt = 13 + 14 + 7 * Nc + 4 * No + 5 * Nt;   // constants.py:285-300
-    p.cam_elems = Nc * p.Dc; p.tgt_elems = Nt * p.Dt;
-    p.tgt_table_off = round_up(p.cam_elems, 4);
-    p.SW = 3 * Nc + 3 * No + 1;
-    p.DF = 2 * Nc + 2 * Nt + 2;
-    p.NI = Nt * TI_STRIDE + EI_COUNT; if (p.NI & 1) p.NI += 1;
-    p.DW = p.DF + p.NI / 2;
-    p.n_sector = Nc * Nt + Nc * Nc; p.n_range = Nt * p.NJ;
-    p.sector_rounds = (p.n_sector + 63) / 64; p.range_rounds = (p.n_range + 63) / 64;
-    p.bit_cc = Nc * Nt;
-    p.bit_range = p.sector_rounds * 64;
-    p.bit_camobs = p.bit_range + p.range_rounds * 64;
-    p.bit_always = p.bit_camobs + Nc * 64;
-    p.MW = p.bit_always / 32 + 1;
-    p.sc_cam = 30; p.sc_tgt = p.sc_cam + 10 * Nc; p.sc_obs = p.sc_tgt + 14 * Nt; p.nscratch = round_up(p.sc_obs + 3 * No, 4);
-    p.kmax = round_up(360 + No * 185 + 2, 8);
-    p.nbucket = 368;
+    fill_shape(p, Nc, Nt, No, cfg->obs_dtype == MATE_OBS_F64);
     p.max_episode_steps = cfg->max_episode_steps; p.sparse_reward = cfg->sparse_reward != 0;
     p.num_cargoes_per_target = cfg->num_cargoes_per_target; p.shuffle = cfg->shuffle_entities != 0;
     p.start_with_cargoes = cfg->targets_start_with_cargoes != 0;
     p.n_high = (int)((double)Nt * std::min(std::max(cfg->high_capacity_target_split, 0.0), 1.0));   // environment.py:1530-1533
-    p.obs_f64 = cfg->obs_dtype == MATE_OBS_F64;
-    p.inv_Nt = 1.0f / (float)Nt; p.inv_NK = p.NK > 0 ? 1.0f / (float)p.NK : 0.f; p.inv_NJ = 1.0f / (float)p.NJ; p.inv_Nc = Nc > 0 ? 1.0f / (float)Nc : 0.f;
     p.tau = std::min(std::max(cfg->transmittance, 0.0), 1.0);
     p.cam_radius = cfg->camera_radius; p.theta_min = cfg->camera_min_viewing_angle; p.rmax = cfg->camera_max_sight_range;
     p.rot = cfg->camera_rotation_step; p.zoom = cfg->camera_zooming_step;
@@ -207,22 +207,8 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     p.max_team_reward = p.reward_scale * cfg->num_cargoes_per_target * Nt;       // environment.py:527-529
     p.obs_r_lo = cfg->obstacle_radius_range[0]; p.obs_r_hi = cfg->obstacle_radius_range[1];
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.first_env = (uint32_t)first_env_index;
-    p.export_width = 2 * Nc + 3 * No + Nt + Nc * No + 2 * Nc + 2 * Nt + Nt + 4 * Nt + 4 * Nt + 5 * Nt + 20 + 7;
-    // LDS carve: [descriptor table][per-wave context] (x4 for the step kernel)
-    const int obs_size = p.obs_f64 ? 8 : 4;
-    p.lds_table_bytes = round_up((p.tgt_table_off + round_up(p.tgt_elems, 4)) * 4, 16);
-    int off = 0;
-    p.off_st = off; off += round_up(p.SW * 8, 16);
-    p.off_dy = off; off += round_up(p.DW * 8, 16);
-    p.off_tmp = off; off += round_up((Nc + 3 * Nt + 64) * 8, 16);
-    p.off_scratch = off; off += round_up(p.nscratch * obs_size, 16);
-    p.off_mask = off; off += round_up(p.MW * 4, 16);
-    p.off_misc = off; off += round_up((4 * Nt + 8) * 4, 16);
-    p.off_flags = off; off += round_up(p.MW * 32 * obs_size, 16);
-    p.off_ent = off; off += round_up(3 * p.NJ * 8, 16);
-    p.inv_No = No > 0 ? 1.0f / (float)No : 0.f;
-    p.lds_wave_bytes = off;
     e->step_lds = 4 * (size_t)p.lds_wave_bytes;
+    e->step_fn = pick_step_kernel(Nc, Nt, No, p.obs_f64 != 0, &e->specialised);
     if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }
     ResetLds &rl = e->rl;
     rl.sort_cap = std::max(512, next_pow2(Nc > 0 ? 360 + No * 185 + 1 : 1));
@@ -246,6 +232,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     const size_t N = (size_t)num_envs;
     Ptrs &g = e->g;
     g.N = num_envs;
+    { const char *sv = getenv("MATE_STAGGER"); g.stagger = sv ? atoi(sv) : 33210; }   // see phase_prio (engine_kernels.hpp)
     do {
         if ((rc = dev_alloc(e, &g.stat, N * p.SW))) break;
         if ((rc = dev_alloc(e, &g.dyn, N * p.DW))) break;
@@ -288,14 +275,13 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     if (rc == MATE_OK && hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice) != hipSuccess) rc = fail(MATE_EHIP, "params upload failed");
     if (rc == MATE_OK) {
         // opt in to large dynamic LDS
-        hipError_t err = hipSuccess;
-        if (p.obs_f64) {
-            err = hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
-            if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->step_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+        if (err != hipSuccess) {
+        } else if (p.obs_f64) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
             if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
         } else {
-            err = hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
-            if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
             if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
         }
         if (err != hipSuccess) rc = fail(MATE_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
@@ -461,8 +447,7 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     }
     // start/stop events attached to the dispatch itself (hipExtLaunchKernelGGL): the elapsed time is the
     // kernel's own begin->end, without the marker-packet latency separate hipEventRecord calls would add
-    if (e->p.obs_f64) hipExtLaunchKernelGGL(step_kernel<double>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->d_params, g);
-    else hipExtLaunchKernelGGL(step_kernel<float>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->d_params, g);
+    hipExtLaunchKernelGGL(e->step_fn, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
     HIP_TRY(hipGetLastError());
     if (mode != MODE_OBSERVE) e->tick += 1;
     if (mode != MODE_OBSERVE && auto_reset == 1) {
