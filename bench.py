@@ -168,7 +168,9 @@ def main():
         b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
         achieved = b_alg * args.batch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         line = {
-            'metric': 'env-steps/sec MATE-4v8-9 batch=4096 per GPU (random policy, auto-reset)',
+            'metric': ('env-steps/sec MATE-4v8-9 batch=4096 per GPU (random policy, auto-reset)'
+                       if (args.workload, args.batch, args.policy) == (WORKLOAD, BATCH_PER_GPU, 'random') else
+                       f'env-steps/sec {args.workload[:-5]} batch={args.batch} per GPU ({args.policy} policy, auto-reset)'),
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -180,7 +182,7 @@ def main():
                 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': measured_traffic() if args.batch == BATCH_PER_GPU and args.workload == WORKLOAD else None,
                 'traffic_unit': 'bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/latest_pmc.json)',
-                'kernel': 'step_kernel<float>', 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches,
+                'kernel': 'step_kernel<float, %s>' % ('FixedShape' if eng.specialised else 'AnyShape'), 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches,
                 'algorithmic_bytes_per_launch': b_alg * args.batch,
             },
             'episode_stats': {'mean_target_reward': float(stats[0]), 'mean_coverage_rate': float(stats[1]),

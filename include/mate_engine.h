@@ -65,6 +65,7 @@ typedef struct mate_layout {
     int32_t export_width;        /* doubles per environment in mate_engine_export_state */
     int32_t lut_capacity;        /* max knots per camera occlusion table */
     int32_t scalars_per_env;     /* floats per environment in the step scalar record (8) */
+    int32_t specialised;         /* 1 = step kernels compiled for exactly this (Nc, Nt, No) run; 0 = generic kernels */
 } mate_layout;
 
 /* Per-step outputs (any pointer may be NULL to skip that output).

@@ -51,7 +51,7 @@ class MateConfig(ctypes.Structure):
 class MateLayout(ctypes.Structure):
     _fields_ = [(name, ctypes.c_int32) for name in (
         'camera_obs_dim', 'target_obs_dim', 'state_dim', 'mask_words', 'bit_camera_target', 'bit_camera_camera',
-        'bit_target_row', 'bit_camera_obstacle', 'export_width', 'lut_capacity', 'scalars_per_env')]
+        'bit_target_row', 'bit_camera_obstacle', 'export_width', 'lut_capacity', 'scalars_per_env', 'specialised')]
 
 
 class MatePolicyTape(ctypes.Structure):

@@ -942,9 +942,10 @@ __global__ __launch_bounds__(256, 4) void step_kernel(const Params *__restrict__
 // wave time per step instead of the slowest wave's, and there is no kernel boundary between steps.
 // An environment whose episode ends stops stepping (rows of the remaining steps carry done = 2 in the
 // scalar record) and is reset by the host-launched reset kernel after the rollout.
-template <typename ObsT>
+template <typename ObsT, typename Shape>
 __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restrict__ pp, const Ptrs g) {
-    const Params &p = *pp;
+    const Shape shape(pp);
+    const Params &p = shape.get();
     extern __shared__ __align__(16) unsigned char smem[];
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;
     // wave-uniform by construction; readfirstlane lets the compiler keep everything derived from it in SGPRs
@@ -967,7 +968,8 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         asm volatile("" : "+s"(wave_r));
         const Params *pr = pp;
         asm volatile("" : "+s"(pr));
-        const Params &p = *pr;
+        const Shape shape_r(pr);
+        const Params &p = shape_r.get();
         const int64_t env_r = (int64_t)blockIdx.x * 4 + wave_r;
         Ctx<ObsT> c(p, g, smem + wave_r * p.lds_wave_bytes, lane_r, env_r);
         c.out = (int64_t)r * g.N + env_r;

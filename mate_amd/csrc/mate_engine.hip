@@ -35,20 +35,30 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 using StepFn = void (*)(const Params *, const Ptrs);
+using PolicyFn = void (*)(const Params *, const Ptrs, const PolicyPtrs);
 
 // Scenario shapes (cameras, targets, obstacles) with a compiled specialisation of the step kernel: the
 // shapes of the reference's shipped scenarios (mate/assets/*.yaml); any other shape runs the generic kernel.
 #define MATE_SHAPES(X) X(4, 8, 9) X(4, 2, 9) X(8, 8, 9) X(4, 8, 0) X(0, 8, 32)
 
-static StepFn pick_step_kernel(int Nc, int Nt, int No, bool f64, int *specialised) {
+static void pick_kernels(int Nc, int Nt, int No, bool f64, StepFn *step, StepFn *rollout, PolicyFn *policy, int *specialised) {
     const char *gen = getenv("MATE_GENERIC");
     *specialised = 0;
     if (!(gen && atoi(gen) != 0)) {
-#define X(C, T, O) if (Nc == C && Nt == T && No == O) { *specialised = 1; return f64 ? (StepFn)step_kernel<double, FixedShape<C, T, O, true>> : (StepFn)step_kernel<float, FixedShape<C, T, O, false>>; }
+#define X(C, T, O)                                                                                                  \
+    if (Nc == C && Nt == T && No == O) {                                                                            \
+        *specialised = 1;                                                                                           \
+        *step = f64 ? (StepFn)step_kernel<double, FixedShape<C, T, O, true>> : (StepFn)step_kernel<float, FixedShape<C, T, O, false>>;          \
+        *rollout = f64 ? (StepFn)rollout_kernel<double, FixedShape<C, T, O, true>> : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>>; \
+        *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, FixedShape<C, T, O, true>> : (PolicyFn)greedy_policy_kernel<float, FixedShape<C, T, O, false>>; \
+        return;                                                                                                     \
+    }
         MATE_SHAPES(X)
 #undef X
     }
-    return f64 ? (StepFn)step_kernel<double, AnyShape> : (StepFn)step_kernel<float, AnyShape>;
+    *step = f64 ? (StepFn)step_kernel<double, AnyShape> : (StepFn)step_kernel<float, AnyShape>;
+    *rollout = f64 ? (StepFn)rollout_kernel<double, AnyShape> : (StepFn)rollout_kernel<float, AnyShape>;
+    *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, AnyShape> : (PolicyFn)greedy_policy_kernel<float, AnyShape>;
 }
 
 struct mate_engine {
@@ -64,7 +74,8 @@ struct mate_engine {
     int64_t steps_since_reset = 0;   // batched auto-reset bookkeeping
     bool was_reset = false;
     size_t step_lds = 0, reset_lds = 0;
-    StepFn step_fn = nullptr;     // step kernel chosen at create: shape-specialised when one was compiled for these counts
+    PolicyFn policy_fn = nullptr;
+    StepFn step_fn = nullptr, rollout_fn = nullptr;   // kernels chosen at create: shape-specialised when compiled for these counts
     int specialised = 0;
     std::vector<void *> allocs;
     // on-device rule-based policies (mate_engine_step_greedy)
@@ -208,7 +219,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     p.obs_r_lo = cfg->obstacle_radius_range[0]; p.obs_r_hi = cfg->obstacle_radius_range[1];
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.first_env = (uint32_t)first_env_index;
     e->step_lds = 4 * (size_t)p.lds_wave_bytes;
-    e->step_fn = pick_step_kernel(Nc, Nt, No, p.obs_f64 != 0, &e->specialised);
+    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, &e->step_fn, &e->rollout_fn, &e->policy_fn, &e->specialised);
     if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }
     ResetLds &rl = e->rl;
     rl.sort_cap = std::max(512, next_pow2(Nc > 0 ? 360 + No * 185 + 1 : 1));
@@ -276,13 +287,14 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     if (rc == MATE_OK) {
         // opt in to large dynamic LDS
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->step_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+        if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rollout_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
         if (err != hipSuccess) {
         } else if (p.obs_f64) {
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
-            if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+
         } else {
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
-            if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(&rollout_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+
         }
         if (err != hipSuccess) rc = fail(MATE_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
     }
@@ -374,6 +386,7 @@ extern "C" int mate_engine_get_layout(const mate_engine *e, mate_layout *out) {
     out->bit_camera_target = 0; out->bit_camera_camera = p.bit_cc; out->bit_target_row = p.bit_range;
     out->bit_camera_obstacle = p.bit_camobs;
     out->export_width = p.export_width; out->lut_capacity = p.kmax; out->scalars_per_env = 8;
+    out->specialised = e->specialised;
     return MATE_OK;
 }
 
@@ -495,8 +508,7 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
         }
         ev0 = e->events[e->events_used].first; ev1 = e->events[e->events_used].second; ++e->events_used;
     }
-    if (e->p.obs_f64) hipExtLaunchKernelGGL(rollout_kernel<double>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->d_params, g);
-    else hipExtLaunchKernelGGL(rollout_kernel<float>, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, e->d_params, g);
+    hipExtLaunchKernelGGL(e->rollout_fn, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
     HIP_TRY(hipGetLastError());
     e->tick += (uint32_t)steps;
     if (auto_reset) {
@@ -525,9 +537,7 @@ static int policy_enable(mate_engine *e) {
     if ((rc = dev_alloc(e, &q.tgt_act, (size_t)e->N * p.Nt * 2))) return rc;
     if (!e->g.own_masks && (rc = dev_alloc(e, &e->g.own_masks, (size_t)e->N * p.MW))) return rc;
     q.masks = e->g.own_masks;
-    hipError_t err = e->p.obs_f64
-        ? hipFuncSetAttribute(reinterpret_cast<const void *>(&greedy_policy_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * q.lds_bytes)
-        : hipFuncSetAttribute(reinterpret_cast<const void *>(&greedy_policy_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * q.lds_bytes);
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->policy_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * q.lds_bytes);
     if (err != hipSuccess) return fail(MATE_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
     e->policy_ready = true;
     return MATE_OK;
@@ -557,8 +567,7 @@ extern "C" int mate_engine_step_greedy(mate_engine *e, const mate_step_io *io, c
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     Ptrs gp = e->g;
     gp.freeze_done = auto_reset > 1;
-    if (e->p.obs_f64) hipLaunchKernelGGL(greedy_policy_kernel<double>, dim3(blocks), dim3(256), 4 * q.lds_bytes, stream, e->d_params, gp, q);
-    else hipLaunchKernelGGL(greedy_policy_kernel<float>, dim3(blocks), dim3(256), 4 * q.lds_bytes, stream, e->d_params, gp, q);
+    hipLaunchKernelGGL(e->policy_fn, dim3(blocks), dim3(256), 4 * q.lds_bytes, stream, (const Params *)e->d_params, (const Ptrs)gp, (const PolicyPtrs)q);
     HIP_TRY(hipGetLastError());
     mate_step_io io2;
     if (io) io2 = *io; else std::memset(&io2, 0, sizeof(io2));

@@ -14,7 +14,12 @@
 
 namespace mate {
 
-enum PolicyStream : uint32_t { S_POL_CAM = 16, S_POL_DELAY = 17, S_POL_TGT = 18, S_POL_TGT_RESET = 19 };
+// Per step every lane draws twice, unconditionally (two Philox calls, no divergent re-draws):
+//   S_POL_A, sub = lane: word 0 -> message delay of the (sender, recipient) pair `lane`; words 1-2 -> the
+//                        agent's Bernoulli uniform; word 3 -> the target's warehouse choice
+//   S_POL_B, sub = lane: two uniforms for the agent's action / noise sample
+// (camera c is lane c, target t is lane 32 + t).  S_POL_TGT_RESET is keyed by the episode counter.
+enum PolicyStream : uint32_t { S_POL_A = 16, S_POL_B = 17, S_POL_TGT_RESET = 19 };
 
 struct PolicyTape {          // all optional (NULL = Philox); device pointers
     const double *cam_binom_u;        // [N][Nc]
@@ -67,11 +72,28 @@ struct PolCtx {
     __device__ int32_t &send_bits(int s, int c) { return i[q.PI + s * p.Nc + c]; }      // bit 31: 'state', bits 0..Nt-1: targets
 };
 
-__device__ __forceinline__ double sin_deg_f64(double x) { double s, c; sincos_deg(x, s, c); return s; }
+// sin of an angle in degrees, 0 <= deg <= 90: Taylor series to x^21 on the un-reduced argument
+// (remainder (pi/2)^23 / 23! = 1.2e-18), a third of the instructions of sincos_deg.
+__device__ __forceinline__ double sin_deg_0_90(double deg) {
+    const double x = deg * kDeg2Rad;
+    const double z = x * x;
+    double ps = 1.95729410633912612308e-20;                       // 1/21!
+    ps = fma(ps, z, -8.22063524662432971696e-18);                 // -1/19!
+    ps = fma(ps, z, 2.81145725434552075980e-15);                  // 1/17!
+    ps = fma(ps, z, -7.64716373181981647590e-13);                 // -1/15!
+    ps = fma(ps, z, 1.60590438368216145994e-10);                  // 1/13!
+    ps = fma(ps, z, -2.50521083854417187751e-08);                 // -1/11!
+    ps = fma(ps, z, 2.75573192239858906526e-06);                  // 1/9!
+    ps = fma(ps, z, -1.98412698412698412698e-04);                 // -1/7!
+    ps = fma(ps, z, 8.33333333333333333333e-03);                  // 1/5!
+    ps = fma(ps, z, -1.66666666666666666667e-01);                 // -1/3!
+    return fma(x * z, ps, x);
+}
 
-template <typename ObsT>
+template <typename ObsT, typename Shape>
 __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q) {
-    const Params &p = *pp;
+    const Shape shape(pp);
+    const Params &p = shape.get();
     extern __shared__ __align__(16) unsigned char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t env = (int64_t)blockIdx.x * 4 + wave;
@@ -105,6 +127,15 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     const uint32_t env_global = p.first_env + (uint32_t)env;
     if (g.freeze_done && env_i[EI_DONE] != 0) return;        // finished, waiting for the batched reset
     const bool fresh = a.episode() != env_i[EI_EPISODE];     // first call of a new episode: agent.reset(observation)
+    // this step's draws (see PolicyStream); skipped when every draw comes from the tape
+    double u_bern = 0.0, u_s0 = 0.0, u_s1 = 0.0;
+    uint32_t w_delay = 0, w_choice = 0;
+    if (!(q.tape.cam_binom_u && q.tape.cam_sample_u && q.tape.cam_delay && q.tape.tgt_choice_u && q.tape.tgt_binom_u && q.tape.tgt_sample_u)) {
+        const U4 ra = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_A, (uint32_t)lane);
+        const U4 rb = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_B, (uint32_t)lane);
+        w_delay = ra.x; u_bern = u53(ra.y, ra.z); w_choice = ra.w;
+        u_s0 = u53(rb.x, rb.y); u_s1 = u53(rb.z, rb.w);
+    }
     const uint64_t capword = reinterpret_cast<const uint64_t *>(st)[3 * Nc + 3 * p.No];
 
     // ------------------------------------------------------------------ reset + observe
@@ -172,8 +203,8 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
             if (bits) {
                 int v;
                 if (q.tape.cam_delay) v = q.tape.cam_delay[(env * Nc + s) * Nc + c];
-                else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_DELAY, (uint32_t)lane);
-                       const int lo = q.memory_period / 4, hi = 2 * q.memory_period; v = lo + (int)(u53(r.x, r.y) * (double)(hi - lo)); if (v >= hi) v = hi - 1; }
+                else { const int lo = q.memory_period / 4, hi = 2 * q.memory_period;        // randint(6, 50)
+                       v = lo + (int)(((double)w_delay * 2.3283064365386963e-10) * (double)(hi - lo)); if (v >= hi) v = hi - 1; }
                 d = v;
             }
         }
@@ -236,7 +267,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
             const double best_orientation = atan2_deg(ry, rx);
             const double distance = best_d;
             double best_va;
-            if (distance * (1.0 + sin_deg_f64(min_va / 2.0)) >= p.rmax) best_va = min_va;
+            if (distance * (1.0 + sin_deg_0_90(min_va / 2.0)) >= p.rmax) best_va = min_va;
             else {
                 const double area_product = theta * (sight * sight);
                 if (distance <= sqrt(area_product / 180.0) / 2.0) best_va = 180.0;
@@ -244,7 +275,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
                     double b = 180.0;
                     for (int it = 0; it < 20; ++it) {
                         const double half = b / 2.0;
-                        const double s2 = distance * (1.0 + sin_deg_f64(half < 90.0 ? half : 90.0));
+                        const double s2 = distance * (1.0 + sin_deg_0_90(half < 90.0 ? half : 90.0));
                         b = area_product / (s2 * s2);
                     }
                     best_va = clipd(b, min_va, 180.0);
@@ -255,11 +286,11 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
         } else {
             double u;
             if (q.tape.cam_binom_u) u = q.tape.cam_binom_u[env * Nc + c];
-            else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_CAM, (uint32_t)c); u = u53(r.x, r.y); }
+            else u = u_bern;
             if (u > 1.0 - 0.1) {                            // np_random.binomial(1, 0.1)
                 double u0, u1;
                 if (q.tape.cam_sample_u) { u0 = q.tape.cam_sample_u[(env * Nc + c) * 2]; u1 = q.tape.cam_sample_u[(env * Nc + c) * 2 + 1]; }
-                else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_CAM, (uint32_t)(Nc + c)); u0 = u53(r.x, r.y); u1 = u53(r.z, r.w); }
+                else { u0 = u_s0; u1 = u_s1; }
                 a0 = -p.rot + (2.0 * p.rot) * u0; a1 = -p.zoom + (2.0 * p.zoom) * u1;
             } else { a0 = a.prev_action(c, 0); a1 = a.prev_action(c, 1); }
         }
@@ -280,7 +311,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
             if (k > 0) {
                 double u;
                 if (q.tape.tgt_choice_u) u = q.tape.tgt_choice_u[env * Nt + t];
-                else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_TGT, (uint32_t)(2 * Nt + t)); u = u53(r.x, r.y); }
+                else u = (double)w_choice * 2.3283064365386963e-10;
                 int j = (int)(u * (double)k);
                 if (j >= k) j = k - 1;
                 for (int w = 0, seen = 0; w < 4; ++w) if ((nonempty >> w) & 1) { if (seen == j) goal = w; ++seen; }
@@ -300,12 +331,12 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
         const double prob = norm2(pax, pay) > 0.2 * step_size ? 0.05 : 0.75;
         double u;
         if (q.tape.tgt_binom_u) u = q.tape.tgt_binom_u[env * Nt + t];
-        else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_TGT, (uint32_t)t); u = u53(r.x, r.y); }
+        else u = u_bern;
         double nx = a.tgt_noise(t, 0), ny = a.tgt_noise(t, 1);
         if ((prob <= 0.5) ? (u > 1.0 - prob) : (u <= prob)) {
             double u0, u1;
             if (q.tape.tgt_sample_u) { u0 = q.tape.tgt_sample_u[(env * Nt + t) * 2]; u1 = q.tape.tgt_sample_u[(env * Nt + t) * 2 + 1]; }
-            else { const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_TGT, (uint32_t)(Nt + t)); u0 = u53(r.x, r.y); u1 = u53(r.z, r.w); }
+            else { u0 = u_s0; u1 = u_s1; }
             nx = q.noise_scale * (-step_size + (2.0 * step_size) * u0);
             ny = q.noise_scale * (-step_size + (2.0 * step_size) * u1);
         }

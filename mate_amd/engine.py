@@ -90,6 +90,7 @@ class Engine:
         check(self.lib.mate_engine_get_layout(self._h, ctypes.byref(layout)))
         self.layout = layout
         self.camera_obs_dim, self.target_obs_dim = layout.camera_obs_dim, layout.target_obs_dim
+        self.specialised = bool(layout.specialised)   # shape-specialised step kernels in use (MATE_GENERIC=1 forces generic)
         self.export_fields, width = export_layout(self.num_cameras, self.num_targets, self.num_obstacles)
         assert width == layout.export_width, (width, layout.export_width)
         N, Nc, Nt = self.num_envs, self.num_cameras, self.num_targets

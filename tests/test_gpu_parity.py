@@ -229,3 +229,28 @@ def test_fused_observation_transforms(name, mode):
             got_c = co[1].double().cpu().numpy()
             tolc = 1e-5 * np.maximum(1.0, np.abs(ref_c)) if 'rescaled' not in mode else 1e-5
             assert np.all(np.abs(got_c - ref_c) <= tolc + 1e-4 * ('rescaled' not in mode)), (s, np.abs(got_c - ref_c).max())
+
+
+@pytest.mark.parametrize('workload', ['MATE-4v8-9.yaml', 'MATE-4v2-9.yaml', 'MATE-8v8-9.yaml', 'MATE-4v8-0.yaml', 'MATE-Navigation.yaml'])
+def test_shape_specialised_kernel_equals_generic(workload, monkeypatch):
+    """The step kernels compiled for the shipped scenario shapes (FixedShape) and the generic kernel (AnyShape,
+    MATE_GENERIC=1) are the same code with different constant folding: every output must be bit-identical."""
+    import torch
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    outs = []
+    for generic in ('0', '1'):
+        monkeypatch.setenv('MATE_GENERIC', generic)
+        eng = Engine(read_config(workload), 64, seed=11)
+        assert eng.specialised == (generic == '0')
+        eng.reset()
+        rec = []
+        for _ in range(40):
+            eng.step_random(auto_reset=True)
+            rec.append([t.clone() for t in (getattr(eng, 'camera_obs', None), eng.target_obs, eng.scalars, eng.masks) if t is not None])
+        rec.append([eng.export_state().clone()])
+        outs.append(rec)
+        del eng
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))

@@ -108,3 +108,14 @@ def test_trace_parity_with_own_lut():
         env.step(fx['step/cam_act'][s], fx['step/tgt_act'][s], fx['step/tape_ct'][s], fx['step/goal_u'][s])
         mism += int(not np.array_equal(env.get('camera_target_view_mask') != 0, fx['step/camera_target_view_mask'][s]))
     assert mism == 0
+
+
+def test_philox_known_answers():
+    """The RNG shared by the oracle and the HIP engine is the published Philox-4x32-10 (Salmon et al., SC'11):
+    the three known-answer vectors of Random123's kat_vectors file."""
+    kat = [((0, 0), (0, 0, 0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff, 0xffffffff), (0xffffffff,) * 4, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0xa4093822, 0x299f31d0), (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for key, ctr, want in kat:
+        assert tuple(O.philox(*key, *ctr)) == want
