@@ -1,9 +1,13 @@
 #!/bin/bash
-# env-steps/s of the step path for the BASELINE.json scenarios (random policy; per-GPU shard sizes)
-for spec in "MATE-4v2-9.yaml 4096" "MATE-4v8-9.yaml 4096" "MATE-4v8-9.yaml 16384" "MATE-8v8-9.yaml 8192" "MATE-4v8-0.yaml 8192" "MATE-4v8-0.yaml 65536" "MATE-Navigation.yaml 4096" "MATE-Navigation.yaml 32768"; do
+# env-steps/s of the step path for the BASELINE.json scenarios (per-GPU shard sizes); one JSON line per case
+out=${1:-/dev/stdout}
+{
+for spec in "MATE-4v2-9.yaml 4096 random" "MATE-4v8-9.yaml 4096 random" "MATE-4v8-9.yaml 16384 random" "MATE-4v8-9.yaml 65536 random" "MATE-8v8-9.yaml 8192 random" "MATE-8v8-9.yaml 8192 greedy" "MATE-4v8-0.yaml 8192 random" "MATE-4v8-0.yaml 65536 random" "MATE-Navigation.yaml 4096 random" "MATE-Navigation.yaml 32768 random"; do
   set -- $spec
-  python bench.py --workload $1 --batch $2 --steps 500 --warmup 50 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+  python bench.py --workload $1 --batch $2 --policy $3 --steps 1000 --warmup 100 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('%-22s batch %6d  %8.1f M env-steps/s  %7.2f us/step  kernel %7.2f us  alg %6.0f GB/s' % ('$1', $2, d['value']/1e6, d['ms_per_step']*1e3, d['roofline']['kernel_avg_us'], d['roofline']['achieved']))"
+r=d['roofline']
+print(json.dumps({'workload':'$1','batch':$2,'policy':'$3','env_steps_per_s':round(d['value']),'us_per_step':round(d['ms_per_step']*1e3,2),'step_kernel_us':round(r['kernel_avg_us'],2),'algorithmic_GBps':round(r['achieved'],1),'roofline_frac':round(r['frac'],3)}))"
 done
+} > $out
