@@ -250,7 +250,13 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         hipDeviceProp_t prop;
         const int64_t cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
         const char *sv = getenv("MATE_STAGGER");
-        g.stagger = sv ? atoi(sv) : (((num_envs + 3) / 4 <= 4 * cus) ? 33210 : 0);
+        const int digits = sv ? atoi(sv) : (((num_envs + 3) / 4 <= 4 * cus) ? 33210 : 0);
+        g.stagger = 0;
+        if (digits > 0) {
+            int d = digits;
+            for (int phase = 4; phase >= 0; --phase, d /= 10) g.stagger |= ((d % 10) & 3) << (2 * phase);
+            g.stagger |= (int32_t)0x40000000;
+        }
     }
     do {
         if ((rc = dev_alloc(e, &g.stat, N * p.SW))) break;
