@@ -143,7 +143,7 @@ struct Ptrs {
 // One priority (0-3) per phase boundary (start, after load/draws, before view, before goals, before pack);
 // the host packs them from the decimal digits of MATE_STAGGER (default 33210, measured best; 0 disables).
 __device__ __forceinline__ void phase_prio(int mode, int phase) {
-    if (mode == 0) return;                              // host-packed: bit 31 = enabled, 2 bits per phase
+    if (mode == 0) return;                              // host-packed: bit 30 = enabled, 2 bits per phase
     const int k = (mode >> (2 * phase)) & 3;
     if (k == 0) __builtin_amdgcn_s_setprio(0);
     else if (k == 1) __builtin_amdgcn_s_setprio(1);
@@ -786,45 +786,30 @@ __device__ __forceinline__ ObsT gather_one(const Ctx<ObsT> &c, uint32_t d) {
     return out;
 }
 
-// One row block (all camera rows or all target rows of the environment, contiguous in the output) in vector
-// stores of VW elements.  Descriptors are fetched four iterations ahead of their use: the gather of a
-// chunk then never waits for its own descriptor load (a lone wave spent 7 dependent L2 round trips here).
-template <typename ObsT, int VW>
-__device__ __forceinline__ void pack_block_v(const Ctx<ObsT> &c, ObsT *__restrict__ dst, const uint32_t *__restrict__ table, int elems) {
-    typedef uint32_t DV __attribute__((ext_vector_type(VW)));
-    typedef ObsT OV __attribute__((ext_vector_type(VW)));
-    const DV *__restrict__ tv = reinterpret_cast<const DV *>(table);
-    OV *__restrict__ out = reinterpret_cast<OV *>(dst);
-    const int nvec = elems / VW;
-    for (int base = c.lane; base < nvec; base += 256) {
-        DV d[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + 64 * k;
-            d[k] = tv[i < nvec ? i : 0];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(d[k]));   // keep the loads here: the optimiser would sink each into its use
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + 64 * k;
-            if (i < nvec) {
-                OV v;
-#pragma unroll
-                for (int e = 0; e < VW; ++e) v[e] = gather_one(c, d[k][e]);
-                __builtin_nontemporal_store(v, &out[i]);   // write-once stream: keep it out of the caches
-            }
-        }
-    }
-}
-
 template <typename ObsT>
 __device__ void pack_block(const Ctx<ObsT> &c, ObsT *dst, const uint32_t *table, int elems) {
-    constexpr int W = Vec<ObsT>::W;              // 16-byte stores when the block keeps every environment 16-byte aligned
-    if ((elems % W) == 0) pack_block_v<ObsT, W>(c, dst, table, elems);
-    else if constexpr (W == 4) {
-        if ((elems % 2) == 0) pack_block_v<ObsT, 2>(c, dst, table, elems);
-        else for (int i = c.lane; i < elems; i += 64) dst[i] = gather_one(c, table[i]);
+    constexpr int W = Vec<ObsT>::W;
+    using V = typename Vec<ObsT>::type;
+    if ((elems % W) == 0) {                       // row block is 16-byte aligned for every environment
+        V *out = reinterpret_cast<V *>(dst);
+        const int nvec = elems / W;
+        for (int i = c.lane; i < nvec; i += 64) {
+            if constexpr (W == 4) {
+                const uint4 d = reinterpret_cast<const uint4 *>(table)[i];
+                float4 v;
+                v.x = gather_one(c, d.x); v.y = gather_one(c, d.y); v.z = gather_one(c, d.z); v.w = gather_one(c, d.w);
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 nv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(nv, reinterpret_cast<f32x4 *>(&out[i]));   // write-once stream: keep it out of the caches
+            } else {
+                const uint2 d = reinterpret_cast<const uint2 *>(table)[i];
+                double2 v;
+                v.x = gather_one(c, d.x); v.y = gather_one(c, d.y);
+                typedef double f64x2 __attribute__((ext_vector_type(2)));
+                const f64x2 nv = {v.x, v.y};
+                __builtin_nontemporal_store(nv, reinterpret_cast<f64x2 *>(&out[i]));
+            }
+        }
     } else {
         for (int i = c.lane; i < elems; i += 64) dst[i] = gather_one(c, table[i]);
     }
