@@ -30,7 +30,11 @@ enum {
 };
 
 enum { MATE_OBS_F32 = 0, MATE_OBS_F64 = 1 };
-enum { MATE_ACT_F32 = 0, MATE_ACT_F64 = 1 };
+enum { MATE_ACT_F32 = 0, MATE_ACT_F64 = 1,
+       /* OR-ed into act_dtype: that team's joint action is int32 grid indices [N][agents] instead of [N][agents][2]
+        * reals (DiscreteCamera / DiscreteTarget, mate/wrappers/discrete_action_spaces.py:59-74, 165-180);
+        * the grids come from mate_engine_set_action_grids */
+       MATE_ACT_CAMERA_DISCRETE = 0x100, MATE_ACT_TARGET_DISCRETE = 0x200 };
 
 /* Scenario description = the validated YAML/JSON/dict configuration of the reference
  * (mate/environment.py:113-269: read_config + validate_config), flattened. */
@@ -157,6 +161,24 @@ int mate_engine_observe(mate_engine *engine, const mate_step_io *io, void *strea
  * All NULL / 0 restores the plain observations. */
 int mate_engine_set_obs_transform(mate_engine *engine, int32_t relative, const double *camera_scale,
                                   const double *camera_bias, const double *target_scale, const double *target_bias);
+
+/* Team observation modes, fused into the packer as well: 0 plain; 1 = EnhancedObservation
+ * (mate/wrappers/enhanced_observation.py:72-126: every opponent / obstacle / teammate block visible, targets see
+ * the true emptiness of all warehouses); 2 = SharedFieldOfView (mate/wrappers/shared_field_of_view.py:72-148:
+ * an opponent or obstacle is visible to the whole team when any member sees it, teammates always visible,
+ * targets share their empty-warehouse knowledge).  The exported view masks are not affected, like in the
+ * reference (the wrappers only rewrite observations). */
+#define MATE_OBS_PLAIN 0
+#define MATE_OBS_ENHANCED 1
+#define MATE_OBS_SHARED 2
+int mate_engine_set_obs_mode(mate_engine *engine, int32_t camera_team_mode, int32_t target_team_mode);
+
+/* Normalised action grids for discrete joint actions (host arrays [n][2], copied; n = 0 / NULL removes one):
+ * continuous action = action_high * grid[index], with action_high = (rotation_step, zooming_step) for a camera
+ * and the target's own step size for a target (discrete_action_spaces.py:71-73, 161-163, 177-179).  Indices
+ * outside [0, n) are clamped on the device; the Python boundary raises like the reference's assert. */
+int mate_engine_set_action_grids(mate_engine *engine, const double *camera_grid, int32_t num_camera_actions,
+                                 const double *target_grid, int32_t num_target_actions);
 
 /* Canonical f64 export / import of the whole simulation state, [N][export_width] doubles
  * (layout documented in DESIGN.md; used by state(), the attribute views and the parity tests). */

@@ -24,6 +24,7 @@ struct Params {
     int32_t SW, DF, NI, DW;
     int32_t n_sector, n_range, sector_rounds, range_rounds;
     int32_t bit_cc, bit_range, bit_camobs, bit_always, MW;
+    int32_t bit_shared;      // first of the Nt + No + Nc + No team-shared visibility flags (SharedFieldOfView mode)
     int32_t nscratch, sc_cam, sc_tgt, sc_obs;
     int32_t tgt_table_off;   // first target descriptor (cam_elems rounded up to 4)
     int32_t kmax, nbucket;
@@ -60,6 +61,7 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
     p.bit_camobs = p.bit_range + p.range_rounds * 64;
     p.bit_always = p.bit_camobs + Nc * 64;
     p.MW = p.bit_always / 32 + 1;
+    p.bit_shared = p.MW * 32;
     p.sc_cam = 30; p.sc_tgt = p.sc_cam + 10 * Nc; p.sc_obs = p.sc_tgt + 14 * Nt; p.nscratch = shape_round_up(p.sc_obs + 3 * No, 4);
     p.kmax = shape_round_up(360 + No * 185 + 2, 8);
     p.nbucket = 368;
@@ -77,7 +79,7 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
     p.off_scratch = off; off += shape_round_up(p.nscratch * obs_size, 16);
     p.off_mask = off; off += shape_round_up(p.MW * 4, 16);
     p.off_misc = off; off += shape_round_up((4 * Nt + 8) * 4, 16);
-    p.off_flags = off; off += shape_round_up(p.MW * 32 * obs_size, 16);
+    p.off_flags = off; off += shape_round_up((p.MW * 32 + Nt + 2 * No + Nc) * obs_size, 16);
     p.off_ent = off; off += shape_round_up(3 * p.NJ * 8, 16);
     p.lds_wave_bytes = off;
 }
@@ -126,6 +128,10 @@ struct Ptrs {
     int32_t freeze_done;          // batched auto-reset: finished environments idle (scalar done = 2) until the next reset launch
     uint32_t tick;                // host step counter: Philox tick of this launch (all environments step together)
     int32_t stagger;              // per-phase wave priorities (see phase_prio)
+    const double2 *cam_grid, *tgt_grid;   // normalised discrete-action grids (or NULL)
+    int32_t n_cam_grid, n_tgt_grid;
+    int32_t act_discrete;         // bit 0 camera actions, bit 1 target actions are int32 grid indices
+    int32_t obs_mode;             // bits 0-1 camera team, bits 2-3 target team: 0 plain, 1 EnhancedObservation, 2 SharedFieldOfView
 };
 
 #ifdef MATE_PHASE_CLOCKS
@@ -308,7 +314,12 @@ __device__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &draws, bool adva
         if (advance) {
             double da, dz;
             if (c.g.mode == MODE_STEP_RANDOM) { da = draws.a0; dz = draws.a1; }
-            else if (c.g.act_f64) {
+            else if (c.g.act_discrete & 1) {                 // DiscreteCamera.action, discrete_action_spaces.py:71-73
+                int idx = reinterpret_cast<const int32_t *>(c.g.cam_act)[c.env * p.Nc + lane];
+                idx = idx < 0 ? 0 : (idx >= c.g.n_cam_grid ? c.g.n_cam_grid - 1 : idx);
+                const double2 gxy = c.g.cam_grid[idx];
+                da = p.rot * gxy.x; dz = p.zoom * gxy.y;
+            } else if (c.g.act_f64) {
                 const double *a = reinterpret_cast<const double *>(c.g.cam_act) + (c.env * p.Nc + lane) * 2;
                 da = a[0]; dz = a[1];
             } else {
@@ -346,7 +357,13 @@ __device__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws) {
     if (is_target) {
         double ax, ay;
         if (c.g.mode == MODE_STEP_RANDOM) { ax = draws.a0; ay = draws.a1; }
-        else if (c.g.act_f64) {
+        else if (c.g.act_discrete & 2) {                     // DiscreteTarget.action, discrete_action_spaces.py:177-179
+            int idx = reinterpret_cast<const int32_t *>(c.g.tgt_act)[c.env * p.Nt + t];
+            idx = idx < 0 ? 0 : (idx >= c.g.n_tgt_grid ? c.g.n_tgt_grid - 1 : idx);
+            const double2 gxy = c.g.tgt_grid[idx];
+            const double high = ((c.capword() >> t) & 1ull) ? p.tgt_step * 0.5 : p.tgt_step;
+            ax = high * gxy.x; ay = high * gxy.y;
+        } else if (c.g.act_f64) {
             const double *a = reinterpret_cast<const double *>(c.g.tgt_act) + (c.env * p.Nt + t) * 2;
             ax = a[0]; ay = a[1];
         } else {
@@ -748,6 +765,7 @@ template <typename ObsT>
 __device__ void fill_scratch(Ctx<ObsT> &c) {
     const Params &p = c.p;
     const int lane = c.lane;
+    const int tgt_mode = (c.g.obs_mode >> 2) & 3;
     if (lane < p.Nt) {                        // Target.state(private=True), entities.py:631-637
         ObsT *sc = c.scratch + p.sc_tgt + lane * 14;
         const int gw = c.ti(lane, TI_GW);
@@ -756,15 +774,42 @@ __device__ void fill_scratch(Ctx<ObsT> &c) {
         sc[0] = (ObsT)c.tx(lane); sc[1] = (ObsT)c.ty(lane);
         sc[3] = (ObsT)(goal >= 0 && weight > 0 ? 1.0 : 0.0);
         sc[4] = (ObsT)(cap == 2 ? p.tgt_step * 0.5 : p.tgt_step); sc[5] = (ObsT)cap;   // step_size / capacity, exact
+        int empty = (gw >> 16) & 0xf;
+        if (tgt_mode == 1) {                  // EnhancedObservation: the true state of every warehouse (enhanced_observation.py:110-112)
+            empty = 0;
+            for (int w = 0; w < 4; ++w) {
+                const int *row = &c.ei(EI_REMAINING + 4 * w);
+                empty |= (int)!(row[0] || row[1] || row[2] || row[3]) << w;
+            }
+        } else if (tgt_mode == 2) {           // SharedFieldOfView: what any teammate knows (shared_field_of_view.py:122-127)
+            for (int t = 0; t < p.Nt; ++t) empty |= (c.ti(t, TI_GW) >> 16) & 0xf;
+        }
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             sc[6 + w] = (ObsT)(goal == w ? weight : 0);
-            sc[10 + w] = (ObsT)((gw >> (16 + w)) & 1);
+            sc[10 + w] = (ObsT)((empty >> w) & 1);
         }
     }
     for (int o = lane; o < p.No; o += 64) {   // Obstacle.state, entities.py:147-148
         ObsT *sc = c.scratch + p.sc_obs + o * 3;
         sc[0] = (ObsT)c.obs_x(o); sc[1] = (ObsT)c.obs_y(o); sc[2] = (ObsT)c.obs_r(o);
+    }
+    // SharedFieldOfView: an entity is visible to the whole team when any member sees it
+    // (shared_field_of_view.py:97-100, 117-120); flags live behind the mask flags, see build_descriptors
+    if ((c.g.obs_mode & 3) == 2) {
+        if (lane < p.Nt) set_flag(c, p.bit_shared + lane, c.tracked(lane) != 0);
+        for (int o = lane; o < p.No; o += 64) {
+            bool any = false;
+            for (int cam = 0; cam < p.Nc; ++cam) any = any || ((c.camobs(cam) >> o) & 1ull);
+            set_flag(c, p.bit_shared + p.Nt + o, any);
+        }
+    }
+    if (tgt_mode == 2) {
+        for (int j = lane; j < p.Nc + p.No; j += 64) {
+            bool any = false;
+            for (int t = 0; t < p.Nt; ++t) any = any || c.mask_bit(p.bit_range + t * p.NJ + j);
+            set_flag(c, p.bit_shared + p.Nt + p.No + j, any);
+        }
     }
     wave_sync();
 }

@@ -81,6 +81,12 @@ struct mate_engine {
     // on-device rule-based policies (mate_engine_step_greedy)
     bool policy_ready = false;
     PolicyPtrs q{};
+    // observation post-processing fused into the packer (set_obs_mode / set_obs_transform)
+    int cam_mode = 0, tgt_mode = 0;
+    bool xf_relative = false, xf_cam = false, xf_tgt = false;
+    std::vector<double> xf_cam_scale, xf_cam_bias, xf_tgt_scale, xf_tgt_bias;
+    uint2 *d_xdesc = nullptr;
+    void *d_xab = nullptr;
     // kernel timing (HIP events on the launch stream)
     int timing = 0;            // 0 = off, k = time every k-th step launch
     int64_t timing_tick = 0;
@@ -108,7 +114,10 @@ static int dev_alloc(mate_engine *e, T **out, size_t count, bool zero = true) {
 
 // Observation descriptors: for every element of a camera / target row block, which scratch slot
 // it copies and which visibility bit gates it (joint_observation, environment.py:908-964).
-static void build_descriptors(const Params &p, std::vector<uint32_t> &desc) {
+// Team modes (mate_engine_set_obs_mode): 0 plain; 1 EnhancedObservation = every entity block visible
+// (wrappers/enhanced_observation.py:96-125); 2 SharedFieldOfView = opponents and obstacles gated by the team-wide
+// flags, teammates always visible (wrappers/shared_field_of_view.py:96-143).
+static void build_descriptors(const Params &p, std::vector<uint32_t> &desc, int cam_mode = 0, int tgt_mode = 0) {
     const int Nc = p.Nc, Nt = p.Nt, No = p.No;
     const int sz = p.obs_f64 ? 8 : 4;
     auto D = [&](int src, int bit) { return (uint32_t)(p.off_scratch + src * sz) | ((uint32_t)(p.off_flags + bit * sz) << 16); };
@@ -138,9 +147,9 @@ static void build_descriptors(const Params &p, std::vector<uint32_t> &desc) {
         preserved(row, c);
         for (int i = 0; i < 9; ++i) row[13 + i] = D(p.sc_cam + c * 10 + i, ALWAYS);
         uint32_t *q = row + 22;
-        for (int t = 0; t < Nt; ++t, q += 5) tgt_pub(q, t, c * Nt + t);
-        for (int o = 0; o < No; ++o, q += 4) obs_pub(q, o, p.bit_camobs + c * 64 + o);
-        for (int c2 = 0; c2 < Nc; ++c2, q += 7) cam_pub(q, c2, p.bit_cc + c * Nc + c2);
+        for (int t = 0; t < Nt; ++t, q += 5) tgt_pub(q, t, cam_mode == 1 ? ALWAYS : cam_mode == 2 ? p.bit_shared + t : c * Nt + t);
+        for (int o = 0; o < No; ++o, q += 4) obs_pub(q, o, cam_mode == 1 ? ALWAYS : cam_mode == 2 ? p.bit_shared + Nt + o : p.bit_camobs + c * 64 + o);
+        for (int c2 = 0; c2 < Nc; ++c2, q += 7) cam_pub(q, c2, cam_mode != 0 ? ALWAYS : p.bit_cc + c * Nc + c2);
     }
     for (int t = 0; t < Nt; ++t) {
         uint32_t *row = desc.data() + p.tgt_table_off + (size_t)t * p.Dt;
@@ -148,9 +157,10 @@ static void build_descriptors(const Params &p, std::vector<uint32_t> &desc) {
         for (int i = 0; i < 14; ++i) row[13 + i] = D(p.sc_tgt + t * 14 + i, ALWAYS);
         uint32_t *q = row + 27;
         const int rb = p.bit_range + t * p.NJ;
-        for (int c = 0; c < Nc; ++c, q += 7) cam_pub(q, c, rb + c);
-        for (int o = 0; o < No; ++o, q += 4) obs_pub(q, o, rb + Nc + o);
-        for (int t2 = 0; t2 < Nt; ++t2, q += 5) tgt_pub(q, t2, rb + Nc + No + t2);
+        const int sb = p.bit_shared + Nt + No;
+        for (int c = 0; c < Nc; ++c, q += 7) cam_pub(q, c, tgt_mode == 1 ? ALWAYS : tgt_mode == 2 ? sb + c : rb + c);
+        for (int o = 0; o < No; ++o, q += 4) obs_pub(q, o, tgt_mode == 1 ? ALWAYS : tgt_mode == 2 ? sb + Nc + o : rb + Nc + o);
+        for (int t2 = 0; t2 < Nt; ++t2, q += 5) tgt_pub(q, t2, tgt_mode != 0 ? ALWAYS : rb + Nc + No + t2);
     }
 }
 
@@ -326,17 +336,16 @@ extern "C" int mate_engine_destroy(mate_engine *e) {
     return MATE_OK;
 }
 
-// Fused observation post-processing tables: descriptor + LDS offset of the row owner's x / y for the
-// coordinate entries (coordinate_mask_of, constants.py:371-426) + (scale, bias) per column.
-extern "C" int mate_engine_set_obs_transform(mate_engine *e, int32_t relative, const double *cam_scale, const double *cam_bias,
-                                             const double *tgt_scale, const double *tgt_bias) {
-    if (!e) return fail(MATE_EINVAL, "null engine");
-    HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
+static int apply_obs_tables(mate_engine *e) {
     const Params &p = e->p;
-    if (!relative && !cam_scale && !tgt_scale) { e->g.xdesc = nullptr; e->g.xab = nullptr; return MATE_OK; }
     std::vector<uint32_t> desc;
-    build_descriptors(p, desc);
+    build_descriptors(p, desc, e->cam_mode, e->tgt_mode);
+    HIP_TRY(hipMemcpy(const_cast<uint32_t *>(e->g.desc), desc.data(), desc.size() * 4, hipMemcpyHostToDevice));
+    e->g.obs_mode = e->cam_mode | (e->tgt_mode << 2);
+    const bool relative = e->xf_relative;
+    const double *cam_scale = e->xf_cam ? e->xf_cam_scale.data() : nullptr, *cam_bias = e->xf_cam ? e->xf_cam_bias.data() : nullptr;
+    const double *tgt_scale = e->xf_tgt ? e->xf_tgt_scale.data() : nullptr, *tgt_bias = e->xf_tgt ? e->xf_tgt_bias.data() : nullptr;
+    if (!relative && !cam_scale && !tgt_scale) { e->g.xdesc = nullptr; e->g.xab = nullptr; return MATE_OK; }
     const size_t n = desc.size();
     const int sz = p.obs_f64 ? 8 : 4;
     const uint32_t zero_slot = (uint32_t)p.off_scratch;   // scratch[0] == 0
@@ -368,27 +377,73 @@ extern "C" int mate_engine_set_obs_transform(mate_engine *e, int32_t relative, c
     for (size_t i = 0; i < n; ++i) xd[i] = make_uint2(desc[i], zero_slot);
     fill(0, p.Nc, p.Dc, 9, p.sc_cam, 10, cam_blocks, cam_strides, cam_scale, cam_bias);
     fill(p.tgt_table_off, p.Nt, p.Dt, 14, p.sc_tgt, 14, tgt_blocks, tgt_strides, tgt_scale, tgt_bias);
-    uint2 *d_xd = nullptr;
-    int rc = dev_alloc(e, &d_xd, n);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(d_xd, xd.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
+    int rc;
+    if (!e->d_xdesc && (rc = dev_alloc(e, &e->d_xdesc, n))) return rc;
+    HIP_TRY(hipMemcpy(e->d_xdesc, xd.data(), n * sizeof(uint2), hipMemcpyHostToDevice));
+    if (!e->d_xab) {
+        unsigned char *buf = nullptr;
+        if ((rc = dev_alloc(e, &buf, 2 * n * (size_t)sz))) return rc;
+        e->d_xab = buf;
+    }
     if (p.obs_f64) {
         std::vector<double> ab(2 * n);
         for (size_t i = 0; i < n; ++i) { ab[2 * i] = a[i]; ab[2 * i + 1] = b[i]; }
-        double *d = nullptr;
-        if ((rc = dev_alloc(e, &d, 2 * n))) return rc;
-        HIP_TRY(hipMemcpy(d, ab.data(), ab.size() * 8, hipMemcpyHostToDevice));
-        e->g.xab = d;
+        HIP_TRY(hipMemcpy(e->d_xab, ab.data(), ab.size() * 8, hipMemcpyHostToDevice));
     } else {
         std::vector<float> ab(2 * n);
         for (size_t i = 0; i < n; ++i) { ab[2 * i] = (float)a[i]; ab[2 * i + 1] = (float)b[i]; }
-        float *d = nullptr;
-        if ((rc = dev_alloc(e, &d, 2 * n))) return rc;
-        HIP_TRY(hipMemcpy(d, ab.data(), ab.size() * 4, hipMemcpyHostToDevice));
-        e->g.xab = d;
+        HIP_TRY(hipMemcpy(e->d_xab, ab.data(), ab.size() * 4, hipMemcpyHostToDevice));
     }
-    e->g.xdesc = d_xd;
+    e->g.xab = e->d_xab;
+    e->g.xdesc = e->d_xdesc;
     return MATE_OK;
+}
+
+// Fused observation post-processing tables: descriptor + LDS offset of the row owner's x / y for the
+// coordinate entries (coordinate_mask_of, constants.py:371-426) + (scale, bias) per column.
+extern "C" int mate_engine_set_obs_transform(mate_engine *e, int32_t relative, const double *cam_scale, const double *cam_bias,
+                                             const double *tgt_scale, const double *tgt_bias) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    if ((cam_scale && !cam_bias) || (tgt_scale && !tgt_bias)) return fail(MATE_EINVAL, "scale without bias");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const Params &p = e->p;
+    e->xf_relative = relative != 0;
+    e->xf_cam = cam_scale != nullptr; e->xf_tgt = tgt_scale != nullptr;
+    if (cam_scale) { e->xf_cam_scale.assign(cam_scale, cam_scale + p.Dc); e->xf_cam_bias.assign(cam_bias, cam_bias + p.Dc); }
+    if (tgt_scale) { e->xf_tgt_scale.assign(tgt_scale, tgt_scale + p.Dt); e->xf_tgt_bias.assign(tgt_bias, tgt_bias + p.Dt); }
+    return apply_obs_tables(e);
+}
+
+// EnhancedObservation / SharedFieldOfView of the reference (wrappers/enhanced_observation.py,
+// wrappers/shared_field_of_view.py) per team, as descriptor variants + a few team-wide flags in the kernel.
+extern "C" int mate_engine_set_obs_mode(mate_engine *e, int32_t camera_mode, int32_t target_mode) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    if (camera_mode < 0 || camera_mode > 2 || target_mode < 0 || target_mode > 2) return fail(MATE_EINVAL, "observation mode must be 0 (plain), 1 (enhanced) or 2 (shared field of view)");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    e->cam_mode = camera_mode; e->tgt_mode = target_mode;
+    return apply_obs_tables(e);
+}
+
+extern "C" int mate_engine_set_action_grids(mate_engine *e, const double *camera_grid, int32_t n_cam, const double *target_grid, int32_t n_tgt) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    if (n_cam < 0 || n_tgt < 0 || (n_cam > 0 && !camera_grid) || (n_tgt > 0 && !target_grid)) return fail(MATE_EINVAL, "invalid action grid");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    auto upload = [&](const double *src, int n, const double2 **dst, int32_t *count) -> int {
+        *dst = nullptr; *count = 0;
+        if (n == 0) return MATE_OK;
+        double2 *buf = nullptr;
+        int rc = dev_alloc(e, &buf, (size_t)n);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(buf, src, (size_t)n * sizeof(double2), hipMemcpyHostToDevice));
+        *dst = buf; *count = n;
+        return MATE_OK;
+    };
+    int rc = upload(camera_grid, n_cam, &e->g.cam_grid, &e->g.n_cam_grid);
+    if (rc == MATE_OK) rc = upload(target_grid, n_tgt, &e->g.tgt_grid, &e->g.n_tgt_grid);
+    return rc;
 }
 
 extern "C" int mate_engine_get_layout(const mate_engine *e, mate_layout *out) {
@@ -415,9 +470,10 @@ extern "C" int mate_engine_seed(mate_engine *e, uint64_t seed) {
 
 static void apply_io(Ptrs &g, const mate_step_io *io) {
     g.cam_act = g.tgt_act = nullptr; g.tape_ct = g.tape_goal = nullptr;
-    g.cam_obs = g.tgt_obs = nullptr; g.scalars = nullptr; g.masks = nullptr; g.act_f64 = 0;
+    g.cam_obs = g.tgt_obs = nullptr; g.scalars = nullptr; g.masks = nullptr; g.act_f64 = 0; g.act_discrete = 0;
     if (!io) return;
-    g.cam_act = io->camera_actions_dev; g.tgt_act = io->target_actions_dev; g.act_f64 = io->act_dtype == MATE_ACT_F64;
+    g.cam_act = io->camera_actions_dev; g.tgt_act = io->target_actions_dev; g.act_f64 = (io->act_dtype & 0xff) == MATE_ACT_F64;
+    g.act_discrete = ((io->act_dtype & MATE_ACT_CAMERA_DISCRETE) ? 1 : 0) | ((io->act_dtype & MATE_ACT_TARGET_DISCRETE) ? 2 : 0);
     g.tape_ct = io->tape_camera_target_dev; g.tape_goal = io->tape_goal_dev;
     g.cam_obs = io->camera_obs_dev; g.tgt_obs = io->target_obs_dev; g.scalars = io->scalars_dev; g.masks = io->masks_dev;
 }
@@ -458,6 +514,8 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     Ptrs g = e->g;
     apply_io(g, io);
     if (mode == MODE_STEP && ((e->p.Nc > 0 && !g.cam_act) || !g.tgt_act)) return fail(MATE_EINVAL, "step() needs camera and target joint actions");
+    if (mode == MODE_STEP && (((g.act_discrete & 1) && !g.cam_grid) || ((g.act_discrete & 2) && !g.tgt_grid)))
+        return fail(MATE_ESTATE, "discrete actions passed before mate_engine_set_action_grids");
     g.mode = mode; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick;
     // auto_reset = 1: finished environments restart inside this call; k > 1: they idle and restart together every k-th call
     g.freeze_done = auto_reset > 1;

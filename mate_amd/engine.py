@@ -115,16 +115,31 @@ class Engine:
         io = MateStepIO()
         keep = []
         if tgt_act is not None:
-            act_dtype = tgt_act.dtype
+            # integer tensors are grid indices (set_action_grids): int32 [N, agents]; reals are [N, agents, 2]
+            ints = (torch.int32, torch.int64, torch.int16, torch.uint8)
+            tgt_discrete = tgt_act.dtype in ints
+            cam_discrete = self.num_cameras > 0 and cam_act is not None and cam_act.dtype in ints
+            reals = [a.dtype for a, d in ((tgt_act, tgt_discrete), (cam_act, cam_discrete)) if a is not None and not d]
+            act_dtype = reals[0] if reals else torch.float64
             assert act_dtype in (torch.float32, torch.float64)
-            tgt_act = tgt_act.contiguous()
-            assert tgt_act.numel() == self.num_envs * self.num_targets * 2 and tgt_act.device == self.device
+            io.act_dtype = (1 if act_dtype == torch.float64 else 0) | (0x100 if cam_discrete else 0) | (0x200 if tgt_discrete else 0)
+            if tgt_discrete:
+                assert getattr(self, 'target_action_grid', None) is not None, 'call set_action_grids(target_levels=...) first'
+                tgt_act = tgt_act.to(torch.int32).contiguous()
+                assert tgt_act.numel() == self.num_envs * self.num_targets and tgt_act.device == self.device
+            else:
+                tgt_act = tgt_act.to(act_dtype).contiguous()
+                assert tgt_act.numel() == self.num_envs * self.num_targets * 2 and tgt_act.device == self.device
             io.target_actions_dev = tgt_act.data_ptr()
-            io.act_dtype = 1 if act_dtype == torch.float64 else 0
             keep.append(tgt_act)
             if self.num_cameras:
-                cam_act = cam_act.to(act_dtype).contiguous()
-                assert cam_act.numel() == self.num_envs * self.num_cameras * 2 and cam_act.device == self.device
+                if cam_discrete:
+                    assert getattr(self, 'camera_action_grid', None) is not None, 'call set_action_grids(camera_levels=...) first'
+                    cam_act = cam_act.to(torch.int32).contiguous()
+                    assert cam_act.numel() == self.num_envs * self.num_cameras and cam_act.device == self.device
+                else:
+                    cam_act = cam_act.to(act_dtype).contiguous()
+                    assert cam_act.numel() == self.num_envs * self.num_cameras * 2 and cam_act.device == self.device
                 io.camera_actions_dev = cam_act.data_ptr()
                 keep.append(cam_act)
         if tape_ct is not None and self.num_cameras:
@@ -169,6 +184,25 @@ class Engine:
             check(self.lib.mate_engine_set_obs_transform(self._h, int(relative_coordinates), ptr(cs), ptr(cb), ptr(ts), ptr(tb)))
         else:
             check(self.lib.mate_engine_set_obs_transform(self._h, int(relative_coordinates), None, None, None, None))
+
+    OBS_MODES = {None: 0, False: 0, 'none': 0, 'plain': 0, 'enhanced': 1, 'shared': 2}
+
+    def set_obs_mode(self, camera='plain', target='plain'):
+        """Per-team observation mode fused into the packer: 'plain', 'enhanced' (the reference's
+        EnhancedObservation wrapper) or 'shared' (SharedFieldOfView)."""
+        check(self.lib.mate_engine_set_obs_mode(self._h, self.OBS_MODES[camera], self.OBS_MODES[target]))
+
+    def set_action_grids(self, camera_levels=None, target_levels=None):
+        """Discrete joint actions (the reference's DiscreteCamera / DiscreteTarget wrappers,
+        wrappers/discrete_action_spaces.py): actions passed as int32 indices into `levels**2` grids are decoded
+        in the step kernel.  The normalised grids are computed here with the reference's own NumPy formulas
+        and handed to the engine as tables."""
+        from mate_amd.spaces import camera_action_grid, target_action_grid
+        cg = np.ascontiguousarray(camera_action_grid(camera_levels), dtype=np.float64) if camera_levels else None
+        tg = np.ascontiguousarray(target_action_grid(target_levels), dtype=np.float64) if target_levels else None
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None  # noqa: E731
+        check(self.lib.mate_engine_set_action_grids(self._h, ptr(cg), 0 if cg is None else len(cg), ptr(tg), 0 if tg is None else len(tg)))
+        self.camera_action_grid, self.target_action_grid = cg, tg
 
     def seed(self, seed):
         check(self.lib.mate_engine_seed(self._h, int(seed)))

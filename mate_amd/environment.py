@@ -523,7 +523,8 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
     larger single-GPU batch (sharding invariance, DESIGN.md section "multi-GPU")."""
 
     def __init__(self, config=None, num_envs=1, device=0, seed=0, first_env_index=0, obs_dtype=torch.float32, auto_reset=True,
-                 relative_coordinates=False, rescaled_observation=False, **kwargs):
+                 relative_coordinates=False, rescaled_observation=False, enhanced_observation=None, shared_field_of_view=None,
+                 discrete_camera_levels=None, discrete_target_levels=None, **kwargs):
         self._setup_scenario(config, kwargs)
         self.num_envs, self.auto_reset = int(num_envs), bool(auto_reset)
         self.engine = Engine(self.config, self.num_envs, device=device, seed=seed, first_env_index=first_env_index, obs_dtype=obs_dtype)
@@ -532,6 +533,19 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
         self.device = self.engine.device
         if relative_coordinates or rescaled_observation:   # the reference's RelativeCoordinates / RescaledObservation wrappers, fused
             self.engine.set_obs_transform(relative_coordinates, rescaled_observation)
+        # EnhancedObservation(team=...) / SharedFieldOfView(team=...) of the reference: 'both', 'camera', 'target' or None
+        modes = {'camera': 'plain', 'target': 'plain'}
+        for name, team in (('shared', shared_field_of_view), ('enhanced', enhanced_observation)):
+            if team in (None, False, 'none'):
+                continue
+            assert team in ('both', 'camera', 'target'), f'Invalid argument team {team!r}. Expect one of ("both", "camera", "target", "none").'
+            for side in (('camera', 'target') if team == 'both' else (team,)):
+                modes[side] = name
+        if modes['camera'] != 'plain' or modes['target'] != 'plain':
+            self.engine.set_obs_mode(**modes)
+        # DiscreteCamera(levels) / DiscreteTarget(levels): integer action tensors are grid indices
+        if discrete_camera_levels or discrete_target_levels:
+            self.engine.set_action_grids(discrete_camera_levels, discrete_target_levels)
 
     def seed(self, seed):
         self.engine.seed(int(seed))

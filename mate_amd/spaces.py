@@ -84,3 +84,26 @@ except Exception:  # gym missing (as in the build image)
 
         def __iter__(self):
             return iter(self.spaces)
+
+
+def _square_grid(levels):
+    """`levels` x `levels` grid on [-1, 1]^2, x fastest (np.meshgrid of two linspaces, discrete_action_spaces.py:107-113)."""
+    if not (isinstance(levels, (int, np.integer)) and levels >= 3 and levels % 2 == 1):
+        raise AssertionError(f'The discrete level must be an odd number that not less than 3. Got levels = {levels}.')
+    axis = np.linspace(start=-1.0, stop=+1.0, num=levels, endpoint=True)
+    return np.stack(np.meshgrid(axis, axis), axis=-1).reshape(-1, 2)
+
+
+def camera_action_grid(levels):
+    """Normalised action grid of the reference's DiscreteCamera wrapper (discrete_action_spaces.py:98-117):
+    action = action_space.high * grid[index]."""
+    return _square_grid(levels)
+
+
+def target_action_grid(levels):
+    """Normalised action grid of DiscreteTarget (discrete_action_spaces.py:204-228): the square grid pulled
+    onto the unit disc along each ray, so that every direction has the same maximum step."""
+    grid = _square_grid(levels)
+    angle = np.arctan2(grid[..., -1], grid[..., 0])
+    bound = 1.0 / np.cos(np.pi * ((angle / np.pi + 0.25) % 0.5 - 0.25))
+    return grid / bound[..., np.newaxis]

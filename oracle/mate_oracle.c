@@ -765,6 +765,82 @@ void mo_observe(const mo_env *e, double *cam_obs, double *tgt_obs) { /* environm
     }
 }
 
+/* The reference's EnhancedObservation (mode 1, wrappers/enhanced_observation.py:72-126) and SharedFieldOfView
+ * (mode 2, wrappers/shared_field_of_view.py:72-148) applied to joint_observation(), per team (0 = plain). */
+void mo_observe_mode(const mo_env *e, int cam_mode, int tgt_mode, double *cam_obs, double *tgt_obs) {
+    int Nc = e->Nc, Nt = e->Nt, No = e->No;
+    int Dc = mo_camera_obs_dim(e), Dt = mo_target_obs_dim(e);
+    mo_observe(e, cam_obs, tgt_obs);
+    double cpub[MO_MAXC][6], tpub[MO_MAXT][4];
+    for (int c = 0; c < Nc; ++c) camera_state(e, c, cpub[c], 0);
+    for (int t = 0; t < Nt; ++t) target_state(e, t, tpub[t], 0);
+    if (cam_mode) {
+        for (int c = 0; c < Nc; ++c) {
+            double *p = cam_obs + (size_t)c * Dc + PRESERVED_DIM + 9;
+            for (int t = 0; t < Nt; ++t, p += 5) {
+                int vis = 1;
+                if (cam_mode == 2) { vis = 0; for (int k = 0; k < Nc; ++k) vis |= e->m_ct[k][t]; }       /* target_mask.any(axis=0) */
+                for (int i = 0; i < 4; ++i) p[i] = vis ? tpub[t][i] : 0.0;
+                p[4] = vis ? 1.0 : 0.0;
+            }
+            for (int o = 0; o < No; ++o, p += 4) {
+                int vis = 1;
+                if (cam_mode == 2) { vis = 0; for (int k = 0; k < Nc; ++k) vis |= e->cam_obs_mask[k][o]; }
+                p[0] = vis ? e->obs_x[o] : 0.0; p[1] = vis ? e->obs_y[o] : 0.0; p[2] = vis ? e->obs_r[o] : 0.0; p[3] = vis ? 1.0 : 0.0;
+            }
+            for (int c2 = 0; c2 < Nc; ++c2, p += 7) { memcpy(p, cpub[c2], sizeof(double) * 6); p[6] = 1.0; }   /* teammates: always */
+        }
+    }
+    if (tgt_mode) {
+        double empty[MO_NW];
+        for (int w = 0; w < MO_NW; ++w) {
+            if (tgt_mode == 1) {                       /* np.logical_not(remaining_cargoes).all(axis=-1) */
+                int any = 0;
+                for (int r = 0; r < MO_NW; ++r) any |= e->remaining[w][r] != 0;
+                empty[w] = any ? 0.0 : 1.0;
+            } else {                                   /* empty_bits.any(axis=0) */
+                int any = 0;
+                for (int t = 0; t < Nt; ++t) any |= tgt_obs[(size_t)t * Dt + PRESERVED_DIM + 10 + w] != 0.0;
+                empty[w] = any ? 1.0 : 0.0;
+            }
+        }
+        for (int t = 0; t < Nt; ++t) {
+            double *row = tgt_obs + (size_t)t * Dt;
+            for (int w = 0; w < MO_NW; ++w) row[PRESERVED_DIM + 10 + w] = empty[w];
+            double *p = row + PRESERVED_DIM + 14;
+            for (int c = 0; c < Nc; ++c, p += 7) {
+                int vis = 1;
+                if (tgt_mode == 2) { vis = 0; for (int k = 0; k < Nt; ++k) vis |= e->m_tc[k][c]; }
+                for (int i = 0; i < 6; ++i) p[i] = vis ? cpub[c][i] : 0.0;
+                p[6] = vis ? 1.0 : 0.0;
+            }
+            for (int o = 0; o < No; ++o, p += 4) {
+                int vis = 1;
+                if (tgt_mode == 2) { vis = 0; for (int k = 0; k < Nt; ++k) vis |= e->m_to[k][o]; }
+                p[0] = vis ? e->obs_x[o] : 0.0; p[1] = vis ? e->obs_y[o] : 0.0; p[2] = vis ? e->obs_r[o] : 0.0; p[3] = vis ? 1.0 : 0.0;
+            }
+            for (int t2 = 0; t2 < Nt; ++t2, p += 5) { memcpy(p, tpub[t2], sizeof(double) * 4); p[4] = 1.0; }
+        }
+    }
+}
+
+/* DiscreteCamera.action / DiscreteTarget.action (wrappers/discrete_action_spaces.py:59-74, 165-180):
+ * continuous = action_high * normalized_grid[index]; the grids are inputs (NumPy builds them). */
+void mo_decode_discrete(const mo_env *e, const int *cam_idx, const double *cam_grid, const int *tgt_idx, const double *tgt_grid,
+                        double *cam_act, double *tgt_act) {
+    if (cam_idx && cam_grid && cam_act)
+        for (int c = 0; c < e->Nc; ++c) {
+            cam_act[2 * c] = e->cam_rot[c] * cam_grid[2 * cam_idx[c]];
+            cam_act[2 * c + 1] = e->cam_zoom[c] * cam_grid[2 * cam_idx[c] + 1];
+        }
+    if (tgt_idx && tgt_grid && tgt_act)
+        for (int t = 0; t < e->Nt; ++t) {
+            double high = e->tgt_step[t];                                      /* Target.step_size, entities.py:612-615 */
+            tgt_act[2 * t] = high * tgt_grid[2 * tgt_idx[t]];
+            tgt_act[2 * t + 1] = high * tgt_grid[2 * tgt_idx[t] + 1];
+        }
+}
+
 void mo_state(const mo_env *e, double *out) { /* environment.py:894-906 */
     double *p = out;
     preserved(e, 0.0, p); p += PRESERVED_DIM;

@@ -63,6 +63,11 @@ void mo_update_view(mo_env *env, const double *tape_ct); /* environment.py:1356-
 void mo_step(mo_env *env, const double *cam_act, const double *tgt_act, const double *tape_ct,
              const double *goal_u);
 void mo_observe(const mo_env *env, double *cam_obs, double *tgt_obs); /* environment.py:908-983 (a9) */
+/* ... followed by the observation wrappers per team: 0 plain, 1 EnhancedObservation, 2 SharedFieldOfView */
+void mo_observe_mode(const mo_env *env, int cam_mode, int tgt_mode, double *cam_obs, double *tgt_obs);
+/* DiscreteCamera / DiscreteTarget action decode (wrappers/discrete_action_spaces.py:59-74, 165-180) */
+void mo_decode_discrete(const mo_env *env, const int *cam_idx, const double *cam_grid, const int *tgt_idx,
+                        const double *tgt_grid, double *cam_act, double *tgt_act);
 void mo_state(const mo_env *env, double *out);                        /* environment.py:894-906 */
 void mo_reset(mo_env *env);   /* environment.py:679-834 with the engine's own Philox reset stream */
 

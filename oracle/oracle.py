@@ -60,6 +60,8 @@ def _load():
     lib.mo_update_view.argtypes = [P, c_double_p]
     lib.mo_step.argtypes = [P, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.mo_observe.argtypes = [P, c_double_p, c_double_p]
+    lib.mo_observe_mode.argtypes = [P, I, I, c_double_p, c_double_p]
+    lib.mo_decode_discrete.argtypes = [P, ctypes.POINTER(ctypes.c_int), c_double_p, ctypes.POINTER(ctypes.c_int), c_double_p, c_double_p, c_double_p]
     lib.mo_state.argtypes = [P, c_double_p]
     lib.mo_reset.argtypes = [P]
     lib.mo_batch_create.restype = P
@@ -258,6 +260,27 @@ class OracleEnv:
         tgt = np.zeros((self.Nt, self.Dt))
         lib.mo_observe(self._h, _dp(cam), _dp(tgt))
         return cam[:self.Nc], tgt
+
+    MODES = {'plain': 0, 'enhanced': 1, 'shared': 2}
+
+    def observe_mode(self, camera='plain', target='plain'):
+        """joint_observation() followed by the reference's EnhancedObservation / SharedFieldOfView per team."""
+        cam = np.zeros((max(self.Nc, 1), self.Dc))
+        tgt = np.zeros((self.Nt, self.Dt))
+        lib.mo_observe_mode(self._h, self.MODES[camera], self.MODES[target], _dp(cam), _dp(tgt))
+        return cam[:self.Nc], tgt
+
+    def decode_discrete(self, cam_idx, cam_grid, tgt_idx, tgt_grid):
+        """DiscreteCamera / DiscreteTarget: grid indices -> continuous joint actions."""
+        ip = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))  # noqa: E731
+        cam_act, tgt_act = np.zeros((max(self.Nc, 1), 2)), np.zeros((self.Nt, 2))
+        ci = np.ascontiguousarray(cam_idx, dtype=np.int32) if cam_idx is not None and self.Nc else None
+        ti = np.ascontiguousarray(tgt_idx, dtype=np.int32) if tgt_idx is not None else None
+        cg = np.ascontiguousarray(cam_grid, dtype=np.float64) if ci is not None else None
+        tg = np.ascontiguousarray(tgt_grid, dtype=np.float64) if ti is not None else None
+        lib.mo_decode_discrete(self._h, ip(ci) if ci is not None else None, _dp(cg) if cg is not None else None,
+                               ip(ti) if ti is not None else None, _dp(tg) if tg is not None else None, _dp(cam_act), _dp(tgt_act))
+        return cam_act[:self.Nc], tgt_act
 
     def state(self):
         out = np.zeros(self.S)

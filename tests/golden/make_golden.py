@@ -274,7 +274,8 @@ def drain_agent_log(cam_agents, tgt_agents):
     return out
 
 
-def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f64_obs_steps=None, record_agents=False):
+def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f64_obs_steps=None, record_agents=False,
+               extra_factory=None, discrete_levels=None):
     env = mate.make('MultiAgentTracking-v0', config=config, **(overrides or {}))
     env.seed(seed)
     cam_obs, tgt_obs = env.reset()
@@ -307,6 +308,19 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
         out['reset/' + k] = v
     out['reset/cam_obs'] = cam_obs
     out['reset/tgt_obs'] = tgt_obs
+    extra = extra_factory(env) if extra_factory is not None else None
+    if extra is not None:
+        for k, v in extra(cam_obs, tgt_obs).items():
+            out['reset/' + k] = v
+    if discrete_levels is not None:     # DiscreteCamera / DiscreteTarget of the reference decode the indices
+        disc_cam = mate.DiscreteCamera(env, levels=discrete_levels[0]) if Nc_of(env) else None
+        disc_tgt = mate.DiscreteTarget(env, levels=discrete_levels[1])
+        for t, target in enumerate(env.targets):     # what DiscreteTarget.reset() does (discrete_action_spaces.py:156-163)
+            disc_tgt.action_high[t] = target.step_size
+        if disc_cam is not None:
+            out['camera_action_grid'] = disc_cam.normalized_action_grid
+        out['target_action_grid'] = disc_tgt.normalized_action_grid
+        out['discrete_levels'] = np.asarray(discrete_levels, dtype=np.int64)
 
     rng = np.random.RandomState(seed + 1000)
     if policy == 'greedy':
@@ -343,6 +357,15 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
             if record_agents:
                 for k, v in drain_agent_log(cam_agents, tgt_agents).items():
                     push('agent_' + k, v)
+        elif policy == 'discrete':
+            cam_idx = rng.randint(0, discrete_levels[0] ** 2, size=Nc)
+            tgt_idx = rng.randint(0, discrete_levels[1] ** 2, size=Nt)
+            cam_act = np.zeros((0, 2))
+            if disc_cam is not None:
+                cam_act = np.asarray(disc_cam.action((cam_idx, None))[0], dtype=np.float64).reshape(Nc, 2)
+            tgt_act = np.asarray(disc_tgt.action((None, tgt_idx))[1], dtype=np.float64).reshape(Nt, 2)
+            push('cam_idx', cam_idx)
+            push('tgt_idx', tgt_idx)
         else:
             cam_act, tgt_act = random_actions(env, rng, step)
         log.clear()
@@ -361,6 +384,9 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
         push('reward_tgt', r_tgt)
         push('normalized_reward_tgt', tgt_infos[0]['normalized_raw_reward'])
         push('done', done)
+        if extra is not None:
+            for k, v in extra(cam_obs, tgt_obs).items():
+                push(k, v)
         for k, v in snapshot_dynamic(env).items():
             push(k, v)
         if done:
@@ -383,6 +409,30 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
     nsee = int(np.isfinite(out['step/tape_ct']).sum()) if Nc else 0
     print(f'{name}: {nsteps} steps, delivered={ndel}, collisions={ncol}, in-sector draws={nsee}, '
           f'done={bool(out["step/done"][-1])}, {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+def Nc_of(env):
+    return env.num_cameras
+
+
+def observation_mode_extras(teams):
+    """Outputs of the reference's EnhancedObservation / SharedFieldOfView wrappers on the observations of a
+    trace (wrappers/enhanced_observation.py:72-126, wrappers/shared_field_of_view.py:72-148), f32."""
+    def factory(env):
+        wrappers = {}
+        for team in teams:
+            wrappers['enhanced_' + team] = mate.EnhancedObservation(env, team=team)
+            wrappers['shared_' + team] = mate.SharedFieldOfView(env, team=team)
+
+        def extra(cam_obs, tgt_obs):
+            res = {}
+            for key, w in wrappers.items():
+                c, t = w.observation((np.array(cam_obs, dtype=np.float64), np.array(tgt_obs, dtype=np.float64)))
+                res['cam_obs_' + key] = np.asarray(c, dtype=np.float32)
+                res['tgt_obs_' + key] = np.asarray(t, dtype=np.float32)
+            return res
+        return extra
+    return factory
 
 
 def tweak_few_cargoes(env):
@@ -597,6 +647,18 @@ def main():
         make_trace('greedy_4v8-9_s5', 'MATE-4v8-9.yaml', 5, 'greedy', 300, record_agents=True)
         make_trace('greedy_8v8-9_s6', 'MATE-8v8-9.yaml', 6, 'greedy', 200, record_agents=True)
         make_trace('greedy_4v2-9_s7', 'MATE-4v2-9.yaml', 7, 'greedy', 200, record_agents=True)
+        return
+    if sys.argv[1:] == ['discrete']:
+        make_trace('discrete_4v8-9_s6', 'MATE-4v8-9.yaml', 6, 'discrete', 64, discrete_levels=(5, 5))
+        make_trace('discrete_4v2-9_s7', 'MATE-4v2-9.yaml', 7, 'discrete', 48, discrete_levels=(3, 9))
+        return
+    if sys.argv[1:] == ['wrappers']:
+        make_trace('obsmode_4v8-9_s4', 'MATE-4v8-9.yaml', 4, 'greedy', 72, extra_factory=observation_mode_extras(('both', 'camera', 'target')))
+        make_trace('obsmode_4v8-9_fewcargo', 'MATE-4v8-9.yaml', 3, 'greedy', 160, tweak=tweak_few_cargoes,
+                   extra_factory=observation_mode_extras(('both',)))
+        make_trace('obsmode_nav_s2', 'MATE-Navigation.yaml', 2, 'greedy', 48, extra_factory=observation_mode_extras(('target',)))
+        make_trace('discrete_4v8-9_s6', 'MATE-4v8-9.yaml', 6, 'discrete', 64, discrete_levels=(5, 5))
+        make_trace('discrete_4v2-9_s7', 'MATE-4v2-9.yaml', 7, 'discrete', 48, discrete_levels=(3, 9))
         return
     if sys.argv[1:] == ['xform']:
         xform_fixture('trace_4v8-9_greedy_s2', 48)

@@ -254,3 +254,75 @@ def test_shape_specialised_kernel_equals_generic(workload, monkeypatch):
     for a, b in zip(*outs):
         for x, y in zip(a, b):
             assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+
+
+def _replay(eng, fx, s, N, cam=None, tgt=None):
+    Nc, Nt, dev = eng.num_cameras, eng.num_targets, eng.device
+    ca = cam if cam is not None else torch.from_numpy(np.broadcast_to(fx['step/cam_act'][s], (N, Nc, 2)).copy()).to(dev)
+    ta = tgt if tgt is not None else torch.from_numpy(np.broadcast_to(fx['step/tgt_act'][s], (N, Nt, 2)).copy()).to(dev)
+    tape = torch.from_numpy(np.broadcast_to(np.nan_to_num(fx['step/tape_ct'][s], nan=0.0), (N, Nc, Nt)).copy()).to(dev)
+    goal = torch.from_numpy(np.broadcast_to(np.nan_to_num(fx['step/goal_u'][s], nan=0.0), (N, Nt)).copy()).to(dev)
+    return eng.step(ca, ta, tape_ct=tape, tape_goal=goal, auto_reset=False)
+
+
+@pytest.mark.parametrize('name,mode,team', [
+    ('obsmode_4v8-9_s4', 'enhanced', 'both'), ('obsmode_4v8-9_s4', 'enhanced', 'camera'), ('obsmode_4v8-9_s4', 'enhanced', 'target'),
+    ('obsmode_4v8-9_s4', 'shared', 'both'), ('obsmode_4v8-9_s4', 'shared', 'camera'), ('obsmode_4v8-9_s4', 'shared', 'target'),
+    ('obsmode_4v8-9_fewcargo', 'enhanced', 'both'), ('obsmode_4v8-9_fewcargo', 'shared', 'both'),
+    ('obsmode_nav_s2', 'enhanced', 'target'), ('obsmode_nav_s2', 'shared', 'target')])
+def test_observation_modes(name, mode, team):
+    """EnhancedObservation / SharedFieldOfView fused into the packer == the reference's wrappers applied to the
+    reference's observations on the same trace (fixtures obsmode_*.npz); the view masks stay the plain ones."""
+    fx = G.load(name + '.npz')
+    N = 2
+    eng = U.engine_from_fixture(fx, N, obs_dtype=torch.float32)
+    sides = ('camera', 'target') if team == 'both' else (team,)
+    eng.set_obs_mode(**{side: mode for side in sides})
+    Nc = eng.num_cameras
+    key = mode + '_' + team
+    tape0 = torch.zeros((N, max(Nc, 1), eng.num_targets), dtype=torch.float64, device=eng.device)
+    co, to = eng.observe(tape_ct=tape0)
+    if Nc:
+        assert rel_close(co[1].double().cpu().numpy(), fx['reset/cam_obs_' + key].astype(np.float64), 1e-5), 'reset camera rows'
+    assert rel_close(to[1].double().cpu().numpy(), fx['reset/tgt_obs_' + key].astype(np.float64), 1e-5), 'reset target rows'
+    for s in range(len(fx['step/done'])):
+        co, to, _ = _replay(eng, fx, s, N)
+        masks = eng.unpack_masks()
+        for m in MASKS:
+            assert np.array_equal(masks[m][1], fx['step/' + m][s].astype(bool)), (m, s)
+        if Nc:
+            got, ref = co[1].double().cpu().numpy(), fx['step/cam_obs_' + key][s].astype(np.float64)
+            assert rel_close(got, ref, 1e-5), (s, 'camera', np.abs(got - ref).max())
+        got, ref = to[1].double().cpu().numpy(), fx['step/tgt_obs_' + key][s].astype(np.float64)
+        assert rel_close(got, ref, 1e-5), (s, 'target', np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize('name', ['discrete_4v8-9_s6', 'discrete_4v2-9_s7'])
+def test_discrete_actions(name):
+    """Joint actions given as grid indices (DiscreteCamera / DiscreteTarget of the reference) are decoded in the
+    kernel: the trace the reference produced from the wrappers' continuous actions is reproduced from the indices."""
+    fx = G.load(name + '.npz')
+    N = 2
+    eng = U.engine_from_fixture(fx, N, obs_dtype=torch.float32)
+    lc, lt = (int(v) for v in fx['discrete_levels'])
+    eng.set_action_grids(camera_levels=lc, target_levels=lt)
+    assert np.array_equal(eng.camera_action_grid, fx['camera_action_grid']) and np.array_equal(eng.target_action_grid, fx['target_action_grid'])
+    dev = eng.device
+    for s in range(len(fx['step/done'])):
+        ci = torch.from_numpy(np.broadcast_to(fx['step/cam_idx'][s], (N, eng.num_cameras)).copy()).to(dev)
+        ti = torch.from_numpy(np.broadcast_to(fx['step/tgt_idx'][s], (N, eng.num_targets)).copy()).to(dev)
+        co, to, sc = _replay(eng, fx, s, N, cam=ci, tgt=ti)
+        masks = eng.unpack_masks()
+        for m in MASKS:
+            assert np.array_equal(masks[m][1], fx['step/' + m][s].astype(bool)), (m, s)
+        sd = eng.state_dict()
+        xy = fx['step/tgt_xy'][s]
+        assert np.abs(sd['tgt_x'][1] - xy[:, 0]).max() < 1e-9 and np.abs(sd['tgt_y'][1] - xy[:, 1]).max() < 1e-9, s
+        assert np.abs(sd['cam_phi'][1] - fx['step/cam_phi'][s]).max() < 1e-9 and np.abs(sd['cam_theta'][1] - fx['step/cam_theta'][s]).max() < 1e-9
+        assert rel_close(co[1].double().cpu().numpy(), fx['step/cam_obs'][s], 1e-5) and rel_close(to[1].double().cpu().numpy(), fx['step/tgt_obs'][s], 1e-5)
+    # mixed: discrete cameras with continuous targets (the common RLlib configuration)
+    eng2 = U.engine_from_fixture(fx, N, obs_dtype=torch.float32)
+    eng2.set_action_grids(camera_levels=lc)
+    ci = torch.from_numpy(np.broadcast_to(fx['step/cam_idx'][0], (N, eng2.num_cameras)).copy()).to(dev)
+    co, to, _ = _replay(eng2, fx, 0, N, cam=ci)
+    assert rel_close(co[1].double().cpu().numpy(), fx['step/cam_obs'][0], 1e-5) and rel_close(to[1].double().cpu().numpy(), fx['step/tgt_obs'][0], 1e-5)

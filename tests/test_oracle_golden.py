@@ -119,3 +119,48 @@ def test_philox_known_answers():
             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
     for key, ctr, want in kat:
         assert tuple(O.philox(*key, *ctr)) == want
+
+
+@pytest.mark.parametrize('name,teams', [('obsmode_4v8-9_s4', ('both', 'camera', 'target')), ('obsmode_4v8-9_fewcargo', ('both',)),
+                                        ('obsmode_nav_s2', ('target',))])
+def test_observation_wrappers(name, teams):
+    """EnhancedObservation / SharedFieldOfView restated in the oracle == the reference's wrappers (f32 fixtures)."""
+    fx = G.load(name + '.npz')
+    env = G.oracle_from_fixture(fx)
+
+    def check(prefix, s=None):
+        for mode in ('enhanced', 'shared'):
+            for team in teams:
+                kw = {side: mode for side in (('camera', 'target') if team == 'both' else (team,))}
+                co, to = env.observe_mode(**kw)
+                ref_c, ref_t = fx[prefix + 'cam_obs_' + mode + '_' + team], fx[prefix + 'tgt_obs_' + mode + '_' + team]
+                if s is not None:
+                    ref_c, ref_t = ref_c[s], ref_t[s]
+                if co.size:
+                    assert np.array_equal(co.astype(np.float32), ref_c), (mode, team, s)
+                assert np.array_equal(to.astype(np.float32), ref_t), (mode, team, s)
+
+    check('reset/')
+    for s in range(len(fx['step/done'])):
+        env.step(fx['step/cam_act'][s], fx['step/tgt_act'][s], fx['step/tape_ct'][s], fx['step/goal_u'][s])
+        check('step/', s)
+
+
+@pytest.mark.parametrize('name', ['discrete_4v8-9_s6', 'discrete_4v2-9_s7'])
+def test_discrete_action_decode(name):
+    """Grids as the host builds them == the reference's; decode == the wrappers' continuous actions, bit for bit."""
+    from mate_amd.spaces import camera_action_grid, target_action_grid
+    fx = G.load(name + '.npz')
+    lc, lt = (int(v) for v in fx['discrete_levels'])
+    assert np.array_equal(camera_action_grid(lc), fx['camera_action_grid'])
+    assert np.array_equal(target_action_grid(lt), fx['target_action_grid'])
+    with pytest.raises(AssertionError):
+        camera_action_grid(4)
+    env = G.oracle_from_fixture(fx)
+    for s in range(len(fx['step/done'])):
+        ca, ta = env.decode_discrete(fx['step/cam_idx'][s], fx['camera_action_grid'], fx['step/tgt_idx'][s], fx['target_action_grid'])
+        assert np.array_equal(ca, fx['step/cam_act'][s]) and np.array_equal(ta, fx['step/tgt_act'][s]), s
+        env.step(ca, ta, fx['step/tape_ct'][s], fx['step/goal_u'][s])
+        co, to = env.observe()
+        np.testing.assert_allclose(co, fx['step/cam_obs'][s], rtol=0, atol=F64_TOL)
+        np.testing.assert_allclose(to, fx['step/tgt_obs'][s], rtol=0, atol=F64_TOL)
