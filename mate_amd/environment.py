@@ -573,6 +573,39 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
     def masks(self):
         return self.engine.unpack_masks()
 
+    AUXILIARY_REWARD_KEYS = ('raw_reward', 'coverage_rate', 'real_coverage_rate', 'mean_transport_rate', 'soft_coverage_score',
+                             'num_tracked', 'baseline')
+
+    def auxiliary_camera_rewards(self, coefficients, reduction='none'):
+        """Per-camera shaped rewards of the last step, the reference's AuxiliaryCameraRewards wrapper
+        (wrappers/auxiliary_camera_rewards.py:110-176) with constant coefficients: a weighted sum of the team reward,
+        the coverage / transport metrics of the step record, the number of targets each camera tracks and a
+        baseline; `reduction` in ('none', 'mean', 'sum', 'max', 'min') shares one value among the cameras.
+        Returns a [num_envs, num_cameras] tensor on the GPU (a handful of elementwise ops on the [N, 8] step record
+        and the packed masks: nothing here touches the observation bytes).  `soft_coverage_score` needs the outer
+        occlusion boundary, which this build does not produce."""
+        assert set(self.AUXILIARY_REWARD_KEYS).issuperset(coefficients.keys()), (
+            f'The coefficient mapping only accepts keys in {self.AUXILIARY_REWARD_KEYS}. Got list(coefficients.keys()) = {list(coefficients.keys())}.')
+        assert reduction in ('mean', 'sum', 'max', 'min', 'none'), f'Invalid reduction method {reduction}.'
+        if 'soft_coverage_score' in coefficients:
+            raise NotImplementedError('soft_coverage_score needs Camera.boundary_between(outer=True)')
+        s = self.engine.scalars.double()
+        N, Nc, Nt = self.num_envs, self.num_cameras, self.num_targets
+        bits = torch.arange(Nc * Nt, device=self.device)
+        words = self.engine.masks.long()[:, bits // 32]                       # camera_target_view_mask lives in the first words
+        seen = ((words >> (bits % 32)) & 1).view(N, Nc, Nt)
+        terms = {'raw_reward': s[:, 0:1].expand(N, Nc), 'coverage_rate': s[:, 3:4].expand(N, Nc),
+                 'real_coverage_rate': s[:, 4:5].expand(N, Nc), 'mean_transport_rate': s[:, 5:6].expand(N, Nc),
+                 'num_tracked': seen.sum(dim=2).double(), 'baseline': torch.ones((N, Nc), dtype=torch.float64, device=self.device)}
+        reward = torch.zeros((N, Nc), dtype=torch.float64, device=self.device)
+        for key, coefficient in coefficients.items():
+            assert isinstance(coefficient, (int, float)), 'only constant coefficients are supported on the batched path'
+            reward = reward + float(coefficient) * terms[key]
+        if reduction != 'none':
+            shared = {'mean': reward.mean(dim=1), 'sum': reward.sum(dim=1), 'max': reward.max(dim=1).values, 'min': reward.min(dim=1).values}[reduction]
+            reward = shared[:, None].expand(N, Nc)
+        return reward
+
     def state_dict(self):
         return self.engine.state_dict()
 
