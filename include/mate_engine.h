@@ -96,7 +96,10 @@ int mate_engine_abi_version(void);
 
 /* MultiAgentTracking.__init__ (environment.py:330-562) for N environments on HIP device `device`.
  * RNG streams are keyed by (seed, first_env_index + i), so results do not depend on how a
- * global batch is sharded over GPUs. */
+ * global batch is sharded over GPUs.
+ * Limits (MATE_EINVAL beyond them, never a silent fallback): at most 16 cameras, 16 targets, 64 obstacles;
+ * with cameras present the occlusion-table build sorts 360 + 185 * obstacles rays inside the 160 KiB LDS, which
+ * holds up to 20 obstacles (the reference's scenarios use 0 or 9; MATE-Navigation has 32 obstacles and no camera). */
 int mate_engine_create(const mate_config *config, int64_t num_envs, int32_t device, uint64_t seed,
                        uint64_t first_env_index, mate_engine **out);
 int mate_engine_destroy(mate_engine *engine);                               /* close(), environment.py:1192 */

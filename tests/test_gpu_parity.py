@@ -91,10 +91,38 @@ def test_trace_parity(path, dtype):
                                        ('MATE-1v1-0.yaml', 7)])
 def test_reset_and_rollout_vs_oracle(config, n, oracle_lib):
     """Native GPU reset + Philox random-policy rollout against the CPU oracle on the same streams."""
+    _reset_and_rollout_vs_oracle(config, n, oracle_lib)
+
+
+def test_largest_supported_scenario_vs_oracle(oracle_lib):
+    """A scenario at the engine's limits (16 cameras, 16 targets, 20 obstacles: 8 sector rounds, 13 range rounds,
+    4k-knot occlusion tables in a 160 KiB-LDS sort, generic kernels) goes through the same reset + rollout parity;
+    one obstacle more per camera table than the LDS sort can hold is refused loudly."""
+    from mate_amd._native import EngineError
+    from mate_amd.engine import Engine
+    from mate_amd.config import read_config
+    cfg = read_config('MATE-8v8-9.yaml')
+    cfg['name'] = 'MultiAgentTracking(16v16, 40)'
+    cam = cfg['camera']['location_random_range']
+    cfg['camera']['location_random_range'] = cam + [[-x1, -x0, y0, y1] if i % 2 else [x0, x1, -y1, -y0] for i, (x0, x1, y0, y1) in enumerate(cam)]
+    cfg['camera']['location_random_range'] = [[float(v) for v in box] for box in cfg['camera']['location_random_range']]
+    cfg['target']['location_random_range'] = [[-300.0, 300.0, -300.0, 300.0]] * 16
+    obs = cfg['obstacle']['location_random_range']
+    cfg['obstacle']['location_random_range'] = (obs * 5)[:20]
+    cfg['obstacle']['radius_random_range'] = [10.0, 40.0]
+    _reset_and_rollout_vs_oracle(cfg, 9, oracle_lib, steps=12)
+    import copy
+    too_big = copy.deepcopy(cfg)
+    too_big['obstacle']['location_random_range'] = (obs * 5)[:40]
+    with pytest.raises(EngineError, match='too large'):
+        Engine(too_big, 4)
+
+
+def _reset_and_rollout_vs_oracle(config, n, oracle_lib, steps=40):
     O = oracle_lib
     from mate_amd.config import read_config
     from mate_amd.engine import Engine
-    cfg = read_config(config)
+    cfg = read_config(config) if isinstance(config, str) else config
     seed, first = 1234, 1000
     eng = Engine(cfg, n, seed=seed, first_env_index=first, obs_dtype=torch.float64)
     eng.reset()
@@ -131,7 +159,6 @@ def test_reset_and_rollout_vs_oracle(config, n, oracle_lib):
     # first observation after reset uses the reset-view draws
     co, to = eng.camera_obs.cpu().numpy(), eng.target_obs.cpu().numpy()
     # (3) rollout
-    steps = 40
     for s in range(steps):
         eng.step_random(auto_reset=False, want_masks=True)
         batch.step(auto_reset=False, threads=4)
