@@ -480,9 +480,27 @@ static void apply_io(Ptrs &g, const mate_step_io *io) {
 
 static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream) {
     g.mode = MODE_OBSERVE; g.reset_kind = kind; g.parity = e->parity; g.freeze_done = 0;
-    const int64_t blocks = kind == RESET_DONE ? std::min<int64_t>(e->N, 256) : e->N;
-    if (e->p.obs_f64) hipLaunchKernelGGL(reset_kernel<double>, dim3((unsigned)blocks), dim3(256), e->reset_lds, stream, e->d_params, g, e->rl, phases);
-    else hipLaunchKernelGGL(reset_kernel<float>, dim3((unsigned)blocks), dim3(256), e->reset_lds, stream, e->d_params, g, e->rl, phases);
+    const Params &p = e->p;
+    auto launch = [&](int ph, int fan, unsigned threads, size_t lds) {
+        const int64_t items = (kind == RESET_DONE ? std::min<int64_t>(e->N, 256) : e->N) * fan;
+        if (p.obs_f64) hipLaunchKernelGGL(reset_kernel<double>, dim3((unsigned)items), dim3(threads), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const ResetLds)e->rl, (const int32_t)ph);
+        else hipLaunchKernelGGL(reset_kernel<float>, dim3((unsigned)items), dim3(threads), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const ResetLds)e->rl, (const int32_t)ph);
+    };
+    const char *mono = getenv("MATE_RESET_MONOLITHIC");
+    // The immediate auto-reset (RESET_DONE) is launched after EVERY step and is idle almost always: it stays one
+    // launch.  Whole-batch, masked and batched (flagged) resets are split:
+    if ((phases & PH_LUT) && p.Nc > 1 && kind != RESET_DONE && !(mono && atoi(mono))) {
+        // placement: one wave per environment; tables: one workgroup per (environment, camera); view: one wave
+        // reset_place scratch behind the wave slice: 5 arrays of placed circles + the shuffle permutations
+        const size_t lds_place = (size_t)e->rl.off_keys + 5 * (size_t)(4 + p.Nc + p.No + p.Nt) * 8 + (size_t)(p.Nc + p.No + 2 * p.Nt) * 4 + 64;
+        const bool later = (phases & (PH_LUT | PH_VIEW)) != 0;
+        if (phases & PH_PLACE) launch(PH_PLACE | (later ? PH_MORE : 0), 1, 64, lds_place);
+        launch(PH_LUT | PH_PER_CAMERA, p.Nc, 256, e->reset_lds);
+        if (phases & PH_VIEW) launch(PH_VIEW, 1, 64, (size_t)p.lds_wave_bytes);
+        else if (kind == RESET_FLAGGED && (phases & PH_PLACE)) return fail(MATE_EINVAL, "a flagged reset needs the view phase");
+    } else {
+        launch(phases, 1, 256, e->reset_lds);
+    }
     HIP_TRY(hipGetLastError());
     return MATE_OK;
 }

@@ -13,7 +13,7 @@
 namespace mate {
 
 enum ResetKind : int32_t { RESET_ALL = 0, RESET_MASK = 1, RESET_DONE = 2, RESET_FLAGGED = 3 };
-enum ResetPhase : int32_t { PH_PLACE = 1, PH_LUT = 2, PH_VIEW = 4 };
+enum ResetPhase : int32_t { PH_PLACE = 1, PH_LUT = 2, PH_VIEW = 4, PH_PER_CAMERA = 8, PH_MORE = 16 };
 
 struct ResetLds {   // byte offsets inside the workgroup's dynamic LDS, after the wave-0 context
     int32_t off_keys, off_vals, off_okeys, off_ovals, off_bucket, off_meta, off_scan, sort_cap, total_bytes;
@@ -339,11 +339,17 @@ __device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, dou
     __syncthreads();
 }
 
+// One launch can run all three phases for an environment in one workgroup, or the host splits them
+// (launch_reset): placement by one wave per environment, then ONE WORKGROUP PER (environment, camera) for the
+// occlusion tables -- they are independent once the geometry is placed, and with 8 cameras the tables are
+// 2/3 of a reset's latency -- then the first view by one wave per environment.  PH_MORE tells the placement
+// launch that later launches select the same environments: under RESET_FLAGGED the selection is the
+// `done` word itself, which then carries the marker 3 ("being reset") until the view launch clears it.
 template <typename ObsT>
 __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ pp, const Ptrs g, const ResetLds rl, const int32_t phases) {
     const Params &p = *pp;
     extern __shared__ __align__(16) unsigned char smem[];
-    if (g.reset_kind == RESET_DONE && (int64_t)blockIdx.x >= (int64_t)g.done_count[g.parity]) return;   // idle: nothing finished
+    if (g.reset_kind == RESET_DONE && (int64_t)blockIdx.x >= (int64_t)g.done_count[g.parity] * ((phases & PH_PER_CAMERA) ? p.Nc : 1)) return;   // idle: nothing finished
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned char *wave_base = smem;
     double *keys = reinterpret_cast<double *>(smem + rl.off_keys);
@@ -353,39 +359,63 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
     uint16_t *lbucket = reinterpret_cast<uint16_t *>(smem + rl.off_bucket);
     double *meta = reinterpret_cast<double *>(smem + rl.off_meta);
     int32_t *scan = reinterpret_cast<int32_t *>(smem + rl.off_scan);
+    const bool per_camera = (phases & PH_PER_CAMERA) != 0;
+    const int fan = per_camera ? p.Nc : 1;
     int64_t count = g.N;
     if (g.reset_kind == RESET_DONE) count = g.done_count[g.parity];
-    for (int64_t item = blockIdx.x; item < count; item += gridDim.x) {
+    for (int64_t v = blockIdx.x; v < count * fan; v += gridDim.x) {
+        const int64_t item = per_camera ? v / p.Nc : v;
+        const int only_cam = per_camera ? (int)(v - item * p.Nc) : -1;
         const int64_t env = g.reset_kind == RESET_DONE ? (int64_t)g.done_list[(int64_t)g.parity * g.N + item] : item;
         if (g.reset_kind == RESET_MASK && !g.reset_mask[env]) continue;
-        if (g.reset_kind == RESET_FLAGGED && !reinterpret_cast<const int32_t *>(g.dyn + env * p.DW + p.DF)[p.Nt * TI_STRIDE + EI_DONE]) continue;
+        if (g.reset_kind == RESET_FLAGGED) {
+            const int done = reinterpret_cast<const int32_t *>(g.dyn + env * p.DW + p.DF)[p.Nt * TI_STRIDE + EI_DONE];
+            if ((phases & PH_PLACE) ? done == 0 : done != 3) continue;
+        }
         __syncthreads();
         Ctx<ObsT> c(p, g, wave_base, lane, env);
         if (wave == 0) {
             load_records(c);
             wave_sync();
-            if ((phases & PH_PLACE) && lane == 0) reset_place(c, keys, 4 + p.Nc + p.No + p.Nt);
+            if ((phases & PH_PLACE) && lane == 0) {
+                reset_place(c, keys, 4 + p.Nc + p.No + p.Nt);
+                if (g.reset_kind == RESET_FLAGGED && (phases & PH_MORE)) c.ei(EI_DONE) = 3;
+            }
             wave_sync();
         }
         __syncthreads();
-        if (phases & PH_LUT)
+        if (phases & PH_LUT) {
+            if (per_camera) {
+                build_lut(c, only_cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap);
+                // this workgroup owns exactly one word of the static record: the camera's obstacle mask row
+                if (threadIdx.x == 0) {
+                    const int w = 2 * p.Nc + 3 * p.No + only_cam;
+                    reinterpret_cast<uint64_t *>(g.stat + env * p.SW)[w] = reinterpret_cast<const uint64_t *>(c.st)[w];
+                }
+                continue;
+            }
             for (int cam = 0; cam < p.Nc; ++cam) build_lut(c, cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap);
+        }
         __syncthreads();
         if (wave == 0) {
             // static record back to HBM
-            double *s = g.stat + env * p.SW;
-            for (int i = lane; i < p.SW; i += 64) s[i] = c.st[i];
+            if (phases & (PH_PLACE | PH_LUT)) {
+                double *s = g.stat + env * p.SW;
+                for (int i = lane; i < p.SW; i += 64) s[i] = c.st[i];
+            }
             if (phases & PH_VIEW) {
-                __threadfence();   // this wave reads the tables other waves of the workgroup just wrote
+                __threadfence();   // this wave reads the tables other waves / workgroups just wrote
                 build_entities(c);
                 simulate_cameras(c, StepDraws{0.0, 0.0}, false);   // camera sight + scratch only
                 wave_sync();
                 update_view(c, (uint32_t)c.ei(EI_EPISODE), S_RESET_VIEW, false);
+                if (lane == 0 && c.ei(EI_DONE) == 3) c.ei(EI_DONE) = 0;
+                wave_sync();
                 score_only(c, g.scalars);
                 fill_scratch(c);
                 pack_observations(c);
             }
-            store_dynamic(c);
+            if (phases & (PH_PLACE | PH_VIEW)) store_dynamic(c);
         }
     }
 }
