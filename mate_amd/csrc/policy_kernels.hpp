@@ -14,12 +14,14 @@
 
 namespace mate {
 
-// Per step every lane draws twice, unconditionally (two Philox calls, no divergent re-draws):
-//   S_POL_A, sub = lane: word 0 -> message delay of the (sender, recipient) pair `lane`; words 1-2 -> the
-//                        agent's Bernoulli uniform; word 3 -> the target's warehouse choice
-//   S_POL_B, sub = lane: two uniforms for the agent's action / noise sample
-// (camera c is lane c, target t is lane 32 + t).  S_POL_TGT_RESET is keyed by the episode counter.
-enum PolicyStream : uint32_t { S_POL_A = 16, S_POL_B = 17, S_POL_TGT_RESET = 19 };
+// Per step every lane makes ONE unconditional Philox call (no divergent re-draws), stream S_POL_STEP, sub = lane:
+//   word 0, low half  -> message delay of the (sender, recipient) pair `lane`  (randint(6, 50), greedy.py:184)
+//   word 0, high half -> the target's warehouse choice                         (np_random.choice, greedy.py:298)
+//   word 1            -> the agent's Bernoulli uniform                          (greedy.py:93, 315)
+//   words 2, 3        -> the two uniforms of the agent's action / noise sample (greedy.py:95, 319)
+// (camera c is lane c, target t is lane 32 + t).  32-bit uniforms: the thresholds are 0.05 .. 0.75 and the
+// samples feed a clipped action.  S_POL_TGT_RESET is keyed by the episode counter.
+enum PolicyStream : uint32_t { S_POL_STEP = 16, S_POL_TGT_RESET = 19 };
 
 struct PolicyTape {          // all optional (NULL = Philox); device pointers
     const double *cam_binom_u;        // [N][Nc]
@@ -131,10 +133,10 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     double u_bern = 0.0, u_s0 = 0.0, u_s1 = 0.0;
     uint32_t w_delay = 0, w_choice = 0;
     if (!(q.tape.cam_binom_u && q.tape.cam_sample_u && q.tape.cam_delay && q.tape.tgt_choice_u && q.tape.tgt_binom_u && q.tape.tgt_sample_u)) {
-        const U4 ra = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_A, (uint32_t)lane);
-        const U4 rb = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_B, (uint32_t)lane);
-        w_delay = ra.x; u_bern = u53(ra.y, ra.z); w_choice = ra.w;
-        u_s0 = u53(rb.x, rb.y); u_s1 = u53(rb.z, rb.w);
+        const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_STEP, (uint32_t)lane);
+        w_delay = r.x & 0xffffu; w_choice = r.x >> 16;
+        u_bern = (double)r.y * 2.3283064365386963e-10;
+        u_s0 = (double)r.z * 2.3283064365386963e-10; u_s1 = (double)r.w * 2.3283064365386963e-10;
     }
     const uint64_t capword = reinterpret_cast<const uint64_t *>(st)[3 * Nc + 3 * p.No];
 
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
                 int v;
                 if (q.tape.cam_delay) v = q.tape.cam_delay[(env * Nc + s) * Nc + c];
                 else { const int lo = q.memory_period / 4, hi = 2 * q.memory_period;        // randint(6, 50)
-                       v = lo + (int)(((double)w_delay * 2.3283064365386963e-10) * (double)(hi - lo)); if (v >= hi) v = hi - 1; }
+                       v = lo + (int)((w_delay * (uint32_t)(hi - lo)) >> 16); }
                 d = v;
             }
         }
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
             if (k > 0) {
                 double u;
                 if (q.tape.tgt_choice_u) u = q.tape.tgt_choice_u[env * Nt + t];
-                else u = (double)w_choice * 2.3283064365386963e-10;
+                else u = (double)w_choice * 1.52587890625e-05;
                 int j = (int)(u * (double)k);
                 if (j >= k) j = k - 1;
                 for (int w = 0, seen = 0; w < 4; ++w) if ((nonempty >> w) & 1) { if (seen == j) goal = w; ++seen; }
