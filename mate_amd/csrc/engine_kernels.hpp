@@ -119,6 +119,8 @@ struct Ptrs {
     uint32_t *own_masks;          // engine-owned copy of the packed masks (input of the on-device policies), or NULL
     int32_t *done_count;          // [2] ping-pong counters
     int32_t *done_list;           // [2][N]
+    int32_t *flag_count;          // [1] environments selected by a batched (flagged) reset ...
+    int32_t *flag_list;           // [N] ... and their indices
     const uint8_t *reset_mask;    // optional
     long long *phase_clocks;      // [N][16] s_memtime stamps (debug builds with -DMATE_PHASE_CLOCKS)
     int32_t debug_skip;           // phase-ablation mask (debug builds only)

@@ -277,6 +277,8 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         if ((rc = dev_alloc(e, &g.lut_deg, N * std::max(Nc, 1) * (size_t)360 * kDegSlots, false))) break;
         if ((rc = dev_alloc(e, &g.done_count, (size_t)2))) break;
         if ((rc = dev_alloc(e, &g.done_list, 2 * N))) break;
+        if ((rc = dev_alloc(e, &g.flag_count, (size_t)4))) break;
+        if ((rc = dev_alloc(e, &g.flag_list, N))) break;
         if ((rc = dev_alloc(e, &g.idle_steps, N))) break;
         std::vector<uint32_t> desc;
         build_descriptors(p, desc);
@@ -482,7 +484,7 @@ static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_
     g.mode = MODE_OBSERVE; g.reset_kind = kind; g.parity = e->parity; g.freeze_done = 0;
     const Params &p = e->p;
     auto launch = [&](int ph, int fan, unsigned threads, size_t lds) {
-        const int64_t items = (kind == RESET_DONE ? std::min<int64_t>(e->N, 256) : e->N) * fan;
+        const int64_t items = ((g.reset_kind == RESET_DONE || g.reset_kind == RESET_LIST) ? std::min<int64_t>(e->N, 256) : e->N) * fan;
         if (p.obs_f64) hipLaunchKernelGGL(reset_kernel<double>, dim3((unsigned)items), dim3(threads), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const ResetLds)e->rl, (const int32_t)ph);
         else hipLaunchKernelGGL(reset_kernel<float>, dim3((unsigned)items), dim3(threads), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const ResetLds)e->rl, (const int32_t)ph);
     };
@@ -493,11 +495,13 @@ static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_
         // placement: one wave per environment; tables: one workgroup per (environment, camera); view: one wave
         // reset_place scratch behind the wave slice: 5 arrays of placed circles + the shuffle permutations
         const size_t lds_place = (size_t)e->rl.off_keys + 5 * (size_t)(4 + p.Nc + p.No + p.Nt) * 8 + (size_t)(p.Nc + p.No + 2 * p.Nt) * 4 + 64;
-        const bool later = (phases & (PH_LUT | PH_VIEW)) != 0;
-        if (phases & PH_PLACE) launch(PH_PLACE | (later ? PH_MORE : 0), 1, 64, lds_place);
+        if (phases & PH_PLACE) {
+            if (kind == RESET_FLAGGED) HIP_TRY(hipMemsetAsync(g.flag_count, 0, sizeof(int32_t), stream));
+            launch(PH_PLACE | PH_MORE, 1, 64, lds_place);
+            if (kind == RESET_FLAGGED) g.reset_kind = RESET_LIST;      // the placement launch listed what it reset
+        }
         launch(PH_LUT | PH_PER_CAMERA, p.Nc, 256, e->reset_lds);
         if (phases & PH_VIEW) launch(PH_VIEW, 1, 64, (size_t)p.lds_wave_bytes);
-        else if (kind == RESET_FLAGGED && (phases & PH_PLACE)) return fail(MATE_EINVAL, "a flagged reset needs the view phase");
     } else {
         launch(phases, 1, 256, e->reset_lds);
     }

@@ -12,7 +12,7 @@
 
 namespace mate {
 
-enum ResetKind : int32_t { RESET_ALL = 0, RESET_MASK = 1, RESET_DONE = 2, RESET_FLAGGED = 3 };
+enum ResetKind : int32_t { RESET_ALL = 0, RESET_MASK = 1, RESET_DONE = 2, RESET_FLAGGED = 3, RESET_LIST = 4 };
 enum ResetPhase : int32_t { PH_PLACE = 1, PH_LUT = 2, PH_VIEW = 4, PH_PER_CAMERA = 8, PH_MORE = 16 };
 
 struct ResetLds {   // byte offsets inside the workgroup's dynamic LDS, after the wave-0 context
@@ -342,14 +342,16 @@ __device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, dou
 // One launch can run all three phases for an environment in one workgroup, or the host splits them
 // (launch_reset): placement by one wave per environment, then ONE WORKGROUP PER (environment, camera) for the
 // occlusion tables -- they are independent once the geometry is placed, and with 8 cameras the tables are
-// 2/3 of a reset's latency -- then the first view by one wave per environment.  PH_MORE tells the placement
-// launch that later launches select the same environments: under RESET_FLAGGED the selection is the
-// `done` word itself, which then carries the marker 3 ("being reset") until the view launch clears it.
+// 2/3 of a reset's latency -- then the first view by one wave per environment.  Under RESET_FLAGGED the
+// selection is the `done` word itself, which the placement clears: with PH_MORE the placement launch appends
+// the environments it resets to `flag_list`, and the later launches (RESET_LIST) walk that list with a small
+// grid instead of scanning N x Nc workgroups that reserve the sort's LDS only to find nothing to do.
 template <typename ObsT>
 __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ pp, const Ptrs g, const ResetLds rl, const int32_t phases) {
     const Params &p = *pp;
     extern __shared__ __align__(16) unsigned char smem[];
     if (g.reset_kind == RESET_DONE && (int64_t)blockIdx.x >= (int64_t)g.done_count[g.parity] * ((phases & PH_PER_CAMERA) ? p.Nc : 1)) return;   // idle: nothing finished
+    if (g.reset_kind == RESET_LIST && (int64_t)blockIdx.x >= (int64_t)g.flag_count[0] * ((phases & PH_PER_CAMERA) ? p.Nc : 1)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned char *wave_base = smem;
     double *keys = reinterpret_cast<double *>(smem + rl.off_keys);
@@ -363,14 +365,16 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
     const int fan = per_camera ? p.Nc : 1;
     int64_t count = g.N;
     if (g.reset_kind == RESET_DONE) count = g.done_count[g.parity];
+    if (g.reset_kind == RESET_LIST) count = g.flag_count[0];
     for (int64_t v = blockIdx.x; v < count * fan; v += gridDim.x) {
         const int64_t item = per_camera ? v / p.Nc : v;
         const int only_cam = per_camera ? (int)(v - item * p.Nc) : -1;
-        const int64_t env = g.reset_kind == RESET_DONE ? (int64_t)g.done_list[(int64_t)g.parity * g.N + item] : item;
+        const int64_t env = g.reset_kind == RESET_DONE ? (int64_t)g.done_list[(int64_t)g.parity * g.N + item]
+                          : g.reset_kind == RESET_LIST ? (int64_t)g.flag_list[item] : item;
         if (g.reset_kind == RESET_MASK && !g.reset_mask[env]) continue;
         if (g.reset_kind == RESET_FLAGGED) {
             const int done = reinterpret_cast<const int32_t *>(g.dyn + env * p.DW + p.DF)[p.Nt * TI_STRIDE + EI_DONE];
-            if ((phases & PH_PLACE) ? done == 0 : done != 3) continue;
+            if (done == 0) continue;
         }
         __syncthreads();
         Ctx<ObsT> c(p, g, wave_base, lane, env);
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
             wave_sync();
             if ((phases & PH_PLACE) && lane == 0) {
                 reset_place(c, keys, 4 + p.Nc + p.No + p.Nt);
-                if (g.reset_kind == RESET_FLAGGED && (phases & PH_MORE)) c.ei(EI_DONE) = 3;
+                if (g.reset_kind == RESET_FLAGGED && (phases & PH_MORE)) g.flag_list[atomicAdd(g.flag_count, 1)] = (int32_t)env;
             }
             wave_sync();
         }
@@ -409,8 +413,6 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
                 simulate_cameras(c, StepDraws{0.0, 0.0}, false);   // camera sight + scratch only
                 wave_sync();
                 update_view(c, (uint32_t)c.ei(EI_EPISODE), S_RESET_VIEW, false);
-                if (lane == 0 && c.ei(EI_DONE) == 3) c.ei(EI_DONE) = 0;
-                wave_sync();
                 score_only(c, g.scalars);
                 fill_scratch(c);
                 pack_observations(c);
