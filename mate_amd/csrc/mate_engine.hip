@@ -496,9 +496,10 @@ static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_
         // reset_place scratch behind the wave slice: 5 arrays of placed circles + the shuffle permutations
         const size_t lds_place = (size_t)e->rl.off_keys + 5 * (size_t)(4 + p.Nc + p.No + p.Nt) * 8 + (size_t)(p.Nc + p.No + 2 * p.Nt) * 4 + 64;
         if (phases & PH_PLACE) {
-            if (kind == RESET_FLAGGED) HIP_TRY(hipMemsetAsync(g.flag_count, 0, sizeof(int32_t), stream));
+            const bool selective = kind == RESET_FLAGGED || kind == RESET_MASK;
+            if (selective) HIP_TRY(hipMemsetAsync(g.flag_count, 0, sizeof(int32_t), stream));
             launch(PH_PLACE | PH_MORE, 1, 64, lds_place);
-            if (kind == RESET_FLAGGED) g.reset_kind = RESET_LIST;      // the placement launch listed what it reset
+            if (selective) g.reset_kind = RESET_LIST;      // the placement launch listed what it reset
         }
         launch(PH_LUT | PH_PER_CAMERA, p.Nc, 256, e->reset_lds);
         if (phases & PH_VIEW) launch(PH_VIEW, 1, 64, (size_t)p.lds_wave_bytes);

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
             wave_sync();
             if ((phases & PH_PLACE) && lane == 0) {
                 reset_place(c, keys, 4 + p.Nc + p.No + p.Nt);
-                if (g.reset_kind == RESET_FLAGGED && (phases & PH_MORE)) g.flag_list[atomicAdd(g.flag_count, 1)] = (int32_t)env;
+                if ((g.reset_kind == RESET_FLAGGED || g.reset_kind == RESET_MASK) && (phases & PH_MORE)) g.flag_list[atomicAdd(g.flag_count, 1)] = (int32_t)env;
             }
             wave_sync();
         }
