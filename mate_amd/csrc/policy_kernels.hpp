@@ -198,8 +198,10 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
             uint32_t list = 0;
             if (seen_now && a.neighbor(s, c)) {            // filterout_beyond_range: 110 % of the teammate's range
                 const double threshold = 1.1 * p.rmax;
-                for (int t = 0; t < Nt; ++t)
-                    if ((seen_now >> t) & 1u) { if (norm2(tx(t) - cam_x(c), ty(t) - cam_y(c)) < threshold) list |= 1u << t; }
+                for (uint32_t m = seen_now; m; m &= m - 1) {          // only the targets seen this step
+                    const int t = __ffs((int)m) - 1;
+                    if (norm2(tx(t) - cam_x(c), ty(t) - cam_y(c)) < threshold) list |= 1u << t;
+                }
             }
             bits = (int)list | (a.has_state(s) ? (int)0x80000000u : 0);
             if (bits) {
@@ -219,9 +221,12 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
         const int c = lane;
         for (int s = 0; s < Nc; ++s) {
             const int bits = a.send_bits(s, c);
+            if (bits == 0) continue;
             if (bits & (int)0x80000000u) a.neighbor(c, s) = 1;
-            for (int t = 0; t < Nt; ++t)
-                if ((bits >> t) & 1) { a.mem(c, t, 0) = tx(t); a.mem(c, t, 1) = ty(t); a.t2f(c, t) = q.memory_period; }
+            for (uint32_t m = (uint32_t)bits & 0xffffu; m; m &= m - 1) {
+                const int t = __ffs((int)m) - 1;
+                a.mem(c, t, 0) = tx(t); a.mem(c, t, 1) = ty(t); a.t2f(c, t) = q.memory_period;
+            }
         }
     }
     wave_sync();
@@ -246,19 +251,19 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     if (lane < Nc) {                                        // GreedyCameraAgent.act (greedy.py:69-156)
         const int c = lane;
         const double phi = dy[c], theta = dy[Nc + c];
-        const double sr = sqrt(p.area / theta);
-        double sn, cs;
-        sincos_deg(phi, sn, cs);
-        // the agent reconstructs these from its observation row (agents/utils.py:206-255)
-        const double vx = sr * cs, vy = sr * sn;
-        const double sight = norm2(vx, vy);
-        const double orientation = atan2_deg(vy, vx);
+        // The agent reconstructs its sight range and orientation from the (sr cos phi, sr sin phi) pair of its
+        // observation row (agents/utils.py:206-255: norm and arctan2 of that pair); that round trip returns
+        // sr and phi to within a few ulp, so the state values are used directly.
+        const double sight = sqrt(p.area / theta);
+        const double orientation = phi;
         const double q2 = sight / p.rmax;
         const double min_va = theta * (q2 * q2);
         const double threshold = 1.1 * p.rmax;
         int best = -1; double best_d = 0.0;
-        for (int t = 0; t < Nt; ++t) {
-            if (a.t2f(c, t) <= 0) continue;
+        uint32_t remembered = 0;
+        for (int t = 0; t < Nt; ++t) remembered |= (uint32_t)(a.t2f(c, t) > 0) << t;
+        for (uint32_t m = remembered; m; m &= m - 1) {               // ascending t, like the reference's loop
+            const int t = __ffs((int)m) - 1;
             const double dnorm = norm2(a.mem(c, t, 0) - cam_x(c), a.mem(c, t, 1) - cam_y(c));
             if (!(dnorm < threshold)) continue;
             if (best < 0 || dnorm < best_d) { best = t; best_d = dnorm; }
@@ -274,11 +279,18 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
                 const double area_product = theta * (sight * sight);
                 if (distance <= sqrt(area_product / 180.0) / 2.0) best_va = 180.0;
                 else {
+                    // b <- area_product / (distance (1 + sin(b/2)))^2, 20 times (greedy.py:139-145).  The map is a
+                    // contraction (|f'| <= 0.65), so last-place differences do not grow: the quotient is taken as
+                    // K * (1/(1+sin))^2 with K = area_product / distance^2 and a Newton-refined reciprocal.
+                    const double K = area_product / (distance * distance);
                     double b = 180.0;
                     for (int it = 0; it < 20; ++it) {
-                        const double half = b / 2.0;
-                        const double s2 = distance * (1.0 + sin_deg_0_90(half < 90.0 ? half : 90.0));
-                        b = area_product / (s2 * s2);
+                        const double half = b * 0.5;
+                        const double y = 1.0 + sin_deg_0_90(half < 90.0 ? half : 90.0);
+                        double r = __builtin_amdgcn_rcp(y);
+                        r = fma(r, fma(-y, r, 1.0), r);
+                        r = fma(r, fma(-y, r, 1.0), r);
+                        b = K * (r * r);
                     }
                     best_va = clipd(b, min_va, 180.0);
                 }
