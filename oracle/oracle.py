@@ -183,7 +183,7 @@ class OracleEnv:
         self.S = lib.mo_state_dim(self._h)
 
     def __del__(self):
-        if getattr(self, '_owner', False) and self._h:
+        if getattr(self, '_owner', False) and self._h and lib is not None:   # `lib` is gone at interpreter shutdown
             lib.mo_destroy(self._h)
             self._h = None
 
@@ -300,7 +300,7 @@ class OracleBatch:
         self._h = lib.mo_batch_create(prototype._h, self.n, int(seed), int(first_env_index))
 
     def __del__(self):
-        if getattr(self, '_h', None):
+        if getattr(self, '_h', None) and lib is not None:
             lib.mo_batch_destroy(self._h)
             self._h = None
 
