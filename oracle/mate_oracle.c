@@ -852,6 +852,201 @@ void mo_state(const mo_env *e, double *out) { /* environment.py:894-906 */
     for (int s = 0; s < MO_NW; ++s) for (int r = 0; r < MO_NW; ++r) *p++ = (double)e->remaining[s][r];
 }
 
+/* ------------------------------------------------------------ rule-based agents (row f1)
+ * GreedyCameraAgent / GreedyTargetAgent (mate/agents/greedy.py:13-227, 229-365) for the agents of ONE
+ * environment, called in the order of mate.group_step (wrappers/single_team.py:79-92): observe -> send ->
+ * receive -> act.  An agent knows its own private state, the opponents its observation row shows (the
+ * view masks of the previous step) and its teammates' messages; every random draw comes from the tape. */
+struct mo_policy {
+    int episode;                                   /* episode the memories belong to (-1: none) */
+    int memory_period;                             /* greedy.py:21 */
+    double noise_scale;                            /* greedy.py:236 */
+    double mem[MO_MAXC][MO_MAXT][2];
+    int t2f[MO_MAXC][MO_MAXT];
+    double prev_action[MO_MAXC][2];
+    int delay[MO_MAXC][MO_MAXC];                   /* [sender][recipient] */
+    int neighbor[MO_MAXC][MO_MAXC];                /* [camera][teammate] */
+    int has_state[MO_MAXC];                        /* message2send still holds 'state' */
+    double tgt_prev[MO_MAXT][2], tgt_noise[MO_MAXT][2];
+    int tgt_goal[MO_MAXT], tgt_nonempty[MO_MAXT], tgt_need[MO_MAXT];
+};
+
+mo_policy *mo_policy_create(void) {
+    mo_policy *p = (mo_policy *)calloc(1, sizeof(mo_policy));
+    if (p) { p->episode = -1; p->memory_period = 25; p->noise_scale = 0.5; }
+    return p;
+}
+void mo_policy_destroy(mo_policy *p) { free(p); }
+
+static inline double sin_deg(double x) { return sin(x * DEG2RAD); }   /* utils.py:134-136 */
+
+void mo_policy_act(mo_policy *a, const mo_env *e, const mo_policy_tape *tape, double *cam_act, double *tgt_act) {
+    const int Nc = e->Nc, Nt = e->Nt;
+    const int fresh = a->episode != (int)e->episode;
+    /* ---- reset (greedy.py:43-61, 262-283) and observe / process_messages (:100-113, :326-332) */
+    for (int c = 0; c < Nc; ++c) {
+        if (fresh) {
+            for (int t = 0; t < Nt; ++t) {
+                int s = e->m_ct[c][t];
+                a->mem[c][t][0] = s ? e->tgt_x[t] : 0.0; a->mem[c][t][1] = s ? e->tgt_y[t] : 0.0;
+                a->t2f[c][t] = s ? a->memory_period : 0;
+            }
+            a->prev_action[c][0] = a->prev_action[c][1] = 0.0;
+            for (int s = 0; s < Nc; ++s) { a->delay[c][s] = 0; a->neighbor[c][s] = 0; }
+            a->has_state[c] = 1;
+        }
+        for (int t = 0; t < Nt; ++t) {
+            int left = a->t2f[c][t] - 1;
+            if (left < 0) left = 0;
+            if (e->m_ct[c][t]) { left = a->memory_period; a->mem[c][t][0] = e->tgt_x[t]; a->mem[c][t][1] = e->tgt_y[t]; }
+            a->t2f[c][t] = left;
+        }
+    }
+    for (int t = 0; t < Nt; ++t) {
+        if (fresh) {
+            double step = e->tgt_step[t];
+            a->tgt_prev[t][0] = e->tgt_x[t]; a->tgt_prev[t][1] = e->tgt_y[t];
+            a->tgt_noise[t][0] = 0.5 * (-step + (2.0 * step) * tape->tgt_reset_sample_u[2 * t]);       /* 0.5 * action_space.sample() */
+            a->tgt_noise[t][1] = 0.5 * (-step + (2.0 * step) * tape->tgt_reset_sample_u[2 * t + 1]);
+            a->tgt_goal[t] = e->goals[t];
+            a->tgt_nonempty[t] = 0xf;
+            a->tgt_need[t] = 0;
+        }
+        int seen_empty = 0;
+        for (int w = 0; w < MO_NW; ++w) seen_empty |= (e->empty_bits[t][w] != 0) << w;
+        if (seen_empty & a->tgt_nonempty[t]) { a->tgt_nonempty[t] &= ~seen_empty; a->tgt_need[t] = 1; }
+    }
+    a->episode = (int)e->episode;
+    /* ---- cameras: send_responses (:158-190) */
+    int send[MO_MAXC][MO_MAXC];
+    for (int s = 0; s < Nc; ++s) {
+        unsigned seen_now = 0;
+        for (int t = 0; t < Nt; ++t) seen_now |= (unsigned)(e->m_ct[s][t] != 0) << t;
+        const int has_content = a->has_state[s] || seen_now;
+        for (int c = 0; c < Nc; ++c) {
+            int d = a->delay[s][c] - 1;
+            if (d < 0) d = 0;
+            int bits = 0;
+            if (has_content && s != c && d == 0) {
+                unsigned list = 0;
+                if (seen_now && a->neighbor[s][c]) {            /* filterout_beyond_range */
+                    double threshold = 1.1 * e->cam_rmax[c];
+                    for (int t = 0; t < Nt; ++t)
+                        if (((seen_now >> t) & 1u) && norm2(e->tgt_x[t] - e->cam_x[c], e->tgt_y[t] - e->cam_y[c]) < threshold) list |= 1u << t;
+                }
+                bits = (int)list | (a->has_state[s] ? (int)0x80000000u : 0);
+                if (bits) d = tape->cam_delay[s * Nc + c];       /* np_random.randint(memory_period // 4, 2 * memory_period) */
+            }
+            a->delay[s][c] = d;
+            send[s][c] = bits;
+        }
+    }
+    /* ---- cameras: receive_responses (:192-226), then message2send.clear() */
+    for (int c = 0; c < Nc; ++c)
+        for (int s = 0; s < Nc; ++s) {
+            int bits = send[s][c];
+            if (bits & (int)0x80000000u) a->neighbor[c][s] = 1;
+            for (int t = 0; t < Nt; ++t)
+                if ((bits >> t) & 1) { a->mem[c][t][0] = e->tgt_x[t]; a->mem[c][t][1] = e->tgt_y[t]; a->t2f[c][t] = a->memory_period; }
+        }
+    for (int c = 0; c < Nc; ++c) {
+        int seen_now = 0;
+        for (int t = 0; t < Nt; ++t) seen_now |= e->m_ct[c][t] != 0;
+        if (a->has_state[c] || seen_now) a->has_state[c] = 0;
+    }
+    /* ---- targets: broadcast the non-empty sets (:334-358) */
+    {
+        int set[MO_MAXT];
+        for (int t = 0; t < Nt; ++t) {
+            set[t] = a->tgt_nonempty[t];
+            for (int s = 0; s < Nt; ++s) if (a->tgt_need[s]) set[t] &= a->tgt_nonempty[s];
+        }
+        for (int t = 0; t < Nt; ++t) { a->tgt_nonempty[t] = set[t]; a->tgt_need[t] = 0; }
+    }
+    /* ---- cameras: act (:69-156) */
+    for (int c = 0; c < Nc; ++c) {
+        double obs_state[9];
+        camera_state(e, c, obs_state, 1);
+        /* what the agent derives from its observation row (agents/utils.py:206-255) */
+        const double sight = norm2(obs_state[3], obs_state[4]);
+        const double orientation = atan2_deg(obs_state[4], obs_state[3]);
+        const double theta = obs_state[5], rmax = obs_state[6];
+        const double q2 = sight / rmax;
+        const double min_va = theta * (q2 * q2);
+        const double threshold = 1.1 * rmax;
+        int best = -1; double best_d = 0.0;
+        for (int t = 0; t < Nt; ++t) {
+            if (a->t2f[c][t] <= 0) continue;
+            double dnorm = norm2(a->mem[c][t][0] - e->cam_x[c], a->mem[c][t][1] - e->cam_y[c]);
+            if (!(dnorm < threshold)) continue;
+            if (best < 0 || dnorm < best_d) { best = t; best_d = dnorm; }
+        }
+        double a0, a1;
+        if (best >= 0) {
+            double rx = a->mem[c][best][0] - e->cam_x[c], ry = a->mem[c][best][1] - e->cam_y[c];
+            double best_orientation = atan2_deg(ry, rx);
+            double distance = best_d, best_va;
+            if (distance * (1.0 + sin_deg(min_va / 2.0)) >= rmax) best_va = min_va;
+            else {
+                double area_product = theta * (sight * sight);
+                if (distance <= sqrt(area_product / 180.0) / 2.0) best_va = 180.0;
+                else {
+                    double b = 180.0;
+                    for (int it = 0; it < 20; ++it) {
+                        double half = b / 2.0;
+                        double sr = distance * (1.0 + sin_deg(half < 90.0 ? half : 90.0));
+                        b = area_product / (sr * sr);
+                    }
+                    best_va = clipd(b, min_va, 180.0);
+                }
+            }
+            a0 = clipd(mo_normalize_angle(best_orientation - orientation), -e->cam_rot[c], e->cam_rot[c]);
+            a1 = clipd(best_va - theta, -e->cam_zoom[c], e->cam_zoom[c]);
+        } else if (tape->cam_binom_u[c] > 1.0 - 0.1) {          /* np_random.binomial(1, 0.1) */
+            a0 = -e->cam_rot[c] + (2.0 * e->cam_rot[c]) * tape->cam_sample_u[2 * c];
+            a1 = -e->cam_zoom[c] + (2.0 * e->cam_zoom[c]) * tape->cam_sample_u[2 * c + 1];
+        } else { a0 = a->prev_action[c][0]; a1 = a->prev_action[c][1]; }
+        a->prev_action[c][0] = a0; a->prev_action[c][1] = a1;
+        cam_act[2 * c] = a0; cam_act[2 * c + 1] = a1;
+    }
+    /* ---- targets: act (:285-324) */
+    for (int t = 0; t < Nt; ++t) {
+        const int state_goal = e->goals[t];
+        const double step_size = e->tgt_step[t];
+        int goal = a->tgt_goal[t];
+        if (state_goal >= 0) goal = state_goal;
+        const int nonempty = a->tgt_nonempty[t];
+        if (goal < 0 || (state_goal < 0 && !((nonempty >> goal) & 1))) {
+            goal = -1;
+            int k = 0;
+            for (int w = 0; w < MO_NW; ++w) k += (nonempty >> w) & 1;
+            if (k > 0) {                                          /* np_random.choice(list(non_empty_warehouses)) */
+                int j = (int)(tape->tgt_choice_u[t] * (double)k);
+                if (j >= k) j = k - 1;
+                for (int w = 0, seen = 0; w < MO_NW; ++w) if ((nonempty >> w) & 1) { if (seen == j) goal = w; ++seen; }
+            }
+        }
+        a->tgt_goal[t] = goal;
+        const double x = e->tgt_x[t], y = e->tgt_y[t];
+        const double pax = x - a->tgt_prev[t][0], pay = y - a->tgt_prev[t][1];
+        double ax = 0.0, ay = 0.0;
+        if (goal >= 0) { ax = WAREHOUSES[goal][0] - x; ay = WAREHOUSES[goal][1] - y; }
+        const double len = norm2(ax, ay);
+        if (len > step_size) { double k2 = step_size / len; ax *= k2; ay *= k2; }
+        const double prob = norm2(pax, pay) > 0.2 * step_size ? 0.05 : 0.75;
+        const double u = tape->tgt_binom_u[t];
+        double nx = a->tgt_noise[t][0], ny = a->tgt_noise[t][1];
+        if ((prob <= 0.5) ? (u > 1.0 - prob) : (u <= prob)) {
+            nx = a->noise_scale * (-step_size + (2.0 * step_size) * tape->tgt_sample_u[2 * t]);
+            ny = a->noise_scale * (-step_size + (2.0 * step_size) * tape->tgt_sample_u[2 * t + 1]);
+        }
+        tgt_act[2 * t] = clipd(ax + nx, -step_size, step_size);
+        tgt_act[2 * t + 1] = clipd(ay + ny, -step_size, step_size);
+        a->tgt_prev[t][0] = x; a->tgt_prev[t][1] = y;
+        a->tgt_noise[t][0] = nx; a->tgt_noise[t][1] = ny;
+    }
+}
+
 /* ---------------------------------------------------------------------- reset */
 static void shuffle_perm(mo_env *e, int *perm, int n) {
     for (int i = 0; i < n; ++i) perm[i] = i;

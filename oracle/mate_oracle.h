@@ -85,6 +85,19 @@ void mo_random_actions(uint64_t seed, uint64_t env_index, uint64_t tick, int Nc,
                        double rot_step, double zoom_step, double step_size, float *cam_act, float *tgt_act);
 
 /* counter-based RNG shared (by specification) with the HIP engine */
+/* Rule-based agents of the reference (mate/agents/greedy.py) for one environment; all random draws on a tape:
+ * cam_binom_u[Nc], cam_sample_u[Nc][2], cam_delay[Nc][Nc] (value drawn for sender -> recipient),
+ * tgt_choice_u[Nt], tgt_binom_u[Nt], tgt_sample_u[Nt][2], tgt_reset_sample_u[Nt][2] (first call of an episode). */
+typedef struct mo_policy mo_policy;
+typedef struct mo_policy_tape {
+    const double *cam_binom_u, *cam_sample_u;
+    const int *cam_delay;
+    const double *tgt_choice_u, *tgt_binom_u, *tgt_sample_u, *tgt_reset_sample_u;
+} mo_policy_tape;
+mo_policy *mo_policy_create(void);
+void mo_policy_destroy(mo_policy *policy);
+void mo_policy_act(mo_policy *policy, const mo_env *env, const mo_policy_tape *tape, double *cam_act, double *tgt_act);
+
 void mo_philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
 
 #ifdef __cplusplus

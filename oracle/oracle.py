@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 __all__ = ['lib', 'build', 'OracleEnv', 'OracleBatch', 'obstruct', 'clamp_step', 'normalize_angle',
-           'camera_simulate', 'build_lut', 'camera_perceive', 'interp', 'random_actions', 'philox']
+           'camera_simulate', 'build_lut', 'camera_perceive', 'interp', 'random_actions', 'philox', 'GreedyPolicies']
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, 'libmate_oracle.so')
@@ -24,6 +24,12 @@ def build(force=False):
     if force or not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < os.path.getmtime(src):
         subprocess.check_call(['make', '-C', HERE, '-B', 'libmate_oracle.so'], stdout=subprocess.DEVNULL)
     return SO_PATH
+
+
+class PolicyTape(ctypes.Structure):
+    _fields_ = [('cam_binom_u', c_double_p), ('cam_sample_u', c_double_p), ('cam_delay', ctypes.POINTER(ctypes.c_int)),
+                ('tgt_choice_u', c_double_p), ('tgt_binom_u', c_double_p), ('tgt_sample_u', c_double_p),
+                ('tgt_reset_sample_u', c_double_p)]
 
 
 def _load():
@@ -60,6 +66,10 @@ def _load():
     lib.mo_update_view.argtypes = [P, c_double_p]
     lib.mo_step.argtypes = [P, c_double_p, c_double_p, c_double_p, c_double_p]
     lib.mo_observe.argtypes = [P, c_double_p, c_double_p]
+    lib.mo_policy_create.restype = P
+    lib.mo_policy_create.argtypes = []
+    lib.mo_policy_destroy.argtypes = [P]
+    lib.mo_policy_act.argtypes = [P, P, ctypes.POINTER(PolicyTape), c_double_p, c_double_p]
     lib.mo_observe_mode.argtypes = [P, I, I, c_double_p, c_double_p]
     lib.mo_decode_discrete.argtypes = [P, ctypes.POINTER(ctypes.c_int), c_double_p, ctypes.POINTER(ctypes.c_int), c_double_p, c_double_p, c_double_p]
     lib.mo_state.argtypes = [P, c_double_p]
@@ -168,6 +178,30 @@ _VECTORS = {
     'tracked_steps': 'Nt', 'tracked_bits': 'Nt', 'target_dones': 'Nt', 'awaiting_cargo_counts': 'NW',
     'obs_radius_range': '2',
 }
+
+
+class GreedyPolicies:
+    """The reference's GreedyCameraAgent / GreedyTargetAgent teams of one environment (mate/agents/greedy.py)."""
+
+    def __init__(self):
+        self._h = lib.mo_policy_create()
+
+    def __del__(self):
+        if getattr(self, '_h', None) and lib is not None:
+            lib.mo_policy_destroy(self._h)
+            self._h = None
+
+    def act(self, env, cam_binom_u, cam_sample_u, cam_delay, tgt_choice_u, tgt_binom_u, tgt_sample_u, tgt_reset_sample_u):
+        keep = [np.ascontiguousarray(np.nan_to_num(np.asarray(a, dtype=np.float64), nan=0.0))
+                for a in (cam_binom_u, cam_sample_u, tgt_choice_u, tgt_binom_u, tgt_sample_u, tgt_reset_sample_u)]
+        delay = np.ascontiguousarray(cam_delay, dtype=np.int32)
+        pad = np.zeros(4)
+        dp = lambda a: _dp(a if a.size else pad)  # noqa: E731
+        tape = PolicyTape(dp(keep[0]), dp(keep[1]), delay.ctypes.data_as(ctypes.POINTER(ctypes.c_int)) if delay.size else None,
+                          dp(keep[2]), dp(keep[3]), dp(keep[4]), dp(keep[5]))
+        cam_act, tgt_act = np.zeros((max(env.Nc, 1), 2)), np.zeros((env.Nt, 2))
+        lib.mo_policy_act(self._h, env._h, ctypes.byref(tape), _dp(cam_act), _dp(tgt_act))
+        return cam_act[:env.Nc], tgt_act
 
 
 class OracleEnv:

@@ -73,3 +73,53 @@ def test_greedy_rollout_on_philox_streams():
     assert delivered >= 4                      # greedy targets do deliver cargo
     assert (sd['episode'] >= 2).all()          # every environment finished an episode (time limit) and restarted
     assert float(eng.scalars[:, 3].mean()) > 0.2   # greedy cameras keep a sizeable coverage
+
+
+@pytest.mark.parametrize('config,n,steps', [('MATE-8v8-9.yaml', 48, 120), ('MATE-4v8-9.yaml', 64, 120), ('MATE-Navigation.yaml', 32, 80)])
+def test_greedy_policies_batch_vs_oracle(config, n, steps, oracle_lib):
+    """The on-device policies against the oracle's restatement of the reference agents, closed loop, on a batch of
+    independently reset environments with random draw tapes (every agent branch fires somewhere in the batch):
+    joint actions to 1e-8, view masks / goals / bounties exact."""
+    O = oracle_lib
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config(config)
+    eng = Engine(cfg, n, seed=21, first_env_index=500, obs_dtype=torch.float32)
+    eng.enable_policies()
+    eng.reset()
+    torch.cuda.synchronize()
+    batch = O.OracleBatch(U.oracle_proto_from_config(cfg, O), n, seed=21, first_env_index=500)
+    batch.reset(threads=4)
+    Nc, Nt = eng.num_cameras, eng.num_targets
+    envs = [batch.env(e) for e in range(n)]
+    for e in range(n):
+        for c in range(Nc):
+            envs[e].set_lut(c, *eng.lut_read(e, c))
+    agents = [O.GreedyPolicies() for _ in range(n)]
+    rng = np.random.RandomState(5)
+    reset_u = rng.random_sample((n, Nt, 2))
+    dev = eng.device
+    worst = 0.0
+    for s in range(steps):
+        t = {'camera_resample_u': rng.random_sample((n, max(Nc, 1))), 'camera_sample_u': rng.random_sample((n, max(Nc, 1), 2)),
+             'camera_delay': rng.randint(6, 50, size=(n, max(Nc, 1), max(Nc, 1))).astype(np.int32),
+             'target_choice_u': rng.random_sample((n, Nt)), 'target_resample_u': rng.random_sample((n, Nt)),
+             'target_sample_u': rng.random_sample((n, Nt, 2)), 'target_reset_sample_u': reset_u}
+        tape_ct, goal_u = rng.random_sample((n, max(Nc, 1), Nt)), rng.random_sample((n, Nt))
+        eng.step_greedy(policy_tape={k: torch.from_numpy(v).to(dev) for k, v in t.items()}, tape_ct=torch.from_numpy(tape_ct).to(dev),
+                        tape_goal=torch.from_numpy(goal_u).to(dev), auto_reset=False)
+        cam_act, tgt_act = (a.cpu().numpy() for a in eng.policy_actions())
+        for e in range(n):
+            ca, ta = agents[e].act(envs[e], t['camera_resample_u'][e, :Nc], t['camera_sample_u'][e, :Nc], t['camera_delay'][e, :Nc, :Nc],
+                                   t['target_choice_u'][e], t['target_resample_u'][e], t['target_sample_u'][e], reset_u[e])
+            worst = max(worst, float(np.abs(ta - tgt_act[e]).max()), float(np.abs(ca - cam_act[e]).max()) if Nc else 0.0)
+            envs[e].step(ca, ta, tape_ct[e, :Nc] if Nc else None, goal_u[e])
+        assert worst < 1e-8, (s, worst)
+        masks = eng.unpack_masks()
+        if Nc:
+            assert np.array_equal(masks['camera_target_view_mask'], batch.gather('camera_target_view_mask').reshape(n, Nc, Nt) != 0), s
+        sd = eng.state_dict()
+        for k in ('tgt_goals', 'bounties', 'freights', 'num_delivered_cargoes'):
+            ref = batch.gather(k)
+            assert np.array_equal(sd[k].reshape(ref.shape), ref), (k, s)
+        assert np.abs(sd['tgt_x'] - batch.gather('tgt_x')).max() < 1e-8

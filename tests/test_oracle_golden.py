@@ -164,3 +164,25 @@ def test_discrete_action_decode(name):
         co, to = env.observe()
         np.testing.assert_allclose(co, fx['step/cam_obs'][s], rtol=0, atol=F64_TOL)
         np.testing.assert_allclose(to, fx['step/tgt_obs'][s], rtol=0, atol=F64_TOL)
+
+
+@pytest.mark.parametrize('name', ['greedy_4v8-9_s5', 'greedy_8v8-9_s6', 'greedy_4v2-9_s7'])
+def test_greedy_agents_closed_loop(name):
+    """GreedyCameraAgent / GreedyTargetAgent restated in the oracle, run closed-loop with the reference agents'
+    recorded draws: the reference's joint actions (1e-9) and its whole environment trace come back."""
+    fx = G.load(name + '.npz')
+    env = G.oracle_from_fixture(fx)
+    env.set('camera_target_view_mask', fx['reset/camera_target_view_mask'].astype(np.float64))   # the view reset() left
+    agents = O.GreedyPolicies()
+    for s in range(len(fx['step/done'])):
+        ca, ta = agents.act(env, fx['step/agent_cam_binom_u'][s], fx['step/agent_cam_sample_u'][s], fx['step/agent_cam_delay'][s],
+                            fx['step/agent_tgt_choice_u'][s], fx['step/agent_tgt_binom_u'][s], fx['step/agent_tgt_sample_u'][s],
+                            fx['agent/tgt_reset_sample_u'])
+        if ca.size:
+            assert np.abs(ca - fx['step/cam_act'][s]).max() < 1e-9, ('camera action', s)
+        assert np.abs(ta - fx['step/tgt_act'][s]).max() < 1e-9, ('target action', s)
+        env.step(ca, ta, fx['step/tape_ct'][s], fx['step/goal_u'][s])
+        for m in G.MASK_FIELDS:
+            assert np.array_equal(np.asarray(env.get(m)) != 0, fx['step/' + m][s].astype(bool)), (m, s)
+        assert np.array_equal(np.asarray(env.get('tgt_goals'), dtype=np.float64), np.asarray(fx['step/tgt_goals'][s], dtype=np.float64)), s
+        assert env.get('episode_reward') == fx['step/episode_reward'][s]
