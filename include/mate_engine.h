@@ -191,6 +191,14 @@ int mate_engine_import_state(mate_engine *engine, const double *src_dev, void *s
 /* Occlusion table of one camera (Camera.sight_range_func, entities.py:457-479): host buffers. */
 int mate_engine_lut_read(mate_engine *engine, int64_t env, int32_t camera, double *phis_host,
                          double *rhos_host, int32_t capacity, int32_t *count);
+
+/* The outer occlusion boundary, Camera.boundary_outer / sight_range_outer_func (entities.py:419-448, 479), read by
+ * boundary_between(outer=True) (entities.py:513-543: AuxiliaryCameraRewards' soft coverage score and the renderer).
+ * Off by default; once enabled every reset / rebuild_luts builds it next to the inner table (`*capacity` = knots
+ * per camera to provide to lut_read_outer).  Needs at most 16 obstacles (360 + 223 * obstacles rays in the LDS sort). */
+int mate_engine_enable_outer_boundary(mate_engine *engine, int32_t *capacity);
+int mate_engine_lut_read_outer(mate_engine *engine, int64_t env, int32_t camera, double *phis, double *rhos,
+                               int32_t capacity, int32_t *count);
 int mate_engine_lut_write(mate_engine *engine, int64_t env, int32_t camera, const double *phis_host,
                           const double *rhos_host, int32_t count);
 /* Rebuild the occlusion tables of all environments from the current static geometry

@@ -138,7 +138,7 @@ __device__ __forceinline__ void obstruct_tangential(double ox, double oy, double
 
 // Obstacle.obstruct(ray) without tangential part on a ray that stays polar (angle fixed, norm
 // shrinks): the occlusion-table builder (entities.py:450-455).  (cs, sn) = cos/sin of the angle.
-__device__ __forceinline__ double clip_polar(double norm, double cs, double sn, double relx, double rely, double rel_norm, double rad) {
+__device__ __forceinline__ double clip_polar(double norm, double cs, double sn, double relx, double rely, double rel_norm, double rad, bool outer = false) {
     if (norm == 0.0 || rel_norm < rad) return norm;   // degenerate (camera inside/touching): left unchanged
     if (rel_norm >= norm + rad) return norm;
     const double vx = norm * cs, vy = norm * sn;
@@ -149,7 +149,7 @@ __device__ __forceinline__ double clip_polar(double norm, double cs, double sn, 
         const double perpendicular = rel_norm * sqrt(1.0 - cosv * cosv);
         if (rad > perpendicular) {
             const double half_chord = sqrt(rad * rad - perpendicular * perpendicular);
-            const double cand = rel_norm * cosv - half_chord;
+            const double cand = outer ? rel_norm * cosv + half_chord : rel_norm * cosv - half_chord;   // far / near crossing, entities.py:172-175
             const double new_norm = cand > 0.0 ? cand : 0.0;
             if (new_norm < norm) return new_norm;
         }

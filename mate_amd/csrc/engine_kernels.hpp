@@ -105,6 +105,9 @@ struct Ptrs {
     uint16_t *lut_bucket;         // [N][Nc][nbucket]
     double2 *lut_deg;             // [N][Nc][360][kDegSlots] per-degree records (fast lookup path)
     int32_t *lut_count;           // [N][Nc]
+    double2 *lut_knots_outer;     // optional (mate_engine_enable_outer_boundary): [N][Nc][kmax_outer] knots of Camera.boundary_outer
+    int32_t *lut_count_outer;     // [N][Nc]
+    int32_t kmax_outer;
     const uint32_t *desc;         // [cam_elems + tgt_elems]  src | bit << 16
     const uint2 *xdesc;           // optional fused post-processing: per element (descriptor, LDS offset of the row's own x or y)
     const void *xab;              // ... and (scale, bias) as ObsT pairs; NULL = plain observations

@@ -723,6 +723,60 @@ extern "C" int mate_engine_lut_read(mate_engine *e, int64_t env, int32_t camera,
     return MATE_OK;
 }
 
+extern "C" int mate_engine_lut_read_outer(mate_engine *e, int64_t env, int32_t camera, double *phis, double *rhos, int32_t capacity, int32_t *count) {
+    if (!e || !phis || !rhos || !count) return fail(MATE_EINVAL, "null argument");
+    if (!e->g.lut_knots_outer) return fail(MATE_ESTATE, "outer boundary not enabled (mate_engine_enable_outer_boundary)");
+    if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_read_outer: index out of range");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t lc = env * e->p.Nc + camera;
+    int32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, e->g.lut_count_outer + lc, sizeof(n), hipMemcpyDeviceToHost));
+    *count = n;
+    if (n > capacity) return fail(MATE_EINVAL, "lut_read_outer: capacity %d < %d knots", capacity, n);
+    std::vector<double2> knots((size_t)n);
+    HIP_TRY(hipMemcpy(knots.data(), e->g.lut_knots_outer + lc * e->g.kmax_outer, sizeof(double2) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) { phis[i] = knots[i].x; rhos[i] = knots[i].y; }
+    return MATE_OK;
+}
+
+// Camera.boundary_outer / sight_range_outer_func (entities.py:419-448, 479): built by every later reset /
+// rebuild_luts next to the inner table.  Off by default: only boundary_between(outer=True) reads it.
+extern "C" int mate_engine_enable_outer_boundary(mate_engine *e, int32_t *capacity) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    const Params &p = e->p;
+    if (p.Nc == 0) return fail(MATE_EINVAL, "no cameras in this scenario");
+    if (e->g.lut_knots_outer) { if (capacity) *capacity = e->g.kmax_outer; return MATE_OK; }
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    // 360 + per obstacle (arc <= 181 rays + two 21-point flanks) rays are sorted in LDS
+    const int rays = 360 + p.No * (181 + 42) + 1;
+    ResetLds rl = e->rl;
+    rl.sort_cap = std::max(rl.sort_cap, next_pow2(rays));
+    int roff = p.lds_wave_bytes;
+    rl.off_keys = roff; roff += rl.sort_cap * 8;
+    rl.off_vals = roff; roff += rl.sort_cap * 8;
+    rl.off_okeys = roff; roff += rl.sort_cap * 8;
+    rl.off_ovals = roff; roff += rl.sort_cap * 8;
+    rl.off_bucket = roff; roff += 368 * 2;
+    rl.off_meta = roff; roff += round_up(8 * p.No * 8 + (2 * p.No + 4) * 4, 16);
+    rl.off_scan = roff; roff += 256 * 4;
+    rl.total_bytes = roff;
+    if ((size_t)roff > 160 * 1024) return fail(MATE_EINVAL, "outer boundary: %d rays do not fit the 160 KiB LDS sort (at most 16 obstacles)", rays);
+    const int kmax_outer = round_up(rays + 2, 8);
+    double2 *knots = nullptr; int32_t *counts = nullptr;
+    int rc = dev_alloc(e, &knots, (size_t)e->N * p.Nc * kmax_outer);
+    if (rc == MATE_OK) rc = dev_alloc(e, &counts, (size_t)e->N * p.Nc);
+    if (rc != MATE_OK) return rc;
+    hipError_t err = p.obs_f64 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, roff)
+                               : hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, roff);
+    if (err != hipSuccess) return fail(MATE_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
+    e->rl = rl; e->reset_lds = (size_t)roff;
+    e->g.lut_knots_outer = knots; e->g.lut_count_outer = counts; e->g.kmax_outer = kmax_outer;
+    if (capacity) *capacity = kmax_outer;
+    return MATE_OK;
+}
+
 extern "C" int mate_engine_lut_write(mate_engine *e, int64_t env, int32_t camera, const double *phis, const double *rhos, int32_t n) {
     if (!e || !phis || !rhos) return fail(MATE_EINVAL, "null argument");
     if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_write: index out of range");

@@ -187,7 +187,7 @@ __device__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][cap] x y r sight
 // R2: occlusion table of camera `cam` by the whole workgroup.
 template <typename ObsT>
 __device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, double *okeys, double *ovals, uint16_t *lbucket,
-                          double *meta, int32_t *scan, int sort_cap) {
+                          double *meta, int32_t *scan, int sort_cap, bool outer = false) {
     const Params &p = c.p;
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int No = p.No;
@@ -228,19 +228,21 @@ __device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, dou
             const int num = m_num[o];
             if (num != 0) bits |= 1ull << o;
             m_off[o] = off;
-            if (num > 0) off += 4 + num;
+            if (num > 0) off += outer ? num + 42 : 4 + num;          // boundary_outer: arc + two 21-point flanks (entities.py:419-448)
             if (num == -1) degenerate = 1;
         }
         hdr[0] = off; hdr[1] = degenerate;
-        reinterpret_cast<uint64_t *>(c.st)[2 * p.Nc + 3 * No + cam] = bits;   // camera_obstacle_view_mask row
+        if (!outer) reinterpret_cast<uint64_t *>(c.st)[2 * p.Nc + 3 * No + cam] = bits;   // camera_obstacle_view_mask row
     }
     __syncthreads();
     const int nr = hdr[0];
     const int64_t lc = c.env * p.Nc + cam;
-    double2 *knots = c.g.lut_knots + lc * p.kmax;
+    double2 *knots = outer ? c.g.lut_knots_outer + lc * c.g.kmax_outer : c.g.lut_knots + lc * p.kmax;
+    int32_t *knot_count = outer ? c.g.lut_count_outer + lc : c.g.lut_count + lc;
     uint16_t *bucket = c.g.lut_bucket + lc * p.nbucket;
     if (hdr[1]) {   // fully blocked view
-        if (tid == 0) { knots[0] = make_double2(-180.0, 0.0); knots[1] = make_double2(180.0, 0.0); c.g.lut_count[lc] = 2; }
+        if (tid == 0) { knots[0] = make_double2(-180.0, 0.0); knots[1] = make_double2(180.0, 0.0); *knot_count = 2; }
+        if (outer) { __syncthreads(); return; }
         for (int d = tid; d < p.nbucket; d += nthreads) bucket[d] = d >= 360 ? 1 : 0;
         for (int d = tid; d < 360; d += nthreads) {
             double2 *rec = c.g.lut_deg + (lc * 360 + d) * kDegSlots;
@@ -261,16 +263,38 @@ __device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, dou
             else {
                 int o = 0;
                 for (int q = 0; q < No; ++q) if (m_num[q] > 0 && i >= m_off[q]) o = q;
-                const int j = i - m_off[o];
+                int j = i - m_off[o];
                 const double al = m_al[o], ar = m_ar[o];
-                if (j < 4) { a = (j < 2 ? al : ar) + ((j & 1) ? 0.01 : -0.01); n0 = p.rmax; }   // entities.py:395-406
-                else { const int m = j - 4; a = (m == m_num[o] - 1) ? ar : ((double)m * m_step[o] + al); n0 = m_rho[o]; }  // :409-415
+                if (!outer && j < 4) { a = (j < 2 ? al : ar) + ((j & 1) ? 0.01 : -0.01); n0 = p.rmax; }   // entities.py:395-406
+                else {
+                    if (!outer) j -= 4;
+                    if (j < m_num[o]) { a = (j == m_num[o] - 1) ? ar : ((double)j * m_step[o] + al); n0 = m_rho[o]; }  // :409-415, :419-428
+                    else {
+                        // boundary_outer flanks (entities.py:430-448): 21 points on the segment from the tangent point
+                        // to the range limit just outside the obstacle's shadow, kept as cartesian vectors
+                        const int f = j - m_num[o];
+                        const bool right = f >= 21;
+                        const double t = (double)(right ? f - 21 : f) * 0.05;
+                        const double near_rho0 = sqrt(m_rn[o] * m_rn[o] + m_rad[o] * m_rad[o]);
+                        const double near_rho = near_rho0 < p.rmax ? near_rho0 : p.rmax;
+                        double sn0, cs0, sn1, cs1;
+                        sincos_deg(normalize_angle(right ? ar : al), sn0, cs0);
+                        sincos_deg(normalize_angle(right ? ar + 0.01 : al - 0.01), sn1, cs1);
+                        const double x = (1.0 - t) * (near_rho * cs0) + t * (p.rmax * cs1);
+                        const double y = (1.0 - t) * (near_rho * sn0) + t * (p.rmax * sn1);
+                        a = atan2_deg(y, x); n0 = norm2(x, y);
+                        // t = 0 is the tangent direction itself: the reference gets it back from an atan2(sin, cos) round
+                        // trip that usually, but not always, returns the angle bit for bit (and then merges it with the
+                        // arc's end ray); the exact angle is used here
+                        if (f == 0 || f == 21) { a = right ? ar : al; n0 = near_rho; }
+                    }
+                }
                 a = normalize_angle(a);
             }
             double sn, cs;
             sincos_deg(a, sn, cs);
-            for (int q = 0; q < No; ++q)                                          // entities.py:450-454
-                if (m_num[q] > 0) n0 = clip_polar(n0, cs, sn, m_relx[q], m_rely[q], m_rn[q], m_rad[q]);
+            for (int q = 0; q < No; ++q)                                          // entities.py:450-455
+                if (m_num[q] > 0) n0 = clip_polar(n0, cs, sn, m_relx[q], m_rely[q], m_rn[q], m_rad[q], outer);
             key = a; val = n0;
         }
         keys[i] = key; vals[i] = val;
@@ -309,7 +333,7 @@ __device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, dou
             double rho = vals[i];
             for (int q = i + 1; q < nr && keys[q] == a; ++q) rho = vals[q] < rho ? vals[q] : rho;
             okeys[pos] = a; ovals[pos] = rho;
-            if (a == floor(a)) lbucket[(int)a + 180] = (uint16_t)pos;     // per-degree index
+            if (!outer && a == floor(a)) lbucket[(int)a + 180] = (uint16_t)pos;     // per-degree index
             ++pos;
         }
     }
@@ -318,10 +342,11 @@ __device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, dou
     if (tid == 0) {
         okeys[m] = okeys[0] + 360.0; ovals[m] = ovals[0];                 // entities.py:470-471
         lbucket[360] = (uint16_t)m; lbucket[361] = (uint16_t)m;
-        c.g.lut_count[lc] = m + 1;
+        *knot_count = m + 1;
     }
     __syncthreads();
     for (int i = tid; i <= m; i += nthreads) knots[i] = make_double2(okeys[i], ovals[i]);
+    if (outer) { __syncthreads(); return; }                                // boundary_between(outer=True) only reads the knots
     for (int d = tid; d < p.nbucket; d += nthreads) bucket[d] = d <= 361 ? lbucket[d] : (uint16_t)m;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     for (int d = tid; d < 360; d += nthreads) {       // per-degree records of the fast lookup path
@@ -391,6 +416,7 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
         if (phases & PH_LUT) {
             if (per_camera) {
                 build_lut(c, only_cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap);
+                if (g.lut_knots_outer) build_lut(c, only_cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap, true);
                 // this workgroup owns exactly one word of the static record: the camera's obstacle mask row
                 if (threadIdx.x == 0) {
                     const int w = 2 * p.Nc + 3 * p.No + only_cam;
@@ -398,7 +424,10 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
                 }
                 continue;
             }
-            for (int cam = 0; cam < p.Nc; ++cam) build_lut(c, cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap);
+            for (int cam = 0; cam < p.Nc; ++cam) {
+                build_lut(c, cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap);
+                if (g.lut_knots_outer) build_lut(c, cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap, true);
+            }
         }
         __syncthreads();
         if (wave == 0) {

@@ -319,12 +319,19 @@ class Engine:
     def rebuild_luts(self):
         check(self.lib.mate_engine_rebuild_luts(self._h, self._stream()))
 
-    def lut_read(self, env, camera):
-        cap = self.layout.lut_capacity
+    def enable_outer_boundary(self):
+        """Also build Camera.boundary_outer at every later reset / rebuild_luts (entities.py:419-448); needed only by
+        boundary_between(outer=True)."""
+        cap = ctypes.c_int32()
+        check(self.lib.mate_engine_enable_outer_boundary(self._h, ctypes.byref(cap)))
+        self.outer_capacity = cap.value
+
+    def lut_read(self, env, camera, outer=False):
+        cap = self.outer_capacity if outer else self.layout.lut_capacity
         phis, rhos = np.zeros(cap), np.zeros(cap)
         n = ctypes.c_int32()
-        check(self.lib.mate_engine_lut_read(self._h, int(env), int(camera), phis.ctypes.data_as(ctypes.c_void_p),
-                                            rhos.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n)))
+        fn = self.lib.mate_engine_lut_read_outer if outer else self.lib.mate_engine_lut_read
+        check(fn(self._h, int(env), int(camera), phis.ctypes.data_as(ctypes.c_void_p), rhos.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n)))
         return phis[:n.value].copy(), rhos[:n.value].copy()
 
     def lut_write(self, env, camera, phis, rhos):

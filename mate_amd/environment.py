@@ -137,21 +137,23 @@ class CameraView(_EntityView):
             out = np.append(out, [self.max_sight_range, self.rotation_step, self.zooming_step])
         return out.astype(np.float64)
 
-    def _table(self):
-        return self._env.engine.lut_read(0, self.index)
+    def _table(self, outer=False):
+        engine = self._env.engine
+        if outer and not getattr(engine, 'outer_capacity', 0):
+            engine.enable_outer_boundary()      # built from now on at every reset; build it once for the running episode
+            engine.rebuild_luts()
+        return engine.lut_read(0, self.index, outer=outer)
 
     def sight_range_at(self, angle, outer=False):
-        if outer:
-            raise NotImplementedError('the outer occlusion boundary is not built on the device yet (DESIGN.md, next rows)')
-        phis, rhos = self._table()
+        """Camera.sight_range_at (entities.py:507-511): linear interpolation of the (outer) occlusion boundary."""
+        phis, rhos = self._table(outer)
         return float(np.interp((angle + 180.0) % 360.0 - 180.0, phis, rhos))
 
     def boundary_between(self, angle_left, angle_right, outer=False):
-        """Knots of the occlusion boundary inside a sector (entities.py:513-543)."""
+        """Knots of the occlusion boundary inside a sector (entities.py:513-543); like the reference, the two end
+        points are interpolated on the INNER boundary whichever table the knots come from."""
         assert 0.0 < angle_right - angle_left <= 360.0
-        if outer:
-            raise NotImplementedError('the outer occlusion boundary is not built on the device yet (DESIGN.md, next rows)')
-        phis_all, rhos_all = self._table()
+        phis_all, rhos_all = self._table(outer)
         left = (angle_left + 180.0) % 360.0 - 180.0
         right = left + (angle_right - angle_left)
         if right <= 180.0:

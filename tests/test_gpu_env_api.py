@@ -174,3 +174,27 @@ def test_auxiliary_camera_rewards_and_wrapper_kwargs():
     with pytest.raises(AssertionError):
         env.auxiliary_camera_rewards({'bogus': 1.0})
     env.close()
+
+
+def test_boundary_between_inner_and_outer():
+    """Camera.boundary_between of the N=1 API (entities.py:513-543) on the reference's geometry: the knots inside a
+    sector from the device-built tables, inner and (lazily enabled) outer, follow the reference's own tables."""
+    import mate_amd
+    env = mate_amd.make('MATE-4v8-9-v0')
+    env.seed(3)
+    env.reset()
+    cam = env.cameras[0]
+    left, right = cam.orientation - cam.viewing_angle / 2.0, cam.orientation + cam.viewing_angle / 2.0
+    for outer in (False, True):
+        phis, rhos = cam.boundary_between(left, right, outer=outer)
+        table_p, table_r = env.engine.lut_read(0, 0, outer=outer)
+        assert phis[0] < phis[-1] and len(phis) >= 2 and np.all(np.diff(phis[1:-1]) > 0)
+        inside = (table_p > phis[0]) & (table_p < phis[-1]) if phis[-1] <= 180.0 else None
+        if inside is not None:
+            assert np.array_equal(phis[1:-1], table_p[inside]) and np.array_equal(rhos[1:-1], table_r[inside])
+        assert rhos[0] == cam.sight_range_at(phis[0]) and rhos[-1] == cam.sight_range_at(phis[-1])   # inner table at the ends
+        assert np.all(rhos >= 0.0) and np.all(rhos <= cam.max_sight_range + 1e-9)
+    outer_r = np.interp(np.linspace(-180, 179, 360), *env.engine.lut_read(0, 0, outer=True))
+    inner_r = np.interp(np.linspace(-180, 179, 360), *env.engine.lut_read(0, 0))
+    assert np.all(outer_r >= inner_r - 1e-9)          # the far side of an obstacle is never nearer than its near side
+    env.close()

@@ -353,3 +353,52 @@ def test_discrete_actions(name):
     ci = torch.from_numpy(np.broadcast_to(fx['step/cam_idx'][0], (N, eng2.num_cameras)).copy()).to(dev)
     co, to, _ = _replay(eng2, fx, 0, N, cam=ci)
     assert rel_close(co[1].double().cpu().numpy(), fx['step/cam_obs'][0], 1e-5) and rel_close(to[1].double().cpu().numpy(), fx['step/tgt_obs'][0], 1e-5)
+
+
+@pytest.mark.parametrize('config,n', [('MATE-4v8-9.yaml', 24), ('MATE-8v8-9.yaml', 12)])
+def test_outer_boundary_vs_oracle(config, n, oracle_lib):
+    """Camera.boundary_outer built by the reset kernel (mate_engine_enable_outer_boundary) against the oracle's builder
+    on the same natively reset geometry: knot for knot, up to the tangent-ray coin flips of the reference."""
+    O = oracle_lib
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config(config)
+    eng = Engine(cfg, n, seed=77, first_env_index=40)
+    eng.enable_outer_boundary()
+    eng.reset()
+    batch = O.OracleBatch(U.oracle_proto_from_config(cfg, O), n, seed=77, first_env_index=40)
+    batch.reset(threads=4)
+    No = eng.num_obstacles
+    grid = np.linspace(-180.0, 180.0, 7201)
+    for e in range(n):
+        oe = batch.env(e)
+        for c in range(eng.num_cameras):
+            gp, gr = eng.lut_read(e, c)
+            op, orr = oe.get_lut(c)
+            assert len(gp) == len(op) and np.abs(gp - op).max() < 1e-9 and (np.abs(gr - orr) > 1e-6).sum() <= 2 * No, (e, c)
+            # outer: the flank points next to a tangent direction may or may not merge with the arc's end ray in the
+            # reference (an atan2(sin, cos) round trip decides), so the piecewise-linear FUNCTIONS are compared
+            gp, gr = eng.lut_read(e, c, outer=True)
+            op, orr = oe.get_lut(c, outer=True)
+            assert abs(len(gp) - len(op)) <= 2 * No, (e, c, len(gp), len(op))
+            diff = np.abs(np.interp(grid, gp, gr) - np.interp(grid, op, orr))
+            assert (diff > 1e-6).mean() < 0.002 * max(No, 1), (e, c, (diff > 1e-6).sum(), diff.max())
+
+
+def test_outer_boundary_of_reference_geometry():
+    """... and against the tables the reference itself built (fixture geometry imported, tables rebuilt on the device);
+    boundary_between(outer=True) of the N=1 API then returns the reference's knots."""
+    fx = G.load('trace_4v8-9_greedy_s2.npz')
+    eng = U.engine_from_fixture(fx, 2)
+    eng.enable_outer_boundary()
+    eng.rebuild_luts()
+    No = eng.num_obstacles
+    grid = np.linspace(-180.0, 180.0, 7201)
+    for c, (phis, rhos) in enumerate(G.luts_of(fx, outer=True)):
+        gp, gr = eng.lut_read(1, c, outer=True)
+        assert abs(len(gp) - len(phis)) <= 2 * No
+        diff = np.abs(np.interp(grid, gp, gr) - np.interp(grid, phis, rhos))
+        assert (diff > 1e-6).mean() < 0.002 * No, (c, (diff > 1e-6).sum(), diff.max())
+    for c, (phis, rhos) in enumerate(G.luts_of(fx)):
+        gp, gr = eng.lut_read(1, c)
+        assert len(gp) == len(phis) and np.abs(gp - phis).max() < 1e-9 and (np.abs(gr - rhos) > 1e-6).sum() <= 2 * No

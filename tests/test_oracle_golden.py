@@ -186,3 +186,17 @@ def test_greedy_agents_closed_loop(name):
             assert np.array_equal(np.asarray(env.get(m)) != 0, fx['step/' + m][s].astype(bool)), (m, s)
         assert np.array_equal(np.asarray(env.get('tgt_goals'), dtype=np.float64), np.asarray(fx['step/tgt_goals'][s], dtype=np.float64)), s
         assert env.get('episode_reward') == fx['step/episode_reward'][s]
+
+
+@pytest.mark.parametrize('name', ['trace_4v8-9_greedy_s2', 'trace_8v8-9_random_s0', 'trace_4v2-9_random_s0', 'trace_4v8-0_random_s0'])
+def test_outer_boundary_builder(name):
+    """Camera.boundary_outer / sight_range_outer_func (entities.py:419-448, 479) from the oracle's own builder against
+    the tables the reference built for the same geometry (same tolerance as the inner table: tangent-ray coin flips)."""
+    fx = G.load(name + '.npz')
+    env = G.oracle_from_fixture(fx, use_golden_lut=False)
+    No = int(fx['num_obstacles'])
+    for c, (phis, rhos) in enumerate(G.luts_of(fx, outer=True)):
+        p2, r2 = env.get_lut(c, outer=True)
+        assert len(p2) == len(phis), (c, len(p2), len(phis))
+        np.testing.assert_allclose(p2, phis, rtol=0, atol=1e-9)
+        assert (np.abs(r2 - rhos) > 1e-8).sum() <= 2 * No, (c, (np.abs(r2 - rhos) > 1e-8).sum())
