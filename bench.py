@@ -151,16 +151,8 @@ def main():
     kernel_ms, launches = eng.kernel_time(enable=False)
 
     stats = eng.scalars[:, [1, 3, 6]].mean(dim=0)    # reward, coverage, delivered: logging only
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        ex = torch.tensor([executed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(ex, op=dist.ReduceOp.SUM)
-        executed = float(ex.item())
-        gathered = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)              # the only collective of the path: episode statistics
-        stats = torch.stack(gathered).mean(dim=0)
+    from mate_amd.distributed import reduce_job
+    elapsed, executed, stats = reduce_job(elapsed, executed, stats, device='cuda')   # MAX time, SUM env-steps, gathered stats
 
     if rank == 0:
         total_envs = args.batch * world

@@ -5,7 +5,7 @@ statistics for logging (RCCL over xGMI when the process group backend is "nccl";
 import torch
 import torch.distributed as dist
 
-__all__ = ['shard_of', 'gather_episode_stats', 'EpisodeStats']
+__all__ = ['shard_of', 'gather_episode_stats', 'EpisodeStats', 'reduce_job']
 
 
 def shard_of(global_batch, rank, world_size):
@@ -45,3 +45,17 @@ def gather_episode_stats(stats):
     dist.all_gather(parts, stats.sums)
     total = torch.stack(parts).sum(dim=0)
     return stats.as_dict(total), parts
+
+
+def reduce_job(elapsed, executed, stats, device='cpu'):
+    """Whole-job numbers of a sharded benchmark run: (MAX over ranks of the timed region, SUM of the env-steps every
+    rank executed, per-rank statistics averaged).  Three tiny collectives after the timed region; identity on one rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(elapsed), float(executed), stats
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ex = torch.tensor([executed], dtype=torch.float64, device=device)
+    dist.all_reduce(ex, op=dist.ReduceOp.SUM)
+    gathered = [torch.zeros_like(stats) for _ in range(dist.get_world_size())]
+    dist.all_gather(gathered, stats)              # the only collective of the path: episode statistics
+    return float(t.item()), float(ex.item()), torch.stack(gathered).mean(dim=0)

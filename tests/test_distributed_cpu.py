@@ -28,8 +28,11 @@ def _worker(rank, world, port, out):
     done = (env_ids % 2 == 0)
     stats.update(done, episode_return=env_ids * 10, episode_length=env_ids + 100, coverage_rate=env_ids / 10, delivered=env_ids)
     total, parts = gather_episode_stats(stats)
+    # the benchmark's job-level reduction: slowest rank's time, all ranks' env-steps, averaged statistics
+    from mate_amd.distributed import reduce_job
+    job = reduce_job(1.0 + rank, 1000.0 * (rank + 1), torch.tensor([float(rank), 10.0 * rank, 1.0]))
     if rank == 0:
-        out.put((total, [p.tolist() for p in parts]))
+        out.put((total, [p.tolist() for p in parts], (job[0], job[1], job[2].tolist())))
     dist.destroy_process_group()
 
 
@@ -40,7 +43,7 @@ def test_gather_episode_stats_two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
     for p in procs:
         p.start()
-    total, parts = out.get(timeout=120)
+    total, parts, job = out.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -49,3 +52,4 @@ def test_gather_episode_stats_two_ranks():
     assert total['mean_return'] == pytest.approx((0 + 20 + 40 + 60 + 80) / 5)
     assert total['mean_length'] == pytest.approx(100 + 4)
     assert parts[0][0] == 3 and parts[1][0] == 2
+    assert job[0] == 2.0 and job[1] == 3000.0 and job[2] == [0.5, 5.0, 1.0]
