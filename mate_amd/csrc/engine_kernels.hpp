@@ -35,7 +35,7 @@ struct Params {
     double freight_scale, bounty_scale, reward_scale, max_team_reward;
     double obs_r_lo, obs_r_hi;
     uint32_t seed_lo, seed_hi, first_env;
-    int32_t lds_table_bytes, lds_wave_bytes, off_st, off_dy, off_tmp, off_scratch, off_mask, off_misc, off_flags, off_ent;
+    int32_t desc_table_bytes, lds_wave_bytes, off_st, off_dy, off_tmp, off_scratch, off_mask, off_misc, off_flags, off_ent;
     float inv_No;
     int32_t export_width;
 };
@@ -71,7 +71,7 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
     p.export_width = 2 * Nc + 3 * No + Nt + Nc * No + 2 * Nc + 2 * Nt + Nt + 4 * Nt + 4 * Nt + 5 * Nt + 20 + 7;
     // LDS carve of one environment-wave
     const int obs_size = obs_f64 ? 8 : 4;
-    p.lds_table_bytes = shape_round_up((p.tgt_table_off + shape_round_up(p.tgt_elems, 4)) * 4, 16);
+    p.desc_table_bytes = shape_round_up((p.tgt_table_off + shape_round_up(p.tgt_elems, 4)) * 4, 16);
     int off = 0;
     p.off_st = off; off += shape_round_up(p.SW * 8, 16);
     p.off_dy = off; off += shape_round_up(p.DW * 8, 16);

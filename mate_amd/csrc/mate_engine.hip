@@ -283,7 +283,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         std::vector<uint32_t> desc;
         build_descriptors(p, desc);
         uint32_t *d_desc = nullptr;
-        if ((rc = dev_alloc(e, &d_desc, (size_t)p.lds_table_bytes / 4))) break;
+        if ((rc = dev_alloc(e, &d_desc, (size_t)p.desc_table_bytes / 4))) break;
         if (hipMemcpy(d_desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(MATE_EHIP, "descriptor upload failed"); break; }
         g.desc = d_desc;
         if (p.obs_f64) {
