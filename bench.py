@@ -41,13 +41,15 @@ def algorithmic_bytes(Nc, Nt, No):
 
 
 def measured_traffic():
-    """HBM bytes per step_kernel launch from the committed rocprofv3 PMC summary (FETCH_SIZE + WRITE_SIZE,
-    KiB, separate --pmc passes; see profiles/README.md).  None when no profile is present."""
+    """HBM bytes per step_kernel launch from the committed rocprofv3 PMC summary (separate --pmc passes, counters in
+    KiB; see profiles/README.md).  gfx950 correction per the microarchitecture guide and this repo's own calibration
+    (tools/pmc_calibrate.py: a 256 MiB copy reports WRITE_SIZE 256.0 MiB and FETCH_SIZE 128.0 MiB): WRITE_SIZE is
+    exact, FETCH_SIZE counts half of the bytes read and is doubled.  None when no profile is present."""
     path = os.path.join(ROOT, 'profiles', 'latest_pmc.json')
     try:
         with open(path) as fh:
             k = json.load(fh)['step_kernel']
-        return (k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
+        return (2.0 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
     except Exception:
         return None
 
@@ -173,7 +175,7 @@ def main():
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': measured_traffic() if args.batch == BATCH_PER_GPU and args.workload == WORKLOAD else None,
-                'traffic_unit': 'bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/latest_pmc.json)',
+                'traffic_unit': 'bytes per launch (rocprofv3 2*FETCH_SIZE + WRITE_SIZE, profiles/latest_pmc.json)',
                 'kernel': 'step_kernel<float, %s>' % ('FixedShape' if eng.specialised else 'AnyShape'), 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches,
                 'algorithmic_bytes_per_launch': b_alg * args.batch,
             },
