@@ -463,9 +463,15 @@ __device__ __noinline__ double lut_lookup(const double2 *knots, const uint16_t *
 }
 
 // Fast path: one 80-byte record per (camera, degree) holding the knots of that degree, the next
-// integer-degree knot and +inf padding (kDegSlots entries); a NaN first angle marks a degree with more
-// knots than fit, which falls back to the general path.  One dependent memory round trip.
+// integer-degree knot and +inf padding (kDegSlots entries): one dependent memory round trip.  A degree
+// with more knots than fit (the arc of a small, distant obstacle) is marked by a NaN first angle and
+// carries (index of its first knot, number of knots incl. the next integer degree) instead: three pivot
+// angles pick the quarter of that degree's knots holding the query, and that quarter is fetched into the
+// same registers as a record (two more round trips, no extra registers; up to 4 (kDegSlots - 1) + 1 knots).
+// Only beyond that the general path with its dependent binary search runs (8+ round trips: it used to set
+// the slowest wave of a launch).
 constexpr int kDegSlots = 5;
+constexpr int kQuarterKnots = 4 * (kDegSlots - 1) + 1;
 __device__ __forceinline__ int degree_of(double x) {
     int d = (int)floor(x + 180.0);
     d = d < 0 ? 0 : (d > 359 ? 359 : d);
@@ -532,12 +538,26 @@ __device__ __forceinline__ void sector_fetch(const Ctx<ObsT> &c, const SectorEva
 }
 
 template <typename ObsT>
-__device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorEval &e, const double2 (&w)[kDegSlots]) {
+__device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorEval &e, double2 (&w)[kDegSlots]) {
     if (!e.need) return e.seen;
     bool overflow;
     double limit = degree_interp(w, e.x, overflow);
-    if (overflow)
-        limit = lut_lookup(c.g.lut_knots + e.lc * c.p.kmax, c.g.lut_bucket + e.lc * c.p.nbucket, c.g.lut_count[e.lc], e.x);
+    if (overflow) {
+        const int start = (int)w[0].y, count = (int)w[1].x;
+        const double2 *knots = c.g.lut_knots + e.lc * c.p.kmax;
+        if (count >= 2 && count <= kQuarterKnots) {
+            const int q = (count + 2) / 4, last = count - 1;                          // q = ceil((count - 1) / 4) <= kDegSlots - 1
+            const double a1 = knots[start + (q < last ? q : last)].x;
+            const double a2 = knots[start + (2 * q < last ? 2 * q : last)].x;
+            const double a3 = knots[start + (3 * q < last ? 3 * q : last)].x;
+            const int base = e.x >= a3 ? 3 * q : (e.x >= a2 ? 2 * q : (e.x >= a1 ? q : 0));
+#pragma unroll
+            for (int i = 0; i < kDegSlots; ++i) w[i] = knots[start + (base + i < last ? base + i : last)];
+            limit = degree_interp(w, e.x, overflow);
+        } else {
+            limit = lut_lookup(knots, c.g.lut_bucket + e.lc * c.p.nbucket, c.g.lut_count[e.lc], e.x);
+        }
+    }
     return e.rn <= limit * (1.0 + 1e-6);                                           // entities.py:505
 }
 

@@ -808,6 +808,8 @@ extern "C" int mate_engine_lut_write(mate_engine *e, int64_t env, int32_t camera
             }
         } else {
             for (int i = 0; i < kDegSlots; ++i) { rec[i].x = NAN; rec[i].y = 0.0; }
+            if (phis[start] == (double)(d - 180)) { rec[0].y = (double)start; rec[1].x = (double)(endk - start + 1); }   // burst path
+            else rec[1].x = 0.0;                                                                                   // general path
         }
     }
     HIP_TRY(hipMemcpy(e->g.lut_deg + lc * 360 * kDegSlots, deg.data(), sizeof(double2) * deg.size(), hipMemcpyHostToDevice));

@@ -357,8 +357,9 @@ __device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, dou
                 const int idx = start + i;
                 rec[i] = idx <= endk ? make_double2(okeys[idx], ovals[idx]) : make_double2(inf, 0.0);
             }
-        } else {
-            rec[0] = make_double2(__longlong_as_double(0x7ff8000000000000ll), 0.0);
+        } else {                                   // overflow: (NaN, first knot) (knots of the degree incl. the next integer one, -)
+            rec[0] = make_double2(__longlong_as_double(0x7ff8000000000000ll), (double)start);
+            rec[1] = make_double2((double)(endk - start + 1), 0.0);
         }
     }
     __syncthreads();
