@@ -263,6 +263,46 @@ __device__ void load_records(Ctx<ObsT> &c) {
     for (int i = c.lane; i < c.p.MW; i += 64) c.mask[i] = 0u;
 }
 
+// The step kernel's version: the record loads are issued into registers first, the step's Philox draws run
+// while they are in flight (all co-resident waves of a SIMD start together: without this they idle through the
+// HBM latency together and then contend for the VALU together), then the data is committed to LDS.
+struct StepDraws { double a0, a1; };
+template <typename ObsT> __device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick);
+
+template <typename ObsT>
+__device__ __forceinline__ StepDraws load_records_with_draws(Ctx<ObsT> &c, uint32_t tick, bool draw) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    const double *s = c.g.stat + c.env * p.SW;
+    const double *d = c.g.dyn + c.env * p.DW;
+    const ObsT *si = reinterpret_cast<const ObsT *>(c.g.scratch_init);
+    double s0 = s[lane < p.SW ? lane : 0], d0 = d[lane < p.DW ? lane : 0], s1 = 0.0, d1 = 0.0;
+    if (p.SW > 64) s1 = s[lane + 64 < p.SW ? lane + 64 : 0];
+    if (p.DW > 64) d1 = d[lane + 64 < p.DW ? lane + 64 : 0];
+    ObsT q[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (si && p.nscratch > 64 * k) q[k] = si[lane + 64 * k < p.nscratch ? lane + 64 * k : 0];
+    asm volatile("" : "+v"(s0), "+v"(s1), "+v"(d0), "+v"(d1));     // keep the loads up here: the optimiser would sink each into its use
+    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+    StepDraws draws{0.0, 0.0};
+    if (draw) draws = step_draws(c, tick);
+    if (lane < p.SW) c.st[lane] = s0;
+    if (lane < p.DW) c.dy[lane] = d0;
+    if (lane + 64 < p.SW) c.st[lane + 64] = s1;
+    if (lane + 64 < p.DW) c.dy[lane + 64] = d1;
+    for (int i = lane + 128; i < p.SW; i += 64) c.st[i] = s[i];
+    for (int i = lane + 128; i < p.DW; i += 64) c.dy[i] = d[i];
+    if (si) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (lane + 64 * k < p.nscratch) c.scratch[lane + 64 * k] = q[k];
+        for (int i = lane + 256; i < p.nscratch; i += 64) c.scratch[i] = si[i];
+    }
+    for (int i = lane; i < p.MW; i += 64) c.mask[i] = 0u;
+    return draws;
+}
+
 // unified entity table (after the records are visible in LDS)
 template <typename ObsT>
 __device__ void build_entities(Ctx<ObsT> &c) {
@@ -286,7 +326,6 @@ __device__ void store_dynamic(Ctx<ObsT> &c) {
 // Random numbers of one step, one Philox call per lane, all lanes at once: lanes [0, Nc) camera
 // actions, [Nc, Nc+Nt) target actions, the remaining lanes pre-draw the see-through uniforms of the
 // first camera->target pairs (cheaper than a second divergent Philox in the visibility phase).
-struct StepDraws { double a0, a1; };
 template <typename ObsT>
 __device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick) {
     const Params &p = c.p;
@@ -960,7 +999,12 @@ __global__ __launch_bounds__(256, 4) void step_kernel(const Params *__restrict__
 #endif
     PHASE_STAMP(1);
     const uint32_t tick = g.tick;
-    load_records(c);
+#ifdef MATE_PHASE_CLOCKS
+#define SKIP(bit) (g.debug_skip & (bit))
+#else
+#define SKIP(bit) false
+#endif
+    const StepDraws draws = load_records_with_draws(c, tick, !SKIP(1));
     if (g.freeze_done && g.mode != MODE_OBSERVE) {
         wave_sync();
         if (c.ei(EI_DONE) != 0) {     // waiting for the next batched reset: no step, no new observation
@@ -969,13 +1013,6 @@ __global__ __launch_bounds__(256, 4) void step_kernel(const Params *__restrict__
             return;
         }
     }
-#ifdef MATE_PHASE_CLOCKS
-#define SKIP(bit) (g.debug_skip & (bit))
-#else
-#define SKIP(bit) false
-#endif
-    StepDraws draws{0.0, 0.0};
-    if (!SKIP(1)) draws = step_draws(c, tick);   // independent of the records: overlaps their latency
     wave_sync();
     build_entities(c);
     wave_sync();
