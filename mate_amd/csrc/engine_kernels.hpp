@@ -944,6 +944,42 @@ __device__ void pack_block_xf(const Ctx<ObsT> &c, ObsT *dst, const uint2 *xdesc,
     }
 }
 
+// Both row blocks of an f32 environment in one pass over their 16-byte chunks (camera chunks, then target chunks).
+// All descriptors of a pass (8 chunks per lane) are loaded BEFORE its first store: loads and stores share one
+// in-order counter on gfx9, so a descriptor load issued behind an observation store can only be waited for
+// together with that store's HBM acknowledgement -- seven such waits per step in the chunk-by-chunk loop.
+template <typename ObsT>
+__device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT> &c) {
+    if constexpr (sizeof(ObsT) == 4) {
+        const Params &p = c.p;
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        constexpr int G = 8;
+        const int nvc = p.cam_elems / 4, nvt = p.tgt_elems / 4, nv = nvc + nvt;
+        const uint4 *tab = reinterpret_cast<const uint4 *>(c.table);
+        const int tshift = p.tgt_table_off / 4 - nvc;                 // table index of target chunk s is s + tshift
+        f32x4 *cam = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.cam_obs) + c.out * p.cam_elems);
+        f32x4 *tgt = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems);
+        for (int base = c.lane; base < nv; base += 64 * G) {
+            uint4 d[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int s = base + 64 * k;
+                d[k] = tab[s < nv ? (s < nvc ? s : s + tshift) : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < G; ++k) asm volatile("" : "+v"(d[k].x), "+v"(d[k].y), "+v"(d[k].z), "+v"(d[k].w));
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int s = base + 64 * k;
+                if (s < nv) {
+                    const f32x4 v = {gather_one(c, d[k].x), gather_one(c, d[k].y), gather_one(c, d[k].z), gather_one(c, d[k].w)};
+                    __builtin_nontemporal_store(v, s < nvc ? &cam[s] : &tgt[s - nvc]);   // write-once stream: keep it out of the caches
+                }
+            }
+        }
+    }
+}
+
 template <typename ObsT>
 __device__ void pack_observations(Ctx<ObsT> &c) {
     const Params &p = c.p;
@@ -954,6 +990,8 @@ __device__ void pack_observations(Ctx<ObsT> &c) {
         if (c.g.tgt_obs)
             pack_block_xf<ObsT>(c, reinterpret_cast<ObsT *>(c.g.tgt_obs) + c.out * p.tgt_elems, c.g.xdesc + p.tgt_table_off,
                                 xab + 2 * p.tgt_table_off, p.tgt_elems);
+    } else if (sizeof(ObsT) == 4 && (p.cam_elems % 4) == 0 && (p.tgt_elems % 4) == 0 && c.g.tgt_obs && (c.g.cam_obs || p.cam_elems == 0)) {
+        pack_rows_f32(c);
     } else {
     if (c.g.cam_obs && p.cam_elems > 0)
         pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.cam_obs) + c.out * p.cam_elems, c.table, p.cam_elems);
@@ -974,7 +1012,8 @@ __device__ void pack_observations(Ctx<ObsT> &c) {
 // =============================================================================================
 // The step kernel: one wave per environment, 4 environments per workgroup.
 template <typename ObsT, typename Shape>
-__global__ __launch_bounds__(256, 4) void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
+__global__ __launch_bounds__(256, 4) __attribute__((amdgpu_num_sgpr(96)))   // above 96 SGPRs a SIMD holds 7 waves instead of 8
+void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     const Shape shape(pp);
     const Params &p = shape.get();   // scenario constants live in device memory: scalar loads on demand instead of ~80 pinned SGPRs
     extern __shared__ __align__(16) unsigned char smem[];
