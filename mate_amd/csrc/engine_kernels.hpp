@@ -944,39 +944,37 @@ __device__ void pack_block_xf(const Ctx<ObsT> &c, ObsT *dst, const uint2 *xdesc,
     }
 }
 
-// Both row blocks of an f32 environment in one pass over their 16-byte chunks (camera chunks, then target chunks).
-// All descriptors of a pass (8 chunks per lane) are loaded BEFORE its first store: loads and stores share one
+// Both row blocks of an f32 environment.  The descriptors of the first GC camera chunks and GT target chunks per
+// lane (all of them for the shipped scenario shapes) are loaded BEFORE the first store: loads and stores share one
 // in-order counter on gfx9, so a descriptor load issued behind an observation store can only be waited for
-// together with that store's HBM acknowledgement -- seven such waits per step in the chunk-by-chunk loop.
+// together with that store's HBM acknowledgement -- seven such waits per step in a chunk-by-chunk loop.
 template <typename ObsT>
 __device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT> &c) {
     if constexpr (sizeof(ObsT) == 4) {
         const Params &p = c.p;
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        constexpr int G = 8;
-        const int nvc = p.cam_elems / 4, nvt = p.tgt_elems / 4, nv = nvc + nvt;
-        const uint4 *tab = reinterpret_cast<const uint4 *>(c.table);
-        const int tshift = p.tgt_table_off / 4 - nvc;                 // table index of target chunk s is s + tshift
+        constexpr int GC = 2, GT = 6;
+        const int nvc = p.cam_elems / 4, nvt = p.tgt_elems / 4;
+        const uint4 *tabc = reinterpret_cast<const uint4 *>(c.table);
+        const uint4 *tabt = reinterpret_cast<const uint4 *>(c.table + p.tgt_table_off);
         f32x4 *cam = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.cam_obs) + c.out * p.cam_elems);
         f32x4 *tgt = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems);
-        for (int base = c.lane; base < nv; base += 64 * G) {
-            uint4 d[G];
+        auto chunk = [&](const uint4 &d) { return f32x4{gather_one(c, d.x), gather_one(c, d.y), gather_one(c, d.z), gather_one(c, d.w)}; };
+        uint4 dc[GC], dt[GT];
 #pragma unroll
-            for (int k = 0; k < G; ++k) {
-                const int s = base + 64 * k;
-                d[k] = tab[s < nv ? (s < nvc ? s : s + tshift) : 0];
-            }
+        for (int k = 0; k < GC; ++k) { const int s = c.lane + 64 * k; dc[k] = tabc[s < nvc ? s : 0]; }
 #pragma unroll
-            for (int k = 0; k < G; ++k) asm volatile("" : "+v"(d[k].x), "+v"(d[k].y), "+v"(d[k].z), "+v"(d[k].w));
+        for (int k = 0; k < GT; ++k) { const int s = c.lane + 64 * k; dt[k] = tabt[s < nvt ? s : 0]; }
 #pragma unroll
-            for (int k = 0; k < G; ++k) {
-                const int s = base + 64 * k;
-                if (s < nv) {
-                    const f32x4 v = {gather_one(c, d[k].x), gather_one(c, d[k].y), gather_one(c, d[k].z), gather_one(c, d[k].w)};
-                    __builtin_nontemporal_store(v, s < nvc ? &cam[s] : &tgt[s - nvc]);   // write-once stream: keep it out of the caches
-                }
-            }
-        }
+        for (int k = 0; k < GC; ++k) asm volatile("" : "+v"(dc[k].x), "+v"(dc[k].y), "+v"(dc[k].z), "+v"(dc[k].w));
+#pragma unroll
+        for (int k = 0; k < GT; ++k) asm volatile("" : "+v"(dt[k].x), "+v"(dt[k].y), "+v"(dt[k].z), "+v"(dt[k].w));
+#pragma unroll
+        for (int k = 0; k < GC; ++k) { const int s = c.lane + 64 * k; if (s < nvc) __builtin_nontemporal_store(chunk(dc[k]), &cam[s]); }
+        for (int s = c.lane + 64 * GC; s < nvc; s += 64) __builtin_nontemporal_store(chunk(tabc[s]), &cam[s]);   // larger scenarios
+#pragma unroll
+        for (int k = 0; k < GT; ++k) { const int s = c.lane + 64 * k; if (s < nvt) __builtin_nontemporal_store(chunk(dt[k]), &tgt[s]); }
+        for (int s = c.lane + 64 * GT; s < nvt; s += 64) __builtin_nontemporal_store(chunk(tabt[s]), &tgt[s]);
     }
 }
 
