@@ -162,6 +162,17 @@ __device__ __forceinline__ void phase_prio(int mode, int phase) {
     else __builtin_amdgcn_s_setprio(3);
 }
 
+// `g` as it lies in the kernel-argument segment (second argument, after the 8-byte `pp`).
+__device__ __forceinline__ const Ptrs &kernarg_ptrs(const Ptrs &g) {
+    static_assert(alignof(Ptrs) == 8 && sizeof(const Params *) == 8, "g follows pp at byte 8 of the kernel arguments");
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)g;
+    return *(const Ptrs *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+#else
+    return g;
+#endif
+}
+
 // Wave-level LDS hand-off: all 64 lanes run in lockstep, so draining this wave's LDS queue and
 // pinning the compiler's order is a complete producer->consumer fence inside the wave.
 __device__ __forceinline__ void wave_sync() {
@@ -1024,8 +1035,12 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     const int64_t env = (int64_t)blockIdx.x * 4 + wave;
     if (env >= g.N) return;
     phase_prio(g.stagger, 0);
+    // The phases read the launch arguments from the kernel-argument segment where they use them (`gk` aliases `g`
+    // there) instead of from the copy the compiler preloads into ~45 SGPRs at entry and keeps for the whole
+    // kernel: with the scenario constants that was more than the 96 SGPRs a wave may hold at full occupancy.
+    const Ptrs &gk = kernarg_ptrs(g);
     // the four waves of a workgroup never synchronise: each owns one environment and its LDS slice
-    Ctx<ObsT> c(p, g, smem + wave * p.lds_wave_bytes, lane, env);
+    Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env);
 #ifdef MATE_PHASE_CLOCKS
     if (lane == 0 && g.phase_clocks) {
         g.phase_clocks[env * 16 + 0] = t_begin;
