@@ -1109,8 +1109,9 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t env = (int64_t)blockIdx.x * 4 + wave;
     if (env >= g.N) return;
+    const Ptrs &gk = kernarg_ptrs(g);     // launch arguments read where they are used (see step_kernel)
     {
-        Ctx<ObsT> c(p, g, smem + wave * p.lds_wave_bytes, lane, env);
+        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env);
         load_records(c);
         wave_sync();
         build_entities(c);
@@ -1128,7 +1129,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         const Shape shape_r(pr);
         const Params &p = shape_r.get();
         const int64_t env_r = (int64_t)blockIdx.x * 4 + wave_r;
-        Ctx<ObsT> c(p, g, smem + wave_r * p.lds_wave_bytes, lane_r, env_r);
+        Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r);
         c.out = (int64_t)r * g.N + env_r;
         if (c.ei(EI_DONE) != 0) {
             if (lane_r == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
@@ -1145,7 +1146,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         wave_sync();
     }
     {
-        Ctx<ObsT> c(p, g, smem + wave * p.lds_wave_bytes, lane, env);
+        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env);
         store_dynamic(c);
     }
 }
