@@ -930,6 +930,23 @@ __device__ void pack_block(const Ctx<ObsT> &c, ObsT *dst, const uint32_t *table,
                 __builtin_nontemporal_store(nv, reinterpret_cast<f64x2 *>(&out[i]));
             }
         }
+    } else if (sizeof(ObsT) == 4 && (elems % 2) == 0) {      // blocks that are only 8-byte aligned (4v2: 202 floats per environment)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 *out = reinterpret_cast<f32x2 *>(dst);
+        const uint2 *tab = reinterpret_cast<const uint2 *>(table);
+        const int nvec = elems / 2;
+        for (int base = c.lane; base < nvec; base += 256) {
+            uint2 d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int i = base + 64 * k; d[k] = tab[i < nvec ? i : 0]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(d[k].x), "+v"(d[k].y));   // descriptors before the first store
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = base + 64 * k;
+                if (i < nvec) { const f32x2 v = {(float)gather_one(c, d[k].x), (float)gather_one(c, d[k].y)}; __builtin_nontemporal_store(v, &out[i]); }
+            }
+        }
     } else {
         for (int i = c.lane; i < elems; i += 64) dst[i] = gather_one(c, table[i]);
     }
