@@ -387,7 +387,7 @@ __device__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &draws, bool adva
             th = clipd(th + dz, p.theta_min, kMaxViewingAngle);
             c.phi(lane) = ph; c.theta(lane) = th;
         }
-        const double sr = sqrt(p.area / th);      // entities.py:360
+        const double sr = sqrt_pos(div_nz(p.area, th));      // entities.py:360
         c.sight(lane) = sr;
         double sn, cs;
         sincos_deg(ph, sn, cs);                    // Camera.state: polar2cartesian(sight_range, orientation), entities.py:318
@@ -433,7 +433,7 @@ __device__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws) {
             // `step.norm = step_size` (entities.py:649-650) goes through the polar form in the reference
             // (s*(cos, sin) of atan2(a)); rescaling the vector is the same quantity to within the
             // last-place noise a device atan2/sincos would add anyway, at a tenth of the instructions.
-            const double k = step_size / n;
+            const double k = div_nz(step_size, n);
             vx = ax * k; vy = ay * k; n = step_size;
         }
         desx = ox + vx; desy = oy + vy;
@@ -654,7 +654,7 @@ __device__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool p
         bool seen;
         if (d2 < lim2 * (1.0 - 1e-14)) seen = true;
         else if (d2 > lim2 * (1.0 + 1e-14)) seen = diag;
-        else seen = diag || (sqrt(d2) <= lim);
+        else seen = diag || (sqrt_pos(d2) <= lim);
         seen_bits |= (uint32_t)(seen && q < p.n_range) << round;
     }
     for (int round = 0; round < p.range_rounds; ++round) {
@@ -792,9 +792,9 @@ __device__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out
         const double epd = c.ep_delayed() + delayed;
         c.ep_reward() = epr; c.ep_delayed() = epd;
         const int delivered = c.ei(EI_DELIVERED);
-        const double coverage = (double)n_tracked / (double)p.Nt;
-        const double real_cov = n_bounty > 0 ? (double)n_both / (double)n_bounty : 0.0;
-        const double transport = delivered > 0 ? epd / (p.reward_scale * (double)delivered) : 0.0;
+        const double coverage = div_nz((double)n_tracked, (double)p.Nt);
+        const double real_cov = n_bounty > 0 ? div_nz((double)n_both, (double)n_bounty) : 0.0;
+        const double transport = delivered > 0 ? div_nz(epd, p.reward_scale * (double)delivered) : 0.0;
         const double r = p.sparse_reward ? delayed : reward;
         const int ep_step = c.ei(EI_EPSTEP) + 1;
         c.ei(EI_EPSTEP) = ep_step;
@@ -805,7 +805,7 @@ __device__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out
         if (scalars_out) {
             float *o = scalars_out + c.out * 8;
             o[0] = (float)(-r); o[1] = (float)r; o[2] = (float)done; o[3] = (float)coverage;
-            o[4] = (float)real_cov; o[5] = (float)transport; o[6] = (float)delivered; o[7] = (float)(r / p.max_team_reward);
+            o[4] = (float)real_cov; o[5] = (float)transport; o[6] = (float)delivered; o[7] = (float)div_nz(r, p.max_team_reward);
         }
         if (done && c.g.done_count) {
             const int slot = atomicAdd(c.g.done_count + c.g.parity, 1);

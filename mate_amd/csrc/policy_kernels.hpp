@@ -254,9 +254,9 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
         // The agent reconstructs its sight range and orientation from the (sr cos phi, sr sin phi) pair of its
         // observation row (agents/utils.py:206-255: norm and arctan2 of that pair); that round trip returns
         // sr and phi to within a few ulp, so the state values are used directly.
-        const double sight = sqrt(p.area / theta);
+        const double sight = sqrt_pos(div_nz(p.area, theta));
         const double orientation = phi;
-        const double q2 = sight / p.rmax;
+        const double q2 = div_nz(sight, p.rmax);
         const double min_va = theta * (q2 * q2);
         const double threshold = 1.1 * p.rmax;
         int best = -1; double best_d = 0.0;
@@ -277,12 +277,12 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
             if (distance * (1.0 + sin_deg_0_90(min_va / 2.0)) >= p.rmax) best_va = min_va;
             else {
                 const double area_product = theta * (sight * sight);
-                if (distance <= sqrt(area_product / 180.0) / 2.0) best_va = 180.0;
+                if (distance <= sqrt_pos(area_product / 180.0) / 2.0) best_va = 180.0;
                 else {
                     // b <- area_product / (distance (1 + sin(b/2)))^2, 20 times (greedy.py:139-145).  The map is a
                     // contraction (|f'| <= 0.65), so last-place differences do not grow: the quotient is taken as
                     // K * (1/(1+sin))^2 with K = area_product / distance^2 and a Newton-refined reciprocal.
-                    const double K = area_product / (distance * distance);
+                    const double K = div_nz(area_product, distance * distance);
                     double b = 180.0;
                     for (int it = 0; it < 20; ++it) {
                         const double half = b * 0.5;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
             ax = wx - x; ay = wy - y;
         }
         const double len = norm2(ax, ay);
-        if (len > step_size) { const double k2 = step_size / len; ax *= k2; ay *= k2; }
+        if (len > step_size) { const double k2 = div_nz(step_size, len); ax *= k2; ay *= k2; }
         const double prob = norm2(pax, pay) > 0.2 * step_size ? 0.05 : 0.75;
         double u;
         if (q.tape.tgt_binom_u) u = q.tape.tgt_binom_u[env * Nt + t];
