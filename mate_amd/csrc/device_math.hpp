@@ -92,7 +92,46 @@ __device__ __forceinline__ double normalize_angle(double a) {   // utils.py:155-
     else r = pymod_pos(x, 360.0);
     return r - 180.0;
 }
-__device__ __forceinline__ double atan2_deg(double y, double x) { return atan2(y, x) * kRad2Deg; }           // utils.py:124-131
+// p * z + C for an f64 literal C.  A 64-bit literal cannot be encoded in a VALU instruction and the compiler parks
+// every polynomial coefficient in a VGPR pair (two v_mov per coefficient, and again in every loop iteration with
+// MachineLICM off); here the literal goes through an SGPR pair written by two scalar moves, which issue beside the
+// vector instructions of other waves.  Same fma, same bits.
+template <unsigned long long BITS>
+__device__ __forceinline__ double fma_sc(double p, double z) {
+    unsigned long long bits = BITS;
+    asm("" : "+s"(bits));                          // the literal, opaque, in a scalar register pair
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(bits));
+    return r;
+}
+#define FMA_SC(p, z, c) fma_sc<__builtin_bit_cast(unsigned long long, (double)(c))>((p), (z))
+#define FMA_SCX(p, z, hex) fma_sc<(hex)>((p), (z))
+
+// atan2 for finite operands that are not both zero: the device library's algorithm (t = min/max of the magnitudes,
+// a degree-19 minimax polynomial in t^2 with the library's own coefficients, octant and quadrant unfolding), without
+// its infinity / NaN / signed-zero cases and with the coefficients routed through SGPRs -- 45 vector instructions
+// instead of 105, bit-identical to atan2() on finite non-zero operands (tools/math_check.hip).
+__device__ __forceinline__ double atan2_finite(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    const double t = div_nz(mn, mx);
+    const double z = t * t;
+    double p = __longlong_as_double(0x3eeba404b5e68a13ll);
+    p = FMA_SCX(p, z, 0xbf23e260bd3237f4ull); p = FMA_SCX(p, z, 0x3f4b2bb069efb384ull); p = FMA_SCX(p, z, 0xbf67952daf56de9bull);
+    p = FMA_SCX(p, z, 0x3f7d6d43a595c56full); p = FMA_SCX(p, z, 0xbf8c6ea4a57d9582ull); p = FMA_SCX(p, z, 0x3f967e295f08b19full);
+    p = FMA_SCX(p, z, 0xbf9e9ae6fc27006aull); p = FMA_SCX(p, z, 0x3fa2c15b5711927aull); p = FMA_SCX(p, z, 0xbfa59976e82d3ff0ull);
+    p = FMA_SCX(p, z, 0x3fa82d5d6ef28734ull); p = FMA_SCX(p, z, 0xbfaae5ce6a214619ull); p = FMA_SCX(p, z, 0x3fae1bb48427b883ull);
+    p = FMA_SCX(p, z, 0xbfb110e48b207f05ull); p = FMA_SCX(p, z, 0x3fb3b13657b87036ull); p = FMA_SCX(p, z, 0xbfb745d119378e4full);
+    p = FMA_SCX(p, z, 0x3fbc71c717e1913cull); p = FMA_SCX(p, z, 0xbfc2492492376b7dull); p = FMA_SCX(p, z, 0x3fc99999999952ccull);
+    p = FMA_SCX(p, z, 0xbfd5555555555523ull);
+    double r = fma(t, z * p, t);
+    const double half_pi = __longlong_as_double(0x3ff921fb54442d18ll), pi = __longlong_as_double(0x400921fb54442d18ll);
+    if (ay > ax) r = half_pi - r;
+    if (x < 0.0) r = pi - r;
+    if (y == 0.0) r = x < 0.0 ? pi : 0.0;
+    return copysign(r, y);
+}
+__device__ __forceinline__ double atan2_deg(double y, double x) { return atan2_finite(y, x) * kRad2Deg; }           // utils.py:124-131
 
 // sin and cos of an angle given in DEGREES, |deg| <= 720.  polar2cartesian (utils.py:144-152) converts
 // with phi * (pi/180) first, and so does this.  Two-term Cody-Waite reduction to [-pi/4, pi/4] plus
@@ -105,22 +144,22 @@ __device__ __forceinline__ void sincos_deg(double deg, double &sn, double &cs) {
     r = fma(-k, 6.12323399573676603587e-17, r);                   // pi/2 low
     const double z = r * r;
     double ps = 2.81145725434552075980e-15;                       // 1/17!
-    ps = fma(ps, z, -7.64716373181981647590e-13);                 // -1/15!
-    ps = fma(ps, z, 1.60590438368216145994e-10);                  // 1/13!
-    ps = fma(ps, z, -2.50521083854417187751e-08);                 // -1/11!
-    ps = fma(ps, z, 2.75573192239858906526e-06);                  // 1/9!
-    ps = fma(ps, z, -1.98412698412698412698e-04);                 // -1/7!
-    ps = fma(ps, z, 8.33333333333333333333e-03);                  // 1/5!
-    ps = fma(ps, z, -1.66666666666666666667e-01);                 // -1/3!
+    ps = FMA_SC(ps, z, -7.64716373181981647590e-13);              // -1/15!
+    ps = FMA_SC(ps, z, 1.60590438368216145994e-10);               // 1/13!
+    ps = FMA_SC(ps, z, -2.50521083854417187751e-08);              // -1/11!
+    ps = FMA_SC(ps, z, 2.75573192239858906526e-06);               // 1/9!
+    ps = FMA_SC(ps, z, -1.98412698412698412698e-04);              // -1/7!
+    ps = FMA_SC(ps, z, 8.33333333333333333333e-03);               // 1/5!
+    ps = FMA_SC(ps, z, -1.66666666666666666667e-01);              // -1/3!
     const double s0 = fma(r * z, ps, r);
     double pc = -1.56192069685862264622e-16;                      // -1/18!
-    pc = fma(pc, z, 4.77947733238738529744e-14);                  // 1/16!
-    pc = fma(pc, z, -1.14707455977297247139e-11);                 // -1/14!
-    pc = fma(pc, z, 2.08767569878680989792e-09);                  // 1/12!
-    pc = fma(pc, z, -2.75573192239858906526e-07);                 // -1/10!
-    pc = fma(pc, z, 2.48015873015873015873e-05);                  // 1/8!
-    pc = fma(pc, z, -1.38888888888888888889e-03);                 // -1/6!
-    pc = fma(pc, z, 4.16666666666666666667e-02);                  // 1/4!
+    pc = FMA_SC(pc, z, 4.77947733238738529744e-14);               // 1/16!
+    pc = FMA_SC(pc, z, -1.14707455977297247139e-11);              // -1/14!
+    pc = FMA_SC(pc, z, 2.08767569878680989792e-09);               // 1/12!
+    pc = FMA_SC(pc, z, -2.75573192239858906526e-07);              // -1/10!
+    pc = FMA_SC(pc, z, 2.48015873015873015873e-05);               // 1/8!
+    pc = FMA_SC(pc, z, -1.38888888888888888889e-03);              // -1/6!
+    pc = FMA_SC(pc, z, 4.16666666666666666667e-02);               // 1/4!
     const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
     const int q = (int)k & 3;
     const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;

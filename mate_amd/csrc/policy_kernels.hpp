@@ -80,15 +80,15 @@ __device__ __forceinline__ double sin_deg_0_90(double deg) {
     const double x = deg * kDeg2Rad;
     const double z = x * x;
     double ps = 1.95729410633912612308e-20;                       // 1/21!
-    ps = fma(ps, z, -8.22063524662432971696e-18);                 // -1/19!
-    ps = fma(ps, z, 2.81145725434552075980e-15);                  // 1/17!
-    ps = fma(ps, z, -7.64716373181981647590e-13);                 // -1/15!
-    ps = fma(ps, z, 1.60590438368216145994e-10);                  // 1/13!
-    ps = fma(ps, z, -2.50521083854417187751e-08);                 // -1/11!
-    ps = fma(ps, z, 2.75573192239858906526e-06);                  // 1/9!
-    ps = fma(ps, z, -1.98412698412698412698e-04);                 // -1/7!
-    ps = fma(ps, z, 8.33333333333333333333e-03);                  // 1/5!
-    ps = fma(ps, z, -1.66666666666666666667e-01);                 // -1/3!
+    ps = FMA_SC(ps, z, -8.22063524662432971696e-18);              // -1/19!
+    ps = FMA_SC(ps, z, 2.81145725434552075980e-15);               // 1/17!
+    ps = FMA_SC(ps, z, -7.64716373181981647590e-13);              // -1/15!
+    ps = FMA_SC(ps, z, 1.60590438368216145994e-10);               // 1/13!
+    ps = FMA_SC(ps, z, -2.50521083854417187751e-08);              // -1/11!
+    ps = FMA_SC(ps, z, 2.75573192239858906526e-06);               // 1/9!
+    ps = FMA_SC(ps, z, -1.98412698412698412698e-04);              // -1/7!
+    ps = FMA_SC(ps, z, 8.33333333333333333333e-03);               // 1/5!
+    ps = FMA_SC(ps, z, -1.66666666666666666667e-01);              // -1/3!
     return fma(x * z, ps, x);
 }
 
