@@ -632,7 +632,7 @@ static int policy_enable(mate_engine *e) {
     if ((rc = dev_alloc(e, &q.tgt_act, (size_t)e->N * p.Nt * 2))) return rc;
     if (!e->g.own_masks && (rc = dev_alloc(e, &e->g.own_masks, (size_t)e->N * p.MW))) return rc;
     q.masks = e->g.own_masks;
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->policy_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * q.lds_bytes);
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->policy_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * q.lds_bytes + 1024);
     if (err != hipSuccess) return fail(MATE_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
     e->policy_ready = true;
     return MATE_OK;
@@ -662,7 +662,8 @@ extern "C" int mate_engine_step_greedy(mate_engine *e, const mate_step_io *io, c
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     Ptrs gp = e->g;
     gp.freeze_done = auto_reset > 1;
-    hipLaunchKernelGGL(e->policy_fn, dim3(blocks), dim3(256), 4 * q.lds_bytes, stream, (const Params *)e->d_params, (const Ptrs)gp, (const PolicyPtrs)q);
+    hipLaunchKernelGGL(e->policy_fn, dim3(blocks), dim3(256), 4 * q.lds_bytes + 1024, stream,   // + the shared zoom-solve exchange
+                       (const Params *)e->d_params, (const Ptrs)gp, (const PolicyPtrs)q);
     HIP_TRY(hipGetLastError());
     mate_step_io io2;
     if (io) io2 = *io; else std::memset(&io2, 0, sizeof(io2));

@@ -98,9 +98,14 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     const Params &p = shape.get();
     extern __shared__ __align__(16) unsigned char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int64_t env = (int64_t)blockIdx.x * 4 + wave;
-    if (env >= g.N) return;
+    // No wave leaves early: the four waves of a workgroup meet at two barriers around the shared zoom solve, so a wave
+    // past the end of the batch or on a frozen environment runs on (duplicate / stale data) and only skips its stores.
+    const int64_t env_raw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t env = env_raw < g.N ? env_raw : g.N - 1;
+    bool active = env_raw < g.N;
     unsigned char *base = smem + wave * q.lds_bytes;
+    double *shared_K = reinterpret_cast<double *>(smem + 4 * q.lds_bytes);      // [4 environments][16 cameras]
+    double *shared_B = shared_K + 64;
     // LDS: [policy record + staging][static record][dynamic record][mask words]
     PolCtx<ObsT> a(p, q, base);
     double *st = reinterpret_cast<double *>(base + (size_t)(q.PW + p.Nc * p.Nc / 2 + 2) * 8);
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     const int32_t *env_i = di + Nt * TI_STRIDE;
     const uint32_t tick = (uint32_t)env_i[EI_TICK];
     const uint32_t env_global = p.first_env + (uint32_t)env;
-    if (g.freeze_done && env_i[EI_DONE] != 0) return;        // finished, waiting for the batched reset
+    if (g.freeze_done && env_i[EI_DONE] != 0) active = false;   // finished, waiting for the batched reset
     const bool fresh = a.episode() != env_i[EI_EPISODE];     // first call of a new episode: agent.reset(observation)
     // this step's draws (see PolicyStream); skipped when every draw comes from the tape
     double u_bern = 0.0, u_s0 = 0.0, u_s1 = 0.0;
@@ -248,18 +253,23 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     wave_sync();
 
     // ------------------------------------------------------------------ act
-    if (lane < Nc) {                                        // GreedyCameraAgent.act (greedy.py:69-156)
+    // GreedyCameraAgent.act (greedy.py:69-156), part 1: pick the target, decide which viewing-angle rule applies
+    int best = -1;
+    double theta = 0.0, orientation = 0.0, min_va = 0.0, best_orientation = 0.0, best_va = 0.0, K = 0.0;
+    bool solve = false;
+    if (lane < Nc) {
         const int c = lane;
-        const double phi = dy[c], theta = dy[Nc + c];
+        const double phi = dy[c];
+        theta = dy[Nc + c];
         // The agent reconstructs its sight range and orientation from the (sr cos phi, sr sin phi) pair of its
         // observation row (agents/utils.py:206-255: norm and arctan2 of that pair); that round trip returns
         // sr and phi to within a few ulp, so the state values are used directly.
         const double sight = sqrt_pos(div_nz(p.area, theta));
-        const double orientation = phi;
+        orientation = phi;
         const double q2 = div_nz(sight, p.rmax);
-        const double min_va = theta * (q2 * q2);
+        min_va = theta * (q2 * q2);
         const double threshold = 1.1 * p.rmax;
-        int best = -1; double best_d = 0.0;
+        double best_d = 0.0;
         uint32_t remembered = 0;
         for (int t = 0; t < Nt; ++t) remembered |= (uint32_t)(a.t2f(c, t) > 0) << t;
         for (uint32_t m = remembered; m; m &= m - 1) {               // ascending t, like the reference's loop
@@ -268,33 +278,44 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
             if (!(dnorm < threshold)) continue;
             if (best < 0 || dnorm < best_d) { best = t; best_d = dnorm; }
         }
-        double a0, a1;
         if (best >= 0) {
             const double rx = a.mem(c, best, 0) - cam_x(c), ry = a.mem(c, best, 1) - cam_y(c);
-            const double best_orientation = atan2_deg(ry, rx);
+            best_orientation = atan2_deg(ry, rx);
             const double distance = best_d;
-            double best_va;
             if (distance * (1.0 + sin_deg_0_90(min_va / 2.0)) >= p.rmax) best_va = min_va;
             else {
                 const double area_product = theta * (sight * sight);
                 if (distance <= sqrt_pos(area_product / 180.0) / 2.0) best_va = 180.0;
-                else {
-                    // b <- area_product / (distance (1 + sin(b/2)))^2, 20 times (greedy.py:139-145).  The map is a
-                    // contraction (|f'| <= 0.65), so last-place differences do not grow: the quotient is taken as
-                    // K * (1/(1+sin))^2 with K = area_product / distance^2 and a Newton-refined reciprocal.
-                    const double K = div_nz(area_product, distance * distance);
-                    double b = 180.0;
-                    for (int it = 0; it < 20; ++it) {
-                        const double half = b * 0.5;
-                        const double y = 1.0 + sin_deg_0_90(half < 90.0 ? half : 90.0);
-                        double r = __builtin_amdgcn_rcp(y);
-                        r = fma(r, fma(-y, r, 1.0), r);
-                        r = fma(r, fma(-y, r, 1.0), r);
-                        b = K * (r * r);
-                    }
-                    best_va = clipd(b, min_va, 180.0);
-                }
+                else { solve = true; K = div_nz(area_product, distance * distance); }
             }
+        }
+    }
+    // The zoom solve: b <- area_product / (distance (1 + sin(b/2)))^2, 20 times from 180 (greedy.py:139-145), is the
+    // longest dependent chain of the kernel and runs on at most Nc lanes of a wave.  The four waves of the workgroup
+    // publish their cameras' K = area_product / distance^2 and ONE wave iterates all of them (4 x Nc lanes busy
+    // instead of Nc, a quarter of the issue slots).  The map is a contraction (|f'| <= 0.65), so last-place
+    // differences do not grow: the quotient is taken as K * (1/(1+sin))^2 with a Newton-refined reciprocal.
+    if (lane < 16) shared_K[wave * 16 + lane] = solve ? K : 1.0;
+    __syncthreads();
+    if (wave == 0) {
+        const double Kc = shared_K[lane];
+        double b = 180.0;
+        for (int it = 0; it < 20; ++it) {
+            const double half = b * 0.5;
+            const double y = 1.0 + sin_deg_0_90(half < 90.0 ? half : 90.0);
+            double r = __builtin_amdgcn_rcp(y);
+            r = fma(r, fma(-y, r, 1.0), r);
+            r = fma(r, fma(-y, r, 1.0), r);
+            b = Kc * (r * r);
+        }
+        shared_B[lane] = b;
+    }
+    __syncthreads();
+    if (lane < Nc) {                                        // part 2: the action
+        const int c = lane;
+        double a0, a1;
+        if (best >= 0) {
+            if (solve) best_va = clipd(shared_B[wave * 16 + c], min_va, 180.0);
             a0 = clipd(normalize_angle(best_orientation - orientation), -p.rot, p.rot);
             a1 = clipd(best_va - theta, -p.zoom, p.zoom);
         } else {
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
             } else { a0 = a.prev_action(c, 0); a1 = a.prev_action(c, 1); }
         }
         a.prev_action(c, 0) = a0; a.prev_action(c, 1) = a1;
-        q.cam_act[(env * Nc + c) * 2] = a0; q.cam_act[(env * Nc + c) * 2 + 1] = a1;
+        if (active) { q.cam_act[(env * Nc + c) * 2] = a0; q.cam_act[(env * Nc + c) * 2 + 1] = a1; }
     }
     if (tl >= 0 && tl < Nt) {                               // GreedyTargetAgent.act (greedy.py:285-324)
         const int t = tl;
@@ -357,10 +378,10 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
         const double outx = clipd(ax + nx, -step_size, step_size), outy = clipd(ay + ny, -step_size, step_size);
         a.tgt_prev(t, 0) = x; a.tgt_prev(t, 1) = y;
         a.tgt_noise(t, 0) = nx; a.tgt_noise(t, 1) = ny;
-        q.tgt_act[(env * Nt + t) * 2] = outx; q.tgt_act[(env * Nt + t) * 2 + 1] = outy;
+        if (active) { q.tgt_act[(env * Nt + t) * 2] = outx; q.tgt_act[(env * Nt + t) * 2 + 1] = outy; }
     }
     wave_sync();
-    {
+    if (active) {
         double *dst = q.pol + env * q.PW;
         for (int k = lane; k < q.PW; k += 64) dst[k] = a.f[k];
     }
