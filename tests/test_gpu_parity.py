@@ -429,3 +429,34 @@ def test_arbitrary_shapes_vs_oracle(shape, oracle_lib):
     if no:
         cfg['obstacle'] = dict(base['obstacle'], location_random_range=boxes(no, -800.0, 700.0, 100.0), radius_random_range=[10.0, 45.0])
     _reset_and_rollout_vs_oracle(cfg, 5, oracle_lib, steps=15)
+
+
+@pytest.mark.parametrize('config,cam_mode,tgt_mode', [('MATE-8v8-9.yaml', 'shared', 'enhanced'), ('MATE-4v8-9.yaml', 'enhanced', 'shared'),
+                                                      ('MATE-4v2-9.yaml', 'shared', 'shared'), ('MATE-Navigation.yaml', 'plain', 'shared'),
+                                                      ('MATE-4v8-0.yaml', 'enhanced', 'plain')])
+def test_observation_modes_vs_oracle_rollout(config, cam_mode, tgt_mode, oracle_lib):
+    """The fused EnhancedObservation / SharedFieldOfView modes on natively reset batches, mixed per team, against the
+    oracle's restatement of the wrappers (which the reference fixtures pin) after a random rollout."""
+    O = oracle_lib
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config(config)
+    n = 24
+    eng = Engine(cfg, n, seed=31, first_env_index=7, obs_dtype=torch.float64)
+    eng.set_obs_mode(camera=cam_mode, target=tgt_mode)
+    eng.reset()
+    batch = O.OracleBatch(U.oracle_proto_from_config(cfg, O), n, seed=31, first_env_index=7)
+    batch.reset(threads=4)
+    for e in range(n):
+        for c in range(eng.num_cameras):
+            batch.env(e).set_lut(c, *eng.lut_read(e, c))
+    for s in range(30):
+        eng.step_random(auto_reset=False, want_masks=True)
+        batch.step(auto_reset=False, threads=4)
+        if s % 10 == 9:
+            co, to = eng.camera_obs.cpu().numpy(), eng.target_obs.cpu().numpy()
+            for e in range(n):
+                oc, ot = batch.env(e).observe_mode(camera=cam_mode, target=tgt_mode)
+                assert np.abs(to[e] - ot).max() < 1e-9, (s, e, 'target rows')
+                if eng.num_cameras:
+                    assert np.abs(co[e] - oc).max() < 1e-9, (s, e, 'camera rows')
