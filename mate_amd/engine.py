@@ -222,8 +222,16 @@ class Engine:
         return self.camera_obs, self.target_obs, self.scalars
 
     def step_random(self, auto_reset=True, want_masks=False):
-        io, keep = self._io(want_masks=want_masks)
-        check(self.lib.mate_engine_step_random(self._h, ctypes.byref(io), int(auto_reset), self._stream()))
+        # the argument structure of this call never changes: built once per (masks or not), the host cost per step
+        # matters when the step kernel is a dozen microseconds
+        cache = self.__dict__.setdefault('_random_io', {})
+        ref = cache.get(want_masks)
+        if ref is None:
+            io, _ = self._io(want_masks=want_masks)
+            ref = cache[want_masks] = (io, ctypes.byref(io))
+        status = self.lib.mate_engine_step_random(self._h, ref[1], int(auto_reset), self._stream())
+        if status != 0:
+            check(status)
         return self.camera_obs, self.target_obs, self.scalars
 
     def rollout_random(self, steps, auto_reset=True, want_masks=False):
