@@ -841,6 +841,54 @@ void mo_decode_discrete(const mo_env *e, const int *cam_idx, const double *cam_g
         }
 }
 
+/* AuxiliaryCameraRewards.compute_soft_coverage_score(s) + the per-camera reduction of its step()
+ * (wrappers/auxiliary_camera_rewards.py:128-139, 181-239): the distance from each target to the nearest POINT of the
+ * camera's sector outline -- 16 points up each flank, the knots of the OUTER occlusion table strictly inside the sector
+ * (Camera.boundary_between(outer=True), entities.py:513-543) and the two sector ends interpolated on the INNER table --
+ * signed by the view mask and divided by the radius of the sector's inscribed circle.  matrix [Nc][Nt], scores [Nc]. */
+void mo_soft_coverage(const mo_env *e, double *matrix, double *scores) {
+    for (int c = 0; c < e->Nc; ++c) {
+        const double theta = e->cam_theta[c], sight = e->cam_sight[c];
+        const double dist_max = theta < 180.0 ? sight / (1.0 + 1.0 / sin(theta / 2.0 * DEG2RAD)) : sight / 2.0;
+        const double left = mo_normalize_angle(e->cam_phi[c] - theta / 2.0);
+        const double right = left + ((e->cam_phi[c] + theta / 2.0) - (e->cam_phi[c] - theta / 2.0));
+        const int n = e->lut_n[1][c];
+        const double *phis_all = e->lut_phi[1][c], *rhos_all = e->lut_rho[1][c];
+        double *phis = (double *)malloc(sizeof(double) * (size_t)(n + 34)), *rhos = (double *)malloc(sizeof(double) * (size_t)(n + 34));
+        int m = 16;
+        phis[m] = left; rhos[m] = mo_interp(e->lut_phi[0][c], e->lut_rho[0][c], e->lut_n[0][c], mo_normalize_angle(left)); ++m;
+        if (right <= 180.0) {
+            for (int i = 0; i < n; ++i) if (left < phis_all[i] && phis_all[i] < right) { phis[m] = phis_all[i]; rhos[m] = rhos_all[i]; ++m; }
+        } else {
+            for (int i = 0; i < n; ++i) if (left < phis_all[i] && phis_all[i] <= 180.0) { phis[m] = phis_all[i]; rhos[m] = rhos_all[i]; ++m; }
+            for (int i = 0; i < n; ++i) if (phis_all[i] > -180.0 && phis_all[i] < right - 360.0) { phis[m] = phis_all[i]; rhos[m] = rhos_all[i]; ++m; }
+        }
+        phis[m] = right; rhos[m] = mo_interp(e->lut_phi[0][c], e->lut_rho[0][c], e->lut_n[0][c], mo_normalize_angle(right)); ++m;
+        for (int k = 0; k < 16; ++k) {                       /* np.linspace(0, rho, 16, endpoint=False) up both flanks */
+            phis[k] = phis[16]; rhos[k] = (double)k * (rhos[16] / 16.0);
+            phis[m + k] = phis[m - 1]; rhos[m + k] = (double)k * (rhos[m - 1] / 16.0);
+        }
+        m += 16;
+        int any = 0; double sum = 0.0, best = -INFINITY;
+        for (int t = 0; t < e->Nt; ++t) {
+            const double dx = e->tgt_x[t] - e->cam_x[c], dy = e->tgt_y[t] - e->cam_y[c];
+            double dist = INFINITY;
+            for (int i = 0; i < m; ++i) {
+                const double a = phis[i] * DEG2RAD;
+                const double d = hypot(dx - rhos[i] * cos(a), dy - rhos[i] * sin(a));
+                if (d < dist) dist = d;
+            }
+            if (!e->m_ct[c][t]) dist = -dist;
+            const double score = dist / dist_max;
+            if (matrix) matrix[c * e->Nt + t] = score;
+            if (e->m_ct[c][t]) { any = 1; sum += score; }
+            if (score > best) best = score;
+        }
+        if (scores) scores[c] = any ? sum : tanh(best);
+        free(phis); free(rhos);
+    }
+}
+
 void mo_state(const mo_env *e, double *out) { /* environment.py:894-906 */
     double *p = out;
     preserved(e, 0.0, p); p += PRESERVED_DIM;

@@ -68,6 +68,7 @@ void mo_observe_mode(const mo_env *env, int cam_mode, int tgt_mode, double *cam_
 /* DiscreteCamera / DiscreteTarget action decode (wrappers/discrete_action_spaces.py:59-74, 165-180) */
 void mo_decode_discrete(const mo_env *env, const int *cam_idx, const double *cam_grid, const int *tgt_idx,
                         const double *tgt_grid, double *cam_act, double *tgt_act);
+void mo_soft_coverage(const mo_env *env, double *matrix, double *scores);  /* wrappers/auxiliary_camera_rewards.py:128-139,181-239 */
 void mo_state(const mo_env *env, double *out);                        /* environment.py:894-906 */
 void mo_reset(mo_env *env);   /* environment.py:679-834 with the engine's own Philox reset stream */
 

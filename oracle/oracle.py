@@ -72,6 +72,7 @@ def _load():
     lib.mo_policy_act.argtypes = [P, P, ctypes.POINTER(PolicyTape), c_double_p, c_double_p]
     lib.mo_observe_mode.argtypes = [P, I, I, c_double_p, c_double_p]
     lib.mo_decode_discrete.argtypes = [P, ctypes.POINTER(ctypes.c_int), c_double_p, ctypes.POINTER(ctypes.c_int), c_double_p, c_double_p, c_double_p]
+    lib.mo_soft_coverage.argtypes = [P, c_double_p, c_double_p]
     lib.mo_state.argtypes = [P, c_double_p]
     lib.mo_reset.argtypes = [P]
     lib.mo_batch_create.restype = P
@@ -315,6 +316,12 @@ class OracleEnv:
         lib.mo_decode_discrete(self._h, ip(ci) if ci is not None else None, _dp(cg) if cg is not None else None,
                                ip(ti) if ti is not None else None, _dp(tg) if tg is not None else None, _dp(cam_act), _dp(tgt_act))
         return cam_act[:self.Nc], tgt_act
+
+    def soft_coverage(self):
+        """AuxiliaryCameraRewards: (score matrix [Nc, Nt], per-camera soft coverage scores [Nc]) of the current view."""
+        matrix, scores = np.zeros((max(self.Nc, 1), self.Nt)), np.zeros(max(self.Nc, 1))
+        lib.mo_soft_coverage(self._h, _dp(matrix), _dp(scores))
+        return matrix[:self.Nc], scores[:self.Nc]
 
     def state(self):
         out = np.zeros(self.S)

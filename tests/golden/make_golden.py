@@ -275,7 +275,7 @@ def drain_agent_log(cam_agents, tgt_agents):
 
 
 def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f64_obs_steps=None, record_agents=False,
-               extra_factory=None, discrete_levels=None):
+               extra_factory=None, discrete_levels=None, aux_rewards=None):
     env = mate.make('MultiAgentTracking-v0', config=config, **(overrides or {}))
     env.seed(seed)
     cam_obs, tgt_obs = env.reset()
@@ -321,6 +321,13 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
             out['camera_action_grid'] = disc_cam.normalized_action_grid
         out['target_action_grid'] = disc_tgt.normalized_action_grid
         out['discrete_levels'] = np.asarray(discrete_levels, dtype=np.int64)
+
+    aux = None
+    if aux_rewards is not None:         # the reference's AuxiliaryCameraRewards shapes the camera rewards of this trace
+        aux = mate.AuxiliaryCameraRewards(mate.RepeatedRewardIndividualDone(env), coefficients=aux_rewards[0], reduction=aux_rewards[1])
+        out['aux_keys'] = np.asarray(list(aux_rewards[0].keys()))
+        out['aux_coefficients'] = np.asarray(list(aux_rewards[0].values()), dtype=np.float64)
+        out['aux_reduction'] = np.str_(aux_rewards[1])
 
     rng = np.random.RandomState(seed + 1000)
     if policy == 'greedy':
@@ -369,7 +376,14 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
         else:
             cam_act, tgt_act = random_actions(env, rng, step)
         log.clear()
-        (cam_obs, tgt_obs), (r_cam, r_tgt), done, (cam_infos, tgt_infos) = env.step((cam_act, tgt_act))
+        if aux is None:
+            (cam_obs, tgt_obs), (r_cam, r_tgt), done, (cam_infos, tgt_infos) = env.step((cam_act, tgt_act))
+        else:
+            (cam_obs, tgt_obs), (shaped, r_tgts), (cam_dones, _), (cam_infos, tgt_infos) = aux.step((cam_act, tgt_act))
+            r_cam, r_tgt, done = cam_infos[0]['raw_reward'], r_tgts[0], cam_dones[0]
+            push('aux_reward_cam', np.asarray(shaped, dtype=np.float64))
+            push('soft_coverage_matrix', np.asarray(aux.soft_coverage_score_matrix, dtype=np.float64))
+            push('soft_coverage_score', np.asarray([info['auxiliary_reward_soft_coverage_score'] for info in cam_infos], dtype=np.float64))
         tape_ct, tape_cc, goal_u, goal_k, goal_j = drain_log(env, log)
 
         push('cam_act', cam_act)
@@ -659,6 +673,14 @@ def main():
         make_trace('obsmode_nav_s2', 'MATE-Navigation.yaml', 2, 'greedy', 48, extra_factory=observation_mode_extras(('target',)))
         make_trace('discrete_4v8-9_s6', 'MATE-4v8-9.yaml', 6, 'discrete', 64, discrete_levels=(5, 5))
         make_trace('discrete_4v2-9_s7', 'MATE-4v2-9.yaml', 7, 'discrete', 48, discrete_levels=(3, 9))
+        return
+    if sys.argv[1:] == ['softcov']:
+        make_trace('softcov_4v8-9_s8', 'MATE-4v8-9.yaml', 8, 'greedy', 64,
+                   aux_rewards=({'raw_reward': 1.0, 'soft_coverage_score': 0.5, 'num_tracked': 0.25, 'coverage_rate': 2.0}, 'none'))
+        make_trace('softcov_8v8-9_s9', 'MATE-8v8-9.yaml', 9, 'greedy', 48,
+                   aux_rewards=({'soft_coverage_score': 1.0, 'real_coverage_rate': 1.0, 'baseline': -0.5}, 'mean'))
+        make_trace('softcov_4v2-9_s10', 'MATE-4v2-9.yaml', 10, 'random', 48,
+                   aux_rewards=({'soft_coverage_score': 1.0, 'mean_transport_rate': 3.0}, 'max'))
         return
     if sys.argv[1:] == ['xform']:
         xform_fixture('trace_4v8-9_greedy_s2', 48)

@@ -200,3 +200,32 @@ def test_outer_boundary_builder(name):
         assert len(p2) == len(phis), (c, len(p2), len(phis))
         np.testing.assert_allclose(p2, phis, rtol=0, atol=1e-9)
         assert (np.abs(r2 - rhos) > 1e-8).sum() <= 2 * No, (c, (np.abs(r2 - rhos) > 1e-8).sum())
+
+
+def aux_reward_terms(fx, s, soft):
+    """The terms of AuxiliaryCameraRewards.step (wrappers/auxiliary_camera_rewards.py:141-150) from a fixture step."""
+    seen = fx['step/camera_target_view_mask'][s].astype(bool)
+    Nc = seen.shape[0]
+    return {'raw_reward': np.full(Nc, float(fx['step/reward_cam'][s])), 'coverage_rate': np.full(Nc, float(fx['step/coverage_rate'][s])),
+            'real_coverage_rate': np.full(Nc, float(fx['step/real_coverage_rate'][s])),
+            'mean_transport_rate': np.full(Nc, float(fx['step/mean_transport_rate'][s])),
+            'soft_coverage_score': np.asarray(soft, dtype=np.float64), 'num_tracked': seen.sum(axis=1).astype(np.float64), 'baseline': np.ones(Nc)}
+
+
+@pytest.mark.parametrize('name', ['softcov_4v8-9_s8', 'softcov_8v8-9_s9', 'softcov_4v2-9_s10'])
+def test_soft_coverage_score(name):
+    """AuxiliaryCameraRewards' soft coverage score restated in the oracle == the reference wrapper's matrix, per-camera
+    scores and shaped rewards on a recorded trace (1e-9: libm vs NumPy sin/cos/hypot last places)."""
+    fx = G.load(name + '.npz')
+    env = G.oracle_from_fixture(fx)
+    keys, coef, reduction = [str(k) for k in fx['aux_keys']], fx['aux_coefficients'], str(fx['aux_reduction'])
+    for s in range(len(fx['step/done'])):
+        env.step(fx['step/cam_act'][s], fx['step/tgt_act'][s], fx['step/tape_ct'][s], fx['step/goal_u'][s])
+        matrix, scores = env.soft_coverage()
+        np.testing.assert_allclose(matrix, fx['step/soft_coverage_matrix'][s], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(scores, fx['step/soft_coverage_score'][s], rtol=1e-9, atol=1e-9)
+        terms = aux_reward_terms(fx, s, scores)
+        shaped = sum(c * terms[k] for k, c in zip(keys, coef))
+        if reduction != 'none':
+            shaped = np.full_like(shaped, {'mean': np.mean, 'sum': np.sum, 'max': np.max, 'min': np.min}[reduction](shaped))
+        np.testing.assert_allclose(shaped, fx['step/aux_reward_cam'][s], rtol=1e-9, atol=1e-9)
