@@ -199,6 +199,17 @@ int mate_engine_lut_read(mate_engine *engine, int64_t env, int32_t camera, doubl
 int mate_engine_enable_outer_boundary(mate_engine *engine, int32_t *capacity);
 int mate_engine_lut_read_outer(mate_engine *engine, int64_t env, int32_t camera, double *phis, double *rhos,
                                int32_t capacity, int32_t *count);
+/* Install a recorded outer table (what sight_range_outer_func.x / .y hold, closing knot included). */
+int mate_engine_lut_write_outer(mate_engine *engine, int64_t env, int32_t camera, const double *phis_host,
+                                const double *rhos_host, int32_t count);
+/* AuxiliaryCameraRewards' soft coverage score of the current state (wrappers/auxiliary_camera_rewards.py:181-239
+ * compute_soft_coverage_scores, :128-139 per-camera reduction): `matrix_dev` [N][Nc][Nt] f64 (or NULL) receives
+ * +-distance(target, nearest point of the camera's sector outline) / radius of the sector's inscribed circle, signed by
+ * camera_target_view_mask; `scores_dev` [N][Nc] f64 (or NULL) the sum over the targets a camera tracks, or tanh(max)
+ * when it tracks none.  `masks_dev` = the packed masks of the step / reset this follows ([N][mask_words] uint32, as
+ * mate_step_io.masks_dev).  Needs the outer boundary (enable + a reset or rebuild_luts since); environments whose outer
+ * table was never built yield NaN. */
+int mate_engine_soft_coverage(mate_engine *engine, const uint32_t *masks_dev, double *matrix_dev, double *scores_dev, void *stream);
 int mate_engine_lut_write(mate_engine *engine, int64_t env, int32_t camera, const double *phis_host,
                           const double *rhos_host, int32_t count);
 /* Rebuild the occlusion tables of all environments from the current static geometry

@@ -15,6 +15,7 @@
 #include "../../include/mate_engine.h"
 #include "reset_kernels.hpp"
 #include "policy_kernels.hpp"
+#include "aux_kernels.hpp"
 
 using namespace mate;
 
@@ -775,6 +776,36 @@ extern "C" int mate_engine_enable_outer_boundary(mate_engine *e, int32_t *capaci
     e->rl = rl; e->reset_lds = (size_t)roff;
     e->g.lut_knots_outer = knots; e->g.lut_count_outer = counts; e->g.kmax_outer = kmax_outer;
     if (capacity) *capacity = kmax_outer;
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_lut_write_outer(mate_engine *e, int64_t env, int32_t camera, const double *phis, const double *rhos, int32_t n) {
+    if (!e || !phis || !rhos) return fail(MATE_EINVAL, "null argument");
+    if (!e->g.lut_knots_outer) return fail(MATE_ESTATE, "outer boundary not enabled (mate_engine_enable_outer_boundary)");
+    if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_write_outer: index out of range");
+    if (n < 2 || n > e->g.kmax_outer) return fail(MATE_EINVAL, "lut_write_outer: %d knots do not fit (capacity %d)", n, e->g.kmax_outer);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<double2> knots((size_t)n);
+    for (int i = 0; i < n; ++i) { knots[i].x = phis[i]; knots[i].y = rhos[i]; }
+    const int64_t lc = env * e->p.Nc + camera;
+    HIP_TRY(hipMemcpy(e->g.lut_knots_outer + lc * e->g.kmax_outer, knots.data(), sizeof(double2) * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->g.lut_count_outer + lc, &n, sizeof(n), hipMemcpyHostToDevice));
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_soft_coverage(mate_engine *e, const uint32_t *masks_dev, double *matrix_dev, double *scores_dev, void *stream) {
+    if (!e || !masks_dev) return fail(MATE_EINVAL, "null argument");
+    if (!matrix_dev && !scores_dev) return fail(MATE_EINVAL, "soft_coverage: no output buffer");
+    if (e->p.Nc == 0) return fail(MATE_EINVAL, "no cameras in this scenario");
+    if (e->p.Nt > kAuxMaxTargets) return fail(MATE_EINVAL, "soft_coverage: at most %d targets", kAuxMaxTargets);
+    if (!e->g.lut_knots_outer) return fail(MATE_ESTATE, "outer boundary not enabled (mate_engine_enable_outer_boundary)");
+    if (!e->was_reset) return fail(MATE_ESTATE, "soft_coverage called before reset() (or import_state)");
+    HIP_TRY(hipSetDevice(e->device));
+    const int64_t items = e->N * e->p.Nc;
+    hipLaunchKernelGGL(soft_coverage_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const Params *)e->d_params, (const Ptrs)e->g, masks_dev, matrix_dev, scores_dev);
+    HIP_TRY(hipGetLastError());
     return MATE_OK;
 }
 

@@ -342,11 +342,25 @@ class Engine:
         check(fn(self._h, int(env), int(camera), phis.ctypes.data_as(ctypes.c_void_p), rhos.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n)))
         return phis[:n.value].copy(), rhos[:n.value].copy()
 
-    def lut_write(self, env, camera, phis, rhos):
+    def lut_write(self, env, camera, phis, rhos, outer=False):
         phis = np.ascontiguousarray(phis, dtype=np.float64)
         rhos = np.ascontiguousarray(rhos, dtype=np.float64)
-        check(self.lib.mate_engine_lut_write(self._h, int(env), int(camera), phis.ctypes.data_as(ctypes.c_void_p),
-                                             rhos.ctypes.data_as(ctypes.c_void_p), len(phis)))
+        fn = self.lib.mate_engine_lut_write_outer if outer else self.lib.mate_engine_lut_write
+        check(fn(self._h, int(env), int(camera), phis.ctypes.data_as(ctypes.c_void_p), rhos.ctypes.data_as(ctypes.c_void_p), len(phis)))
+
+    def soft_coverage(self, masks=None):
+        """AuxiliaryCameraRewards' soft coverage score of the current state (wrappers/auxiliary_camera_rewards.py:128-139,
+        181-239): (score matrix [N, Nc, Nt], per-camera scores [N, Nc]) f64 on the GPU.  `masks` = packed masks of the
+        step this follows (default: the engine's own output buffer).  Needs enable_outer_boundary() + a reset /
+        rebuild_luts since."""
+        masks = self.masks if masks is None else masks
+        assert masks.dtype == torch.int32 and masks.is_contiguous() and masks.shape == (self.num_envs, self.layout.mask_words)
+        if getattr(self, '_softcov', None) is None:
+            self._softcov = (torch.empty((self.num_envs, self.num_cameras, self.num_targets), dtype=torch.float64, device=self.device),
+                             torch.empty((self.num_envs, self.num_cameras), dtype=torch.float64, device=self.device))
+        matrix, scores = self._softcov
+        check(self.lib.mate_engine_soft_coverage(self._h, masks.data_ptr(), matrix.data_ptr(), scores.data_ptr(), self._stream()))
+        return matrix, scores
 
     def idle_steps(self):
         """(environment, step) slots spent idle waiting for a batched reset since creation."""

@@ -584,13 +584,11 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
         the coverage / transport metrics of the step record, the number of targets each camera tracks and a
         baseline; `reduction` in ('none', 'mean', 'sum', 'max', 'min') shares one value among the cameras.
         Returns a [num_envs, num_cameras] tensor on the GPU (a handful of elementwise ops on the [N, 8] step record
-        and the packed masks: nothing here touches the observation bytes).  `soft_coverage_score` needs the outer
-        occlusion boundary, which this build does not produce."""
+        and the packed masks: nothing here touches the observation bytes).  `soft_coverage_score` (:181-239) is one more
+        small kernel over the outer occlusion boundary, which the engine builds from the first request on."""
         assert set(self.AUXILIARY_REWARD_KEYS).issuperset(coefficients.keys()), (
             f'The coefficient mapping only accepts keys in {self.AUXILIARY_REWARD_KEYS}. Got list(coefficients.keys()) = {list(coefficients.keys())}.')
         assert reduction in ('mean', 'sum', 'max', 'min', 'none'), f'Invalid reduction method {reduction}.'
-        if 'soft_coverage_score' in coefficients:
-            raise NotImplementedError('soft_coverage_score needs Camera.boundary_between(outer=True)')
         s = self.engine.scalars.double()
         N, Nc, Nt = self.num_envs, self.num_cameras, self.num_targets
         bits = torch.arange(Nc * Nt, device=self.device)
@@ -599,6 +597,11 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
         terms = {'raw_reward': s[:, 0:1].expand(N, Nc), 'coverage_rate': s[:, 3:4].expand(N, Nc),
                  'real_coverage_rate': s[:, 4:5].expand(N, Nc), 'mean_transport_rate': s[:, 5:6].expand(N, Nc),
                  'num_tracked': seen.sum(dim=2).double(), 'baseline': torch.ones((N, Nc), dtype=torch.float64, device=self.device)}
+        if 'soft_coverage_score' in coefficients:
+            if not getattr(self.engine, 'outer_capacity', 0):
+                self.engine.enable_outer_boundary()     # built at every reset from now on; once now for the running episodes
+                self.engine.rebuild_luts()
+            terms['soft_coverage_score'] = self.engine.soft_coverage()[1]
         reward = torch.zeros((N, Nc), dtype=torch.float64, device=self.device)
         for key, coefficient in coefficients.items():
             assert isinstance(coefficient, (int, float)), 'only constant coefficients are supported on the batched path'

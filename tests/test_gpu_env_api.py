@@ -169,8 +169,12 @@ def test_auxiliary_camera_rewards_and_wrapper_kwargs():
     assert np.allclose(got, want, rtol=0, atol=1e-12)
     shared = env.auxiliary_camera_rewards(coef, reduction='mean').cpu().numpy()
     assert np.allclose(shared, want.mean(axis=1, keepdims=True).repeat(4, axis=1), atol=1e-12)
-    with pytest.raises(NotImplementedError):
-        env.auxiliary_camera_rewards({'soft_coverage_score': 1.0})
+    soft = env.auxiliary_camera_rewards({'soft_coverage_score': 2.0, 'baseline': 1.0}).cpu().numpy()   # builds the outer tables on first use
+    matrix, scores = (x.cpu().numpy() for x in env.engine.soft_coverage())
+    assert np.allclose(soft, 2.0 * scores + 1.0, atol=1e-12) and np.isfinite(matrix).all()
+    seen = m['camera_target_view_mask']
+    assert ((matrix > 0) == seen)[np.abs(matrix) > 1e-12].all()             # signed by the view mask
+    assert (scores <= 8 + 1e-9).all() and (scores >= -1 - 1e-9).all()         # documented range [-1, Nt]
     with pytest.raises(AssertionError):
         env.auxiliary_camera_rewards({'bogus': 1.0})
     env.close()

@@ -460,3 +460,68 @@ def test_observation_modes_vs_oracle_rollout(config, cam_mode, tgt_mode, oracle_
                 assert np.abs(to[e] - ot).max() < 1e-9, (s, e, 'target rows')
                 if eng.num_cameras:
                     assert np.abs(co[e] - oc).max() < 1e-9, (s, e, 'camera rows')
+
+
+@pytest.mark.parametrize('name', ['softcov_4v8-9_s8', 'softcov_8v8-9_s9', 'softcov_4v2-9_s10'])
+def test_soft_coverage_score_fixtures(name):
+    """AuxiliaryCameraRewards' soft coverage score (mate_engine_soft_coverage) on traces the reference wrapper shaped:
+    score matrix, per-camera scores and shaped rewards, with the reference's own inner and outer tables installed.
+    f64 arithmetic throughout; tolerance 1e-9 relative (last places of sin/cos and hypot vs sqrt)."""
+    fx = G.load(name + '.npz')
+    N = 3
+    eng = U.engine_from_fixture(fx, N, obs_dtype=torch.float32)
+    eng.enable_outer_boundary()
+    for c, (phis, rhos) in enumerate(G.luts_of(fx, outer=True)):
+        for e in range(N):
+            eng.lut_write(e, c, phis, rhos, outer=True)
+    keys, coef, reduction = [str(k) for k in fx['aux_keys']], fx['aux_coefficients'], str(fx['aux_reduction'])
+    for s in range(len(fx['step/done'])):
+        _replay(eng, fx, s, N)
+        matrix, scores = (x.cpu().numpy() for x in eng.soft_coverage())
+        for e in range(N):
+            np.testing.assert_allclose(matrix[e], fx['step/soft_coverage_matrix'][s], rtol=1e-9, atol=1e-9, err_msg=str(s))
+            np.testing.assert_allclose(scores[e], fx['step/soft_coverage_score'][s], rtol=1e-9, atol=1e-9, err_msg=str(s))
+        seen = eng.unpack_masks()['camera_target_view_mask'][1]
+        sc = eng.scalars.double().cpu().numpy()[1]
+        terms = {'raw_reward': sc[0], 'coverage_rate': sc[3], 'real_coverage_rate': sc[4], 'mean_transport_rate': sc[5],
+                 'soft_coverage_score': scores[1], 'num_tracked': seen.sum(axis=1).astype(np.float64), 'baseline': 1.0}
+        shaped = sum(c * terms[k] for k, c in zip(keys, coef)) * np.ones(eng.num_cameras)
+        if reduction != 'none':
+            shaped = np.full_like(shaped, {'mean': np.mean, 'sum': np.sum, 'max': np.max, 'min': np.min}[reduction](shaped))
+        np.testing.assert_allclose(shaped, fx['step/aux_reward_cam'][s], rtol=1e-6, atol=1e-6, err_msg=str(s))   # f32 step record
+
+
+@pytest.mark.parametrize('config,n', [('MATE-4v8-9.yaml', 20), ('MATE-8v8-9.yaml', 10)])
+def test_soft_coverage_vs_oracle_rollout(config, n, oracle_lib):
+    """... and on natively reset batches with the device-built tables, against the oracle's restatement on the same
+    state, view masks and tables, along a random rollout (wide and narrow sectors, sectors across +-180 degrees)."""
+    O = oracle_lib
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config(config)
+    eng = Engine(cfg, n, seed=5, first_env_index=3)
+    eng.enable_outer_boundary()
+    eng.reset()
+    proto = U.oracle_proto_from_config(cfg, O)
+    envs = [O.OracleEnv(eng.num_cameras, eng.num_targets, eng.num_obstacles) for _ in range(n)]
+    tables = [[(eng.lut_read(e, c), eng.lut_read(e, c, outer=True)) for c in range(eng.num_cameras)] for e in range(n)]
+    del proto
+    wrapped = 0
+    for s in range(40):
+        eng.step_random(auto_reset=False, want_masks=True)
+        if s % 8 != 7:
+            continue
+        matrix, scores = (x.cpu().numpy() for x in eng.soft_coverage())
+        sd, masks = eng.state_dict(), eng.unpack_masks()
+        for e in range(n):
+            U.oracle_load_engine_state(envs[e], sd, e, cfg)
+            for c in range(eng.num_cameras):
+                envs[e].set_lut(c, *tables[e][c][0])
+                envs[e].set_lut(c, *tables[e][c][1], outer=True)
+            envs[e].set('camera_target_view_mask', masks['camera_target_view_mask'][e].astype(np.float64))
+            om, osc = envs[e].soft_coverage()
+            np.testing.assert_allclose(matrix[e], om, rtol=1e-9, atol=1e-9, err_msg=str((s, e)))
+            np.testing.assert_allclose(scores[e], osc, rtol=1e-9, atol=1e-9, err_msg=str((s, e)))
+            left = (sd['cam_phi'][e] - sd['cam_theta'][e] / 2 + 180.0) % 360.0 - 180.0
+            wrapped += int((left + sd['cam_theta'][e] > 180.0).sum())
+    assert wrapped > 0        # sectors crossing the +-180 degree seam were part of the check
