@@ -176,7 +176,7 @@ def main():
                 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': measured_traffic() if args.batch == BATCH_PER_GPU and args.workload == WORKLOAD else None,
                 'traffic_unit': 'bytes per launch (rocprofv3 2*FETCH_SIZE + WRITE_SIZE, profiles/latest_pmc.json)',
-                'kernel': 'step_kernel<float, %s>' % ('FixedShape' if eng.specialised else 'AnyShape'), 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches,
+                'kernel': 'step_kernel<float, %s, %s>' % ('FixedShape' if eng.specialised else 'AnyShape', ('FLOW_ANY', 'FLOW_RANDOM', 'FLOW_ACT_F32')[eng.last_flow]), 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches,
                 'algorithmic_bytes_per_launch': b_alg * args.batch,
             },
             'episode_stats': {'mean_target_reward': float(stats[0]), 'mean_coverage_rate': float(stats[1]),

@@ -225,6 +225,12 @@ int mate_engine_idle_steps(mate_engine *engine, int64_t *total);
  * `enable` = k > 0 arms the timer for every k-th step launch from now on, 0 disarms it. */
 int mate_engine_kernel_time(mate_engine *engine, int32_t enable, double *avg_ms, int64_t *launches);
 
+/* Which compilation of the step kernel the last step()/step_random() launch ran: 0 = the generic flow (every launch
+ * switch read on the device), 1 = the on-device random policy flow, 2 = the f32-continuous-actions flow.  1 and 2 are
+ * the same code with the switches folded at compile time (no tapes, no discrete actions, plain observations, all four
+ * outputs present, immediate auto-reset); results are bit-identical.  MATE_FLOW_GENERIC=1 forces 0. */
+int mate_engine_last_flow(const mate_engine *engine);
+
 #ifdef __cplusplus
 }
 #endif

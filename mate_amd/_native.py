@@ -16,7 +16,7 @@ EXPORTED_SYMBOLS = (
     'mate_engine_get_layout', 'mate_engine_set_obs_transform', 'mate_engine_set_obs_mode', 'mate_engine_set_action_grids', 'mate_engine_seed', 'mate_engine_reset', 'mate_engine_step', 'mate_engine_step_random',
     'mate_engine_rollout_random', 'mate_engine_policy_enable', 'mate_engine_step_greedy', 'mate_engine_policy_actions',
     'mate_engine_observe', 'mate_engine_export_state', 'mate_engine_import_state', 'mate_engine_lut_read',
-    'mate_engine_lut_write', 'mate_engine_enable_outer_boundary', 'mate_engine_lut_read_outer', 'mate_engine_lut_write_outer', 'mate_engine_soft_coverage', 'mate_engine_rebuild_luts', 'mate_engine_idle_steps', 'mate_engine_kernel_time',
+    'mate_engine_lut_write', 'mate_engine_enable_outer_boundary', 'mate_engine_lut_read_outer', 'mate_engine_lut_write_outer', 'mate_engine_soft_coverage', 'mate_engine_rebuild_luts', 'mate_engine_idle_steps', 'mate_engine_kernel_time', 'mate_engine_last_flow',
 )
 
 
@@ -115,6 +115,7 @@ def load():
     handle.mate_engine_rebuild_luts.argtypes = [P, P]
     handle.mate_engine_idle_steps.argtypes = [P, ctypes.POINTER(I64)]
     handle.mate_engine_kernel_time.argtypes = [P, I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I64)]
+    handle.mate_engine_last_flow.argtypes = [P]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(handle, name)
         if name not in ('mate_engine_last_error',):

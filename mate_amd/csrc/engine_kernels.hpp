@@ -181,10 +181,21 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Launch-flag specialisation of the step kernel.  A launch carries a dozen wave-uniform switches (policy mode, action
+// type, tapes, observation post-processing, optional outputs); read on demand each costs a scalar load, a wait and a
+// branch on the critical path of every wave.  The two flows every training / benchmark loop runs are compiled with the
+// switches fixed (the host picks the kernel per launch, launch_step in mate_engine.hip); FLOW_ANY reads them all.
+enum Flow : int {
+    FLOW_ANY = 0,
+    FLOW_RANDOM = 1,    // step_random: on-device uniform policy, Philox draws, plain observations, all outputs present
+    FLOW_ACT_F32 = 2,   // step: f32 continuous joint actions, Philox draws, plain observations, all outputs present
+};
+
 template <typename ObsT>
 struct Ctx {
     const Params &p;
     const Ptrs &g;
+    const int flow;               // a compile-time constant of the kernel instantiation (folds once Ctx is scalarised)
     int lane;
     int64_t env;
     int64_t out;                  // row of this environment in the output buffers (env, or step*N + env in rollouts)
@@ -197,8 +208,8 @@ struct Ctx {
     unsigned char *base;
     double *ex, *ey, *er;         // unified entity table [cameras | obstacles | targets]: x, y, radius
 
-    __device__ Ctx(const Params &p_, const Ptrs &g_, unsigned char *wave_base, int lane_, int64_t env_)
-        : p(p_), g(g_), lane(lane_), env(env_), out(env_) {
+    __device__ Ctx(const Params &p_, const Ptrs &g_, unsigned char *wave_base, int lane_, int64_t env_, int flow_ = FLOW_ANY)
+        : p(p_), g(g_), flow(flow_), lane(lane_), env(env_), out(env_) {
         st = reinterpret_cast<double *>(wave_base + p.off_st);
         dy = reinterpret_cast<double *>(wave_base + p.off_dy);
         di = reinterpret_cast<int32_t *>(dy + p.DF);
@@ -210,6 +221,19 @@ struct Ctx {
         base = wave_base;
         ex = reinterpret_cast<double *>(wave_base + p.off_ent); ey = ex + p.NJ; er = ey + p.NJ;
     }
+    // launch switches (constants in the specialised flows)
+    __device__ __forceinline__ int mode() const { return flow == FLOW_RANDOM ? (int)MODE_STEP_RANDOM : flow == FLOW_ACT_F32 ? (int)MODE_STEP : g.mode; }
+    __device__ __forceinline__ int act_f64() const { return flow == FLOW_ACT_F32 ? 0 : g.act_f64; }
+    __device__ __forceinline__ int act_discrete() const { return flow != FLOW_ANY ? 0 : g.act_discrete; }
+    __device__ __forceinline__ const double *tape_ct() const { return flow != FLOW_ANY ? nullptr : g.tape_ct; }
+    __device__ __forceinline__ const double *tape_goal() const { return flow != FLOW_ANY ? nullptr : g.tape_goal; }
+    __device__ __forceinline__ int obs_mode() const { return flow != FLOW_ANY ? 0 : g.obs_mode; }
+    __device__ __forceinline__ const uint2 *xdesc() const { return flow != FLOW_ANY ? nullptr : g.xdesc; }
+    __device__ __forceinline__ bool freeze_done() const { return flow != FLOW_ANY ? false : g.freeze_done != 0; }
+    __device__ __forceinline__ bool has_scratch_init() const { return flow != FLOW_ANY ? true : g.scratch_init != nullptr; }
+    __device__ __forceinline__ bool has_cam_obs() const { return flow != FLOW_ANY ? true : g.cam_obs != nullptr; }
+    __device__ __forceinline__ bool has_tgt_obs() const { return flow != FLOW_ANY ? true : g.tgt_obs != nullptr; }
+    __device__ __forceinline__ bool has_scalars() const { return flow != FLOW_ANY ? true : g.scalars != nullptr; }
     // static record
     __device__ double cam_x(int c) const { return st[c]; }
     __device__ double cam_y(int c) const { return st[p.Nc + c]; }
@@ -262,12 +286,12 @@ __device__ __forceinline__ void set_flag(const Ctx<ObsT> &c, int bit, bool on) {
 // ---------------------------------------------------------------------------------------------
 // record <-> LDS
 template <typename ObsT>
-__device__ void load_records(Ctx<ObsT> &c) {
+__device__ __forceinline__ void load_records(Ctx<ObsT> &c) {
     const double *s = c.g.stat + c.env * c.p.SW;
     const double *d = c.g.dyn + c.env * c.p.DW;
     for (int i = c.lane; i < c.p.SW; i += 64) c.st[i] = s[i];
     for (int i = c.lane; i < c.p.DW; i += 64) c.dy[i] = d[i];
-    if (c.g.scratch_init) {
+    if (c.has_scratch_init()) {
         const ObsT *si = reinterpret_cast<const ObsT *>(c.g.scratch_init);
         for (int i = c.lane; i < c.p.nscratch; i += 64) c.scratch[i] = si[i];
     }
@@ -286,7 +310,7 @@ __device__ __forceinline__ StepDraws load_records_with_draws(Ctx<ObsT> &c, uint3
     const int lane = c.lane;
     const double *s = c.g.stat + c.env * p.SW;
     const double *d = c.g.dyn + c.env * p.DW;
-    const ObsT *si = reinterpret_cast<const ObsT *>(c.g.scratch_init);
+    const ObsT *si = c.has_scratch_init() ? reinterpret_cast<const ObsT *>(c.g.scratch_init) : nullptr;
     double s0 = s[lane < p.SW ? lane : 0], d0 = d[lane < p.DW ? lane : 0], s1 = 0.0, d1 = 0.0;
     if (p.SW > 64) s1 = s[lane + 64 < p.SW ? lane + 64 : 0];
     if (p.DW > 64) d1 = d[lane + 64 < p.DW ? lane + 64 : 0];
@@ -316,7 +340,7 @@ __device__ __forceinline__ StepDraws load_records_with_draws(Ctx<ObsT> &c, uint3
 
 // unified entity table (after the records are visible in LDS)
 template <typename ObsT>
-__device__ void build_entities(Ctx<ObsT> &c) {
+__device__ __forceinline__ void build_entities(Ctx<ObsT> &c) {
     const Params &p = c.p;
     for (int j = c.lane; j < p.NJ; j += 64) {
         double x, y, r;
@@ -328,7 +352,7 @@ __device__ void build_entities(Ctx<ObsT> &c) {
 }
 
 template <typename ObsT>
-__device__ void store_dynamic(Ctx<ObsT> &c) {
+__device__ __forceinline__ void store_dynamic(Ctx<ObsT> &c) {
     double *d = c.g.dyn + c.env * c.p.DW;
     for (int i = c.lane; i < c.p.DW; i += 64) d[i] = c.dy[i];
 }
@@ -338,13 +362,13 @@ __device__ void store_dynamic(Ctx<ObsT> &c) {
 // actions, [Nc, Nc+Nt) target actions, the remaining lanes pre-draw the see-through uniforms of the
 // first camera->target pairs (cheaper than a second divergent Philox in the visibility phase).
 template <typename ObsT>
-__device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick) {
+__device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick) {
     const Params &p = c.p;
     const int lane = c.lane;
     StepDraws d{0.0, 0.0};
     const int nact = p.Nc + p.Nt;
-    const bool random_policy = c.g.mode == MODE_STEP_RANDOM;
-    const bool need_draws = !c.g.tape_ct && p.Nc > 0;
+    const bool random_policy = c.mode() == MODE_STEP_RANDOM;
+    const bool need_draws = !c.tape_ct() && p.Nc > 0;
     uint32_t stream = 0, sub = 0;
     bool active = false;
     if (lane < p.Nc) { stream = S_ACT_CAM; sub = (uint32_t)lane; active = random_policy; }
@@ -361,20 +385,20 @@ __device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick) {
 
 // Phase A: kinematics.  Camera.simulate (entities.py:347-360), Target.simulate (entities.py:645-668).
 template <typename ObsT>
-__device__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &draws, bool advance) {
+__device__ __forceinline__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &draws, bool advance) {
     const Params &p = c.p;
     const int lane = c.lane;
     if (lane < p.Nc) {
         double ph = c.phi(lane), th = c.theta(lane);
         if (advance) {
             double da, dz;
-            if (c.g.mode == MODE_STEP_RANDOM) { da = draws.a0; dz = draws.a1; }
-            else if (c.g.act_discrete & 1) {                 // DiscreteCamera.action, discrete_action_spaces.py:71-73
+            if (c.mode() == MODE_STEP_RANDOM) { da = draws.a0; dz = draws.a1; }
+            else if (c.act_discrete() & 1) {                 // DiscreteCamera.action, discrete_action_spaces.py:71-73
                 int idx = reinterpret_cast<const int32_t *>(c.g.cam_act)[c.env * p.Nc + lane];
                 idx = idx < 0 ? 0 : (idx >= c.g.n_cam_grid ? c.g.n_cam_grid - 1 : idx);
                 const double2 gxy = c.g.cam_grid[idx];
                 da = p.rot * gxy.x; dz = p.zoom * gxy.y;
-            } else if (c.g.act_f64) {
+            } else if (c.act_f64()) {
                 const double *a = reinterpret_cast<const double *>(c.g.cam_act) + (c.env * p.Nc + lane) * 2;
                 da = a[0]; dz = a[1];
             } else {
@@ -403,7 +427,7 @@ __device__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &draws, bool adva
 // order.  A hit never lengthens the step (|v'|^2 = |v|^2 - a s^2 (2|v| - a) <= |v|^2 for penetration a and
 // s = half_chord/r), so a circle out of reach of the original step stays out of reach.
 template <typename ObsT>
-__device__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws) {
+__device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws) {
     const Params &p = c.p;
     const int lane = c.lane;
     const int t = lane - p.Nc;
@@ -411,14 +435,14 @@ __device__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws) {
     double ox = 0.0, oy = 0.0, vx = 0.0, vy = 0.0, n = 0.0, desx = 0.0, desy = 0.0;
     if (is_target) {
         double ax, ay;
-        if (c.g.mode == MODE_STEP_RANDOM) { ax = draws.a0; ay = draws.a1; }
-        else if (c.g.act_discrete & 2) {                     // DiscreteTarget.action, discrete_action_spaces.py:177-179
+        if (c.mode() == MODE_STEP_RANDOM) { ax = draws.a0; ay = draws.a1; }
+        else if (c.act_discrete() & 2) {                     // DiscreteTarget.action, discrete_action_spaces.py:177-179
             int idx = reinterpret_cast<const int32_t *>(c.g.tgt_act)[c.env * p.Nt + t];
             idx = idx < 0 ? 0 : (idx >= c.g.n_tgt_grid ? c.g.n_tgt_grid - 1 : idx);
             const double2 gxy = c.g.tgt_grid[idx];
             const double high = ((c.capword() >> t) & 1ull) ? p.tgt_step * 0.5 : p.tgt_step;
             ax = high * gxy.x; ay = high * gxy.y;
-        } else if (c.g.act_f64) {
+        } else if (c.act_f64()) {
             const double *a = reinterpret_cast<const double *>(c.g.tgt_act) + (c.env * p.Nt + t) * 2;
             ax = a[0]; ay = a[1];
         } else {
@@ -569,7 +593,7 @@ __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t 
     if (is_target) {                                                               // np_random.binomial(1, tau), entities.py:503
         const int pair = cam * p.Nt + other;
         double u;
-        if (c.g.tape_ct) u = c.g.tape_ct[c.env * p.Nc * p.Nt + pair];
+        if (c.tape_ct()) u = c.tape_ct()[c.env * p.Nc * p.Nt + pair];
         else if (predrawn && pair < 64 - p.Nc - p.Nt) u = c.udraw(pair);
         else u = c.draw(tick, stream, (uint32_t)pair);
         if ((p.tau <= 0.5) ? (u > 1.0 - p.tau) : (u <= p.tau)) { e.seen = true; return e; }
@@ -612,7 +636,7 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorE
 }
 
 template <typename ObsT>
-__device__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn) {
+__device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn) {
     const Params &p = c.p;
     const int lane = c.lane;
     double2 w[kDegSlots];
@@ -705,7 +729,7 @@ __device__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool p
 
 // Phase C: _assign_goals + the bookkeeping of step() (environment.py:1271-1324, 613-632).
 template <typename ObsT>
-__device__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out) {
+__device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out) {
     const Params &p = c.p;
     const int lane = c.lane;
     bool penal = false;
@@ -749,7 +773,7 @@ __device__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out
                     int k = 0;
                     for (int gq = 0; gq < 4; ++gq) k += row[gq] > 0;
                     if (k > 0) {                                // environment.py:1302-1315
-                        const double u = c.g.tape_goal ? c.g.tape_goal[c.env * p.Nt + t] : c.draw(tick, S_GOAL, (uint32_t)t);
+                        const double u = c.tape_goal() ? c.tape_goal()[c.env * p.Nt + t] : c.draw(tick, S_GOAL, (uint32_t)t);
                         int j = (int)(u * (double)k);
                         if (j >= k) j = k - 1;
                         int new_goal = 0;
@@ -802,7 +826,7 @@ __device__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out
         const int done = !(ep_step <= p.max_episode_steps && awaiting);
         c.ei(EI_DONE) = done;
         c.ei(EI_TICK) = (int)(tick + 1u);
-        if (scalars_out) {
+        if (c.has_scalars() && scalars_out) {
             float *o = scalars_out + c.out * 8;
             o[0] = (float)(-r); o[1] = (float)r; o[2] = (float)done; o[3] = (float)coverage;
             o[4] = (float)real_cov; o[5] = (float)transport; o[6] = (float)delivered; o[7] = (float)div_nz(r, p.max_team_reward);
@@ -817,7 +841,7 @@ __device__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out
 
 // metrics only (after reset / observe): no counters advance
 template <typename ObsT>
-__device__ void score_only(Ctx<ObsT> &c, float *scalars_out) {
+__device__ __forceinline__ void score_only(Ctx<ObsT> &c, float *scalars_out) {
     const Params &p = c.p;
     bool with_bounty = false, tr = false;
     if (c.lane < p.Nt) { with_bounty = c.ti(c.lane, TI_BOUNTY) > 0; tr = c.tracked(c.lane) != 0; }
@@ -837,10 +861,10 @@ __device__ void score_only(Ctx<ObsT> &c, float *scalars_out) {
 // ---------------------------------------------------------------------------------------------
 // Phase D: joint_observation (environment.py:908-964): fill the per-environment scratch, then gather.
 template <typename ObsT>
-__device__ void fill_scratch(Ctx<ObsT> &c) {
+__device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c) {
     const Params &p = c.p;
     const int lane = c.lane;
-    const int tgt_mode = (c.g.obs_mode >> 2) & 3;
+    const int tgt_mode = (c.obs_mode() >> 2) & 3;
     if (lane < p.Nt) {                        // Target.state(private=True), entities.py:631-637
         ObsT *sc = c.scratch + p.sc_tgt + lane * 14;
         const int gw = c.ti(lane, TI_GW);
@@ -871,7 +895,7 @@ __device__ void fill_scratch(Ctx<ObsT> &c) {
     }
     // SharedFieldOfView: an entity is visible to the whole team when any member sees it
     // (shared_field_of_view.py:97-100, 117-120); flags live behind the mask flags, see build_descriptors
-    if ((c.g.obs_mode & 3) == 2) {
+    if ((c.obs_mode() & 3) == 2) {
         if (lane < p.Nt) set_flag(c, p.bit_shared + lane, c.tracked(lane) != 0);
         for (int o = lane; o < p.No; o += 64) {
             bool any = false;
@@ -907,7 +931,7 @@ __device__ __forceinline__ ObsT gather_one(const Ctx<ObsT> &c, uint32_t d) {
 }
 
 template <typename ObsT>
-__device__ void pack_block(const Ctx<ObsT> &c, ObsT *dst, const uint32_t *table, int elems) {
+__device__ __forceinline__ void pack_block(const Ctx<ObsT> &c, ObsT *dst, const uint32_t *table, int elems) {
     constexpr int W = Vec<ObsT>::W;
     using V = typename Vec<ObsT>::type;
     if ((elems % W) == 0) {                       // row block is 16-byte aligned for every environment
@@ -955,7 +979,7 @@ __device__ void pack_block(const Ctx<ObsT> &c, ObsT *dst, const uint32_t *table,
 // Fused observation post-processing (RelativeCoordinates = agents/utils.py:40-94, RescaledObservation =
 // agents/utils.py:97-137 of the reference): out = ((value - own coordinate) if visible else 0) * scale + bias.
 template <typename ObsT>
-__device__ void pack_block_xf(const Ctx<ObsT> &c, ObsT *dst, const uint2 *xdesc, const ObsT *xab, int elems) {
+__device__ __forceinline__ void pack_block_xf(const Ctx<ObsT> &c, ObsT *dst, const uint2 *xdesc, const ObsT *xab, int elems) {
     using U = typename Bits<ObsT>::type;
     for (int i = c.lane; i < elems; i += 64) {
         const uint2 d = xdesc[i];
@@ -1007,21 +1031,21 @@ __device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT> &c) {
 }
 
 template <typename ObsT>
-__device__ void pack_observations(Ctx<ObsT> &c) {
+__device__ __forceinline__ void pack_observations(Ctx<ObsT> &c) {
     const Params &p = c.p;
-    if (c.g.xdesc) {
+    if (c.xdesc()) {
         const ObsT *xab = reinterpret_cast<const ObsT *>(c.g.xab);
-        if (c.g.cam_obs && p.cam_elems > 0)
+        if (c.has_cam_obs() && p.cam_elems > 0)
             pack_block_xf<ObsT>(c, reinterpret_cast<ObsT *>(c.g.cam_obs) + c.out * p.cam_elems, c.g.xdesc, xab, p.cam_elems);
-        if (c.g.tgt_obs)
+        if (c.has_tgt_obs())
             pack_block_xf<ObsT>(c, reinterpret_cast<ObsT *>(c.g.tgt_obs) + c.out * p.tgt_elems, c.g.xdesc + p.tgt_table_off,
                                 xab + 2 * p.tgt_table_off, p.tgt_elems);
-    } else if (sizeof(ObsT) == 4 && (p.cam_elems % 4) == 0 && (p.tgt_elems % 4) == 0 && c.g.tgt_obs && (c.g.cam_obs || p.cam_elems == 0)) {
+    } else if (sizeof(ObsT) == 4 && (p.cam_elems % 4) == 0 && (p.tgt_elems % 4) == 0 && c.has_tgt_obs() && (c.has_cam_obs() || p.cam_elems == 0)) {
         pack_rows_f32(c);
     } else {
-    if (c.g.cam_obs && p.cam_elems > 0)
+    if (c.has_cam_obs() && p.cam_elems > 0)
         pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.cam_obs) + c.out * p.cam_elems, c.table, p.cam_elems);
-    if (c.g.tgt_obs)
+    if (c.has_tgt_obs())
         pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.tgt_obs) + c.out * p.tgt_elems, c.table + p.tgt_table_off, p.tgt_elems);
     }
     if (c.g.masks) {
@@ -1037,7 +1061,7 @@ __device__ void pack_observations(Ctx<ObsT> &c) {
 
 // =============================================================================================
 // The step kernel: one wave per environment, 4 environments per workgroup.
-template <typename ObsT, typename Shape>
+template <typename ObsT, typename Shape, int FLOW = FLOW_ANY>
 __global__ __launch_bounds__(256, 4) __attribute__((amdgpu_num_sgpr(96)))   // above 96 SGPRs a SIMD holds 7 waves instead of 8
 void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     const Shape shape(pp);
@@ -1057,7 +1081,7 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     // kernel: with the scenario constants that was more than the 96 SGPRs a wave may hold at full occupancy.
     const Ptrs &gk = kernarg_ptrs(g);
     // the four waves of a workgroup never synchronise: each owns one environment and its LDS slice
-    Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env);
+    Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
 #ifdef MATE_PHASE_CLOCKS
     if (lane == 0 && g.phase_clocks) {
         g.phase_clocks[env * 16 + 0] = t_begin;
@@ -1074,7 +1098,8 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
 #define SKIP(bit) false
 #endif
     const StepDraws draws = load_records_with_draws(c, tick, !SKIP(1));
-    if (g.freeze_done && g.mode != MODE_OBSERVE) {
+    const int mode = c.mode();
+    if (c.freeze_done() && mode != MODE_OBSERVE) {
         wave_sync();
         if (c.ei(EI_DONE) != 0) {     // waiting for the next batched reset: no step, no new observation
             if (lane == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; }
@@ -1088,16 +1113,16 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     PHASE_STAMP(2);
     phase_prio(g.stagger, 1);
     SUB_STAMP(c, 9);
-    if (!SKIP(2)) simulate_cameras(c, draws, g.mode != MODE_OBSERVE);
+    if (!SKIP(2)) simulate_cameras(c, draws, mode != MODE_OBSERVE);
     SUB_STAMP(c, 12);
-    if (g.mode != MODE_OBSERVE && !SKIP(4)) simulate_targets(c, draws);
+    if (mode != MODE_OBSERVE && !SKIP(4)) simulate_targets(c, draws);
     else wave_sync();
     PHASE_STAMP(3);
     phase_prio(g.stagger, 2);
     if (!SKIP(8)) update_view(c, tick, S_TRANSMIT, true);
     PHASE_STAMP(4);
     phase_prio(g.stagger, 3);
-    if (g.mode == MODE_OBSERVE) score_only(c, g.scalars);
+    if (mode == MODE_OBSERVE) score_only(c, g.scalars);
     else if (!SKIP(32)) assign_and_score(c, tick, g.scalars);
     PHASE_STAMP(5);
     if (!SKIP(64)) fill_scratch(c);
@@ -1105,7 +1130,7 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     phase_prio(g.stagger, 4);
     if (!SKIP(128)) pack_observations(c);
     PHASE_STAMP(7);
-    if (g.mode != MODE_OBSERVE) store_dynamic(c);
+    if (mode != MODE_OBSERVE) store_dynamic(c);
     PHASE_STAMP(8);
 }
 

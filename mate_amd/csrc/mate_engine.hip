@@ -42,6 +42,8 @@ using PolicyFn = void (*)(const Params *, const Ptrs, const PolicyPtrs);
 // shapes of the reference's shipped scenarios (mate/assets/*.yaml); any other shape runs the generic kernel.
 #define MATE_SHAPES(X) X(4, 8, 9) X(4, 2, 9) X(8, 8, 9) X(4, 8, 0) X(0, 8, 32)
 
+// step[flow]: the launch-flag specialisations (enum Flow) exist for f32 observations, the product path; f64
+// observations (the parity mirror) run the generic flow everywhere.
 static void pick_kernels(int Nc, int Nt, int No, bool f64, StepFn *step, StepFn *rollout, PolicyFn *policy, int *specialised) {
     const char *gen = getenv("MATE_GENERIC");
     *specialised = 0;
@@ -49,7 +51,9 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, StepFn *step, StepFn 
 #define X(C, T, O)                                                                                                  \
     if (Nc == C && Nt == T && No == O) {                                                                            \
         *specialised = 1;                                                                                           \
-        *step = f64 ? (StepFn)step_kernel<double, FixedShape<C, T, O, true>> : (StepFn)step_kernel<float, FixedShape<C, T, O, false>>;          \
+        step[FLOW_ANY] = f64 ? (StepFn)step_kernel<double, FixedShape<C, T, O, true>> : (StepFn)step_kernel<float, FixedShape<C, T, O, false>>;   \
+        step[FLOW_RANDOM] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                            \
+        step[FLOW_ACT_F32] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, FixedShape<C, T, O, false>, FLOW_ACT_F32>;                          \
         *rollout = f64 ? (StepFn)rollout_kernel<double, FixedShape<C, T, O, true>> : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>>; \
         *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, FixedShape<C, T, O, true>> : (PolicyFn)greedy_policy_kernel<float, FixedShape<C, T, O, false>>; \
         return;                                                                                                     \
@@ -57,7 +61,9 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, StepFn *step, StepFn 
         MATE_SHAPES(X)
 #undef X
     }
-    *step = f64 ? (StepFn)step_kernel<double, AnyShape> : (StepFn)step_kernel<float, AnyShape>;
+    step[FLOW_ANY] = f64 ? (StepFn)step_kernel<double, AnyShape> : (StepFn)step_kernel<float, AnyShape>;
+    step[FLOW_RANDOM] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, AnyShape, FLOW_RANDOM>;
+    step[FLOW_ACT_F32] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, AnyShape, FLOW_ACT_F32>;
     *rollout = f64 ? (StepFn)rollout_kernel<double, AnyShape> : (StepFn)rollout_kernel<float, AnyShape>;
     *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, AnyShape> : (PolicyFn)greedy_policy_kernel<float, AnyShape>;
 }
@@ -76,7 +82,9 @@ struct mate_engine {
     bool was_reset = false;
     size_t step_lds = 0, reset_lds = 0;
     PolicyFn policy_fn = nullptr;
-    StepFn step_fn = nullptr, rollout_fn = nullptr;   // kernels chosen at create: shape-specialised when compiled for these counts
+    StepFn step_fn[3] = {nullptr, nullptr, nullptr}, rollout_fn = nullptr;   // kernels chosen at create: shape-specialised when compiled for these counts; step_fn[flow]
+    int last_flow = 0;
+    bool flow_generic = false;                        // MATE_FLOW_GENERIC=1: every launch runs the FLOW_ANY kernel (tests)
     int specialised = 0;
     std::vector<void *> allocs;
     // on-device rule-based policies (mate_engine_step_greedy)
@@ -230,7 +238,8 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     p.obs_r_lo = cfg->obstacle_radius_range[0]; p.obs_r_hi = cfg->obstacle_radius_range[1];
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.first_env = (uint32_t)first_env_index;
     e->step_lds = 4 * (size_t)p.lds_wave_bytes;
-    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, &e->step_fn, &e->rollout_fn, &e->policy_fn, &e->specialised);
+    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->step_fn, &e->rollout_fn, &e->policy_fn, &e->specialised);
+    { const char *fg = getenv("MATE_FLOW_GENERIC"); e->flow_generic = fg && atoi(fg) != 0; }
     if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }
     ResetLds &rl = e->rl;
     rl.sort_cap = std::max(512, next_pow2(Nc > 0 ? 360 + No * 185 + 1 : 1));
@@ -313,7 +322,9 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     if (rc == MATE_OK && hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice) != hipSuccess) rc = fail(MATE_EHIP, "params upload failed");
     if (rc == MATE_OK) {
         // opt in to large dynamic LDS
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->step_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+        hipError_t err = hipSuccess;
+        for (int f = 0; f < 3 && err == hipSuccess; ++f)
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->step_fn[f]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
         if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rollout_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
         if (err != hipSuccess) {
         } else if (p.obs_f64) {
@@ -556,7 +567,15 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     }
     // start/stop events attached to the dispatch itself (hipExtLaunchKernelGGL): the elapsed time is the
     // kernel's own begin->end, without the marker-packet latency separate hipEventRecord calls would add
-    hipExtLaunchKernelGGL(e->step_fn, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
+    // the kernel compiled for this launch's switches (enum Flow), when they are the common ones
+    int flow = FLOW_ANY;
+    if (!e->flow_generic && !g.tape_ct && !g.tape_goal && !g.act_discrete && g.obs_mode == 0 && !g.xdesc && !g.xab && !g.freeze_done &&
+        g.scratch_init && (g.cam_obs || e->p.Nc == 0) && g.tgt_obs && g.scalars) {
+        if (mode == MODE_STEP_RANDOM) flow = FLOW_RANDOM;
+        else if (mode == MODE_STEP && !g.act_f64) flow = FLOW_ACT_F32;
+    }
+    e->last_flow = flow;
+    hipExtLaunchKernelGGL(e->step_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
     HIP_TRY(hipGetLastError());
     if (mode != MODE_OBSERVE) e->tick += 1;
     if (mode != MODE_OBSERVE && auto_reset == 1) {
@@ -876,6 +895,8 @@ extern "C" int mate_engine_idle_steps(mate_engine *e, int64_t *total) {
     *total = sum;
     return MATE_OK;
 }
+
+extern "C" int mate_engine_last_flow(const mate_engine *e) { return e ? e->last_flow : MATE_EINVAL; }
 
 extern "C" int mate_engine_kernel_time(mate_engine *e, int32_t enable, double *avg_ms, int64_t *launches) {
     if (!e) return fail(MATE_EINVAL, "null engine");

@@ -42,7 +42,7 @@ __device__ __forceinline__ int pick_goal(const int32_t *row, double u) {  // np_
 
 // R1: runs on ONE lane; all state lives in the wave context's LDS records.
 template <typename ObsT>
-__device__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][cap] x y r sight iscam */, int placed_cap) {
+__device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][cap] x y r sight iscam */, int placed_cap) {
     const Params &p = c.p;
     const int Nc = p.Nc, Nt = p.Nt, No = p.No;
     const uint32_t episode = (uint32_t)c.ei(EI_EPISODE) + 1u;
@@ -186,7 +186,7 @@ __device__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][cap] x y r sight
 
 // R2: occlusion table of camera `cam` by the whole workgroup.
 template <typename ObsT>
-__device__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, double *okeys, double *ovals, uint16_t *lbucket,
+__device__ __forceinline__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, double *okeys, double *ovals, uint16_t *lbucket,
                           double *meta, int32_t *scan, int sort_cap, bool outer = false) {
     const Params &p = c.p;
     const int tid = threadIdx.x, nthreads = blockDim.x;

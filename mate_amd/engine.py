@@ -375,6 +375,11 @@ class Engine:
         check(self.lib.mate_engine_kernel_time(self._h, int(enable), ctypes.byref(avg), ctypes.byref(n)))
         return avg.value, n.value
 
+    @property
+    def last_flow(self):
+        """Compilation of the step kernel the last launch ran: 0 generic, 1 random-policy flow, 2 f32-actions flow."""
+        return int(self.lib.mate_engine_last_flow(self._h))
+
     # decoded masks ------------------------------------------------------------
     def unpack_masks(self, masks=None):
         """Packed u32 words -> dict of boolean numpy arrays [N, ...] (environment.py:475-494 names)."""

@@ -283,6 +283,49 @@ def test_shape_specialised_kernel_equals_generic(workload, monkeypatch):
             assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
 
 
+@pytest.mark.parametrize('workload,generic_shape', [('MATE-4v8-9.yaml', '0'), ('MATE-4v8-9.yaml', '1'), ('MATE-Navigation.yaml', '0'), ('MATE-8v8-9.yaml', '0')])
+@pytest.mark.parametrize('policy', ['random', 'actions'])
+def test_flow_specialised_kernel_equals_generic(workload, generic_shape, policy, monkeypatch):
+    """The step kernels compiled with the launch switches folded (Flow: on-device random policy / f32 joint actions)
+    and the generic flow (MATE_FLOW_GENERIC=1) are the same code: every output and the state must be bit-identical,
+    and a launch outside the folded switches (a tape, masks-only outputs, f64 actions) must fall back to the generic flow."""
+    import torch
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    monkeypatch.setenv('MATE_GENERIC', generic_shape)
+    outs = []
+    for generic in ('0', '1'):
+        monkeypatch.setenv('MATE_FLOW_GENERIC', generic)
+        eng = Engine(read_config(workload), 64, seed=13)
+        eng.reset()
+        gen = torch.Generator(device='cpu').manual_seed(5)
+        rec = []
+        for _ in range(40):
+            if policy == 'random':
+                eng.step_random(auto_reset=True, want_masks=True)
+            else:
+                ca = ((torch.rand((64, eng.num_cameras, 2), generator=gen) * 2 - 1) * 6).cuda()
+                ta = ((torch.rand((64, eng.num_targets, 2), generator=gen) * 2 - 1) * 25).cuda()
+                eng.step(ca, ta, auto_reset=True)
+            assert eng.last_flow == (0 if generic == '1' else (1 if policy == 'random' else 2))
+            rec.append([t.clone() for t in (getattr(eng, 'camera_obs', None), eng.target_obs, eng.scalars, eng.masks) if t is not None])
+        rec.append([eng.export_state().clone()])
+        outs.append(rec)
+        if generic == '0':      # launches the folded flows do not cover
+            ta = torch.zeros((64, eng.num_targets, 2), dtype=torch.float64, device='cuda')
+            ca = torch.zeros((64, eng.num_cameras, 2), dtype=torch.float64, device='cuda')
+            eng.step(ca, ta, auto_reset=False)
+            assert eng.last_flow == 0
+            eng.step(ca.float(), ta.float(), tape_goal=torch.zeros((64, eng.num_targets), dtype=torch.float64, device='cuda'), auto_reset=False)
+            assert eng.last_flow == 0
+            eng.step_random(auto_reset=4)
+            assert eng.last_flow == 0
+        del eng
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+
+
 def _replay(eng, fx, s, N, cam=None, tgt=None):
     Nc, Nt, dev = eng.num_cameras, eng.num_targets, eng.device
     ca = cam if cam is not None else torch.from_numpy(np.broadcast_to(fx['step/cam_act'][s], (N, Nc, 2)).copy()).to(dev)

@@ -139,3 +139,22 @@ def test_export_layout_is_dense():
         assert off == pos
         pos += n
     assert pos == width == 242
+
+
+def test_kernels_need_no_scratch_and_keep_full_occupancy():
+    """The compiler's resource report of every kernel in the library (written by mate_amd/build.py): no private scratch
+    memory anywhere (a kernel with scratch costs ~5 us more per launch, a third of the headline step), and the step
+    kernels stay inside the register budget of 8 waves per SIMD (<= 96 SGPRs, <= 64 VGPRs, no spills)."""
+    import json
+    from mate_amd import build
+    build.build_engine()
+    if not os.path.exists(build.RESOURCES):      # library built before the report existed
+        build.build_engine(force=True)
+    with open(build.RESOURCES) as f:
+        kernels = json.load(f)
+    step = {k: r for k, r in kernels.items() if 'step_kernel' in k}
+    assert len(step) >= 24 and any('soft_coverage' in k for k in kernels) and any('greedy_policy' in k for k in kernels)
+    for name, r in kernels.items():
+        assert r['ScratchSize'] == 0 and r['Dynamic Stack'] == 'False', name
+    for name, r in step.items():
+        assert r['TotalSGPRs'] <= 96 and r['VGPRs'] <= 64 and r['SGPRs Spill'] == 0 and r['VGPRs Spill'] == 0 and r['Occupancy'] == 8, (name, r)
