@@ -1069,6 +1069,7 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     extern __shared__ __align__(16) unsigned char smem[];
 #ifdef MATE_PHASE_CLOCKS
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
+    const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();   // constant 100 MHz: calibrates the s_memtime ticks
 #endif
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;  // next step's counter
     // wave-uniform by construction; readfirstlane lets the compiler keep everything derived from it in SGPRs
@@ -1085,9 +1086,6 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
 #ifdef MATE_PHASE_CLOCKS
     if (lane == 0 && g.phase_clocks) {
         g.phase_clocks[env * 16 + 0] = t_begin;
-        uint32_t hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        g.phase_clocks[env * 16 + 15] = (long long)hwid;
     }
 #endif
     PHASE_STAMP(1);
@@ -1132,6 +1130,9 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     PHASE_STAMP(7);
     if (mode != MODE_OBSERVE) store_dynamic(c);
     PHASE_STAMP(8);
+#ifdef MATE_PHASE_CLOCKS
+    if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
+#endif
 }
 
 // =============================================================================================

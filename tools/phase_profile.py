@@ -31,11 +31,23 @@ for _ in range(reps):
     t = buf.cpu().numpy().astype(np.float64)
     acc += np.diff(t[:, :9], axis=1).mean(axis=0)
     spans.append((t[:, 8].max() - t[:, 0].min(), (t[:, 8] - t[:, 0]).mean()))
+    starts = t[:, 0] - t[:, 0].min()
+    ends = t[:, 8].max() - t[:, 8]
 acc /= reps
-print('s_memtime ticks (100 MHz constant clock on gfx9: 1 tick = 10 ns)')
+print('s_memtime ticks')
 for n, v in zip(names, acc):
-    print(f'  {n:12s} {v:9.1f} ticks  {v * 10 / 1000:7.2f} us')
-print('  per-wave total %.2f us; kernel span first-start..last-end %.2f us' % (np.mean([s[1] for s in spans]) / 100, np.mean([s[0] for s in spans]) / 100))
+    print(f'  {n:12s} {v:9.1f}')
+print('  per-wave total %.0f cycles; kernel span first-start..last-end %.0f cycles' % (np.mean([s[1] for s in spans]), np.mean([s[0] for s in spans])))
+# every XCD counts its own clock: compare start / end times only inside one XCD (clusters of start stamps)
+order = np.argsort(t[:, 0])
+gaps = np.where(np.diff(t[order, 0]) > 1e6)[0]
+groups = np.split(order, gaps + 1)
+print('  %d clock domains (XCDs)' % len(groups))
+for grp in groups:
+    st, en = t[grp, 0] - t[grp, 0].min(), t[grp, 8] - t[grp, 0].min()
+    print('   waves %4d  start p50/p90/max %s  end p50/p90/max %s' % (len(grp), np.percentile(st, [50, 90, 100]).round(0), np.percentile(en, [50, 90, 100]).round(0)))
+kt = eng.kernel_time(0)
+
 
 
 t = buf.cpu().numpy().astype(np.float64)
@@ -45,6 +57,7 @@ for i, n in enumerate(names):
     print(f'  {n:12s}', np.percentile(d[:, i], [50, 90, 99, 100]).round(0))
 life = t[:, 8] - t[:, 0]
 print('  wave life   ', np.percentile(life, [50, 90, 99, 100]).round(0))
+print('  s_memtime ticks per microsecond (against the 100 MHz s_memrealtime over every wave): %.0f' % (life.sum() / (t[:, 15].sum() / 100.0)))
 slow = np.argsort(life)[-5:]
 for e in slow:
     print('  slow env', e, d[e].round(0))
