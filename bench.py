@@ -8,14 +8,23 @@
 One "step" = one `step()` of every environment of the batch (BASELINE.json config[1]:
 MATE-4v8-9.yaml, 4096 environments per GPU, uniform random policy generated on-device by the
 engine's Philox streams, auto-reset of finished episodes inside the timed loop).  State,
-actions and observations are resident in HBM for the whole timed region.  For N > 1 the
+actions and observations are resident in HBM for the whole timed region.  With the random
+policy the K timed steps run as fused `--rollout R`-step launches (default 32: rollout_kernel
+keeps an environment's records in LDS across the R steps and writes every step's observations,
+rewards and masks to [R][N][...] buffers; an environment whose episode ends inside a rollout
+idles until the reset launch that follows it, and those idle slots are NOT counted in `value`);
+`--rollout 0` launches step_kernel once per step, and the default run reports that mode too
+(`per_step_launch`).  For N > 1 the
 batch is sharded (4096 environments per rank, env index = rank * 4096 + i; no data-path
 collective); RCCL only all-gathers the episode statistics after the timed region.
 
 Rank 0 prints ONE JSON line (see the driver contract).  Extra objects:
-  roofline      HBM roofline of the dominant kernel (step_kernel): algorithmic bytes per launch
-                (7504 B/env-step x 4096) / average launch duration measured with
-                HIP events on the launch stream over the timed region.
+  roofline      HBM roofline of the dominant kernel (rollout_kernel, or step_kernel with --rollout 0):
+                algorithmic bytes per launch (7504 B/env-step x the env-steps of one
+                launch) / average launch duration measured with HIP events on the launch stream over
+                the timed region.  `achieved_resident` / `frac_resident` price a rollout launch at the
+                bytes it must really move (R observation sets, ONE state round trip and one geometry
+                read per environment) -- the stricter figure.
   cpu_baseline  the CPU oracle (oracle/, a parity-checked port of the reference's step path)
                 stepping + packing f32 observations for the same workload on the host cores.
 """
@@ -40,15 +49,15 @@ def algorithmic_bytes(Nc, Nt, No):
     return 4 * (Nc * Dc + Nt * Dt) + 8 * (Nc + Nt) + 2 * (16 * Nc + 35 * Nt + 72) + (24 * Nc + 24 * No + Nt) + 48
 
 
-def measured_traffic():
-    """HBM bytes per step_kernel launch from the committed rocprofv3 PMC summary (separate --pmc passes, counters in
+def measured_traffic(kernel='step_kernel'):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc passes, counters in
     KiB; see profiles/README.md).  gfx950 correction per the microarchitecture guide and this repo's own calibration
     (tools/pmc_calibrate.py: a 256 MiB copy reports WRITE_SIZE 256.0 MiB and FETCH_SIZE 128.0 MiB): WRITE_SIZE is
     exact, FETCH_SIZE counts half of the bytes read and is doubled.  None when no profile is present."""
     path = os.path.join(ROOT, 'profiles', 'latest_pmc.json')
     try:
         with open(path) as fh:
-            k = json.load(fh)['step_kernel']
+            k = json.load(fh)[kernel]
         return (2.0 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
     except Exception:
         return None
@@ -105,6 +114,7 @@ def main():
     ap.add_argument('--policy', choices=['random', 'greedy'], default='random',
                     help='on-device policy: uniform random (headline) or GreedyCamera vs GreedyTarget (BASELINE config 3)')
     ap.add_argument('--reset-interval', type=int, default=32, help='greedy policy: batched auto-reset every k steps (1 = immediate)')
+    ap.add_argument('--rollout', type=int, default=32, help='random policy: steps fused per launch (0 = one step_kernel launch per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
     args = ap.parse_args()
@@ -126,15 +136,32 @@ def main():
 
     cfg = read_config(args.workload)
     eng = Engine(cfg, args.batch, device=local_rank, seed=0, first_env_index=rank * args.batch)
+    b_obs = 4 * (eng.num_cameras * eng.camera_obs_dim + eng.num_targets * eng.target_obs_dim) + 48   # written per env-step
+    R = args.rollout if args.policy == 'random' else 0
+    if R > 0:        # rollout buffers [R][N][...] capped at 4 GiB
+        R = max(1, min(R, args.steps, (4 << 30) // (args.batch * b_obs)))
     if args.policy == 'greedy':
         eng.enable_policies()
         step = lambda: eng.step_greedy(auto_reset=args.reset_interval)     # noqa: E731
     else:
         step = lambda: eng.step_random(auto_reset=True)     # noqa: E731
+
+    def run(steps):
+        """exactly `steps` env.step()s of the whole batch"""
+        if R > 0:
+            for _ in range(steps // R):
+                eng.rollout_random(R, auto_reset=True)
+            if steps % R:
+                eng.rollout_random(steps % R, auto_reset=True)
+        else:
+            for _ in range(steps):
+                step()
+
     eng.reset()
-    for _ in range(args.warmup):
-        step()
-    eng.kernel_time(enable=16)            # HIP-event pair around every 16th step_kernel launch of the timed region
+    run(args.warmup)
+    if R > 0 and args.steps % R:
+        eng.rollout_random(args.steps % R, auto_reset=True)      # the remainder launch of the timed region, warmed too
+    eng.kernel_time(enable=1 if R > 0 else 16)   # HIP-event pair around (every 16th) launch of the dominant kernel in the timed region
 
     def barrier():
         torch.cuda.synchronize()
@@ -145,12 +172,26 @@ def main():
     barrier()
     idle0 = eng.idle_steps()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     executed = args.batch * args.steps - (eng.idle_steps() - idle0)   # env-steps actually simulated by this rank
     kernel_ms, launches = eng.kernel_time(enable=False)
+    flow = eng.last_flow
+    per_step = None
+    if R > 0:        # the same workload with one step_kernel launch per step, reported beside the headline
+        k2 = min(args.steps, 1000)
+        eng.kernel_time(enable=16)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        barrier()
+        e2 = time.perf_counter() - t1
+        km2, _ = eng.kernel_time(enable=False)
+        per_step = {'value': args.batch * world * k2 / e2, 'unit': 'env-steps/s', 'steps': k2, 'ms_per_step': e2 / k2 * 1e3,
+                    'kernel': 'step_kernel', 'kernel_avg_us': km2 * 1e3,
+                    'roofline_frac': (algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles) * args.batch / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS) if km2 > 0 else 0.0}
 
     stats = eng.scalars[:, [1, 3, 6]].mean(dim=0)    # reward, coverage, delivered: logging only
     from mate_amd.distributed import reduce_job
@@ -160,28 +201,40 @@ def main():
         total_envs = args.batch * world
         value = executed / elapsed            # == total_envs * steps / elapsed unless environments idled for a batched reset
         b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
-        achieved = b_alg * args.batch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # env-steps of the average timed launch (rollouts: R, and the remainder launch when K % R != 0)
+        steps_per_launch = (args.steps / launches) if (R > 0 and launches > 0) else 1.0
+        bytes_per_launch = b_alg * args.batch * steps_per_launch
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # what a rollout launch must really move: every step's observations + scalars, the state and geometry once
+        resident = args.batch * (steps_per_launch * b_obs + (b_alg - b_obs - 8 * (eng.num_cameras + eng.num_targets)))
+        kernel = ('rollout_kernel' if R > 0 else 'step_kernel')
+        default_case = args.batch == BATCH_PER_GPU and args.workload == WORKLOAD and (R == 32 or args.policy == 'greedy' or R == 0)
         line = {
-            'metric': ('env-steps/sec MATE-4v8-9 batch=4096 per GPU (random policy, auto-reset)'
-                       if (args.workload, args.batch, args.policy) == (WORKLOAD, BATCH_PER_GPU, 'random') else
-                       f'env-steps/sec {args.workload[:-5]} batch={args.batch} per GPU ({args.policy} policy, auto-reset)'),
+            'metric': f'env-steps/sec {args.workload[:-5]} batch={args.batch} per GPU ({args.policy} policy, auto-reset)',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'{args.workload} batch={args.batch} envs per GPU, '
                                    + ('uniform random policy (on-device Philox), ' if args.policy == 'random' else 'on-device GreedyCamera vs GreedyTarget policies, ')
-                                   + 'auto-reset', 'global_batch': total_envs, 'parallelism': f'env-shard x{world}'},
+                                   + (f'fused {R}-step rollout launches, auto-reset after each launch' if R > 0 else 'one launch per step, auto-reset'),
+                       'global_batch': total_envs, 'parallelism': f'env-shard x{world}', 'steps_per_launch': R if R > 0 else 1},
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': measured_traffic() if args.batch == BATCH_PER_GPU and args.workload == WORKLOAD else None,
+                'traffic': measured_traffic(kernel) if default_case and args.policy == 'random' else None,
                 'traffic_unit': 'bytes per launch (rocprofv3 2*FETCH_SIZE + WRITE_SIZE, profiles/latest_pmc.json)',
-                'kernel': 'step_kernel<float, %s, %s>' % ('FixedShape' if eng.specialised else 'AnyShape', ('FLOW_ANY', 'FLOW_RANDOM', 'FLOW_ACT_F32')[eng.last_flow]), 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches,
-                'algorithmic_bytes_per_launch': b_alg * args.batch,
+                'kernel': '%s<float, %s, %s>' % (kernel, 'FixedShape' if eng.specialised else 'AnyShape', ('FLOW_ANY', 'FLOW_RANDOM', 'FLOW_ACT_F32')[flow]),
+                'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches, 'env_steps_per_launch': args.batch * steps_per_launch,
+                'algorithmic_bytes_per_launch': bytes_per_launch,
+                'resident_bytes_per_launch': resident,
+                'achieved_resident': resident / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
+                'frac_resident': resident / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0,
             },
             'episode_stats': {'mean_target_reward': float(stats[0]), 'mean_coverage_rate': float(stats[1]),
                               'mean_delivered': float(stats[2])},
         }
+        if per_step is not None:
+            line['per_step_launch'] = per_step
         if not args.no_cpu_baseline and world == 1 and args.policy == 'random' and args.workload == WORKLOAD:
             line['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)

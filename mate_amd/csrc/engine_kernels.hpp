@@ -1000,38 +1000,56 @@ __device__ __forceinline__ void pack_block_xf(const Ctx<ObsT> &c, ObsT *dst, con
 // lane (all of them for the shipped scenario shapes) are loaded BEFORE the first store: loads and stores share one
 // in-order counter on gfx9, so a descriptor load issued behind an observation store can only be waited for
 // together with that store's HBM acknowledgement -- seven such waits per step in a chunk-by-chunk loop.
+constexpr int kPackGC = 2, kPackGT = 6;
+struct PackDescriptors { uint4 dc[kPackGC], dt[kPackGT]; };
+
 template <typename ObsT>
-__device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT> &c) {
+__device__ __forceinline__ void load_pack_descriptors(const Ctx<ObsT> &c, PackDescriptors &d) {
+    const Params &p = c.p;
+    const int nvc = p.cam_elems / 4, nvt = p.tgt_elems / 4;
+    const uint4 *tabc = reinterpret_cast<const uint4 *>(c.table);
+    const uint4 *tabt = reinterpret_cast<const uint4 *>(c.table + p.tgt_table_off);
+#pragma unroll
+    for (int k = 0; k < kPackGC; ++k) { const int s = c.lane + 64 * k; d.dc[k] = tabc[s < nvc ? s : 0]; }
+#pragma unroll
+    for (int k = 0; k < kPackGT; ++k) { const int s = c.lane + 64 * k; d.dt[k] = tabt[s < nvt ? s : 0]; }
+#pragma unroll
+    for (int k = 0; k < kPackGC; ++k) asm volatile("" : "+v"(d.dc[k].x), "+v"(d.dc[k].y), "+v"(d.dc[k].z), "+v"(d.dc[k].w));
+#pragma unroll
+    for (int k = 0; k < kPackGT; ++k) asm volatile("" : "+v"(d.dt[k].x), "+v"(d.dt[k].y), "+v"(d.dt[k].z), "+v"(d.dt[k].w));
+}
+
+template <typename ObsT>
+__device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT> &c, const PackDescriptors &d) {
     if constexpr (sizeof(ObsT) == 4) {
         const Params &p = c.p;
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        constexpr int GC = 2, GT = 6;
+        constexpr int GC = kPackGC, GT = kPackGT;
         const int nvc = p.cam_elems / 4, nvt = p.tgt_elems / 4;
         const uint4 *tabc = reinterpret_cast<const uint4 *>(c.table);
         const uint4 *tabt = reinterpret_cast<const uint4 *>(c.table + p.tgt_table_off);
         f32x4 *cam = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.cam_obs) + c.out * p.cam_elems);
         f32x4 *tgt = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems);
         auto chunk = [&](const uint4 &d) { return f32x4{gather_one(c, d.x), gather_one(c, d.y), gather_one(c, d.z), gather_one(c, d.w)}; };
-        uint4 dc[GC], dt[GT];
 #pragma unroll
-        for (int k = 0; k < GC; ++k) { const int s = c.lane + 64 * k; dc[k] = tabc[s < nvc ? s : 0]; }
-#pragma unroll
-        for (int k = 0; k < GT; ++k) { const int s = c.lane + 64 * k; dt[k] = tabt[s < nvt ? s : 0]; }
-#pragma unroll
-        for (int k = 0; k < GC; ++k) asm volatile("" : "+v"(dc[k].x), "+v"(dc[k].y), "+v"(dc[k].z), "+v"(dc[k].w));
-#pragma unroll
-        for (int k = 0; k < GT; ++k) asm volatile("" : "+v"(dt[k].x), "+v"(dt[k].y), "+v"(dt[k].z), "+v"(dt[k].w));
-#pragma unroll
-        for (int k = 0; k < GC; ++k) { const int s = c.lane + 64 * k; if (s < nvc) __builtin_nontemporal_store(chunk(dc[k]), &cam[s]); }
+        for (int k = 0; k < GC; ++k) { const int s = c.lane + 64 * k; if (s < nvc) __builtin_nontemporal_store(chunk(d.dc[k]), &cam[s]); }
         for (int s = c.lane + 64 * GC; s < nvc; s += 64) __builtin_nontemporal_store(chunk(tabc[s]), &cam[s]);   // larger scenarios
 #pragma unroll
-        for (int k = 0; k < GT; ++k) { const int s = c.lane + 64 * k; if (s < nvt) __builtin_nontemporal_store(chunk(dt[k]), &tgt[s]); }
+        for (int k = 0; k < GT; ++k) { const int s = c.lane + 64 * k; if (s < nvt) __builtin_nontemporal_store(chunk(d.dt[k]), &tgt[s]); }
         for (int s = c.lane + 64 * GT; s < nvt; s += 64) __builtin_nontemporal_store(chunk(tabt[s]), &tgt[s]);
     }
 }
 
 template <typename ObsT>
-__device__ __forceinline__ void pack_observations(Ctx<ObsT> &c) {
+__device__ __forceinline__ bool packs_rows_f32(const Ctx<ObsT> &c) {
+    const Params &p = c.p;
+    return !c.xdesc() && sizeof(ObsT) == 4 && (p.cam_elems % 4) == 0 && (p.tgt_elems % 4) == 0 && c.has_tgt_obs() && (c.has_cam_obs() || p.cam_elems == 0);
+}
+
+// HELD: the caller loaded this lane's descriptors before (the rollout kernel, once per launch); otherwise they are
+// loaded here.  A template switch, not a pointer: a nullable pointer to the register array would force it into memory.
+template <bool HELD, typename ObsT>
+__device__ __forceinline__ void pack_observations(Ctx<ObsT> &c, PackDescriptors &held) {
     const Params &p = c.p;
     if (c.xdesc()) {
         const ObsT *xab = reinterpret_cast<const ObsT *>(c.g.xab);
@@ -1040,8 +1058,9 @@ __device__ __forceinline__ void pack_observations(Ctx<ObsT> &c) {
         if (c.has_tgt_obs())
             pack_block_xf<ObsT>(c, reinterpret_cast<ObsT *>(c.g.tgt_obs) + c.out * p.tgt_elems, c.g.xdesc + p.tgt_table_off,
                                 xab + 2 * p.tgt_table_off, p.tgt_elems);
-    } else if (sizeof(ObsT) == 4 && (p.cam_elems % 4) == 0 && (p.tgt_elems % 4) == 0 && c.has_tgt_obs() && (c.has_cam_obs() || p.cam_elems == 0)) {
-        pack_rows_f32(c);
+    } else if (packs_rows_f32(c)) {
+        if constexpr (!HELD) load_pack_descriptors(c, held);
+        pack_rows_f32(c, held);
     } else {
     if (c.has_cam_obs() && p.cam_elems > 0)
         pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.cam_obs) + c.out * p.cam_elems, c.table, p.cam_elems);
@@ -1126,7 +1145,7 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     if (!SKIP(64)) fill_scratch(c);
     PHASE_STAMP(6);
     phase_prio(g.stagger, 4);
-    if (!SKIP(128)) pack_observations(c);
+    if (!SKIP(128)) { PackDescriptors d; pack_observations<false>(c, d); }
     PHASE_STAMP(7);
     if (mode != MODE_OBSERVE) store_dynamic(c);
     PHASE_STAMP(8);
@@ -1142,7 +1161,7 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
 // wave time per step instead of the slowest wave's, and there is no kernel boundary between steps.
 // An environment whose episode ends stops stepping (rows of the remaining steps carry done = 2 in the
 // scalar record) and is reset by the host-launched reset kernel after the rollout.
-template <typename ObsT, typename Shape>
+template <typename ObsT, typename Shape, int FLOW = FLOW_ANY>
 __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restrict__ pp, const Ptrs g) {
     const Shape shape(pp);
     const Params &p = shape.get();
@@ -1160,6 +1179,14 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         build_entities(c);
         wave_sync();
     }
+    // The observation descriptors of this lane are the same for every step: loaded once and held in 32 VGPRs (the
+    // headline batch runs 4 waves per SIMD, the register file has room), which takes the table's two global-load
+    // round trips out of every step's pack phase.
+    PackDescriptors held;
+    {
+        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
+        load_pack_descriptors(c, held);      // (indices clamped: harmless when another pack path runs)
+    }
 #pragma clang loop unroll(disable)
     for (int r = 0; r < g.rollout_steps; ++r) {
         // an opaque copy of the lane id per iteration keeps the compiler from hoisting every lane-role
@@ -1172,10 +1199,11 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         const Shape shape_r(pr);
         const Params &p = shape_r.get();
         const int64_t env_r = (int64_t)blockIdx.x * 4 + wave_r;
-        Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r);
+        Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW);
         c.out = (int64_t)r * g.N + env_r;
         if (c.ei(EI_DONE) != 0) {
             if (lane_r == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
+            if (lane_r == 0 && g.idle_steps) g.idle_steps[env_r] += 1;      // a slot of the rollout, not an executed step
             continue;
         }
         const uint32_t tick = g.tick + (uint32_t)r;
@@ -1185,7 +1213,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         update_view(c, tick, S_TRANSMIT, true);
         assign_and_score(c, tick, g.scalars);
         fill_scratch(c);
-        pack_observations(c);
+        pack_observations<true>(c, held);
         wave_sync();
     }
     {

@@ -54,7 +54,8 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, StepFn *step, StepFn 
         step[FLOW_ANY] = f64 ? (StepFn)step_kernel<double, FixedShape<C, T, O, true>> : (StepFn)step_kernel<float, FixedShape<C, T, O, false>>;   \
         step[FLOW_RANDOM] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                            \
         step[FLOW_ACT_F32] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, FixedShape<C, T, O, false>, FLOW_ACT_F32>;                          \
-        *rollout = f64 ? (StepFn)rollout_kernel<double, FixedShape<C, T, O, true>> : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>>; \
+        rollout[0] = f64 ? (StepFn)rollout_kernel<double, FixedShape<C, T, O, true>> : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>>; \
+        rollout[1] = f64 ? rollout[0] : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                                   \
         *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, FixedShape<C, T, O, true>> : (PolicyFn)greedy_policy_kernel<float, FixedShape<C, T, O, false>>; \
         return;                                                                                                     \
     }
@@ -64,7 +65,8 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, StepFn *step, StepFn 
     step[FLOW_ANY] = f64 ? (StepFn)step_kernel<double, AnyShape> : (StepFn)step_kernel<float, AnyShape>;
     step[FLOW_RANDOM] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, AnyShape, FLOW_RANDOM>;
     step[FLOW_ACT_F32] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, AnyShape, FLOW_ACT_F32>;
-    *rollout = f64 ? (StepFn)rollout_kernel<double, AnyShape> : (StepFn)rollout_kernel<float, AnyShape>;
+    rollout[0] = f64 ? (StepFn)rollout_kernel<double, AnyShape> : (StepFn)rollout_kernel<float, AnyShape>;
+    rollout[1] = f64 ? rollout[0] : (StepFn)rollout_kernel<float, AnyShape, FLOW_RANDOM>;
     *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, AnyShape> : (PolicyFn)greedy_policy_kernel<float, AnyShape>;
 }
 
@@ -82,7 +84,7 @@ struct mate_engine {
     bool was_reset = false;
     size_t step_lds = 0, reset_lds = 0;
     PolicyFn policy_fn = nullptr;
-    StepFn step_fn[3] = {nullptr, nullptr, nullptr}, rollout_fn = nullptr;   // kernels chosen at create: shape-specialised when compiled for these counts; step_fn[flow]
+    StepFn step_fn[3] = {nullptr, nullptr, nullptr}, rollout_fn[2] = {nullptr, nullptr};   // kernels chosen at create: shape-specialised when compiled for these counts; step_fn[flow]
     int last_flow = 0;
     bool flow_generic = false;                        // MATE_FLOW_GENERIC=1: every launch runs the FLOW_ANY kernel (tests)
     int specialised = 0;
@@ -238,7 +240,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     p.obs_r_lo = cfg->obstacle_radius_range[0]; p.obs_r_hi = cfg->obstacle_radius_range[1];
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.first_env = (uint32_t)first_env_index;
     e->step_lds = 4 * (size_t)p.lds_wave_bytes;
-    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->step_fn, &e->rollout_fn, &e->policy_fn, &e->specialised);
+    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->step_fn, e->rollout_fn, &e->policy_fn, &e->specialised);
     { const char *fg = getenv("MATE_FLOW_GENERIC"); e->flow_generic = fg && atoi(fg) != 0; }
     if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }
     ResetLds &rl = e->rl;
@@ -325,7 +327,8 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         hipError_t err = hipSuccess;
         for (int f = 0; f < 3 && err == hipSuccess; ++f)
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->step_fn[f]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
-        if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rollout_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+        for (int f = 0; f < 2 && err == hipSuccess; ++f)
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rollout_fn[f]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
         if (err != hipSuccess) {
         } else if (p.obs_f64) {
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
@@ -623,7 +626,10 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
         }
         ev0 = e->events[e->events_used].first; ev1 = e->events[e->events_used].second; ++e->events_used;
     }
-    hipExtLaunchKernelGGL(e->rollout_fn, dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
+    const int flow = (!e->flow_generic && !g.act_discrete && g.obs_mode == 0 && !g.xdesc && !g.xab && g.scratch_init &&
+                      (g.cam_obs || e->p.Nc == 0) && g.tgt_obs && g.scalars) ? FLOW_RANDOM : FLOW_ANY;
+    e->last_flow = flow;
+    hipExtLaunchKernelGGL(e->rollout_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
     HIP_TRY(hipGetLastError());
     e->tick += (uint32_t)steps;
     if (auto_reset) {

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
                 update_view(c, (uint32_t)c.ei(EI_EPISODE), S_RESET_VIEW, false);
                 score_only(c, g.scalars);
                 fill_scratch(c);
-                pack_observations(c);
+                { PackDescriptors d; pack_observations<false>(c, d); }
             }
             if (phases & (PH_PLACE | PH_VIEW)) store_dynamic(c);
         }

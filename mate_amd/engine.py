@@ -240,7 +240,7 @@ class Engine:
         steps skipped because the episode had already ended inside this rollout."""
         steps = int(steps)
         buf = getattr(self, '_rollout', None)
-        if buf is None or buf['steps'] != steps or (want_masks and buf['masks'] is None):
+        if buf is None or buf['steps'] < steps or (want_masks and buf['masks'] is None):     # a shorter rollout fills a prefix
             N, Nc, Nt, L = self.num_envs, self.num_cameras, self.num_targets, self.layout
             with torch.cuda.device(self.device):
                 buf = {
@@ -257,7 +257,7 @@ class Engine:
         io.scalars_dev = buf['scalars'].data_ptr()
         io.masks_dev = buf['masks'].data_ptr() if want_masks else None
         check(self.lib.mate_engine_rollout_random(self._h, ctypes.byref(io), steps, int(auto_reset), self._stream()))
-        return buf['camera_obs'], buf['target_obs'], buf['scalars']
+        return buf['camera_obs'][:steps], buf['target_obs'][:steps], buf['scalars'][:steps]
 
     def enable_policies(self):
         """Allocate the on-device policy state (call before the reset whose observations the agents act on)."""

@@ -309,6 +309,10 @@ def test_flow_specialised_kernel_equals_generic(workload, generic_shape, policy,
                 eng.step(ca, ta, auto_reset=True)
             assert eng.last_flow == (0 if generic == '1' else (1 if policy == 'random' else 2))
             rec.append([t.clone() for t in (getattr(eng, 'camera_obs', None), eng.target_obs, eng.scalars, eng.masks) if t is not None])
+        if policy == 'random':  # the fused K-step rollout has the same two compilations
+            ro = eng.rollout_random(6, auto_reset=True)
+            assert eng.last_flow == (0 if generic == '1' else 1)
+            rec.append([t.clone() for t in ro if t is not None and t.numel()])
         rec.append([eng.export_state().clone()])
         outs.append(rec)
         if generic == '0':      # launches the folded flows do not cover

@@ -19,14 +19,14 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + '/pmc_*/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
         name = row['Kernel_Name']
-        key = 'step_kernel' if 'step_kernel' in name else ('reset_kernel' if 'reset_kernel' in name else None)
+        key = next((k for k in ('step_kernel', 'rollout_kernel', 'reset_kernel') if k in name), None)
         if key:
             acc[key][row['Counter_Name']].append(float(row['Counter_Value']))
 summary = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 for k, d in summary.items():
     d['launches_sampled'] = len(next(iter(acc[k].values())))
 json.dump(summary, open(out + '/pmc_summary.json', 'w'), indent=1, sort_keys=True)
-print(json.dumps(summary.get('step_kernel', {}), sort_keys=True))
+print(json.dumps(summary.get('rollout_kernel', summary.get('step_kernel', {})), sort_keys=True))
 PY
 rm -rf "$out"/kt "$out"/pmc_*/
 head -4 "$out/kernel_stats.csv" | cut -c1-180
