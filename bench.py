@@ -107,8 +107,8 @@ def cpu_baseline(seconds=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=2048)
+    ap.add_argument('--warmup', type=int, default=128)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='environments per GPU')
     ap.add_argument('--workload', default=WORKLOAD)
     ap.add_argument('--policy', choices=['random', 'greedy'], default='random',

@@ -137,6 +137,7 @@ struct Ptrs {
     int32_t n_cam_grid, n_tgt_grid;
     int32_t act_discrete;         // bit 0 camera actions, bit 1 target actions are int32 grid indices
     int32_t obs_mode;             // bits 0-1 camera team, bits 2-3 target team: 0 plain, 1 EnhancedObservation, 2 SharedFieldOfView
+    int32_t rotate_prio;          // rollout kernel: rotate the wave priorities (fair SIMD shares, see rollout_kernel)
 };
 
 #ifdef MATE_PHASE_CLOCKS
@@ -1187,6 +1188,21 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
         load_pack_descriptors(c, held);      // (indices clamped: harmless when another pack path runs)
     }
+    // Fair shares of the SIMD.  Its arbiter serves the oldest resident wave first, and in a launch that lasts for
+    // tens of steps the age order never changes: of the four environment-waves of a SIMD the oldest ran a step in
+    // 13 k cycles and the youngest in 21 k (measured), and the launch lasts as long as its slowest wave.
+    // Rotating the issue priority by step and wave slot gives every wave each priority level equally often
+    // (+13 % at 4096 environments; rotating at every phase boundary is no better, and a laggard-first controller that read the SIMD-mates' progress through a table keyed
+    // by the hardware wave id equalised them perfectly and gained nothing more: waves kept in lockstep contend for the
+    // same units at the same time).
+    uint32_t hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    const int wave_slot = (int)(hw_id & 15u);
+#ifdef MATE_PHASE_CLOCKS
+    long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // cycles per phase summed over the steps of this launch
+    long long t_prev = (long long)__builtin_amdgcn_s_memtime();
+    const long long t_first = t_prev, r_first = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 #pragma clang loop unroll(disable)
     for (int r = 0; r < g.rollout_steps; ++r) {
         // an opaque copy of the lane id per iteration keeps the compiler from hoisting every lane-role
@@ -1207,15 +1223,47 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
             continue;
         }
         const uint32_t tick = g.tick + (uint32_t)r;
+        if (g.rotate_prio) {
+            const int turn = (r + wave_slot) & 3;
+            if (turn == 0) __builtin_amdgcn_s_setprio(0);
+            else if (turn == 1) __builtin_amdgcn_s_setprio(1);
+            else if (turn == 2) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(3);
+        }
+#ifdef MATE_PHASE_CLOCKS
+#define ROLL_STAMP(i) do { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define ROLL_STAMP(i) do { } while (0)
+#endif
+        ROLL_STAMP(7);         // loop overhead: from the end of the previous step to here
         const StepDraws draws = step_draws(c, tick);
+        ROLL_STAMP(0);
         simulate_cameras(c, draws, true);
+        ROLL_STAMP(1);
         simulate_targets(c, draws);
+        ROLL_STAMP(2);
         update_view(c, tick, S_TRANSMIT, true);
+        ROLL_STAMP(3);
         assign_and_score(c, tick, g.scalars);
+        ROLL_STAMP(4);
         fill_scratch(c);
+        ROLL_STAMP(5);
         pack_observations<true>(c, held);
         wave_sync();
+        ROLL_STAMP(6);
     }
+#ifdef MATE_PHASE_CLOCKS
+    if (lane == 0 && g.phase_clocks)
+        for (int i = 0; i < 8; ++i) g.phase_clocks[env * 16 + i] = acc[i];
+    if (lane == 0 && g.phase_clocks) {      // clock calibration: s_memtime ticks against the constant 100 MHz counter
+        uint32_t hwid, xccid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xccid));
+        g.phase_clocks[env * 16 + 13] = ((long long)xccid << 32) | (long long)hwid;
+        g.phase_clocks[env * 16 + 14] = (long long)__builtin_amdgcn_s_memtime() - t_first;
+        g.phase_clocks[env * 16 + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_first;
+    }
+#endif
     {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env);
         store_dynamic(c);

@@ -615,6 +615,7 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
     apply_io(g, io);
     g.mode = MODE_STEP_RANDOM; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick; g.rollout_steps = steps;
     g.tape_ct = nullptr; g.tape_goal = nullptr;
+    { const char *rv = getenv("MATE_ROLLOUT_ROTATE"); g.rotate_prio = rv ? atoi(rv) : 1; }
     if (!auto_reset) g.done_count = nullptr;
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
