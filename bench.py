@@ -114,7 +114,9 @@ def main():
     ap.add_argument('--policy', choices=['random', 'greedy'], default='random',
                     help='on-device policy: uniform random (headline) or GreedyCamera vs GreedyTarget (BASELINE config 3)')
     ap.add_argument('--reset-interval', type=int, default=32, help='greedy policy: batched auto-reset every k steps (1 = immediate)')
-    ap.add_argument('--rollout', type=int, default=32, help='random policy: steps fused per launch (0 = one step_kernel launch per step)')
+    ap.add_argument('--rollout', type=int, default=-1,
+                    help='random policy: steps fused per launch; 0 = one step_kernel launch per step; -1 (default) = 32 while the batch '
+                         'is at most 64 environment-waves per CU, else 0 (the rollout kernel trades occupancy for registers)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
     args = ap.parse_args()
@@ -138,6 +140,8 @@ def main():
     eng = Engine(cfg, args.batch, device=local_rank, seed=0, first_env_index=rank * args.batch)
     b_obs = 4 * (eng.num_cameras * eng.camera_obs_dim + eng.num_targets * eng.target_obs_dim) + 48   # written per env-step
     R = args.rollout if args.policy == 'random' else 0
+    if R < 0:
+        R = 32 if args.batch <= 64 * torch.cuda.get_device_properties(local_rank).multi_processor_count else 0
     if R > 0:        # rollout buffers [R][N][...] capped at 4 GiB
         R = max(1, min(R, args.steps, (4 << 30) // (args.batch * b_obs)))
     if args.policy == 'greedy':
