@@ -127,7 +127,9 @@ int mate_engine_step_random(mate_engine *engine, const mate_step_io *io, int32_t
  * collection, the `for _ in range(T): env.step(...)` loop of examples/random.py).  Every io output
  * buffer is rollout-shaped: [steps][N][...] (row r*N + i = step r of environment i).  An environment
  * whose episode ends at step r stops there: its scalar rows of later steps carry done = 2 and its
- * observation rows are left untouched; with auto_reset it starts a new episode before the next call. */
+ * observation rows are left untouched; with auto_reset it starts a new episode before the next call.
+ * Those skipped slots are added to mate_engine_idle_steps.  This is the fastest way to step: the records stay in LDS
+ * for the whole launch and the waves of a SIMD take turns in issue priority (MATE_ROLLOUT_ROTATE=0 turns that off). */
 int mate_engine_rollout_random(mate_engine *engine, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream);
 
 /* On-device rule-based policies: the reference's GreedyCameraAgent / GreedyTargetAgent
