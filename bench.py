@@ -210,7 +210,8 @@ def main():
         bytes_per_launch = b_alg * args.batch * steps_per_launch
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # what a rollout launch must really move: every step's observations + scalars, the state and geometry once
-        resident = args.batch * (steps_per_launch * b_obs + (b_alg - b_obs - 8 * (eng.num_cameras + eng.num_targets)))
+        resident = (args.batch * (steps_per_launch * b_obs + (b_alg - b_obs - 8 * (eng.num_cameras + eng.num_targets)))
+                    if R > 0 else bytes_per_launch)
         kernel = ('rollout_kernel' if R > 0 else 'step_kernel')
         default_case = args.batch == BATCH_PER_GPU and args.workload == WORKLOAD and (R == 32 or args.policy == 'greedy' or R == 0)
         line = {
