@@ -92,37 +92,14 @@ __device__ __forceinline__ double sin_deg_0_90(double deg) {
     return fma(x * z, ps, x);
 }
 
-template <typename ObsT, typename Shape>
-__global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q) {
-    const Shape shape(pp);
-    const Params &p = shape.get();
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    // No wave leaves early: the four waves of a workgroup meet at two barriers around the shared zoom solve, so a wave
-    // past the end of the batch or on a frozen environment runs on (duplicate / stale data) and only skips its stores.
-    const int64_t env_raw = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t env = env_raw < g.N ? env_raw : g.N - 1;
-    bool active = env_raw < g.N;
-    unsigned char *base = smem + wave * q.lds_bytes;
-    double *shared_K = reinterpret_cast<double *>(smem + 4 * q.lds_bytes);      // [4 environments][16 cameras]
-    double *shared_B = shared_K + 64;
-    // LDS: [policy record + staging][static record][dynamic record][mask words]
-    PolCtx<ObsT> a(p, q, base);
-    double *st = reinterpret_cast<double *>(base + (size_t)(q.PW + p.Nc * p.Nc / 2 + 2) * 8);
-    double *dy = st + p.SW;
-    int32_t *di = reinterpret_cast<int32_t *>(dy + p.DF);
-    uint32_t *mk = reinterpret_cast<uint32_t *>(dy + p.DW);
-    {
-        const double *src = q.pol + env * q.PW;
-        for (int k = lane; k < q.PW; k += 64) a.f[k] = src[k];
-        const double *s = g.stat + env * p.SW;
-        for (int k = lane; k < p.SW; k += 64) st[k] = s[k];
-        const double *d = g.dyn + env * p.DW;
-        for (int k = lane; k < p.DW; k += 64) dy[k] = d[k];
-        const uint32_t *m = q.masks + env * p.MW;
-        for (int k = lane; k < p.MW; k += 64) mk[k] = m[k];
-    }
-    wave_sync();
+// One step of both teams' agents of ONE environment on LDS-resident data: `a` the agents' memory record, `st` / `dy` /
+// `di` the static and dynamic records, `mk` the packed view masks of the previous step.  Called by every wave of the
+// workgroup together (two barriers around the shared zoom solve).  Joint actions go to q.cam_act / q.tgt_act when
+// `active`, and to lds_cam_act / lds_tgt_act when those are given (the fused rollout steps from them).
+template <typename ObsT>
+__device__ __forceinline__ void greedy_policy_body(const Params &p, const PolicyPtrs &q, PolCtx<ObsT> &a, const double *st, const double *dy,
+                                                   const int32_t *di, const uint32_t *mk, double *shared_K, double *shared_B,
+                                                   int wave, int lane, int64_t env, bool active, double *lds_cam_act, double *lds_tgt_act) {
     const int Nc = p.Nc, Nt = p.Nt;
     auto cam_x = [&](int c) { return st[c]; };
     auto cam_y = [&](int c) { return st[Nc + c]; };
@@ -132,7 +109,6 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     const int32_t *env_i = di + Nt * TI_STRIDE;
     const uint32_t tick = (uint32_t)env_i[EI_TICK];
     const uint32_t env_global = p.first_env + (uint32_t)env;
-    if (g.freeze_done && env_i[EI_DONE] != 0) active = false;   // finished, waiting for the batched reset
     const bool fresh = a.episode() != env_i[EI_EPISODE];     // first call of a new episode: agent.reset(observation)
     // this step's draws (see PolicyStream); skipped when every draw comes from the tape
     double u_bern = 0.0, u_s0 = 0.0, u_s1 = 0.0;
@@ -330,6 +306,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
             } else { a0 = a.prev_action(c, 0); a1 = a.prev_action(c, 1); }
         }
         a.prev_action(c, 0) = a0; a.prev_action(c, 1) = a1;
+        if (lds_cam_act) { lds_cam_act[2 * c] = a0; lds_cam_act[2 * c + 1] = a1; }
         if (active) { q.cam_act[(env * Nc + c) * 2] = a0; q.cam_act[(env * Nc + c) * 2 + 1] = a1; }
     }
     if (tl >= 0 && tl < Nt) {                               // GreedyTargetAgent.act (greedy.py:285-324)
@@ -378,8 +355,44 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
         const double outx = clipd(ax + nx, -step_size, step_size), outy = clipd(ay + ny, -step_size, step_size);
         a.tgt_prev(t, 0) = x; a.tgt_prev(t, 1) = y;
         a.tgt_noise(t, 0) = nx; a.tgt_noise(t, 1) = ny;
+        if (lds_tgt_act) { lds_tgt_act[2 * t] = outx; lds_tgt_act[2 * t + 1] = outy; }
         if (active) { q.tgt_act[(env * Nt + t) * 2] = outx; q.tgt_act[(env * Nt + t) * 2 + 1] = outy; }
     }
+}
+
+template <typename ObsT, typename Shape>
+__global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q) {
+    const Shape shape(pp);
+    const Params &p = shape.get();
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    // No wave leaves early: the four waves of a workgroup meet at two barriers around the shared zoom solve, so a wave
+    // past the end of the batch or on a frozen environment runs on (duplicate / stale data) and only skips its stores.
+    const int64_t env_raw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t env = env_raw < g.N ? env_raw : g.N - 1;
+    bool active = env_raw < g.N;
+    unsigned char *base = smem + wave * q.lds_bytes;
+    double *shared_K = reinterpret_cast<double *>(smem + 4 * q.lds_bytes);      // [4 environments][16 cameras]
+    double *shared_B = shared_K + 64;
+    // LDS: [policy record + staging][static record][dynamic record][mask words]
+    PolCtx<ObsT> a(p, q, base);
+    double *st = reinterpret_cast<double *>(base + (size_t)(q.PW + p.Nc * p.Nc / 2 + 2) * 8);
+    double *dy = st + p.SW;
+    int32_t *di = reinterpret_cast<int32_t *>(dy + p.DF);
+    uint32_t *mk = reinterpret_cast<uint32_t *>(dy + p.DW);
+    {
+        const double *src = q.pol + env * q.PW;
+        for (int k = lane; k < q.PW; k += 64) a.f[k] = src[k];
+        const double *s = g.stat + env * p.SW;
+        for (int k = lane; k < p.SW; k += 64) st[k] = s[k];
+        const double *d = g.dyn + env * p.DW;
+        for (int k = lane; k < p.DW; k += 64) dy[k] = d[k];
+        const uint32_t *m = q.masks + env * p.MW;
+        for (int k = lane; k < p.MW; k += 64) mk[k] = m[k];
+    }
+    wave_sync();
+    if (g.freeze_done && (di + p.Nt * TI_STRIDE)[EI_DONE] != 0) active = false;   // finished, waiting for the batched reset
+    greedy_policy_body<ObsT>(p, q, a, st, dy, di, mk, shared_K, shared_B, wave, lane, env, active, nullptr, nullptr);
     wave_sync();
     if (active) {
         double *dst = q.pol + env * q.PW;
