@@ -115,8 +115,9 @@ def main():
                     help='on-device policy: uniform random (headline) or GreedyCamera vs GreedyTarget (BASELINE config 3)')
     ap.add_argument('--reset-interval', type=int, default=32, help='greedy policy: batched auto-reset every k steps (1 = immediate)')
     ap.add_argument('--rollout', type=int, default=-1,
-                    help='random policy: steps fused per launch; 0 = one step_kernel launch per step; -1 (default) = 32 while the batch '
-                         'is at most 64 environment-waves per CU, else 0 (the rollout kernel trades occupancy for registers)')
+                    help='steps fused per launch (rollout_kernel / rollout_greedy_kernel); 0 = one launch per step; -1 (default) = 32 '
+                         'while the batch is at most 64 (random) / 32 (greedy) environment-waves per CU, else 0 (the fused kernels '
+                         'trade occupancy for registers and LDS)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
     args = ap.parse_args()
@@ -139,9 +140,10 @@ def main():
     cfg = read_config(args.workload)
     eng = Engine(cfg, args.batch, device=local_rank, seed=0, first_env_index=rank * args.batch)
     b_obs = 4 * (eng.num_cameras * eng.camera_obs_dim + eng.num_targets * eng.target_obs_dim) + 48   # written per env-step
-    R = args.rollout if args.policy == 'random' else 0
+    R = args.rollout
     if R < 0:
-        R = 32 if args.batch <= 64 * torch.cuda.get_device_properties(local_rank).multi_processor_count else 0
+        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        R = 32 if args.batch <= (64 if args.policy == 'random' else 32) * cus else 0
     if R > 0:        # rollout buffers [R][N][...] capped at 4 GiB
         R = max(1, min(R, args.steps, (4 << 30) // (args.batch * b_obs)))
     if args.policy == 'greedy':
@@ -153,10 +155,11 @@ def main():
     def run(steps):
         """exactly `steps` env.step()s of the whole batch"""
         if R > 0:
+            rollout = eng.rollout_greedy if args.policy == 'greedy' else eng.rollout_random
             for _ in range(steps // R):
-                eng.rollout_random(R, auto_reset=True)
+                rollout(R, auto_reset=True)
             if steps % R:
-                eng.rollout_random(steps % R, auto_reset=True)
+                rollout(steps % R, auto_reset=True)
         else:
             for _ in range(steps):
                 step()
@@ -164,7 +167,7 @@ def main():
     eng.reset()
     run(args.warmup)
     if R > 0 and args.steps % R:
-        eng.rollout_random(args.steps % R, auto_reset=True)      # the remainder launch of the timed region, warmed too
+        run(args.steps % R)      # the remainder launch of the timed region, warmed too
     eng.kernel_time(enable=1 if R > 0 else 16)   # HIP-event pair around (every 16th) launch of the dominant kernel in the timed region
 
     def barrier():
@@ -187,13 +190,14 @@ def main():
         k2 = min(args.steps, 1000)
         eng.kernel_time(enable=16)
         barrier()
+        idle1 = eng.idle_steps()
         t1 = time.perf_counter()
         for _ in range(k2):
             step()
         barrier()
         e2 = time.perf_counter() - t1
         km2, _ = eng.kernel_time(enable=False)
-        per_step = {'value': args.batch * world * k2 / e2, 'unit': 'env-steps/s', 'steps': k2, 'ms_per_step': e2 / k2 * 1e3,
+        per_step = {'value': (args.batch * k2 - (eng.idle_steps() - idle1)) * world / e2, 'unit': 'env-steps/s', 'steps': k2, 'ms_per_step': e2 / k2 * 1e3,
                     'kernel': 'step_kernel', 'kernel_avg_us': km2 * 1e3,
                     'roofline_frac': (algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles) * args.batch / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS) if km2 > 0 else 0.0}
 
@@ -212,7 +216,7 @@ def main():
         # what a rollout launch must really move: every step's observations + scalars, the state and geometry once
         resident = (args.batch * (steps_per_launch * b_obs + (b_alg - b_obs - 8 * (eng.num_cameras + eng.num_targets)))
                     if R > 0 else bytes_per_launch)
-        kernel = ('rollout_kernel' if R > 0 else 'step_kernel')
+        kernel = ('step_kernel' if R == 0 else 'rollout_greedy_kernel' if args.policy == 'greedy' else 'rollout_kernel')
         default_case = args.batch == BATCH_PER_GPU and args.workload == WORKLOAD and (R == 32 or args.policy == 'greedy' or R == 0)
         line = {
             'metric': f'env-steps/sec {args.workload[:-5]} batch={args.batch} per GPU ({args.policy} policy, auto-reset)',
@@ -228,7 +232,7 @@ def main():
                 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': measured_traffic(kernel) if default_case and args.policy == 'random' else None,
                 'traffic_unit': 'bytes per launch (rocprofv3 2*FETCH_SIZE + WRITE_SIZE, profiles/latest_pmc.json)',
-                'kernel': '%s<float, %s, %s>' % (kernel, 'FixedShape' if eng.specialised else 'AnyShape', ('FLOW_ANY', 'FLOW_RANDOM', 'FLOW_ACT_F32')[flow]),
+                'kernel': '%s<float, %s, %s>' % (kernel, 'FixedShape' if eng.specialised else 'AnyShape', ('FLOW_ANY', 'FLOW_RANDOM', 'FLOW_ACT_F32', 'FLOW_GREEDY')[flow]),
                 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches, 'env_steps_per_launch': args.batch * steps_per_launch,
                 'algorithmic_bytes_per_launch': bytes_per_launch,
                 'resident_bytes_per_launch': resident,

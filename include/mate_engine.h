@@ -151,6 +151,15 @@ typedef struct mate_policy_tape {
 int mate_engine_policy_enable(mate_engine *engine);
 int mate_engine_step_greedy(mate_engine *engine, const mate_step_io *io, const mate_policy_tape *tape,
                             int32_t auto_reset, void *stream);
+/* `steps` consecutive (agents act, environment steps) iterations of GreedyCameraAgent vs GreedyTargetAgent fused into ONE
+ * launch: mate.group_step + env.step of the evaluation loop (mate/evaluate.py:104-139, agents/greedy.py), with the
+ * environment records, the agents' memory and the view masks resident in LDS.  Outputs are rollout-shaped like
+ * mate_engine_rollout_random ([steps][N][...]); observations and scalars are required.  An environment whose episode ends
+ * stops there (done = 2 in its later scalar rows, counted by mate_engine_idle_steps) and, with auto_reset, starts a new
+ * episode before the next call.  Philox draws only (no policy tape).  Bit-identical to `steps` calls of
+ * mate_engine_step_greedy. */
+int mate_engine_rollout_greedy(mate_engine *engine, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream);
+
 /* copies the joint actions of the last step_greedy into caller buffers [N][Nc][2] / [N][Nt][2] f64 (either may be NULL) */
 int mate_engine_policy_actions(mate_engine *engine, double *camera_actions_dev, double *target_actions_dev, void *stream);
 

@@ -24,7 +24,11 @@ struct Params {
     int32_t SW, DF, NI, DW;
     int32_t n_sector, n_range, sector_rounds, range_rounds;
     int32_t bit_cc, bit_range, bit_camobs, bit_always, MW;
-    int32_t bit_shared;      // first of the Nt + No + Nc + No team-shared visibility flags (SharedFieldOfView mode)
+    // Visibility FLAGS (one ObsT-wide word each, all-ones or zero, in LDS) are numbered compactly -- the packed mask
+    // words pad every group of bits to 64, which as flags wasted half of the largest LDS region: sector flags
+    // [0, n_sector) coincide with their mask bits, then the range tests, camera->obstacle, the always-true flag and
+    // the Nt + No + Nc + No team-shared flags of the SharedFieldOfView mode.
+    int32_t fs_range, fs_camobs, fs_always, fs_shared, nflags;
     int32_t nscratch, sc_cam, sc_tgt, sc_obs;
     int32_t tgt_table_off;   // first target descriptor (cam_elems rounded up to 4)
     int32_t kmax, nbucket;
@@ -61,7 +65,8 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
     p.bit_camobs = p.bit_range + p.range_rounds * 64;
     p.bit_always = p.bit_camobs + Nc * 64;
     p.MW = p.bit_always / 32 + 1;
-    p.bit_shared = p.MW * 32;
+    p.fs_range = p.n_sector; p.fs_camobs = p.fs_range + p.n_range; p.fs_always = p.fs_camobs + Nc * No;
+    p.fs_shared = p.fs_always + 1; p.nflags = p.fs_shared + Nt + 2 * No + Nc;
     p.sc_cam = 30; p.sc_tgt = p.sc_cam + 10 * Nc; p.sc_obs = p.sc_tgt + 14 * Nt; p.nscratch = shape_round_up(p.sc_obs + 3 * No, 4);
     p.kmax = shape_round_up(360 + No * 185 + 2, 8);
     p.nbucket = 368;
@@ -79,7 +84,7 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
     p.off_scratch = off; off += shape_round_up(p.nscratch * obs_size, 16);
     p.off_mask = off; off += shape_round_up(p.MW * 4, 16);
     p.off_misc = off; off += shape_round_up((4 * Nt + 8) * 4, 16);
-    p.off_flags = off; off += shape_round_up((p.MW * 32 + Nt + 2 * No + Nc) * obs_size, 16);
+    p.off_flags = off; off += shape_round_up(p.nflags * obs_size, 16);
     p.off_ent = off; off += shape_round_up(3 * p.NJ * 8, 16);
     p.lds_wave_bytes = off;
 }
@@ -190,6 +195,7 @@ enum Flow : int {
     FLOW_ANY = 0,
     FLOW_RANDOM = 1,    // step_random: on-device uniform policy, Philox draws, plain observations, all outputs present
     FLOW_ACT_F32 = 2,   // step: f32 continuous joint actions, Philox draws, plain observations, all outputs present
+    FLOW_GREEDY = 3,    // rollout_greedy_kernel: joint actions of the on-device Greedy agents, handed over in LDS
 };
 
 template <typename ObsT>
@@ -208,6 +214,7 @@ struct Ctx {
     const uint32_t *table;
     unsigned char *base;
     double *ex, *ey, *er;         // unified entity table [cameras | obstacles | targets]: x, y, radius
+    const double *act_cam = nullptr, *act_tgt = nullptr;   // FLOW_GREEDY: this step's joint actions in LDS ([Nc][2], [Nt][2])
 
     __device__ Ctx(const Params &p_, const Ptrs &g_, unsigned char *wave_base, int lane_, int64_t env_, int flow_ = FLOW_ANY)
         : p(p_), g(g_), flow(flow_), lane(lane_), env(env_), out(env_) {
@@ -223,7 +230,8 @@ struct Ctx {
         ex = reinterpret_cast<double *>(wave_base + p.off_ent); ey = ex + p.NJ; er = ey + p.NJ;
     }
     // launch switches (constants in the specialised flows)
-    __device__ __forceinline__ int mode() const { return flow == FLOW_RANDOM ? (int)MODE_STEP_RANDOM : flow == FLOW_ACT_F32 ? (int)MODE_STEP : g.mode; }
+    __device__ __forceinline__ int mode() const { return flow == FLOW_RANDOM ? (int)MODE_STEP_RANDOM : (flow == FLOW_ACT_F32 || flow == FLOW_GREEDY) ? (int)MODE_STEP : g.mode; }
+    __device__ __forceinline__ bool act_from_lds() const { return flow == FLOW_GREEDY; }
     __device__ __forceinline__ int act_f64() const { return flow == FLOW_ACT_F32 ? 0 : g.act_f64; }
     __device__ __forceinline__ int act_discrete() const { return flow != FLOW_ANY ? 0 : g.act_discrete; }
     __device__ __forceinline__ const double *tape_ct() const { return flow != FLOW_ANY ? nullptr : g.tape_ct; }
@@ -394,6 +402,7 @@ __device__ __forceinline__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &
         if (advance) {
             double da, dz;
             if (c.mode() == MODE_STEP_RANDOM) { da = draws.a0; dz = draws.a1; }
+            else if (c.act_from_lds()) { da = c.act_cam[2 * lane]; dz = c.act_cam[2 * lane + 1]; }
             else if (c.act_discrete() & 1) {                 // DiscreteCamera.action, discrete_action_spaces.py:71-73
                 int idx = reinterpret_cast<const int32_t *>(c.g.cam_act)[c.env * p.Nc + lane];
                 idx = idx < 0 ? 0 : (idx >= c.g.n_cam_grid ? c.g.n_cam_grid - 1 : idx);
@@ -437,6 +446,7 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
     if (is_target) {
         double ax, ay;
         if (c.mode() == MODE_STEP_RANDOM) { ax = draws.a0; ay = draws.a1; }
+        else if (c.act_from_lds()) { ax = c.act_tgt[2 * t]; ay = c.act_tgt[2 * t + 1]; }
         else if (c.act_discrete() & 2) {                     // DiscreteTarget.action, discrete_action_spaces.py:177-179
             int idx = reinterpret_cast<const int32_t *>(c.g.tgt_act)[c.env * p.Nt + t];
             idx = idx < 0 ? 0 : (idx >= c.g.n_tgt_grid ? c.g.n_tgt_grid - 1 : idx);
@@ -685,7 +695,7 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     for (int round = 0; round < p.range_rounds; ++round) {
         const int q = round * 64 + lane;
         const bool seen = (seen_bits >> round) & 1u;
-        if (q < p.n_range) set_flag(c, p.bit_range + q, seen);
+        if (q < p.n_range) set_flag(c, p.fs_range + q, seen);
         const unsigned long long b = __ballot(seen);
         if (lane == 0) { c.mask[rbase + 2 * round] = (uint32_t)b; c.mask[rbase + 2 * round + 1] = (uint32_t)(b >> 32); }
     }
@@ -702,11 +712,11 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         c.mask[(p.bit_camobs >> 5) + 2 * lane] = (uint32_t)m;
         c.mask[(p.bit_camobs >> 5) + 2 * lane + 1] = (uint32_t)(m >> 32);
     }
-    if (lane == 0) { c.mask[p.bit_always >> 5] = 1u; set_flag(c, p.bit_always, true); }
+    if (lane == 0) { c.mask[p.bit_always >> 5] = 1u; set_flag(c, p.fs_always, true); }
     for (int q = lane; q < p.Nc * p.No; q += 64) {
         const int cam = (int)(((float)q + 0.5f) * p.inv_No);
         const int o = q - cam * p.No;
-        set_flag(c, p.bit_camobs + cam * 64 + o, (c.camobs(cam) >> o) & 1ull);
+        set_flag(c, p.fs_camobs + cam * p.No + o, (c.camobs(cam) >> o) & 1ull);
     }
     wave_sync();
     // ---- tracked_bits = camera_target_view_mask.any(axis=0) (environment.py:1388); which warehouse holds the target
@@ -897,18 +907,18 @@ __device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c) {
     // SharedFieldOfView: an entity is visible to the whole team when any member sees it
     // (shared_field_of_view.py:97-100, 117-120); flags live behind the mask flags, see build_descriptors
     if ((c.obs_mode() & 3) == 2) {
-        if (lane < p.Nt) set_flag(c, p.bit_shared + lane, c.tracked(lane) != 0);
+        if (lane < p.Nt) set_flag(c, p.fs_shared + lane, c.tracked(lane) != 0);
         for (int o = lane; o < p.No; o += 64) {
             bool any = false;
             for (int cam = 0; cam < p.Nc; ++cam) any = any || ((c.camobs(cam) >> o) & 1ull);
-            set_flag(c, p.bit_shared + p.Nt + o, any);
+            set_flag(c, p.fs_shared + p.Nt + o, any);
         }
     }
     if (tgt_mode == 2) {
         for (int j = lane; j < p.Nc + p.No; j += 64) {
             bool any = false;
             for (int t = 0; t < p.Nt; ++t) any = any || c.mask_bit(p.bit_range + t * p.NJ + j);
-            set_flag(c, p.bit_shared + p.Nt + p.No + j, any);
+            set_flag(c, p.fs_shared + p.Nt + p.No + j, any);
         }
     }
     wave_sync();

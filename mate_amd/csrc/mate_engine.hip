@@ -44,7 +44,7 @@ using PolicyFn = void (*)(const Params *, const Ptrs, const PolicyPtrs);
 
 // step[flow]: the launch-flag specialisations (enum Flow) exist for f32 observations, the product path; f64
 // observations (the parity mirror) run the generic flow everywhere.
-static void pick_kernels(int Nc, int Nt, int No, bool f64, StepFn *step, StepFn *rollout, PolicyFn *policy, int *specialised) {
+static void pick_kernels(int Nc, int Nt, int No, bool f64, StepFn *step, StepFn *rollout, PolicyFn *policy, PolicyFn *rollout_greedy, int *specialised) {
     const char *gen = getenv("MATE_GENERIC");
     *specialised = 0;
     if (!(gen && atoi(gen) != 0)) {
@@ -57,6 +57,7 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, StepFn *step, StepFn 
         rollout[0] = f64 ? (StepFn)rollout_kernel<double, FixedShape<C, T, O, true>> : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>>; \
         rollout[1] = f64 ? rollout[0] : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                                   \
         *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, FixedShape<C, T, O, true>> : (PolicyFn)greedy_policy_kernel<float, FixedShape<C, T, O, false>>; \
+        *rollout_greedy = f64 ? (PolicyFn)rollout_greedy_kernel<double, FixedShape<C, T, O, true>> : (PolicyFn)rollout_greedy_kernel<float, FixedShape<C, T, O, false>>; \
         return;                                                                                                     \
     }
         MATE_SHAPES(X)
@@ -68,6 +69,7 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, StepFn *step, StepFn 
     rollout[0] = f64 ? (StepFn)rollout_kernel<double, AnyShape> : (StepFn)rollout_kernel<float, AnyShape>;
     rollout[1] = f64 ? rollout[0] : (StepFn)rollout_kernel<float, AnyShape, FLOW_RANDOM>;
     *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, AnyShape> : (PolicyFn)greedy_policy_kernel<float, AnyShape>;
+    *rollout_greedy = f64 ? (PolicyFn)rollout_greedy_kernel<double, AnyShape> : (PolicyFn)rollout_greedy_kernel<float, AnyShape>;
 }
 
 struct mate_engine {
@@ -83,7 +85,7 @@ struct mate_engine {
     int64_t steps_since_reset = 0;   // batched auto-reset bookkeeping
     bool was_reset = false;
     size_t step_lds = 0, reset_lds = 0;
-    PolicyFn policy_fn = nullptr;
+    PolicyFn policy_fn = nullptr, rollout_greedy_fn = nullptr;
     StepFn step_fn[3] = {nullptr, nullptr, nullptr}, rollout_fn[2] = {nullptr, nullptr};   // kernels chosen at create: shape-specialised when compiled for these counts; step_fn[flow]
     int last_flow = 0;
     bool flow_generic = false;                        // MATE_FLOW_GENERIC=1: every launch runs the FLOW_ANY kernel (tests)
@@ -131,8 +133,8 @@ static int dev_alloc(mate_engine *e, T **out, size_t count, bool zero = true) {
 static void build_descriptors(const Params &p, std::vector<uint32_t> &desc, int cam_mode = 0, int tgt_mode = 0) {
     const int Nc = p.Nc, Nt = p.Nt, No = p.No;
     const int sz = p.obs_f64 ? 8 : 4;
-    auto D = [&](int src, int bit) { return (uint32_t)(p.off_scratch + src * sz) | ((uint32_t)(p.off_flags + bit * sz) << 16); };
-    const int ALWAYS = p.bit_always;
+    auto D = [&](int src, int flag) { return (uint32_t)(p.off_scratch + src * sz) | ((uint32_t)(p.off_flags + flag * sz) << 16); };   // flag slots: Params::fs_*
+    const int ALWAYS = p.fs_always;
     const int SC_ZERO = 0, SC_ONE = 1, SC_CONST = 2, SC_IDX = 14;
     (void)SC_ZERO;
     desc.assign((size_t)p.tgt_table_off + round_up(p.tgt_elems, 4), D(0, ALWAYS));
@@ -158,8 +160,8 @@ static void build_descriptors(const Params &p, std::vector<uint32_t> &desc, int 
         preserved(row, c);
         for (int i = 0; i < 9; ++i) row[13 + i] = D(p.sc_cam + c * 10 + i, ALWAYS);
         uint32_t *q = row + 22;
-        for (int t = 0; t < Nt; ++t, q += 5) tgt_pub(q, t, cam_mode == 1 ? ALWAYS : cam_mode == 2 ? p.bit_shared + t : c * Nt + t);
-        for (int o = 0; o < No; ++o, q += 4) obs_pub(q, o, cam_mode == 1 ? ALWAYS : cam_mode == 2 ? p.bit_shared + Nt + o : p.bit_camobs + c * 64 + o);
+        for (int t = 0; t < Nt; ++t, q += 5) tgt_pub(q, t, cam_mode == 1 ? ALWAYS : cam_mode == 2 ? p.fs_shared + t : c * Nt + t);
+        for (int o = 0; o < No; ++o, q += 4) obs_pub(q, o, cam_mode == 1 ? ALWAYS : cam_mode == 2 ? p.fs_shared + Nt + o : p.fs_camobs + c * No + o);
         for (int c2 = 0; c2 < Nc; ++c2, q += 7) cam_pub(q, c2, cam_mode != 0 ? ALWAYS : p.bit_cc + c * Nc + c2);
     }
     for (int t = 0; t < Nt; ++t) {
@@ -167,8 +169,8 @@ static void build_descriptors(const Params &p, std::vector<uint32_t> &desc, int 
         preserved(row, t);
         for (int i = 0; i < 14; ++i) row[13 + i] = D(p.sc_tgt + t * 14 + i, ALWAYS);
         uint32_t *q = row + 27;
-        const int rb = p.bit_range + t * p.NJ;
-        const int sb = p.bit_shared + Nt + No;
+        const int rb = p.fs_range + t * p.NJ;
+        const int sb = p.fs_shared + Nt + No;
         for (int c = 0; c < Nc; ++c, q += 7) cam_pub(q, c, tgt_mode == 1 ? ALWAYS : tgt_mode == 2 ? sb + c : rb + c);
         for (int o = 0; o < No; ++o, q += 4) obs_pub(q, o, tgt_mode == 1 ? ALWAYS : tgt_mode == 2 ? sb + Nc + o : rb + Nc + o);
         for (int t2 = 0; t2 < Nt; ++t2, q += 5) tgt_pub(q, t2, tgt_mode != 0 ? ALWAYS : rb + Nc + No + t2);
@@ -240,7 +242,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     p.obs_r_lo = cfg->obstacle_radius_range[0]; p.obs_r_hi = cfg->obstacle_radius_range[1];
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.first_env = (uint32_t)first_env_index;
     e->step_lds = 4 * (size_t)p.lds_wave_bytes;
-    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->step_fn, e->rollout_fn, &e->policy_fn, &e->specialised);
+    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->step_fn, e->rollout_fn, &e->policy_fn, &e->rollout_greedy_fn, &e->specialised);
     { const char *fg = getenv("MATE_FLOW_GENERIC"); e->flow_generic = fg && atoi(fg) != 0; }
     if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }
     ResetLds &rl = e->rl;
@@ -660,6 +662,11 @@ static int policy_enable(mate_engine *e) {
     if (!e->g.own_masks && (rc = dev_alloc(e, &e->g.own_masks, (size_t)e->N * p.MW))) return rc;
     q.masks = e->g.own_masks;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->policy_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * q.lds_bytes + 1024);
+    if (err == hipSuccess) {
+        const size_t fused = 4 * (size_t)p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(q.PW, p.Nc, p.Nt) + 1024;
+        if (fused <= 160 * 1024)
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rollout_greedy_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused);
+    }
     if (err != hipSuccess) return fail(MATE_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
     e->policy_ready = true;
     return MATE_OK;
@@ -696,6 +703,49 @@ extern "C" int mate_engine_step_greedy(mate_engine *e, const mate_step_io *io, c
     if (io) io2 = *io; else std::memset(&io2, 0, sizeof(io2));
     io2.camera_actions_dev = q.cam_act; io2.target_actions_dev = q.tgt_act; io2.act_dtype = MATE_ACT_F64;
     return launch_step(e, &io2, MODE_STEP, auto_reset, stream);
+}
+
+extern "C" int mate_engine_rollout_greedy(mate_engine *e, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    if (!e->was_reset) return fail(MATE_ESTATE, "rollout_greedy called before reset() (or import_state)");
+    if (!e->policy_ready) return fail(MATE_ESTATE, "call mate_engine_policy_enable() before the reset whose observations the policies act on");
+    if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(e->device));
+    Ptrs g = e->g;
+    apply_io(g, io);
+    if ((e->p.Nc > 0 && !g.cam_obs) || !g.tgt_obs || !g.scalars) return fail(MATE_EINVAL, "rollout_greedy needs the observation and scalar outputs");
+    if (g.obs_mode != 0 || g.xdesc) return fail(MATE_EINVAL, "rollout_greedy packs plain observations (no fused transform / team mode)");
+    const size_t lds = 4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt) + 1024;
+    if (lds > 160 * 1024) return fail(MATE_EINVAL, "rollout_greedy: %zu bytes of LDS per workgroup do not fit", lds);
+    g.mode = MODE_STEP; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick; g.rollout_steps = steps;
+    g.tape_ct = nullptr; g.tape_goal = nullptr; g.freeze_done = 0;
+    { const char *rv = getenv("MATE_ROLLOUT_ROTATE"); g.rotate_prio = rv ? atoi(rv) : 1; }
+    if (!auto_reset) g.done_count = nullptr;
+    PolicyPtrs q = e->q;
+    std::memset(&q.tape, 0, sizeof(q.tape));
+    const unsigned blocks = (unsigned)((e->N + 3) / 4);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (e->timing > 0 && (e->timing_tick++ % e->timing) == 0) {
+        if (e->events_used == e->events.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+            e->events.emplace_back(a, b);
+        }
+        ev0 = e->events[e->events_used].first; ev1 = e->events[e->events_used].second; ++e->events_used;
+    }
+    e->last_flow = FLOW_GREEDY;
+    hipExtLaunchKernelGGL(e->rollout_greedy_fn, dim3(blocks), dim3(256), lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g, (const PolicyPtrs)q);
+    HIP_TRY(hipGetLastError());
+    e->tick += (uint32_t)steps;
+    if (auto_reset) {
+        Ptrs r = e->g;
+        apply_io(r, nullptr);     // state and the engine's own masks: the agents of the next rollout act on the fresh view
+        int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream);
+        if (rc != MATE_OK) return rc;
+        e->parity ^= 1;
+    }
+    return MATE_OK;
 }
 
 // Copy the joint actions the last mate_engine_step_greedy produced into caller buffers ([N][Nc][2], [N][Nt][2] f64).

@@ -400,4 +400,98 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     }
 }
 
+// =============================================================================================
+// K fused steps of Greedy cameras vs Greedy targets: the agents' step (greedy_policy_body) and the environment's step
+// in one loop, with the environment records, the agents' memory and the view masks resident in LDS for the whole
+// launch and the joint actions handed over in LDS.  Same results as K x (greedy_policy_kernel + step_kernel), bit for
+// bit (tested).  The four waves of a workgroup meet at the two barriers of the shared zoom solve in every step, so no
+// wave leaves the loop early: a wave past the end of the batch, or whose episode has ended, keeps running the
+// agents' step on its stale data (no stores) and skips the environment's step.
+__host__ __device__ constexpr int policy_slice_bytes(int PW, int Nc, int Nt) { return shape_round_up((PW + Nc * Nc / 2 + 2 + 2 * (Nc + Nt)) * 8, 16); }
+
+template <typename ObsT, typename Shape>
+__global__ __launch_bounds__(256, 4) void rollout_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q) {
+    const Shape shape(pp);
+    const Params &p = shape.get();
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int64_t env_raw = (int64_t)blockIdx.x * 4 + wave;
+    const bool in_batch = env_raw < g.N;
+    const int64_t env = in_batch ? env_raw : g.N - 1;
+    const Ptrs &gk = kernarg_ptrs(g);
+    const int pol_bytes = policy_slice_bytes(q.PW, p.Nc, p.Nt);
+    unsigned char *pol_base = smem + 4 * p.lds_wave_bytes + wave * pol_bytes;
+    double *shared_K = reinterpret_cast<double *>(smem + 4 * p.lds_wave_bytes + 4 * pol_bytes);
+    double *shared_B = shared_K + 64;
+    PolCtx<ObsT> a(p, q, pol_base);
+    double *act_cam = a.f + (q.PW + p.Nc * p.Nc / 2 + 2), *act_tgt = act_cam + 2 * p.Nc;
+    {
+        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
+        load_records(c);
+        wave_sync();
+        const uint32_t *m = q.masks + env * p.MW;                 // the view the previous step / reset left
+        for (int i = lane; i < p.MW; i += 64) c.mask[i] = m[i];
+        const double *src = q.pol + env * q.PW;
+        for (int k = lane; k < q.PW; k += 64) a.f[k] = src[k];
+        build_entities(c);
+        wave_sync();
+    }
+    PackDescriptors held;
+    {
+        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
+        load_pack_descriptors(c, held);
+    }
+    uint32_t hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    const int wave_slot = (int)(hw_id & 15u);
+#pragma clang loop unroll(disable)
+    for (int r = 0; r < g.rollout_steps; ++r) {
+        int lane_r = lane, wave_r = wave;                          // opaque per iteration, see rollout_kernel
+        asm volatile("" : "+v"(lane_r));
+        asm volatile("" : "+s"(wave_r));
+        const Params *pr = pp;
+        asm volatile("" : "+s"(pr));
+        const Shape shape_r(pr);
+        const Params &p = shape_r.get();
+        const int64_t env_w = (int64_t)blockIdx.x * 4 + wave_r;
+        const int64_t env_r = env_w < g.N ? env_w : g.N - 1;
+        Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW_GREEDY);
+        c.out = (int64_t)r * g.N + env_r;
+        c.act_cam = act_cam; c.act_tgt = act_tgt;
+        const bool active = in_batch && c.ei(EI_DONE) == 0;
+        if (g.rotate_prio) {
+            const int turn = (r + wave_slot) & 3;
+            if (turn == 0) __builtin_amdgcn_s_setprio(0);
+            else if (turn == 1) __builtin_amdgcn_s_setprio(1);
+            else if (turn == 2) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(3);
+        }
+        greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, c.mask, shared_K, shared_B, wave_r, lane_r, env_r, active, act_cam, act_tgt);
+        wave_sync();
+        if (!active) {
+            if (in_batch && lane_r == 0) {
+                if (g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
+                if (g.idle_steps) g.idle_steps[env_r] += 1;
+            }
+            continue;                                              // the next barrier is in the next step's agents
+        }
+        const uint32_t tick = g.tick + (uint32_t)r;
+        const StepDraws draws = step_draws(c, tick);               // see-through uniforms only (mode() is MODE_STEP)
+        simulate_cameras(c, draws, true);
+        simulate_targets(c, draws);
+        update_view(c, tick, S_TRANSMIT, true);
+        assign_and_score(c, tick, g.scalars);
+        fill_scratch(c);
+        pack_observations<true>(c, held);
+        wave_sync();
+    }
+    if (in_batch) {
+        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
+        store_dynamic(c);
+        double *dst = q.pol + env * q.PW;
+        for (int k = lane; k < q.PW; k += 64) dst[k] = a.f[k];
+    }
+}
+
 }  // namespace mate

@@ -234,7 +234,12 @@ class Engine:
             check(status)
         return self.camera_obs, self.target_obs, self.scalars
 
-    def rollout_random(self, steps, auto_reset=True, want_masks=False):
+    def rollout_greedy(self, steps, auto_reset=True, want_masks=False):
+        """`steps` fused (agents act, environment steps) iterations of the on-device Greedy policies (enable_policies()
+        first).  Same rollout-shaped tensors as rollout_random."""
+        return self.rollout_random(steps, auto_reset, want_masks, _greedy=True)
+
+    def rollout_random(self, steps, auto_reset=True, want_masks=False, _greedy=False):
         """`steps` fused steps under the on-device random policy.  Returns rollout-shaped tensors
         (camera_obs [T,N,Nc,Dc], target_obs [T,N,Nt,Dt], scalars [T,N,8]); scalars[..., 2] == 2 marks
         steps skipped because the episode had already ended inside this rollout."""
@@ -256,7 +261,8 @@ class Engine:
         io.target_obs_dev = buf['target_obs'].data_ptr()
         io.scalars_dev = buf['scalars'].data_ptr()
         io.masks_dev = buf['masks'].data_ptr() if want_masks else None
-        check(self.lib.mate_engine_rollout_random(self._h, ctypes.byref(io), steps, int(auto_reset), self._stream()))
+        fn = self.lib.mate_engine_rollout_greedy if _greedy else self.lib.mate_engine_rollout_random
+        check(fn(self._h, ctypes.byref(io), steps, int(auto_reset), self._stream()))
         return buf['camera_obs'][:steps], buf['target_obs'][:steps], buf['scalars'][:steps]
 
     def enable_policies(self):

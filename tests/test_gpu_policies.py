@@ -123,3 +123,44 @@ def test_greedy_policies_batch_vs_oracle(config, n, steps, oracle_lib):
             ref = batch.gather(k)
             assert np.array_equal(sd[k].reshape(ref.shape), ref), (k, s)
         assert np.abs(sd['tgt_x'] - batch.gather('tgt_x')).max() < 1e-8
+
+
+@pytest.mark.parametrize('config,n,kw', [('MATE-4v8-9.yaml', 37, {}), ('MATE-8v8-9.yaml', 22, {}), ('MATE-4v2-9.yaml', 16, {}),
+                                         ('MATE-4v8-9.yaml', 24, {'max_episode_steps': 20})])
+def test_fused_greedy_rollout_equals_single_steps(config, n, kw):
+    """rollout_greedy(K) == K x step_greedy(): observations, scalars, masks, joint actions, final state and agent memory,
+    bit for bit -- including a batch size that is not a multiple of the workgroup's four environments, and episodes
+    that end inside the rollout (time limit 20): those environments idle until the reset after the launch, exactly like
+    the batched auto-reset of the single-step flow."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config(config, **kw)
+    K = 12
+    a = Engine(cfg, n, seed=9, first_env_index=11)
+    b = Engine(cfg, n, seed=9, first_env_index=11)
+    for e in (a, b):
+        e.enable_policies()
+        e.reset()
+    rounds = 3 if kw else 2
+    idled = False
+    for rnd in range(rounds):
+        cam_r, tgt_r, sc_r = a.rollout_greedy(K, auto_reset=True, want_masks=True)
+        idle = (sc_r[:, :, 2] == 2)
+        for r in range(K):
+            b.step_greedy(auto_reset=10 ** 6)     # batched mode: finished environments idle (the reset comes below)
+            live = ~idle[r]
+            assert torch.equal(sc_r[r][live], b.scalars[live]), (rnd, r)
+            assert torch.equal(tgt_r[r][live], b.target_obs[live]), (rnd, r)
+            if a.num_cameras:
+                assert torch.equal(cam_r[r][live], b.camera_obs[live]), (rnd, r)
+            assert torch.equal(a._rollout['masks'][r][live], b.masks[live]), (rnd, r)
+            assert bool((b.scalars[idle[r]][:, 2] == 2).all())
+        idled = idled or bool(idle.any())
+        # the launch after the rollout restarted the finished environments; do the same on the single-step engine
+        done = torch.from_numpy(b.state_dict()['done'] != 0).to(b.device)
+        if bool(done.any()):
+            b.reset(env_mask=done)
+        sa, sb = a.state_dict(), b.state_dict()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), (rnd, k)
+    assert idled == bool(kw)         # the time-limit case did end episodes inside a rollout
