@@ -159,3 +159,39 @@ def test_greedy_workload_sharding_and_progress():
     assert float(eng.scalars[:, 3].mean()) > 0.2                       # coverage the greedy cameras keep
     idle = eng.idle_steps() - idle0
     assert 0 < idle < 0.12 * n * steps                                 # finished environments waited for the next batched reset
+
+
+def test_benchmark_flow_equals_single_steps_at_the_headline_size():
+    """bench.py's default flow -- 32-step fused rollout launches of MATE-4v8-9 x 4096 with auto-reset after each launch --
+    against 32 single-step launches: every row of both observation blocks, the scalar records and the masks, then the
+    state, bit for bit, over two launches."""
+    cfg = read_config('MATE-4v8-9.yaml')
+    n, K = 4096, 32
+    a = Engine(cfg, n, seed=21)
+    b = Engine(cfg, n, seed=21)
+    a.reset(); b.reset()
+    for launch in range(2):
+        cam, tgt, sc = a.rollout_random(K, auto_reset=True, want_masks=True)
+        assert a.last_flow == 1
+        for r in range(K):
+            b.step_random(auto_reset=False, want_masks=True)
+            assert torch.equal(cam[r], b.camera_obs) and torch.equal(tgt[r], b.target_obs), (launch, r)
+            assert torch.equal(sc[r], b.scalars) and torch.equal(a._rollout['masks'][r], b.masks), (launch, r)
+        assert not bool((sc[:, :, 2] != 0).any())           # nothing ends this early: no idle slot, no reset
+        assert torch.equal(a.export_state(), b.export_state())
+
+
+def test_fused_greedy_rollout_equals_single_steps_at_config3_size():
+    """BASELINE config 3 (MATE-8v8-9 x 8192, Greedy vs Greedy): one fused 8-step launch == 8 x (policy launch + step launch)."""
+    cfg = read_config('MATE-8v8-9.yaml')
+    n, K = 8192, 8
+    a = Engine(cfg, n, seed=5)
+    b = Engine(cfg, n, seed=5)
+    for e in (a, b):
+        e.enable_policies()
+        e.reset()
+    cam, tgt, sc = a.rollout_greedy(K, auto_reset=True)
+    for r in range(K):
+        b.step_greedy(auto_reset=10 ** 6)
+        assert torch.equal(cam[r], b.camera_obs) and torch.equal(tgt[r], b.target_obs) and torch.equal(sc[r], b.scalars), r
+    assert torch.equal(a.export_state(), b.export_state())
