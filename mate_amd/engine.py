@@ -237,12 +237,15 @@ class Engine:
     def rollout_greedy(self, steps, auto_reset=True, want_masks=False):
         """`steps` fused (agents act, environment steps) iterations of the on-device Greedy policies (enable_policies()
         first).  Same rollout-shaped tensors as rollout_random."""
-        return self.rollout_random(steps, auto_reset, want_masks, _greedy=True)
+        return self._run_rollout(self.lib.mate_engine_rollout_greedy, steps, auto_reset, want_masks)
 
-    def rollout_random(self, steps, auto_reset=True, want_masks=False, _greedy=False):
+    def rollout_random(self, steps, auto_reset=True, want_masks=False):
         """`steps` fused steps under the on-device random policy.  Returns rollout-shaped tensors
         (camera_obs [T,N,Nc,Dc], target_obs [T,N,Nt,Dt], scalars [T,N,8]); scalars[..., 2] == 2 marks
         steps skipped because the episode had already ended inside this rollout."""
+        return self._run_rollout(self.lib.mate_engine_rollout_random, steps, auto_reset, want_masks)
+
+    def _run_rollout(self, entry_point, steps, auto_reset, want_masks):
         steps = int(steps)
         buf = getattr(self, '_rollout', None)
         if buf is None or buf['steps'] < steps or (want_masks and buf['masks'] is None):     # a shorter rollout fills a prefix
@@ -261,8 +264,7 @@ class Engine:
         io.target_obs_dev = buf['target_obs'].data_ptr()
         io.scalars_dev = buf['scalars'].data_ptr()
         io.masks_dev = buf['masks'].data_ptr() if want_masks else None
-        fn = self.lib.mate_engine_rollout_greedy if _greedy else self.lib.mate_engine_rollout_random
-        check(fn(self._h, ctypes.byref(io), steps, int(auto_reset), self._stream()))
+        check(entry_point(self._h, ctypes.byref(io), steps, int(auto_reset), self._stream()))
         return buf['camera_obs'][:steps], buf['target_obs'][:steps], buf['scalars'][:steps]
 
     def enable_policies(self):

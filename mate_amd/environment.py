@@ -572,6 +572,29 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
         self.engine.step_random(auto_reset=self.auto_reset)
         return self._result()
 
+    def _rollout_result(self, out):
+        cam, tgt, s = out
+        info = {'coverage_rate': s[..., 3], 'real_coverage_rate': s[..., 4], 'mean_transport_rate': s[..., 5],
+                'num_delivered_cargoes': s[..., 6], 'normalized_raw_reward': s[..., 7],
+                'skipped': s[..., 2] == 2}          # slots after the end of an episode inside the launch (no step, stale rows)
+        return (cam, tgt), (s[..., 0], s[..., 1]), s[..., 2] == 1, info
+
+    def rollout_random(self, steps):
+        """`steps` env.step(random action) iterations in ONE launch (the fastest flow): every tensor of
+        step()'s result with a leading [steps] axis.  Finished episodes restart after the launch."""
+        return self._rollout_result(self.engine.rollout_random(steps, auto_reset=bool(self.auto_reset)))
+
+    def rollout_greedy(self, steps):
+        """`steps` iterations of mate.group_step with the reference's Greedy camera / target agents + env.step in ONE
+        launch (agents on the device)."""
+        if not getattr(self, '_policies_on', False):
+            raise RuntimeError('enable_greedy_policies() must precede the reset() the agents first act on')
+        return self._rollout_result(self.engine.rollout_greedy(steps, auto_reset=bool(self.auto_reset)))
+
+    def enable_greedy_policies(self):
+        self.engine.enable_policies()
+        self._policies_on = True
+
     def masks(self):
         return self.engine.unpack_masks()
 
