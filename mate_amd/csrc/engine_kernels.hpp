@@ -215,6 +215,8 @@ struct Ctx {
     unsigned char *base;
     double *ex, *ey, *er;         // unified entity table [cameras | obstacles | targets]: x, y, radius
     const double *act_cam = nullptr, *act_tgt = nullptr;   // FLOW_GREEDY: this step's joint actions in LDS ([Nc][2], [Nt][2])
+    bool statics_done = false;    // fused rollouts, steps after the first: what never changes inside an episode (static
+                                  // mask words and flags, obstacle / capacity slots of the scratch) is in LDS already
 
     __device__ Ctx(const Params &p_, const Ptrs &g_, unsigned char *wave_base, int lane_, int64_t env_, int flow_ = FLOW_ANY)
         : p(p_), g(g_), flow(flow_), lane(lane_), env(env_), out(env_) {
@@ -707,16 +709,18 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     }
     SUB_STAMP(c, 14);
     // ---- static camera->obstacle bits (environment.py:752-755) and the always-true bit
-    if (lane < p.Nc) {
-        const uint64_t m = c.camobs(lane);
-        c.mask[(p.bit_camobs >> 5) + 2 * lane] = (uint32_t)m;
-        c.mask[(p.bit_camobs >> 5) + 2 * lane + 1] = (uint32_t)(m >> 32);
-    }
-    if (lane == 0) { c.mask[p.bit_always >> 5] = 1u; set_flag(c, p.fs_always, true); }
-    for (int q = lane; q < p.Nc * p.No; q += 64) {
-        const int cam = (int)(((float)q + 0.5f) * p.inv_No);
-        const int o = q - cam * p.No;
-        set_flag(c, p.fs_camobs + cam * p.No + o, (c.camobs(cam) >> o) & 1ull);
+    if (!c.statics_done) {
+        if (lane < p.Nc) {
+            const uint64_t m = c.camobs(lane);
+            c.mask[(p.bit_camobs >> 5) + 2 * lane] = (uint32_t)m;
+            c.mask[(p.bit_camobs >> 5) + 2 * lane + 1] = (uint32_t)(m >> 32);
+        }
+        if (lane == 0) { c.mask[p.bit_always >> 5] = 1u; set_flag(c, p.fs_always, true); }
+        for (int q = lane; q < p.Nc * p.No; q += 64) {
+            const int cam = (int)(((float)q + 0.5f) * p.inv_No);
+            const int o = q - cam * p.No;
+            set_flag(c, p.fs_camobs + cam * p.No + o, (c.camobs(cam) >> o) & 1ull);
+        }
     }
     wave_sync();
     // ---- tracked_bits = camera_target_view_mask.any(axis=0) (environment.py:1388); which warehouse holds the target
@@ -883,7 +887,7 @@ __device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c) {
         const int cap = 1 + (int)((c.capword() >> lane) & 1ull);
         sc[0] = (ObsT)c.tx(lane); sc[1] = (ObsT)c.ty(lane);
         sc[3] = (ObsT)(goal >= 0 && weight > 0 ? 1.0 : 0.0);
-        sc[4] = (ObsT)(cap == 2 ? p.tgt_step * 0.5 : p.tgt_step); sc[5] = (ObsT)cap;   // step_size / capacity, exact
+        if (!c.statics_done) { sc[4] = (ObsT)(cap == 2 ? p.tgt_step * 0.5 : p.tgt_step); sc[5] = (ObsT)cap; }   // step_size / capacity, exact
         int empty = (gw >> 16) & 0xf;
         if (tgt_mode == 1) {                  // EnhancedObservation: the true state of every warehouse (enhanced_observation.py:110-112)
             empty = 0;
@@ -900,10 +904,11 @@ __device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c) {
             sc[10 + w] = (ObsT)((empty >> w) & 1);
         }
     }
-    for (int o = lane; o < p.No; o += 64) {   // Obstacle.state, entities.py:147-148
-        ObsT *sc = c.scratch + p.sc_obs + o * 3;
-        sc[0] = (ObsT)c.obs_x(o); sc[1] = (ObsT)c.obs_y(o); sc[2] = (ObsT)c.obs_r(o);
-    }
+    if (!c.statics_done)
+        for (int o = lane; o < p.No; o += 64) {   // Obstacle.state, entities.py:147-148
+            ObsT *sc = c.scratch + p.sc_obs + o * 3;
+            sc[0] = (ObsT)c.obs_x(o); sc[1] = (ObsT)c.obs_y(o); sc[2] = (ObsT)c.obs_r(o);
+        }
     // SharedFieldOfView: an entity is visible to the whole team when any member sees it
     // (shared_field_of_view.py:97-100, 117-120); flags live behind the mask flags, see build_descriptors
     if ((c.obs_mode() & 3) == 2) {
@@ -1213,6 +1218,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     long long t_prev = (long long)__builtin_amdgcn_s_memtime();
     const long long t_first = t_prev, r_first = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
+    bool stepped = false;            // a full step has written the static mask words, flags and scratch slots
 #pragma clang loop unroll(disable)
     for (int r = 0; r < g.rollout_steps; ++r) {
         // an opaque copy of the lane id per iteration keeps the compiler from hoisting every lane-role
@@ -1227,6 +1233,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         const int64_t env_r = (int64_t)blockIdx.x * 4 + wave_r;
         Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW);
         c.out = (int64_t)r * g.N + env_r;
+        c.statics_done = stepped;
         if (c.ei(EI_DONE) != 0) {
             if (lane_r == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
             if (lane_r == 0 && g.idle_steps) g.idle_steps[env_r] += 1;      // a slot of the rollout, not an executed step
@@ -1260,6 +1267,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         ROLL_STAMP(5);
         pack_observations<true>(c, held);
         wave_sync();
+        stepped = true;
         ROLL_STAMP(6);
     }
 #ifdef MATE_PHASE_CLOCKS
