@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256, 4) void rollout_greedy_kernel(const Params *__
     uint32_t hw_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     const int wave_slot = (int)(hw_id & 15u);
+    bool stepped = false;                                          // statics written (see Ctx::statics_done)
 #pragma clang loop unroll(disable)
     for (int r = 0; r < g.rollout_steps; ++r) {
         int lane_r = lane, wave_r = wave;                          // opaque per iteration, see rollout_kernel
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(256, 4) void rollout_greedy_kernel(const Params *__
         Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW_GREEDY);
         c.out = (int64_t)r * g.N + env_r;
         c.act_cam = act_cam; c.act_tgt = act_tgt;
+        c.statics_done = stepped;
         const bool active = in_batch && c.ei(EI_DONE) == 0;
         if (g.rotate_prio) {
             const int turn = (r + wave_slot) & 3;
@@ -485,6 +487,7 @@ __global__ __launch_bounds__(256, 4) void rollout_greedy_kernel(const Params *__
         fill_scratch(c);
         pack_observations<true>(c, held);
         wave_sync();
+        stepped = true;
     }
     if (in_batch) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
