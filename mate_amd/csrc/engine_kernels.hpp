@@ -92,12 +92,15 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
 // Kernel shape policies: AnyShape reads every constant from the device-resident Params on demand;
 // FixedShape<Nc, Nt, No> is compiled for one scenario shape (the host picks it when the counts match).
 struct AnyShape {
+    static constexpr bool kHoldRoles = false;      // rollout kernel: lane roles in registers (needs compile-time round counts)
     const Params *pp;
     __device__ __forceinline__ explicit AnyShape(const Params *q) : pp(q) {}
     __device__ __forceinline__ const Params &get() const { return *pp; }
 };
+constexpr int shape_range_rounds(int Nc, int Nt, int No) { return (Nt * (Nc + No + Nt) + 63) / 64; }
 template <int NC, int NT, int NO, bool F64>
 struct FixedShape {
+    static constexpr bool kHoldRoles = shape_range_rounds(NC, NT, NO) <= 3;      // 9 more VGPRs: fits beside the held descriptors
     Params local;
     __device__ __forceinline__ explicit FixedShape(const Params *q) : local(*q) { fill_shape(local, NC, NT, NO, F64); }
     __device__ __forceinline__ const Params &get() const { return local; }
@@ -584,6 +587,35 @@ __device__ __forceinline__ double degree_interp(const double2 (&w)[kDegSlots], d
 // Phase B: _update_view (environment.py:1356-1388).
 struct SectorEval { bool seen, need; double rn, x; int64_t lc; };
 
+// What a lane's range tests look like is the same at every step: which (target, other) pair it holds in each round,
+// whether that is the diagonal, and the squared limit (sight + the other's radius)^2 -- all static inside an episode.
+// The fused rollout, which is VALU-bound, computes them once per launch and keeps them in registers (`HELD`); the
+// single-step kernel derives them in place.
+constexpr int kRoleRounds = 3;
+struct RangeRoles {
+    int32_t pair[kRoleRounds];       // entity slot of the target | entity slot of the other << 16
+    double lim2[kRoleRounds];        // (target sight range + other's radius)^2
+    uint32_t diag_bits, valid_bits;  // bit `round`: the pair is (t, t) / the lane holds a pair in this round
+};
+template <typename ObsT>
+__device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &roles) {
+    const Params &p = c.p;
+    roles.diag_bits = 0; roles.valid_bits = 0;
+#pragma unroll
+    for (int round = 0; round < kRoleRounds; ++round) {
+        const int q = round * 64 + c.lane;
+        const int qq = q < p.n_range ? q : 0;
+        const int t = (int)(((float)qq + 0.5f) * p.inv_NJ);
+        const int j = qq - t * p.NJ;
+        const int tj = c.tgt_slot(t);
+        const double lim = p.tgt_sight + c.er[j];
+        roles.pair[round] = tj | (j << 16);
+        roles.lim2[round] = lim * lim;
+        roles.diag_bits |= (uint32_t)(j == tj) << round;
+        roles.valid_bits |= (uint32_t)(q < p.n_range && round < p.range_rounds) << round;
+    }
+}
+
 // Camera.perceive (entities.py:491-505) up to the occlusion lookup.
 template <typename ObsT>
 __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t tick, uint32_t stream, bool predrawn) {
@@ -648,8 +680,8 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorE
     return e.rn <= limit * (1.0 + 1e-6);                                           // entities.py:505
 }
 
-template <typename ObsT>
-__device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn) {
+template <bool HELD, typename ObsT>
+__device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn, const RangeRoles &held) {
     const Params &p = c.p;
     const int lane = c.lane;
     double2 w[kDegSlots];
@@ -675,6 +707,23 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     // latency), results collected in a per-lane bit set; (2) flags, ballots and mask words.
     const int rbase = p.bit_range >> 5;
     uint32_t seen_bits = 0;
+    if constexpr (HELD) {
+#pragma unroll
+        for (int round = 0; round < kRoleRounds; ++round) {
+            if (round < p.range_rounds) {
+                const int tj = held.pair[round] & 0xffff, j = held.pair[round] >> 16;
+                const bool diag = (held.diag_bits >> round) & 1u;
+                const double dx = c.ex[tj] - c.ex[j], dy = c.ey[tj] - c.ey[j];
+                const double d2 = fma(dy, dy, dx * dx);
+                const double lim2 = held.lim2[round];
+                bool seen;
+                if (d2 < lim2 * (1.0 - 1e-14)) seen = true;
+                else if (d2 > lim2 * (1.0 + 1e-14)) seen = diag;
+                else seen = diag || (sqrt_pos(d2) <= p.tgt_sight + c.er[j]);
+                seen_bits |= (uint32_t)(seen && ((held.valid_bits >> round) & 1u)) << round;
+            }
+        }
+    } else {
 #pragma unroll 4
     for (int round = 0; round < p.range_rounds; ++round) {
         const int q = round * 64 + lane;
@@ -693,6 +742,7 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         else if (d2 > lim2 * (1.0 + 1e-14)) seen = diag;
         else seen = diag || (sqrt_pos(d2) <= lim);
         seen_bits |= (uint32_t)(seen && q < p.n_range) << round;
+    }
     }
     for (int round = 0; round < p.range_rounds; ++round) {
         const int q = round * 64 + lane;
@@ -740,6 +790,12 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         c.inside(lane) = w_in;
     }
     wave_sync();
+}
+
+template <typename ObsT>
+__device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn) {
+    RangeRoles none;
+    update_view<false>(c, tick, stream, predrawn, none);
 }
 
 // Phase C: _assign_goals + the bookkeeping of step() (environment.py:1271-1324, 613-632).
@@ -1203,6 +1259,11 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
         load_pack_descriptors(c, held);      // (indices clamped: harmless when another pack path runs)
     }
+    RangeRoles roles;                        // the lane's range-test pairs and limits, static inside an episode
+    if constexpr (Shape::kHoldRoles) {
+        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
+        range_roles(c, roles);
+    }
     // Fair shares of the SIMD.  Its arbiter serves the oldest resident wave first, and in a launch that lasts for
     // tens of steps the age order never changes: of the four environment-waves of a SIMD the oldest ran a step in
     // 13 k cycles and the youngest in 21 k (measured), and the launch lasts as long as its slowest wave.
@@ -1259,7 +1320,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         ROLL_STAMP(1);
         simulate_targets(c, draws);
         ROLL_STAMP(2);
-        update_view(c, tick, S_TRANSMIT, true);
+        update_view<Shape::kHoldRoles>(c, tick, S_TRANSMIT, true, roles);
         ROLL_STAMP(3);
         assign_and_score(c, tick, g.scalars);
         ROLL_STAMP(4);
