@@ -778,16 +778,14 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         int any = 0;
         for (int cam = 0; cam < p.Nc; ++cam) any |= (int)c.mask_bit(cam * p.Nt + lane);
         c.tracked(lane) = any;
-        int w_in = -1;
+        // warehouses (constants.py:70-72): 0 (+,+), 1 (-,+), 2 (-,-), 3 (+,-), Chebyshev radius 75 around (+-925, +-925)
+        // (environment.py:1283).  Only the warehouse of the target's own quadrant can hold it (any other centre is at
+        // least 925 away in one coordinate), so one test with that centre is the reference's loop over the four.
         const double x = c.tx(lane), y = c.ty(lane);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {   // constants.py:70-72: (+,+), (-,+), (-,-), (+,-)
-            const double wx = (w == 0 || w == 3) ? kWarehouseCenter : -kWarehouseCenter;
-            const double wy = (w < 2) ? kWarehouseCenter : -kWarehouseCenter;
-            const double sup = fmax(fabs(x - wx), fabs(y - wy));    // environment.py:1283
-            if (sup <= kWarehouseRadius && w_in < 0) w_in = w;
-        }
-        c.inside(lane) = w_in;
+        const bool px = x > 0.0, py = y > 0.0;
+        const double wx = px ? kWarehouseCenter : -kWarehouseCenter, wy = py ? kWarehouseCenter : -kWarehouseCenter;
+        const double sup = fmax(fabs(x - wx), fabs(y - wy));
+        c.inside(lane) = sup <= kWarehouseRadius ? (px ? (py ? 0 : 3) : (py ? 1 : 2)) : -1;
     }
     wave_sync();
 }
