@@ -431,7 +431,7 @@ __device__ __forceinline__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &
         double sn, cs;
         sincos_deg(ph, sn, cs);                    // Camera.state: polar2cartesian(sight_range, orientation), entities.py:318
         ObsT *sc = c.scratch + p.sc_cam + lane * 10;
-        sc[0] = (ObsT)c.cam_x(lane); sc[1] = (ObsT)c.cam_y(lane);
+        if (!c.statics_done) { sc[0] = (ObsT)c.cam_x(lane); sc[1] = (ObsT)c.cam_y(lane); }
         sc[3] = (ObsT)(sr * cs); sc[4] = (ObsT)(sr * sn); sc[5] = (ObsT)th;
     }
 }
@@ -596,11 +596,13 @@ struct RangeRoles {
     int32_t pair[kRoleRounds];       // entity slot of the target | entity slot of the other << 16
     double lim2[kRoleRounds];        // (target sight range + other's radius)^2
     uint32_t diag_bits, valid_bits;  // bit `round`: the pair is (t, t) / the lane holds a pair in this round
+    int32_t sector;                  // sector_role of the lane's pair in the last sector round
 };
 template <typename ObsT>
 __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &roles) {
     const Params &p = c.p;
     roles.diag_bits = 0; roles.valid_bits = 0;
+    roles.sector = sector_role(p, (p.sector_rounds - 1) * 64 + c.lane);
 #pragma unroll
     for (int round = 0; round < kRoleRounds; ++round) {
         const int q = round * 64 + c.lane;
@@ -617,14 +619,23 @@ __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &role
 }
 
 // Camera.perceive (entities.py:491-505) up to the occlusion lookup.
-template <typename ObsT>
-__device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t tick, uint32_t stream, bool predrawn) {
-    const Params &p = c.p;
-    SectorEval e{false, false, 0.0, 0.0, 0};
-    if (q >= p.n_sector) return e;
+__device__ __forceinline__ int sector_role(const Params &p, int q) {      // camera | other << 8 | is_target << 16, or -1
+    if (q >= p.n_sector) return -1;
     int cam, other; bool is_target;
     if (q < p.bit_cc) { cam = (int)(((float)q + 0.5f) * p.inv_Nt); other = q - cam * p.Nt; is_target = true; }
     else { const int r = q - p.bit_cc; cam = (int)(((float)r + 0.5f) * p.inv_Nc); other = r - cam * p.Nc; is_target = false; }
+    return cam | (other << 8) | ((int)is_target << 16);
+}
+// `role`: sector_role of the pair, or kNoRole = derive it here (the fused rollout holds the last round's in a register)
+constexpr int kNoRole = -2;
+template <typename ObsT>
+__device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t tick, uint32_t stream, bool predrawn, int role = kNoRole) {
+    const Params &p = c.p;
+    SectorEval e{false, false, 0.0, 0.0, 0};
+    if (role == kNoRole) role = sector_role(p, q);
+    if (role < 0) return e;
+    const int cam = role & 0xff, other = (role >> 8) & 0xff;
+    const bool is_target = (role >> 16) & 1;
     if (!is_target && cam == other) { e.seen = true; return e; }                   // environment.py:1383-1384
     const int oj = is_target ? c.tgt_slot(other) : other;
     const double rx = c.ex[oj] - c.ex[cam], ry = c.ey[oj] - c.ey[cam];
@@ -698,7 +709,7 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     const int last = p.sector_rounds - 1;
     SectorEval pending{false, false, 0.0, 0.0, 0};
     if (last >= 0) {
-        pending = sector_eval(c, last * 64 + lane, tick, stream, predrawn);
+        pending = sector_eval(c, last * 64 + lane, tick, stream, predrawn, HELD ? held.sector : kNoRole);
         sector_fetch(c, pending, w);
     }
     SUB_STAMP(c, 13);
@@ -929,19 +940,26 @@ __device__ __forceinline__ void score_only(Ctx<ObsT> &c, float *scalars_out) {
 
 // ---------------------------------------------------------------------------------------------
 // Phase D: joint_observation (environment.py:908-964): fill the per-environment scratch, then gather.
+// `last_gw`: the packed goal word (goal, cargo weight, known-empty warehouses) this lane's target had when its slots were
+// last written -- the fused rollout carries it from step to step and rewrites the ten slots it determines only when
+// it changes (a pick-up, a delivery, a newly seen empty warehouse); -1 = write.
 template <typename ObsT>
-__device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c) {
+__device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c, int &last_gw) {
     const Params &p = c.p;
     const int lane = c.lane;
     const int tgt_mode = (c.obs_mode() >> 2) & 3;
     if (lane < p.Nt) {                        // Target.state(private=True), entities.py:631-637
         ObsT *sc = c.scratch + p.sc_tgt + lane * 14;
-        const int gw = c.ti(lane, TI_GW);
-        const int goal = (gw & 0xff) - 1, weight = (gw >> 8) & 0xff;
-        const int cap = 1 + (int)((c.capword() >> lane) & 1ull);
+        const int gw = c.ti(lane, TI_GW) & 0xffffff;            // bit 24 (colliding) is not part of the observation
         sc[0] = (ObsT)c.tx(lane); sc[1] = (ObsT)c.ty(lane);
+        if (!c.statics_done) {                                   // step_size / capacity, exact
+            const int cap = 1 + (int)((c.capword() >> lane) & 1ull);
+            sc[4] = (ObsT)(cap == 2 ? p.tgt_step * 0.5 : p.tgt_step); sc[5] = (ObsT)cap;
+        }
+      if (!c.statics_done || tgt_mode != 0 || gw != last_gw) {
+        last_gw = gw;
+        const int goal = (gw & 0xff) - 1, weight = (gw >> 8) & 0xff;
         sc[3] = (ObsT)(goal >= 0 && weight > 0 ? 1.0 : 0.0);
-        if (!c.statics_done) { sc[4] = (ObsT)(cap == 2 ? p.tgt_step * 0.5 : p.tgt_step); sc[5] = (ObsT)cap; }   // step_size / capacity, exact
         int empty = (gw >> 16) & 0xf;
         if (tgt_mode == 1) {                  // EnhancedObservation: the true state of every warehouse (enhanced_observation.py:110-112)
             empty = 0;
@@ -957,6 +975,7 @@ __device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c) {
             sc[6 + w] = (ObsT)(goal == w ? weight : 0);
             sc[10 + w] = (ObsT)((empty >> w) & 1);
         }
+      }
     }
     if (!c.statics_done)
         for (int o = lane; o < p.No; o += 64) {   // Obstacle.state, entities.py:147-148
@@ -981,6 +1000,12 @@ __device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c) {
         }
     }
     wave_sync();
+}
+
+template <typename ObsT>
+__device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c) {
+    int always = -1;
+    fill_scratch(c, always);
 }
 
 template <typename ObsT> struct Vec;
@@ -1278,6 +1303,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     const long long t_first = t_prev, r_first = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
     bool stepped = false;            // a full step has written the static mask words, flags and scratch slots
+    int last_gw = -1;                // fill_scratch: the goal word behind the target's goal / cargo slots
 #pragma clang loop unroll(disable)
     for (int r = 0; r < g.rollout_steps; ++r) {
         // an opaque copy of the lane id per iteration keeps the compiler from hoisting every lane-role
@@ -1322,7 +1348,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         ROLL_STAMP(3);
         assign_and_score(c, tick, g.scalars);
         ROLL_STAMP(4);
-        fill_scratch(c);
+        fill_scratch(c, last_gw);
         ROLL_STAMP(5);
         pack_observations<true>(c, held);
         wave_sync();
