@@ -9,7 +9,8 @@ One "step" = one `step()` of every environment of the batch (BASELINE.json confi
 MATE-4v8-9.yaml, 4096 environments per GPU, uniform random policy generated on-device by the
 engine's Philox streams, auto-reset of finished episodes inside the timed loop).  State,
 actions and observations are resident in HBM for the whole timed region.  With the random
-policy the K timed steps run as fused `--rollout R`-step launches (default 32: rollout_kernel
+policy the K timed steps run as fused `--rollout R`-step launches (default 128, the usual horizon of an on-policy
+update, or 64 / 32 when K holds fewer than eight such launches: rollout_kernel
 keeps an environment's records in LDS across the R steps and writes every step's observations,
 rewards and masks to [R][N][...] buffers; an environment whose episode ends inside a rollout
 idles until the reset launch that follows it, and those idle slots are NOT counted in `value`);
@@ -115,9 +116,9 @@ def main():
                     help='on-device policy: uniform random (headline) or GreedyCamera vs GreedyTarget (BASELINE config 3)')
     ap.add_argument('--reset-interval', type=int, default=32, help='greedy policy: batched auto-reset every k steps (1 = immediate)')
     ap.add_argument('--rollout', type=int, default=-1,
-                    help='steps fused per launch (rollout_kernel / rollout_greedy_kernel); 0 = one launch per step; -1 (default) = 32 '
-                         'while the batch is at most 64 (random) / 32 (greedy) environment-waves per CU, else 0 (the fused kernels '
-                         'trade occupancy for registers and LDS)')
+                    help='steps fused per launch (rollout_kernel / rollout_greedy_kernel); 0 = one launch per step; -1 (default) = 128 '
+                         '(random) / 32 (greedy) while the batch is at most 64 / 32 environment-waves per CU, else 0 (the fused '
+                         'kernels trade occupancy for registers and LDS); capped so that the [R][N][...] buffers stay under 4 GiB')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
     args = ap.parse_args()
@@ -144,6 +145,8 @@ def main():
     if R < 0:
         cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
         R = 32 if args.batch <= (64 if args.policy == 'random' else 32) * cus else 0
+        if R and args.policy == 'random':       # longer launches while the timed region still holds eight of them
+            R = next((r for r in (128, 64) if args.steps // r >= 8), 32)
     if R > 0:        # rollout buffers [R][N][...] capped at 4 GiB
         R = max(1, min(R, args.steps, (4 << 30) // (args.batch * b_obs)))
     if args.policy == 'greedy':
@@ -217,7 +220,7 @@ def main():
         resident = (args.batch * (steps_per_launch * b_obs + (b_alg - b_obs - 8 * (eng.num_cameras + eng.num_targets)))
                     if R > 0 else bytes_per_launch)
         kernel = ('step_kernel' if R == 0 else 'rollout_greedy_kernel' if args.policy == 'greedy' else 'rollout_kernel')
-        default_case = args.batch == BATCH_PER_GPU and args.workload == WORKLOAD and (R == 32 or args.policy == 'greedy' or R == 0)
+        default_case = args.batch == BATCH_PER_GPU and args.workload == WORKLOAD and (R == 128 or args.policy == 'greedy' or R == 0)
         line = {
             'metric': f'env-steps/sec {args.workload[:-5]} batch={args.batch} per GPU ({args.policy} policy, auto-reset)',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

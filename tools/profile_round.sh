@@ -10,7 +10,7 @@ grep '"metric"' "$out/kt_bench.log" > "$out/bench_under_rocprof.json"
 cp "$out"/kt/bench_kernel_stats.csv "$out/kernel_stats.csv" 2>/dev/null
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$out/pmc_$tag" -o pmc -- python3 bench.py --steps 256 --warmup 32 --no-cpu-baseline > "$out/pmc_$tag.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$out/pmc_$tag" -o pmc -- python3 bench.py --steps 1024 --warmup 128 --no-cpu-baseline > "$out/pmc_$tag.log" 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, json, sys, collections
