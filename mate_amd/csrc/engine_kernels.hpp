@@ -390,9 +390,10 @@ __device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick) {
     else if (lane - nact < p.Nc * p.Nt) { stream = S_TRANSMIT; sub = (uint32_t)(lane - nact); active = need_draws; }
     if (active) {
         const U4 r = philox(p.seed_lo, p.seed_hi, c.env_global(), tick, stream, sub);
-        if (lane < p.Nc) { d.a0 = action_component(r.x, p.rot); d.a1 = action_component(r.y, p.zoom); }
-        else if (lane < nact) { d.a0 = action_component(r.x, p.tgt_step); d.a1 = action_component(r.y, p.tgt_step); }
-        else c.udraw(lane - nact) = u53(r.x, r.y);
+        if (lane < nact) {                        // one instruction stream for both kinds of agent
+            const double m0 = lane < p.Nc ? p.rot : p.tgt_step, m1 = lane < p.Nc ? p.zoom : p.tgt_step;
+            d.a0 = action_component(r.x, m0); d.a1 = action_component(r.y, m1);
+        } else c.udraw(lane - nact) = u53(r.x, r.y);
     }
     return d;
 }
