@@ -10,14 +10,24 @@ MATE-4v8-9.yaml, 4096 environments per GPU, uniform random policy generated on-d
 engine's Philox streams, auto-reset of finished episodes inside the timed loop).  State,
 actions and observations are resident in HBM for the whole timed region.  With the random
 policy the K timed steps run as fused `--rollout R`-step launches (default 128, the usual horizon of an on-policy
-update, or 64 / 32 when K holds fewer than eight such launches: rollout_kernel
+update, or 64 / 32 when K holds fewer than eight such launches, or K itself when K is smaller: rollout_kernel
 keeps an environment's records in LDS across the R steps and writes every step's observations,
 rewards and masks to [R][N][...] buffers; an environment whose episode ends inside a rollout
 idles until the reset launch that follows it, and those idle slots are NOT counted in `value`);
 `--rollout 0` launches step_kernel once per step, and the default run reports that mode too
-(`per_step_launch`).  For N > 1 the
-batch is sharded (4096 environments per rank, env index = rank * 4096 + i; no data-path
-collective); RCCL only all-gathers the episode statistics after the timed region.
+(`per_step_launch`), as well as the learner-in-the-loop flow (`external_actions`: step(actions) with the joint actions in a
+caller-owned device buffer, the step + auto-reset launch pairs replayed from one HIP graph).
+
+Timing: W untimed warm-up steps (plus one untimed launch of every launch shape of the timed region, so that no
+buffer is allocated and no kernel is first loaded inside it), then the timed region of EXACTLY K steps, bracketed by a
+barrier + torch.cuda.synchronize() on both sides, is run `--reps` times (default 5) and the MEDIAN is reported
+(`ms_per_step` x `steps` = the median repetition; every repetition is listed in `rep_ms`).
+
+`--gpus N` (N > 1) started without a torchrun environment launches the N ranks itself (a `torch.distributed.run`
+child process, started before this process touches the GPU) and exits with its status; under torchrun WORLD_SIZE must
+equal N.  The batch is sharded (4096 environments per rank, env index = rank * 4096 + i; no data-path collective);
+RCCL only all-gathers the episode statistics: every `--stats-interval` launches inside the timed loop on a side
+stream, and once after it.
 
 Rank 0 prints ONE JSON line (see the driver contract).  Extra objects:
   roofline      HBM roofline of the dominant kernel (rollout_kernel, or step_kernel with --rollout 0):
@@ -25,13 +35,20 @@ Rank 0 prints ONE JSON line (see the driver contract).  Extra objects:
                 launch) / average launch duration measured with HIP events on the launch stream over
                 the timed region.  `achieved_resident` / `frac_resident` price a rollout launch at the
                 bytes it must really move (R observation sets, ONE state round trip and one geometry
-                read per environment) -- the stricter figure.
+                read per environment) -- the stricter figure.  `peak` is the vendor HBM peak, `peak_measured` the
+                device-to-device copy rate measured on this pool.
   cpu_baseline  the CPU oracle (oracle/, a parity-checked port of the reference's step path)
                 stepping + packing f32 observations for the same workload on the host cores.
+
+`--dry-run` exercises the launcher and the job-level reduction without a GPU (gloo, fabricated timings; the line says
+`"data": "dry-run"`): it exists for the CPU test of the N-rank launch path and measures nothing.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -40,7 +57,8 @@ sys.path.insert(0, ROOT)
 
 WORKLOAD = 'MATE-4v8-9.yaml'
 BATCH_PER_GPU = 4096
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); measured copy peak ~6290 GB/s
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
+HBM_PEAK_MEASURED_GBS = 6290.0   # device-to-device copy on this pool (tools/pmc_calibrate.py, profiles/README.md)
 
 
 def algorithmic_bytes(Nc, Nt, No):
@@ -50,16 +68,20 @@ def algorithmic_bytes(Nc, Nt, No):
     return 4 * (Nc * Dc + Nt * Dt) + 8 * (Nc + Nt) + 2 * (16 * Nc + 35 * Nt + 72) + (24 * Nc + 24 * No + Nt) + 48
 
 
-def measured_traffic(kernel='step_kernel'):
+def measured_traffic(kernel, env_steps_per_launch):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc passes, counters in
     KiB; see profiles/README.md).  gfx950 correction per the microarchitecture guide and this repo's own calibration
     (tools/pmc_calibrate.py: a 256 MiB copy reports WRITE_SIZE 256.0 MiB and FETCH_SIZE 128.0 MiB): WRITE_SIZE is
-    exact, FETCH_SIZE counts half of the bytes read and is doubled.  None when no profile is present."""
+    exact, FETCH_SIZE counts half of the bytes read and is doubled.  The summary was collected on launches of
+    `env_steps_per_launch` env-steps (4096 environments x 128 steps for rollout_kernel when the field is absent); for
+    another launch length the per-env-step figure is scaled.  None when no profile is present."""
     path = os.path.join(ROOT, 'profiles', 'latest_pmc.json')
     try:
         with open(path) as fh:
             k = json.load(fh)[kernel]
-        return (2.0 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
+        per_launch = (2.0 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
+        profiled = float(k.get('env_steps_per_launch', BATCH_PER_GPU * (1 if kernel == 'step_kernel' else 128)))
+        return per_launch * env_steps_per_launch / profiled
     except Exception:
         return None
 
@@ -105,32 +127,132 @@ def cpu_baseline(seconds=10.0):
     }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2048)
     ap.add_argument('--warmup', type=int, default=128)
+    ap.add_argument('--reps', type=int, default=5, help='repetitions of the timed region; the median is reported')
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='environments per GPU')
     ap.add_argument('--workload', default=WORKLOAD)
-    ap.add_argument('--policy', choices=['random', 'greedy'], default='random',
-                    help='on-device policy: uniform random (headline) or GreedyCamera vs GreedyTarget (BASELINE config 3)')
+    ap.add_argument('--policy', choices=['random', 'greedy', 'external'], default='random',
+                    help='on-device policy: uniform random (headline), GreedyCamera vs GreedyTarget (BASELINE config 3), or '
+                         'external = step(actions) with the joint actions in a caller-owned device buffer (learner in the loop)')
     ap.add_argument('--reset-interval', type=int, default=32, help='greedy policy: batched auto-reset every k steps (1 = immediate)')
     ap.add_argument('--rollout', type=int, default=-1,
                     help='steps fused per launch (rollout_kernel / rollout_greedy_kernel); 0 = one launch per step; -1 (default) = 128 '
                          '(random) / 32 (greedy) while the batch is at most 64 / 32 environment-waves per CU, else 0 (the fused '
                          'kernels trade occupancy for registers and LDS); capped so that the [R][N][...] buffers stay under 4 GiB')
+    ap.add_argument('--stats-interval', type=int, default=8, help='launches between two episode-statistics gathers inside the timed loop (0 = none)')
+    ap.add_argument('--graph-steps', type=int, default=64, help='external policy: step + auto-reset pairs captured per HIP graph (0 = direct launches)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the per_step_launch / external_actions side measurements')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
-    args = ap.parse_args()
+    ap.add_argument('--dry-run', action='store_true', help='launcher / reduction plumbing on CPU with gloo: measures nothing')
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`--gpus N` without a torchrun environment: start the N ranks (one process per GPU over RCCL) and exit with
+    their status.  Runs before anything here initialises the GPU (counting devices does not)."""
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f'bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    return subprocess.call(cmd, env=env)
+
+
+class StatsGather:
+    """Episode statistics of the finished rollout, all-gathered OFF the critical path: the reduction of the rollout's
+    scalar rows is enqueued on the launch stream (it reads buffers the next launch overwrites), the collective on a
+    side stream behind an event."""
+
+    def __init__(self, torch, dist, distributed, device):
+        self.torch, self.dist, self.distributed = torch, dist, distributed
+        self.side = torch.cuda.Stream(device=device)
+        self.slots = [torch.zeros(5, dtype=torch.float64, device=device) for _ in range(2)]
+        self.gathered = [[torch.zeros(5, dtype=torch.float64, device=device) for _ in range(dist.get_world_size() if distributed else 1)] for _ in range(2)]
+        self.turn = 0
+        self.count = 0
+
+    def submit(self, scalars):
+        """`scalars`: [T, N, 8] (or [N, 8]) of the launch that was just enqueued."""
+        torch = self.torch
+        s = scalars.reshape(-1, 8)
+        done = (s[:, 2] == 1.0).to(torch.float64)
+        slot = self.slots[self.turn]
+        torch.stack([done.sum(), s[:, 1].sum(dtype=torch.float64), (done * s[:, 3]).sum(), (done * s[:, 6]).sum(),
+                     torch.tensor(float(s.shape[0]), dtype=torch.float64, device=s.device)], out=slot)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            if self.distributed:
+                self.dist.all_gather(self.gathered[self.turn], slot)
+            else:
+                self.gathered[self.turn][0].copy_(slot)
+        self.last = self.turn
+        self.turn ^= 1
+        self.count += 1
+
+    def result(self):
+        self.side.synchronize()
+        if not self.count:
+            return None
+        total = self.torch.stack(self.gathered[self.last]).sum(dim=0).tolist()
+        episodes = max(total[0], 1.0)
+        return {'gathers_in_timed_loop': self.count, 'episodes_finished_last_window': total[0], 'mean_step_reward': total[1] / max(total[4], 1.0),
+                'mean_final_coverage_rate': total[2] / episodes, 'mean_delivered': total[3] / episodes}
+
+
+def dry_run(args, world, rank):
+    """The N-rank launch path and the job-level reduction with gloo and fabricated numbers (CPU test only)."""
+    import torch
+    import torch.distributed as dist
+    from mate_amd.distributed import reduce_job, shard_of
+    if world > 1:
+        dist.init_process_group('gloo')
+    first, count = shard_of(args.batch * world, rank, world)
+    elapsed, executed = 1.0 + 0.25 * rank, float(count * args.steps)
+    elapsed, executed, stats = reduce_job(elapsed, executed, torch.tensor([float(rank), float(first), 1.0], dtype=torch.float64))
+    if rank == 0:
+        print(json.dumps({'metric': 'dry-run (no GPU work)', 'value': executed / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'f64', 'data': 'dry-run', 'config': {'workload': 'none', 'global_batch': args.batch * world},
+                          'ranks': world, 'shard_first_env_mean': float(stats[1])}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(args))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus} started with WORLD_SIZE={world}: launch one rank per GPU')
+    if args.dry_run:
+        return dry_run(args, world, rank)
 
     import torch
     import torch.distributed as dist
     from mate_amd.config import read_config
     from mate_amd.engine import Engine
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
@@ -142,6 +264,8 @@ def main():
     eng = Engine(cfg, args.batch, device=local_rank, seed=0, first_env_index=rank * args.batch)
     b_obs = 4 * (eng.num_cameras * eng.camera_obs_dim + eng.num_targets * eng.target_obs_dim) + 48   # written per env-step
     R = args.rollout
+    if args.policy == 'external':
+        R = 0
     if R < 0:
         cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
         R = 32 if args.batch <= (64 if args.policy == 'random' else 32) * cus else 0
@@ -149,29 +273,47 @@ def main():
             R = next((r for r in (128, 64) if args.steps // r >= 8), 32)
     if R > 0:        # rollout buffers [R][N][...] capped at 4 GiB
         R = max(1, min(R, args.steps, (4 << 30) // (args.batch * b_obs)))
+    external = None
     if args.policy == 'greedy':
         eng.enable_policies()
         step = lambda: eng.step_greedy(auto_reset=args.reset_interval)     # noqa: E731
+    elif args.policy == 'external':
+        external = ExternalActions(torch, eng, args.graph_steps)
+        step = external.step
     else:
         step = lambda: eng.step_random(auto_reset=True)     # noqa: E731
+    rollout = eng.rollout_greedy if args.policy == 'greedy' else eng.rollout_random
+    gather = StatsGather(torch, dist, distributed, torch.device('cuda', local_rank)) if args.stats_interval > 0 else None
 
-    def run(steps):
+    def run(steps, timed=False):
         """exactly `steps` env.step()s of the whole batch"""
-        if R > 0:
-            rollout = eng.rollout_greedy if args.policy == 'greedy' else eng.rollout_random
-            for _ in range(steps // R):
-                rollout(R, auto_reset=True)
-            if steps % R:
-                rollout(steps % R, auto_reset=True)
+        if external is not None:
+            external.run(steps)
+            if timed and gather is not None:
+                gather.submit(eng.scalars)
+        elif R > 0:
+            lengths = [R] * (steps // R) + ([steps % R] if steps % R else [])
+            for i, n in enumerate(lengths):
+                out = rollout(n, auto_reset=True)
+                if timed and gather is not None and (i + 1) % args.stats_interval == 0:
+                    gather.submit(out[2])
+            if timed and gather is not None and len(lengths) < args.stats_interval:
+                gather.submit(out[2])          # short timed regions: one gather per repetition
         else:
-            for _ in range(steps):
+            for i in range(steps):
                 step()
+                if timed and gather is not None and (i + 1) % (args.stats_interval * 128) == 0:
+                    gather.submit(eng.scalars)
 
     eng.reset()
+    if R > 0:
+        eng.reserve_rollout(R)       # [R][N][...] output buffers: allocated here, never inside the timed region
     run(args.warmup)
-    if R > 0 and args.steps % R:
-        run(args.steps % R)      # the remainder launch of the timed region, warmed too
-    eng.kernel_time(enable=1 if R > 0 else 16)   # HIP-event pair around (every 16th) launch of the dominant kernel in the timed region
+    # one untimed pass over every launch shape of the timed region (kernel code objects loaded, graphs instantiated)
+    if R > 0:
+        run(R + (args.steps % R))
+    elif external is not None:
+        external.run(min(args.steps, max(args.graph_steps, 1) + args.steps % max(args.graph_steps, 1)))
 
     def barrier():
         torch.cuda.synchronize()
@@ -179,34 +321,62 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    idle0 = eng.idle_steps()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    executed = args.batch * args.steps - (eng.idle_steps() - idle0)   # env-steps actually simulated by this rank
-    kernel_ms, launches = eng.kernel_time(enable=False)
-    flow = eng.last_flow
-    per_step = None
-    if R > 0:        # the same workload with one step_kernel launch per step, reported beside the headline
-        k2 = min(args.steps, 1000)
-        eng.kernel_time(enable=16)
-        barrier()
-        idle1 = eng.idle_steps()
-        t1 = time.perf_counter()
-        for _ in range(k2):
-            step()
-        barrier()
-        e2 = time.perf_counter() - t1
-        km2, _ = eng.kernel_time(enable=False)
-        per_step = {'value': (args.batch * k2 - (eng.idle_steps() - idle1)) * world / e2, 'unit': 'env-steps/s', 'steps': k2, 'ms_per_step': e2 / k2 * 1e3,
-                    'kernel': 'step_kernel', 'kernel_avg_us': km2 * 1e3,
-                    'roofline_frac': (algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles) * args.batch / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS) if km2 > 0 else 0.0}
-
-    stats = eng.scalars[:, [1, 3, 6]].mean(dim=0)    # reward, coverage, delivered: logging only
     from mate_amd.distributed import reduce_job
-    elapsed, executed, stats = reduce_job(elapsed, executed, stats, device='cuda')   # MAX time, SUM env-steps, gathered stats
+    rep_ms, rep_executed, kernel_times = [], [], []
+    for _ in range(max(1, args.reps)):
+        eng.kernel_time(enable=1 if R > 0 else 16)   # HIP-event pair around (every 16th) launch of the dominant kernel
+        barrier()
+        idle0 = eng.idle_steps()
+        allocated0 = torch.cuda.memory_allocated()
+        t0 = time.perf_counter()
+        run(args.steps, timed=True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        executed = args.batch * args.steps - (eng.idle_steps() - idle0)   # env-steps actually simulated by this rank
+        assert gather is not None or torch.cuda.memory_allocated() <= allocated0, 'allocation inside the timed region'
+        kernel_times.append(eng.kernel_time(enable=False))
+        stats = eng.scalars[:, [1, 3, 6]].mean(dim=0)    # reward, coverage, delivered: logging only
+        elapsed, executed, stats = reduce_job(elapsed, executed, stats, device='cuda')   # MAX time, SUM env-steps, gathered stats
+        rep_ms.append(elapsed * 1e3)
+        rep_executed.append(executed)
+    order = sorted(range(len(rep_ms)), key=lambda i: rep_ms[i])
+    mid = order[len(order) // 2]                      # the median repetition (upper median for an even count)
+    elapsed, executed = rep_ms[mid] * 1e-3, rep_executed[mid]
+    kernel_ms, launches = kernel_times[mid]
+    flow = eng.last_flow
+    gathered_stats = gather.result() if gather is not None else None
+
+    extras = {}
+    if not args.no_extras and args.policy == 'random' and R > 0:
+        # the same workload with one step_kernel launch per step, and with externally supplied actions (learner in the loop)
+        k2 = min(max(args.steps, 256), 1024)
+        for name in ('per_step_launch', 'external_actions'):
+            if name == 'external_actions':
+                ext = ExternalActions(torch, eng, args.graph_steps)
+                runner = ext.run
+            else:
+                runner = lambda n: [step() for _ in range(n)]     # noqa: E731
+            runner(max(args.graph_steps, 1) * 2)
+            times = []
+            for _ in range(3):
+                eng.kernel_time(enable=16)
+                barrier()
+                idle1 = eng.idle_steps()
+                t1 = time.perf_counter()
+                runner(k2)
+                barrier()
+                e2 = time.perf_counter() - t1
+                km2, _ = eng.kernel_time(enable=False)
+                times.append((e2, args.batch * k2 - (eng.idle_steps() - idle1), km2))
+            e2, ex2, km2 = sorted(times)[1]
+            b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
+            extras[name] = {'value': ex2 * world / e2, 'unit': 'env-steps/s', 'steps': k2, 'ms_per_step': e2 / k2 * 1e3,
+                            'kernel': 'step_kernel', 'kernel_avg_us': km2 * 1e3,
+                            'roofline_frac': (b_alg * args.batch / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS) if km2 > 0 else 0.0,
+                            'end_to_end_frac': b_alg * ex2 / e2 / 1e9 / HBM_PEAK_GBS}
+            if name == 'external_actions':
+                extras[name]['flow'] = (f'step(actions): f32 joint actions read from a caller-owned device buffer, {args.graph_steps} step + auto-reset '
+                                        'launch pairs per HIP graph replay') if args.graph_steps > 0 else 'step(actions), direct launches'
 
     if rank == 0:
         total_envs = args.batch * world
@@ -220,38 +390,68 @@ def main():
         resident = (args.batch * (steps_per_launch * b_obs + (b_alg - b_obs - 8 * (eng.num_cameras + eng.num_targets)))
                     if R > 0 else bytes_per_launch)
         kernel = ('step_kernel' if R == 0 else 'rollout_greedy_kernel' if args.policy == 'greedy' else 'rollout_kernel')
-        default_case = args.batch == BATCH_PER_GPU and args.workload == WORKLOAD and (R == 128 or args.policy == 'greedy' or R == 0)
+        headline_case = args.batch == BATCH_PER_GPU and args.workload == WORKLOAD and args.policy != 'greedy'
+        policy_text = {'random': 'uniform random policy (on-device Philox), ', 'greedy': 'on-device GreedyCamera vs GreedyTarget policies, ',
+                       'external': 'joint actions read from a caller-owned device buffer (learner in the loop), '}[args.policy]
         line = {
             'metric': f'env-steps/sec {args.workload[:-5]} batch={args.batch} per GPU ({args.policy} policy, auto-reset)',
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'{args.workload} batch={args.batch} envs per GPU, '
-                                   + ('uniform random policy (on-device Philox), ' if args.policy == 'random' else 'on-device GreedyCamera vs GreedyTarget policies, ')
+            'reps': len(rep_ms), 'rep_ms': [round(v, 4) for v in rep_ms], 'timing': 'median repetition of the K-step timed region',
+            'config': {'workload': f'{args.workload} batch={args.batch} envs per GPU, ' + policy_text
                                    + (f'fused {R}-step rollout launches, auto-reset after each launch' if R > 0 else 'one launch per step, auto-reset'),
                        'global_batch': total_envs, 'parallelism': f'env-shard x{world}', 'steps_per_launch': R if R > 0 else 1},
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': measured_traffic(kernel) if default_case and args.policy == 'random' else None,
-                'traffic_unit': 'bytes per launch (rocprofv3 2*FETCH_SIZE + WRITE_SIZE, profiles/latest_pmc.json)',
+                'traffic': measured_traffic(kernel, args.batch * steps_per_launch) if headline_case else None,
+                'traffic_unit': 'bytes per launch (rocprofv3 2*FETCH_SIZE + WRITE_SIZE per env-step from profiles/latest_pmc.json x the env-steps of this launch)',
+                'peak_measured': HBM_PEAK_MEASURED_GBS, 'frac_of_measured_peak': achieved / HBM_PEAK_MEASURED_GBS,
                 'kernel': '%s<float, %s, %s>' % (kernel, 'FixedShape' if eng.specialised else 'AnyShape', ('FLOW_ANY', 'FLOW_RANDOM', 'FLOW_ACT_F32', 'FLOW_GREEDY')[flow]),
                 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches, 'env_steps_per_launch': args.batch * steps_per_launch,
                 'algorithmic_bytes_per_launch': bytes_per_launch,
                 'resident_bytes_per_launch': resident,
                 'achieved_resident': resident / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
                 'frac_resident': resident / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0,
+                'end_to_end_frac': b_alg * value / world / 1e9 / HBM_PEAK_GBS,
             },
             'episode_stats': {'mean_target_reward': float(stats[0]), 'mean_coverage_rate': float(stats[1]),
-                              'mean_delivered': float(stats[2])},
+                              'mean_delivered': float(stats[2]), 'gathered_in_loop': gathered_stats},
         }
-        if per_step is not None:
-            line['per_step_launch'] = per_step
+        line.update(extras)
         if not args.no_cpu_baseline and world == 1 and args.policy == 'random' and args.workload == WORKLOAD:
             line['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
+
+
+class ExternalActions:
+    """The learner-in-the-loop flow: `step((camera_actions, target_actions))` with the joint actions in caller-owned
+    device buffers that a policy rewrites between steps.  Here the "policy" is one elementwise torch kernel per team
+    that refreshes the buffers in place (a stand-in for a network's output layer), so the environment really consumes
+    new externally produced actions at every step."""
+
+    def __init__(self, torch, eng, graph_steps):
+        self.torch, self.eng, self.graph_steps = torch, eng, int(graph_steps)
+        N, Nc, Nt = eng.num_envs, eng.num_cameras, eng.num_targets
+        gen = torch.Generator(device=eng.device)
+        gen.manual_seed(1234)
+        self.cam = (torch.rand((N, Nc, 2), device=eng.device, generator=gen) * 2 - 1) * torch.tensor([5.0, 2.5], device=eng.device)
+        self.tgt = (torch.rand((N, Nt, 2), device=eng.device, generator=gen) * 2 - 1) * 20.0
+        self.stepper = eng.make_stepper(self.cam, self.tgt, auto_reset=True, graph_steps=self.graph_steps, between=self.policy)
+
+    def policy(self):
+        # a new joint action every step, produced on the device by "someone else's" kernels
+        self.cam.mul_(-1.0)
+        self.tgt.mul_(-1.0)
+
+    def step(self):
+        self.stepper.run(1)
+
+    def run(self, steps):
+        self.stepper.run(steps)
 
 
 if __name__ == '__main__':

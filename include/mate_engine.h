@@ -110,6 +110,18 @@ int mate_engine_seed(mate_engine *engine, uint64_t seed);                   /* s
  * non-zero byte in env_mask_dev[N].  Writes the initial observations/masks like a step does. */
 int mate_engine_reset(mate_engine *engine, const uint8_t *env_mask_dev, const mate_step_io *io, void *stream);
 
+/* reset() with every random draw of environment.py:679-834 on a tape (parity runs against the reference):
+ * `tape_dev` [N][tape_len] uniforms in the reference's call order -- shuffles of the three entity lists, the
+ * high-capacity choice, per placement attempt (camera: radius box, x, y, orientation index, viewing angle; obstacle:
+ * radius, x, y; target: x, y), cargo pairs, goal choices of targets that spawn inside a warehouse, and per still
+ * unloaded target a warehouse permutation + goal choice; how a uniform becomes a shuffle / choice / integer is stated
+ * in oracle/mate_oracle.c above reset_impl (Fisher-Yates, a + int(u * n)).  io->tape_camera_target_dev, if set,
+ * supplies the see-through uniforms of the first _update_view (environment.py:766).  `draws_used_dev` (optional,
+ * [N] int32) receives the number of uniforms each environment consumed, -1 if its tape ran out.  tests/golden/
+ * reset_*.npz hold such tapes recorded from the reference's own reset() together with the state it produced. */
+int mate_engine_reset_tape(mate_engine *engine, const uint8_t *env_mask_dev, const mate_step_io *io,
+                           const double *tape_dev, int32_t tape_len, int32_t *draws_used_dev, void *stream);
+
 /* step() (environment.py:590-676).  auto_reset == 1: environments whose episode ended are reset in
  * the same call and their observation rows hold the first observation of the new episode (rewards/done
  * in `scalars_dev` still describe the finished step).  auto_reset == k > 1: batched resets -- a
@@ -117,6 +129,18 @@ int mate_engine_reset(mate_engine *engine, const uint8_t *env_mask_dev, const ma
  * call restarts all finished environments together, which amortises the reset latency (occlusion-table
  * build) when episodes end every step somewhere in the batch.  auto_reset == 0: the caller resets. */
 int mate_engine_step(mate_engine *engine, const mate_step_io *io, int32_t auto_reset, void *stream);
+
+/* Graph-replayable stepping (the learner-in-the-loop flow: policy kernels write the joint actions into caller
+ * buffers, step() consumes them, K such iterations are captured once in a HIP graph and replayed).  A step() launch
+ * normally carries the step counter (the Philox tick) and the ping-pong index of the finished-episode lists as launch
+ * arguments, which change at every step.  enable != 0 moves both to device memory: the step kernel reads them there
+ * and the immediate auto-reset launch behind it advances them, so the (step, auto-reset) launch pair has identical
+ * arguments at every step and may be captured (hipStreamBeginCapture on `stream`, or torch.cuda.graph) and replayed
+ * any number of times.  Results are bit-identical to the host-counted flow.  While enabled only step() /
+ * step_random() with auto_reset = 1, observe() and reset() are accepted (MATE_ESTATE otherwise).  enable == 0 drains
+ * `stream` and takes the counter back to the host.  The reference has no counterpart (environment.py:590 runs one
+ * Python call per step); this is how its `for t in range(T): env.step(policy(obs))` loop is enqueued on a GPU. */
+int mate_engine_device_tick(mate_engine *engine, int32_t enable, void *stream);
 
 /* step() with the uniform random policy of SURVEY.md section 8d generated on-device
  * (camera U[-rot,rot] x U[-zoom,zoom], target U[-v,v]^2, Philox keyed by seed/env/tick);

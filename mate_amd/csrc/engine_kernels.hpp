@@ -42,6 +42,12 @@ struct Params {
     int32_t desc_table_bytes, lds_wave_bytes, off_st, off_dy, off_tmp, off_scratch, off_mask, off_misc, off_flags, off_ent;
     float inv_No;
     int32_t export_width;
+    // Device-resident step counter (mate_engine_device_tick): while `dev_tick_on` the step kernels take the Philox
+    // tick and the ping-pong parity of the finished-episode lists from here instead of from the launch arguments, and
+    // the auto-reset launch that follows every step advances it -- a (step, auto-reset) pair then has the same
+    // arguments at every step and a captured HIP graph of K pairs can be replayed.
+    uint32_t dev_tick;            // written only by the auto-reset launch, through Ptrs::dev_tick_ptr
+    int32_t dev_tick_on;
 };
 
 // Everything in Params that follows from the entity counts and the observation type alone.  Shared by the
@@ -133,6 +139,11 @@ struct Ptrs {
     int32_t *flag_count;          // [1] environments selected by a batched (flagged) reset ...
     int32_t *flag_list;           // [N] ... and their indices
     const uint8_t *reset_mask;    // optional
+    const double *reset_tape;     // tape mode of reset (mate_engine_reset_tape): [N][reset_tape_len] uniforms, or NULL = Philox
+    int32_t reset_tape_len;
+    int32_t *reset_draws;         // optional [N]: uniforms each reset consumed (-1: the tape ran out)
+    uint32_t *dev_tick_ptr;       // &Params::dev_tick of the device-resident parameter block (advanced by the auto-reset launch)
+    int32_t *ctrl;                // [0]: list parity the last step launch used (device-resident step counter mode)
     long long *phase_clocks;      // [N][16] s_memtime stamps (debug builds with -DMATE_PHASE_CLOCKS)
     int32_t debug_skip;           // phase-ablation mask (debug builds only)
     int64_t N;
@@ -218,11 +229,12 @@ struct Ctx {
     unsigned char *base;
     double *ex, *ey, *er;         // unified entity table [cameras | obstacles | targets]: x, y, radius
     const double *act_cam = nullptr, *act_tgt = nullptr;   // FLOW_GREEDY: this step's joint actions in LDS ([Nc][2], [Nt][2])
+    int32_t parity;               // which of the two finished-episode lists this launch appends to
     bool statics_done = false;    // fused rollouts, steps after the first: what never changes inside an episode (static
                                   // mask words and flags, obstacle / capacity slots of the scratch) is in LDS already
 
     __device__ Ctx(const Params &p_, const Ptrs &g_, unsigned char *wave_base, int lane_, int64_t env_, int flow_ = FLOW_ANY)
-        : p(p_), g(g_), flow(flow_), lane(lane_), env(env_), out(env_) {
+        : p(p_), g(g_), flow(flow_), lane(lane_), env(env_), out(env_), parity(g_.parity) {
         st = reinterpret_cast<double *>(wave_base + p.off_st);
         dy = reinterpret_cast<double *>(wave_base + p.off_dy);
         di = reinterpret_cast<int32_t *>(dy + p.DF);
@@ -913,8 +925,8 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
             o[4] = (float)real_cov; o[5] = (float)transport; o[6] = (float)delivered; o[7] = (float)div_nz(r, p.max_team_reward);
         }
         if (done && c.g.done_count) {
-            const int slot = atomicAdd(c.g.done_count + c.g.parity, 1);
-            c.g.done_list[(int64_t)c.g.parity * c.g.N + slot] = (int32_t)c.env;
+            const int slot = atomicAdd(c.g.done_count + c.parity, 1);
+            c.g.done_list[(int64_t)c.parity * c.g.N + slot] = (int32_t)c.env;
         }
     }
     wave_sync();
@@ -1186,7 +1198,13 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
     const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();   // constant 100 MHz: calibrates the s_memtime ticks
 #endif
-    if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;  // next step's counter
+    // tick and list parity: launch arguments, or the device-resident counter (graph-replayable launches, see Params)
+    const uint32_t tick = p.dev_tick_on ? p.dev_tick : g.tick;
+    const int32_t parity = p.dev_tick_on ? (int32_t)(tick & 1u) : g.parity;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) {
+        g.done_count[parity ^ 1] = 0;  // next step's counter
+        if (p.dev_tick_on) g.ctrl[0] = parity;
+    }
     // wave-uniform by construction; readfirstlane lets the compiler keep everything derived from it in SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t env = (int64_t)blockIdx.x * 4 + wave;
@@ -1198,13 +1216,13 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     const Ptrs &gk = kernarg_ptrs(g);
     // the four waves of a workgroup never synchronise: each owns one environment and its LDS slice
     Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
+    c.parity = parity;
 #ifdef MATE_PHASE_CLOCKS
     if (lane == 0 && g.phase_clocks) {
         g.phase_clocks[env * 16 + 0] = t_begin;
     }
 #endif
     PHASE_STAMP(1);
-    const uint32_t tick = g.tick;
 #ifdef MATE_PHASE_CLOCKS
 #define SKIP(bit) (g.debug_skip & (bit))
 #else
@@ -1250,6 +1268,17 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
 #endif
 }
 
+// An environment whose episode had ended BEFORE a fused rollout began (a step or rollout with auto_reset = 0, or an
+// imported done flag) is skipped by every step of the launch, so the step that would have listed it for the reset
+// launch never runs: list it here, or it would idle forever.
+template <typename ObsT>
+__device__ __forceinline__ void list_finished_at_entry(Ctx<ObsT> &c) {
+    if (c.lane == 0 && c.g.done_count && c.ei(EI_DONE) != 0) {
+        const int slot = atomicAdd(c.g.done_count + c.parity, 1);
+        c.g.done_list[(int64_t)c.parity * c.g.N + slot] = (int32_t)c.env;
+    }
+}
+
 // =============================================================================================
 // K-step fused rollout under the on-device random policy: the same phases as step_kernel in a loop, with
 // the environment's records resident in LDS for the whole launch.  Outputs of step r go to row r*N + env
@@ -1273,6 +1302,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         load_records(c);
         wave_sync();
         build_entities(c);
+        list_finished_at_entry(c);
         wave_sync();
     }
     // The observation descriptors of this lane are the same for every step: loaded once and held in 32 VGPRs (the

@@ -84,6 +84,7 @@ struct mate_engine {
     uint32_t tick = 0;         // Philox tick of the next step launch
     int64_t steps_since_reset = 0;   // batched auto-reset bookkeeping
     bool was_reset = false;
+    bool dev_tick = false;     // mate_engine_device_tick: the step counter lives on the device (graph-replayable launches)
     size_t step_lds = 0, reset_lds = 0;
     PolicyFn policy_fn = nullptr, rollout_greedy_fn = nullptr;
     StepFn step_fn[3] = {nullptr, nullptr, nullptr}, rollout_fn[2] = {nullptr, nullptr};   // kernels chosen at create: shape-specialised when compiled for these counts; step_fn[flow]
@@ -294,6 +295,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         if ((rc = dev_alloc(e, &g.flag_count, (size_t)4))) break;
         if ((rc = dev_alloc(e, &g.flag_list, N))) break;
         if ((rc = dev_alloc(e, &g.idle_steps, N))) break;
+        if ((rc = dev_alloc(e, &g.ctrl, (size_t)4))) break;
         std::vector<uint32_t> desc;
         build_descriptors(p, desc);
         uint32_t *d_desc = nullptr;
@@ -323,6 +325,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         g.reset_ranges = d_ranges;
     } while (0);
     if (rc == MATE_OK) rc = dev_alloc(e, &e->d_params, (size_t)1);
+    if (rc == MATE_OK) g.dev_tick_ptr = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->d_params) + offsetof(Params, dev_tick));
     if (rc == MATE_OK && hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice) != hipSuccess) rc = fail(MATE_EHIP, "params upload failed");
     if (rc == MATE_OK) {
         // opt in to large dynamic LDS
@@ -480,6 +483,7 @@ extern "C" int mate_engine_get_layout(const mate_engine *e, mate_layout *out) {
 
 extern "C" int mate_engine_seed(mate_engine *e, uint64_t seed) {
     if (!e) return fail(MATE_EINVAL, "null engine");
+    if (e->dev_tick) return fail(MATE_ESTATE, "seed() while the step counter is device-resident (mate_engine_device_tick)");
     e->p.seed_lo = (uint32_t)seed; e->p.seed_hi = (uint32_t)(seed >> 32);
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
@@ -539,6 +543,22 @@ extern "C" int mate_engine_reset(mate_engine *e, const uint8_t *env_mask_dev, co
     return rc;
 }
 
+// reset() with every random draw taken from a tape recorded from the reference (parity runs).
+extern "C" int mate_engine_reset_tape(mate_engine *e, const uint8_t *env_mask_dev, const mate_step_io *io, const double *tape_dev,
+                                      int32_t tape_len, int32_t *draws_used_dev, void *stream) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    if (!tape_dev || tape_len < 1) return fail(MATE_EINVAL, "reset_tape needs a tape");
+    HIP_TRY(hipSetDevice(e->device));
+    Ptrs g = e->g;
+    apply_io(g, io);
+    g.tape_goal = nullptr;                  // io->tape_camera_target_dev: see-through uniforms of the first view
+    g.reset_mask = env_mask_dev;
+    g.reset_tape = tape_dev; g.reset_tape_len = tape_len; g.reset_draws = draws_used_dev;
+    int rc = launch_reset(e, g, env_mask_dev ? RESET_MASK : RESET_ALL, PH_PLACE | PH_LUT | PH_VIEW, (hipStream_t)stream);
+    if (rc == MATE_OK && !env_mask_dev) e->was_reset = true;
+    return rc;
+}
+
 extern "C" int mate_engine_rebuild_luts(mate_engine *e, void *stream) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     HIP_TRY(hipSetDevice(e->device));
@@ -547,9 +567,34 @@ extern "C" int mate_engine_rebuild_luts(mate_engine *e, void *stream) {
     return launch_reset(e, g, RESET_ALL, PH_LUT, (hipStream_t)stream);
 }
 
+// Device-resident step counter: see Params::dev_tick.  enable: the host's tick goes to the device and stays there;
+// disable: the stream is drained and the counter comes back.
+extern "C" int mate_engine_device_tick(mate_engine *e, int32_t enable, void *stream_) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(e->device));
+    if ((enable != 0) == e->dev_tick) return MATE_OK;
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (enable) {
+        // on the device the list parity is tick & 1; both finished-episode lists are consumed between two calls
+        HIP_TRY(hipMemsetAsync(e->g.done_count, 0, 2 * sizeof(int32_t), stream));
+        e->p.dev_tick = e->tick; e->p.dev_tick_on = 1;
+    } else {
+        uint32_t tick = 0;
+        HIP_TRY(hipMemcpy(&tick, reinterpret_cast<const char *>(e->d_params) + offsetof(Params, dev_tick), sizeof(tick), hipMemcpyDeviceToHost));
+        e->tick = tick; e->parity = (int)(tick & 1u);
+        e->p.dev_tick = tick; e->p.dev_tick_on = 0;
+    }
+    HIP_TRY(hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice));
+    e->dev_tick = enable != 0;
+    return MATE_OK;
+}
+
 static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int auto_reset, hipStream_t stream) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (!e->was_reset) return fail(MATE_ESTATE, "step()/observe() called before reset() (or import_state)");
+    if (e->dev_tick && mode != MODE_OBSERVE && auto_reset != 1)
+        return fail(MATE_ESTATE, "with a device-resident step counter (mate_engine_device_tick) step() needs auto_reset = 1: the auto-reset launch advances it");
     HIP_TRY(hipSetDevice(e->device));
     Ptrs g = e->g;
     apply_io(g, io);
@@ -562,7 +607,7 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     if (mode == MODE_OBSERVE || auto_reset != 1) g.done_count = nullptr;
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (e->timing > 0 && mode != MODE_OBSERVE && (e->timing_tick++ % e->timing) == 0) {
+    if (e->timing > 0 && !e->dev_tick && mode != MODE_OBSERVE && (e->timing_tick++ % e->timing) == 0) {
         if (e->events_used == e->events.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
@@ -580,16 +625,17 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
         else if (mode == MODE_STEP && !g.act_f64) flow = FLOW_ACT_F32;
     }
     e->last_flow = flow;
-    hipExtLaunchKernelGGL(e->step_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
+    if (ev0) hipExtLaunchKernelGGL(e->step_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
+    else hipLaunchKernelGGL(e->step_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, (const Params *)e->d_params, (const Ptrs)g);   // (capturable)
     HIP_TRY(hipGetLastError());
-    if (mode != MODE_OBSERVE) e->tick += 1;
+    if (mode != MODE_OBSERVE && !e->dev_tick) e->tick += 1;
     if (mode != MODE_OBSERVE && auto_reset == 1) {
         Ptrs r = e->g;
         apply_io(r, io);
         r.scalars = nullptr; r.tape_ct = nullptr; r.tape_goal = nullptr;   // keep the finished step's reward/done
         int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream);
         if (rc != MATE_OK) return rc;
-        e->parity ^= 1;
+        if (!e->dev_tick) e->parity ^= 1;
     } else if (mode != MODE_OBSERVE && auto_reset > 1 && ++e->steps_since_reset >= auto_reset) {
         e->steps_since_reset = 0;
         Ptrs r = e->g;
@@ -610,6 +656,7 @@ extern "C" int mate_engine_step_random(mate_engine *e, const mate_step_io *io, i
 extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (!e->was_reset) return fail(MATE_ESTATE, "rollout called before reset() (or import_state)");
+    if (e->dev_tick) return fail(MATE_ESTATE, "not available while the step counter is device-resident (mate_engine_device_tick)");
     if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
@@ -682,6 +729,7 @@ extern "C" int mate_engine_policy_enable(mate_engine *e) {
 extern "C" int mate_engine_step_greedy(mate_engine *e, const mate_step_io *io, const mate_policy_tape *tape, int32_t auto_reset, void *stream_) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (!e->was_reset) return fail(MATE_ESTATE, "step_greedy called before reset() (or import_state)");
+    if (e->dev_tick) return fail(MATE_ESTATE, "not available while the step counter is device-resident (mate_engine_device_tick)");
     if (!e->policy_ready) return fail(MATE_ESTATE, "call mate_engine_policy_enable() before the reset whose observations the policies act on");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
@@ -708,6 +756,7 @@ extern "C" int mate_engine_step_greedy(mate_engine *e, const mate_step_io *io, c
 extern "C" int mate_engine_rollout_greedy(mate_engine *e, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (!e->was_reset) return fail(MATE_ESTATE, "rollout_greedy called before reset() (or import_state)");
+    if (e->dev_tick) return fail(MATE_ESTATE, "not available while the step counter is device-resident (mate_engine_device_tick)");
     if (!e->policy_ready) return fail(MATE_ESTATE, "call mate_engine_policy_enable() before the reset whose observations the policies act on");
     if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
     hipStream_t stream = (hipStream_t)stream_;
@@ -773,6 +822,7 @@ extern "C" int mate_engine_export_state(mate_engine *e, double *dst_dev, void *s
 
 extern "C" int mate_engine_import_state(mate_engine *e, const double *src_dev, void *stream) {
     if (!e || !src_dev) return fail(MATE_EINVAL, "null argument");
+    if (e->dev_tick) return fail(MATE_ESTATE, "import_state while the step counter is device-resident (mate_engine_device_tick)");
     HIP_TRY(hipSetDevice(e->device));
     hipLaunchKernelGGL(import_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->d_params, e->g, src_dev);
     HIP_TRY(hipGetLastError());

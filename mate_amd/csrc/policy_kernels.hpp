@@ -435,6 +435,7 @@ __global__ __launch_bounds__(256, 4) void rollout_greedy_kernel(const Params *__
         const double *src = q.pol + env * q.PW;
         for (int k = lane; k < q.PW; k += 64) a.f[k] = src[k];
         build_entities(c);
+        if (in_batch) list_finished_at_entry(c);
         wave_sync();
     }
     PackDescriptors held;

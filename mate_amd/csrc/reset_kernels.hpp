@@ -19,10 +19,16 @@ struct ResetLds {   // byte offsets inside the workgroup's dynamic LDS, after th
     int32_t off_keys, off_vals, off_okeys, off_ovals, off_bucket, off_meta, off_scan, sort_cap, total_bytes;
 };
 
+// The reset stream: uniforms in the reference's call order (oracle/mate_oracle.c above reset_impl states how each
+// becomes a shuffle / choice / integer).  Philox keyed by (seed, environment, episode), or -- tape mode,
+// mate_engine_reset_tape -- the uniforms recorded from the reference's own reset() (tests/golden/reset_*.npz).
 struct ResetRng {
     uint32_t k0, k1, env, episode, n;
+    const double *tape;      // this environment's row of the tape, or nullptr
+    uint32_t tape_len;
     __device__ double draw() {
         const uint32_t idx = n++;
+        if (tape) return idx < tape_len ? tape[idx] : 0.0;      // an overrun shows in the returned draw count
         const U4 r = philox(k0, k1, env, episode, S_RESET, idx >> 1);
         return (idx & 1u) ? u53(r.z, r.w) : u53(r.x, r.y);
     }
@@ -47,7 +53,8 @@ __device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][
     const int Nc = p.Nc, Nt = p.Nt, No = p.No;
     const uint32_t episode = (uint32_t)c.ei(EI_EPISODE) + 1u;
     c.ei(EI_EPISODE) = (int32_t)episode;
-    ResetRng rng{p.seed_lo, p.seed_hi, c.env_global(), episode, 0u};
+    ResetRng rng{p.seed_lo, p.seed_hi, c.env_global(), episode, 0u,
+                 c.g.reset_tape ? c.g.reset_tape + c.env * (int64_t)c.g.reset_tape_len : nullptr, (uint32_t)c.g.reset_tape_len};
     double *px = placed, *py = placed + placed_cap, *pr = placed + 2 * placed_cap, *ps = placed + 3 * placed_cap, *pk = placed + 4 * placed_cap;
     int32_t *perm = reinterpret_cast<int32_t *>(placed + 5 * placed_cap);   // [Nc + Nt + No]
     int32_t *perm_c = perm, *perm_t = perm + Nc, *perm_o = perm + Nc + Nt;
@@ -88,7 +95,9 @@ __device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][
         double x = 0, y = 0, rad = 0, sight = 0, phi = 0, theta = 0;
         bool ok = false;
         for (int attempt = 0; attempt < 500 && !ok; ++attempt) {
-            rad = kind == 0 ? p.cam_radius : 0.0;
+            rad = 0.0;
+            // Camera(Sensor, Obstacle) resets through Obstacle.reset too: it samples its (degenerate) radius box first (entities.py:235, 150-152)
+            if (kind == 0) rad = p.cam_radius + (p.cam_radius - p.cam_radius) * rng.draw();
             if (kind == 1) rad = p.obs_r_lo + (p.obs_r_hi - p.obs_r_lo) * rng.draw();   // entities.py:151
             const double sx = xlo + (xhi - xlo) * rng.draw();                               // entities.py:61
             const double sy = ylo + (yhi - ylo) * rng.draw();
@@ -119,9 +128,10 @@ __device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][
     for (int i = 0; i < 16; ++i) remaining[i] = 0;
     for (;;) {
         for (int k = 0; k < p.num_cargoes_per_target * Nt; ++k) {
+            // choice(4, size=2, replace=False): partial Fisher-Yates on (0, 1, 2, 3)
             const int s = rng.randint(4);
-            int r = rng.randint(3);
-            if (r >= s) r += 1;
+            int r = 1 + rng.randint(3);
+            if (r == s) r = 0;
             remaining[4 * s + r] += 1;
         }
         bool all = true;
@@ -182,6 +192,7 @@ __device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][
         }
     }
     c.ei(EI_EPSTEP) = 0; c.ei(EI_DONE) = 0;
+    if (c.g.reset_draws) c.g.reset_draws[c.env] = (int32_t)((rng.tape && rng.n > rng.tape_len) ? -1 : (int32_t)rng.n);
 }
 
 // R2: occlusion table of camera `cam` by the whole workgroup.
@@ -376,7 +387,11 @@ template <typename ObsT>
 __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ pp, const Ptrs g, const ResetLds rl, const int32_t phases) {
     const Params &p = *pp;
     extern __shared__ __align__(16) unsigned char smem[];
-    if (g.reset_kind == RESET_DONE && (int64_t)blockIdx.x >= (int64_t)g.done_count[g.parity] * ((phases & PH_PER_CAMERA) ? p.Nc : 1)) return;   // idle: nothing finished
+    // device-resident step counter (Params::dev_tick): the immediate auto-reset launch behind a step takes the list
+    // parity that step used and advances the counter for the next one (this kernel touches the counter only here)
+    const int32_t parity = (p.dev_tick_on && g.reset_kind == RESET_DONE) ? g.ctrl[0] : g.parity;
+    if (p.dev_tick_on && g.reset_kind == RESET_DONE && blockIdx.x == 0 && threadIdx.x == 0) *g.dev_tick_ptr += 1u;
+    if (g.reset_kind == RESET_DONE && (int64_t)blockIdx.x >= (int64_t)g.done_count[parity] * ((phases & PH_PER_CAMERA) ? p.Nc : 1)) return;   // idle: nothing finished
     if (g.reset_kind == RESET_LIST && (int64_t)blockIdx.x >= (int64_t)g.flag_count[0] * ((phases & PH_PER_CAMERA) ? p.Nc : 1)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned char *wave_base = smem;
@@ -390,12 +405,12 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
     const bool per_camera = (phases & PH_PER_CAMERA) != 0;
     const int fan = per_camera ? p.Nc : 1;
     int64_t count = g.N;
-    if (g.reset_kind == RESET_DONE) count = g.done_count[g.parity];
+    if (g.reset_kind == RESET_DONE) count = g.done_count[parity];
     if (g.reset_kind == RESET_LIST) count = g.flag_count[0];
     for (int64_t v = blockIdx.x; v < count * fan; v += gridDim.x) {
         const int64_t item = per_camera ? v / p.Nc : v;
         const int only_cam = per_camera ? (int)(v - item * p.Nc) : -1;
-        const int64_t env = g.reset_kind == RESET_DONE ? (int64_t)g.done_list[(int64_t)g.parity * g.N + item]
+        const int64_t env = g.reset_kind == RESET_DONE ? (int64_t)g.done_list[(int64_t)parity * g.N + item]
                           : g.reset_kind == RESET_LIST ? (int64_t)g.flag_list[item] : item;
         if (g.reset_kind == RESET_MASK && !g.reset_mask[env]) continue;
         if (g.reset_kind == RESET_FLAGGED) {

@@ -11,7 +11,7 @@ import torch
 from mate_amd import _native
 from mate_amd._native import MateConfig, MateLayout, MatePolicyTape, MateStepIO, check
 
-__all__ = ['Engine', 'export_layout', 'SCALAR_NAMES']
+__all__ = ['Engine', 'Stepper', 'export_layout', 'SCALAR_NAMES']
 
 SCALAR_NAMES = ('camera_team_reward', 'target_team_reward', 'done', 'coverage_rate', 'real_coverage_rate',
                 'mean_transport_rate', 'num_delivered_cargoes', 'normalized_target_team_reward')
@@ -216,6 +216,22 @@ class Engine:
         check(self.lib.mate_engine_reset(self._h, mask_ptr, ctypes.byref(io), self._stream()))
         return self.camera_obs, self.target_obs
 
+    def reset_tape(self, tape, tape_ct=None, env_mask=None):
+        """reset() with the random draws taken from `tape` ([N, L] uniforms in the reference's call order, see
+        mate_engine_reset_tape) and the see-through draws of the first view from `tape_ct` ([N, Nc, Nt]).  Returns
+        (camera_obs, target_obs, draws_used [N] int32)."""
+        tape = tape.to(device=self.device, dtype=torch.float64).contiguous()
+        assert tape.dim() == 2 and tape.shape[0] == self.num_envs
+        io, keep = self._io(tape_ct=tape_ct)
+        used = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        mask_ptr = None
+        if env_mask is not None:
+            env_mask = env_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            mask_ptr = ctypes.c_void_p(env_mask.data_ptr())
+        check(self.lib.mate_engine_reset_tape(self._h, mask_ptr, ctypes.byref(io), ctypes.c_void_p(tape.data_ptr()), int(tape.shape[1]),
+                                              ctypes.c_void_p(used.data_ptr()), self._stream()))
+        return self.camera_obs, self.target_obs, used
+
     def step(self, cam_act, tgt_act, tape_ct=None, tape_goal=None, auto_reset=False):
         io, keep = self._io(cam_act, tgt_act, tape_ct, tape_goal)
         check(self.lib.mate_engine_step(self._h, ctypes.byref(io), int(auto_reset), self._stream()))
@@ -245,11 +261,16 @@ class Engine:
         steps skipped because the episode had already ended inside this rollout."""
         return self._run_rollout(self.lib.mate_engine_rollout_random, steps, auto_reset, want_masks)
 
-    def _run_rollout(self, entry_point, steps, auto_reset, want_masks):
+    def reserve_rollout(self, steps, want_masks=False):
+        """Allocate the rollout-shaped output buffers ([steps][N][...]) now, so that a later rollout of up to `steps`
+        steps allocates nothing (a training loop or a timed region calls this once up front).  Rows a launch does not
+        write -- the observation rows of an environment that had finished earlier in the launch -- keep whatever they
+        held; its scalar rows say done = 2."""
         steps = int(steps)
         buf = getattr(self, '_rollout', None)
         if buf is None or buf['steps'] < steps or (want_masks and buf['masks'] is None):     # a shorter rollout fills a prefix
             N, Nc, Nt, L = self.num_envs, self.num_cameras, self.num_targets, self.layout
+            self._rollout = None
             with torch.cuda.device(self.device):
                 buf = {
                     'steps': steps,
@@ -259,6 +280,11 @@ class Engine:
                     'masks': torch.zeros((steps, N, L.mask_words), dtype=torch.int32, device=self.device) if want_masks else None,
                 }
             self._rollout = buf
+        return buf
+
+    def _run_rollout(self, entry_point, steps, auto_reset, want_masks):
+        steps = int(steps)
+        buf = self.reserve_rollout(steps, want_masks)
         io = MateStepIO()
         io.camera_obs_dev = buf['camera_obs'].data_ptr() if self.num_cameras else None
         io.target_obs_dev = buf['target_obs'].data_ptr()
@@ -266,6 +292,16 @@ class Engine:
         io.masks_dev = buf['masks'].data_ptr() if want_masks else None
         check(entry_point(self._h, ctypes.byref(io), steps, int(auto_reset), self._stream()))
         return buf['camera_obs'][:steps], buf['target_obs'][:steps], buf['scalars'][:steps]
+
+    def device_tick(self, enable=True):
+        """Keep the step counter on the device (mate_engine_device_tick): step()/step_random() launches with
+        auto_reset=True then carry identical arguments at every step and can be captured in a HIP graph."""
+        check(self.lib.mate_engine_device_tick(self._h, int(bool(enable)), self._stream()))
+
+    def make_stepper(self, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None):
+        """A replayable `for _ in range(n): between(); step((cam_act, tgt_act))` loop over caller-owned action tensors
+        (see Stepper)."""
+        return Stepper(self, cam_act, tgt_act, auto_reset, graph_steps, between)
 
     def enable_policies(self):
         """Allocate the on-device policy state (call before the reset whose observations the agents act on)."""
@@ -408,3 +444,63 @@ class Engine:
             'target_target_view_mask': rows[:, :, Nc + No:], 'camera_obstacle_view_mask': co,
             'tracked_bits': ct.any(axis=1),
         }
+
+
+class Stepper:
+    """The learner-in-the-loop stepping flow: `between()` (the caller's policy: any torch code that rewrites the joint
+    action tensors in place) then `step((cam_act, tgt_act))`, with outputs in the engine's own observation / scalar /
+    mask tensors.  With `graph_steps` = K > 0 the step counter moves to the device (Engine.device_tick) and K
+    iterations are captured once in a HIP graph (torch.cuda.CUDAGraph: the policy's kernels and the engine's launches
+    in one graph); `run(n)` replays it n // K times and launches the remainder directly.  The host then spends one
+    graph launch per K steps instead of two kernel launches through ctypes per step.  Bit-identical to calling
+    Engine.step in a loop (tested).  `close()` gives the step counter back to the host."""
+
+    def __init__(self, eng, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None):
+        self.eng, self.between, self.graph_steps = eng, between, int(graph_steps)
+        self.auto_reset = int(bool(auto_reset))
+        self.io, self.keep = eng._io(cam_act, tgt_act)
+        # _io may have made contiguous copies: the stepper must read the caller's own storage
+        assert self.keep[0].data_ptr() == tgt_act.data_ptr() and (eng.num_cameras == 0 or self.keep[1].data_ptr() == cam_act.data_ptr()), \
+            'action tensors must be contiguous f32/f64 (or int32 grid indices) on the engine device'
+        self.ref = ctypes.byref(self.io)
+        self.graph = None
+        if self.graph_steps > 0:
+            assert self.auto_reset == 1, 'graph replay needs auto_reset=True (the auto-reset launch advances the device step counter)'
+            eng.device_tick(True)
+            self._one()                                   # code objects loaded before the capture
+            torch.cuda.synchronize(eng.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                for _ in range(self.graph_steps):
+                    self._one()
+
+    def _one(self):
+        if self.between is not None:
+            self.between()
+        eng = self.eng
+        status = eng.lib.mate_engine_step(eng._h, self.ref, self.auto_reset, eng._stream())
+        if status != 0:
+            check(status)
+
+    def run(self, steps):
+        steps = int(steps)
+        if self.graph is not None:
+            for _ in range(steps // self.graph_steps):
+                self.graph.replay()
+            steps %= self.graph_steps
+        for _ in range(steps):
+            self._one()
+        eng = self.eng
+        return eng.camera_obs, eng.target_obs, eng.scalars
+
+    def close(self):
+        if self.graph is not None:
+            torch.cuda.synchronize(self.eng.device)
+            self.graph = None
+            self.eng.device_tick(False)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -80,6 +80,10 @@ struct mo_env {
     uint64_t seed;
     uint32_t env_index, tick, episode;
     uint32_t reset_draws;
+    /* tape mode of reset (mo_reset_tape): the uniforms the reference's RNG proxies logged, in call order */
+    const double *reset_tape;
+    uint32_t reset_tape_n;
+    int reset_tape_overrun;
 };
 
 /* ======================================================================== RNG */
@@ -111,6 +115,10 @@ static double draw_stream(const mo_env *e, uint32_t tick, uint32_t stream, uint3
 static double draw_reset(mo_env *e) {
     uint32_t r[4];
     uint32_t idx = e->reset_draws++;
+    if (e->reset_tape) {
+        if (idx >= e->reset_tape_n) { e->reset_tape_overrun = 1; return 0.0; }
+        return e->reset_tape[idx];
+    }
     mo_philox4x32((uint32_t)e->seed, (uint32_t)(e->seed >> 32), e->env_index, e->episode, S_RESET, idx >> 1, r);
     return (idx & 1) ? u53(r[2], r[3]) : u53(r[0], r[1]);
 }
@@ -1115,10 +1123,28 @@ static int overlaps(const placed_t *a, const placed_t *b, double min_distance) {
     return 0;
 }
 
-/* reset (environment.py:679-834) driven by the engine's own Philox reset
- * stream.  The draw ORDER below is part of the engine specification (the HIP
- * reset kernel consumes the same stream in the same order). */
-void mo_reset(mo_env *e) {
+/* reset (environment.py:679-834) driven by ONE stream of uniforms: the engine's own Philox reset stream, or -- tape
+ * mode -- the uniforms recorded from the reference (tests/golden/make_golden.py `reset_fixture`: every RandomState the
+ * reference's reset() touches is replaced by a proxy that draws uniforms, logs them in call order and turns them into
+ * shuffles / choices / integers by the rules below; the reference consumes the proxies unchanged).  The rules:
+ *   shuffle(x), permutation(n)          Fisher-Yates, i = n-1 .. 1: j = int(u * (i + 1)), swap(x[i], x[j])
+ *   choice(n, size=k, replace=False)    partial Fisher-Yates on 0..n-1, i = 0 .. k-1: j = i + int(u * (n - i)), swap
+ *   choice(array)                       array[int(u * len)]
+ *   randint(lo, hi)                     lo + int(u * (hi - lo));   uniform(a, b) and Box.sample: a + (b - a) * u
+ * The draw ORDER below is the reference's call order (pinned by tests/golden/reset_*.npz) and part of the engine
+ * specification: the HIP reset kernel consumes the same stream in the same order.  The see-through draws of the
+ * first _update_view (environment.py:766) come from `tape_ct` ([Nc*Nt], tape mode) or the reset-view Philox stream. */
+static void reset_impl(mo_env *e, const double *tape_ct);
+void mo_reset(mo_env *e) { e->reset_tape = NULL; reset_impl(e, NULL); }
+int mo_reset_tape(mo_env *e, const double *tape, int n, const double *tape_ct) {
+    e->reset_tape = tape; e->reset_tape_n = (uint32_t)n; e->reset_tape_overrun = 0;
+    reset_impl(e, tape_ct);
+    e->reset_tape = NULL;
+    return e->reset_tape_overrun ? -1 : (int)e->reset_draws;
+}
+/* the first view of the episode again (e.g. after the occlusion tables were replaced): reset-view stream */
+void mo_update_view_reset(mo_env *e) { update_view(e, NULL, S_RESET_VIEW, e->episode); update_metrics(e); }
+static void reset_impl(mo_env *e, const double *tape_ct) {
     int Nc = e->Nc, Nt = e->Nt, No = e->No;
     e->episode += 1;
     e->reset_draws = 0;
@@ -1150,7 +1176,9 @@ void mo_reset(mo_env *e) {
         double phi = 0.0, theta = 0.0;
         int ok = 0;
         for (int attempt = 0; attempt < NUM_RESET_RETRIES && !ok; ++attempt) {
-            double radius = kind == 0 ? e->cfg_cam_radius : 0.0;
+            double radius = 0.0;
+            /* Camera(Sensor, Obstacle) resets through Obstacle.reset as well: it samples its (degenerate) radius box first (entities.py:235, 150-152) */
+            if (kind == 0) radius = e->cfg_cam_radius + (e->cfg_cam_radius - e->cfg_cam_radius) * draw_reset(e);
             if (kind == 1) radius = e->obs_radius_range[0] + (e->obs_radius_range[1] - e->obs_radius_range[0]) * draw_reset(e); /* entities.py:151 */
             double x = range[0] + (range[1] - range[0]) * draw_reset(e);       /* entities.py:61 */
             double y = range[2] + (range[3] - range[2]) * draw_reset(e);
@@ -1180,14 +1208,15 @@ void mo_reset(mo_env *e) {
         }
     }
     mo_build_luts(e);                                                            /* :739-764 */
-    update_view(e, NULL, S_RESET_VIEW, e->episode);                              /* :766 */
+    update_view(e, tape_ct, S_RESET_VIEW, e->episode);                           /* :766 */
 
     memset(e->remaining, 0, sizeof(e->remaining));                               /* :768-775 */
     for (;;) {
         for (int k = 0; k < e->num_cargoes_per_target * Nt; ++k) {
+            /* choice(4, size=2, replace=False): partial Fisher-Yates on (0, 1, 2, 3) */
             int s = randint_reset(e, MO_NW);
-            int r = randint_reset(e, MO_NW - 1);
-            if (r >= s) r += 1;
+            int r = 1 + randint_reset(e, MO_NW - 1);
+            if (r == s) r = 0;
             e->remaining[s][r] += 1;
         }
         for (int g = 0; g < MO_NW; ++g) { e->awaiting[g] = 0; for (int s = 0; s < MO_NW; ++s) e->awaiting[g] += e->remaining[s][g]; }

@@ -71,6 +71,11 @@ void mo_decode_discrete(const mo_env *env, const int *cam_idx, const double *cam
 void mo_soft_coverage(const mo_env *env, double *matrix, double *scores);  /* wrappers/auxiliary_camera_rewards.py:128-139,181-239 */
 void mo_state(const mo_env *env, double *out);                        /* environment.py:894-906 */
 void mo_reset(mo_env *env);   /* environment.py:679-834 with the engine's own Philox reset stream */
+/* ... and with the uniforms recorded from the reference (tests/golden/reset_*.npz): `tape` [n] in call order,
+ * `tape_ct` [Nc*Nt] see-through uniforms of the first view.  Returns the number of draws consumed, -1 if the tape
+ * ran out. */
+int mo_reset_tape(mo_env *env, const double *tape, int n, const double *tape_ct);
+void mo_update_view_reset(mo_env *env);   /* recompute the first view of the episode (reset-view stream) */
 
 /* ---- batch (cpu_baseline and GPU-vs-CPU rollouts) ---------------------- */
 typedef struct mo_batch mo_batch;

@@ -75,6 +75,9 @@ def _load():
     lib.mo_soft_coverage.argtypes = [P, c_double_p, c_double_p]
     lib.mo_state.argtypes = [P, c_double_p]
     lib.mo_reset.argtypes = [P]
+    lib.mo_reset_tape.argtypes = [P, c_double_p, ctypes.c_int, c_double_p]
+    lib.mo_reset_tape.restype = ctypes.c_int
+    lib.mo_update_view_reset.argtypes = [P]
     lib.mo_batch_create.restype = P
     lib.mo_batch_create.argtypes = [P, I, ctypes.c_uint64, ctypes.c_uint64]
     lib.mo_batch_destroy.argtypes = [P]
@@ -331,6 +334,19 @@ class OracleEnv:
     def reset(self):
         lib.mo_reset(self._h)
 
+    def reset_tape(self, tape, tape_ct=None):
+        """reset() consuming the uniforms recorded from the reference (tests/golden/reset_*.npz); returns the number of
+        draws consumed (-1: the tape ran out)."""
+        tape = np.ascontiguousarray(tape, dtype=np.float64)
+        tp = None
+        if tape_ct is not None and self.Nc:
+            tape_ct = np.ascontiguousarray(np.nan_to_num(tape_ct, nan=0.0), dtype=np.float64)
+            tp = _dp(tape_ct)
+        return lib.mo_reset_tape(self._h, _dp(tape if tape.size else np.zeros(1)), tape.size, tp)
+
+    def update_view_reset(self):
+        lib.mo_update_view_reset(self._h)
+
 
 class OracleBatch:
     """N oracle environments stepped with OpenMP (cpu_baseline, GPU parity at scale)."""
@@ -367,6 +383,11 @@ class OracleBatch:
         tgt = np.zeros((self.n, p.Nt, p.Dt), dtype=np.float32)
         lib.mo_batch_observe(self._h, _fp(cam), _fp(tgt), int(threads))
         return cam[:, :p.Nc], tgt
+
+    def update_view_reset(self):
+        """Recompute every environment's first view of the episode (after its occlusion tables were replaced)."""
+        for i in range(self.n):
+            lib.mo_update_view_reset(lib.mo_batch_env(self._h, i))
 
     def gather(self, field):
         return np.stack([self.env(i).get(field) for i in range(self.n)])

@@ -14,6 +14,7 @@ Fixture families:
   kat_obstruct.npz                   F3 ray/circle known answers (entities.py:158-184)
   kat_scalar.npz                     F3 normalize_angle / polar clamp (utils.py:155,223-229)
   kat_perceive.npz                   F3 Camera.perceive on crafted geometry (entities.py:491-511)
+  reset_<cfg>_s<seed>.npz            F1 reset() with EVERY random draw on a tape (environment.py:679-834)
 
 Random draws are captured by replacing each RandomState with a recording proxy
 (the reference source is not modified): every in-sector `binomial(1, tau)` draw
@@ -22,6 +23,7 @@ numpy's legacy inversion sampler, asserted below), and every goal `choice`
 becomes a logged (k candidates, picked j).
 """
 
+import json
 import os
 import sys
 
@@ -631,6 +633,138 @@ def kat_perceive():
     print(f'kat_perceive: {len(cases)} cases, seen={int(np.array(cases)[:, -1].sum())}')
 
 
+# --------------------------------------------------------------------------- reset() on a tape
+RESET_TAPE = []
+
+
+class TapeDrivenRNG:
+    """Stands in for a numpy RandomState while the reference's reset() runs: every draw is ONE uniform taken from the
+    wrapped generator, appended to RESET_TAPE in call order, and turned into the requested quantity by a fixed rule
+    (the rules are restated in oracle/mate_oracle.c above reset_impl and in reset_kernels.hpp).  The reference's
+    source is untouched; it simply consumes this object through the RandomState API.  The see-through Bernoulli draws
+    of the first _update_view go to a per-pair log instead (they are keyed by (camera, target), not by order)."""
+
+    def __init__(self, real, pair_log, owner):
+        self._real, self._pair_log, self._owner = real, pair_log, owner
+
+    def _u(self):
+        u = float(self._real.random_sample())
+        RESET_TAPE.append(u)
+        return u
+
+    def shuffle(self, x):                              # Fisher-Yates
+        for i in range(len(x) - 1, 0, -1):
+            j = int(self._u() * (i + 1))
+            x[i], x[j] = x[j], x[i]
+
+    def permutation(self, n):
+        arr = np.arange(int(n))
+        self.shuffle(arr)
+        return arr
+
+    def choice(self, a, size=None, replace=True, p=None):
+        assert p is None
+        if np.isscalar(a):                             # choice(n, size=k, replace=False): partial Fisher-Yates
+            assert size is not None and not replace
+            idx = list(range(int(a)))
+            for i in range(int(size)):
+                j = i + int(self._u() * (len(idx) - i))
+                idx[i], idx[j] = idx[j], idx[i]
+            return np.asarray(idx[:int(size)])
+        a = np.asarray(a)
+        assert size is None
+        return a[int(self._u() * len(a))]
+
+    def randint(self, low, high=None, size=None, dtype=int):
+        assert size is None
+        if high is None:
+            low, high = 0, low
+        return int(low) + int(self._u() * (int(high) - int(low)))
+
+    def uniform(self, low=0.0, high=1.0, size=None):
+        assert size is None
+        return low + (high - low) * self._u()
+
+    def random(self, size=None):                       # target headings for the renderer only (environment.py:821): not on the tape
+        return self._real.random_sample(size)
+
+    def binomial(self, n, p, size=None):
+        assert n == 1 and size is None
+        other = sys._getframe(1).f_locals.get('other', None)
+        u = float(self._real.random_sample())
+        self._pair_log.append((self._owner, other, u))
+        return int(u > 1.0 - p) if p <= 0.5 else int(u <= p)
+
+
+def _tape_box_sample(self):
+    """Box.sample of the build-owned gym stand-in with its uniforms on RESET_TAPE: low + (high - low) * U per element
+    (what gym's own Box.sample computes for a bounded box through RandomState.uniform)."""
+    rng = self.np_random
+    real = rng._real if isinstance(rng, TapeDrivenRNG) else rng
+    u = np.asarray(real.random_sample(self.shape), dtype=np.float64)
+    # reset() builds four stand-in obstacles for the warehouses (environment.py:724-727); constructing an entity seeds its
+    # degenerate boxes with the constant 0 and samples them (entities.py:54-55): not randomness of reset(), not on the tape
+    frame, constructing = sys._getframe(1), False
+    for _ in range(6):
+        if frame is None:
+            break
+        constructing = constructing or frame.f_code.co_name == '__init__'
+        frame = frame.f_back
+    if not constructing:
+        RESET_TAPE.extend(float(v) for v in u.ravel())
+    return (self.low + (self.high - self.low) * u).astype(self.dtype)
+
+
+def reset_fixture(name, config, seed, overrides=None):
+    """reset() of the reference with every RandomState replaced by a TapeDrivenRNG: the tape + the state it produced."""
+    env = mate.make('MultiAgentTracking-v0', config=config, **(overrides or {}))
+    env.seed(seed)
+    pair_log = []
+    for entity in list(env.cameras_ordered) + list(env.targets_ordered) + list(env.obstacles_ordered):
+        box = entity.location_random_range
+        box._np_random = TapeDrivenRNG(box.np_random, pair_log, entity)
+    env._np_random = TapeDrivenRNG(env.np_random, pair_log, 'env')
+    RESET_TAPE.clear()
+    gym.spaces.Box.sample = _tape_box_sample
+    try:
+        cam_obs, tgt_obs = env.reset()
+    finally:
+        gym.spaces.Box.sample = _ORIG_BOX_SAMPLE
+    tape = np.asarray(RESET_TAPE, dtype=np.float64)
+    Nc, Nt, No = env.num_cameras, env.num_targets, env.num_obstacles
+    tape_ct = np.full((Nc, Nt), np.nan)
+    for cam, other, u in pair_log:
+        if isinstance(other, Target):
+            c, t = env.cameras.index(cam), env.targets.index(other)
+            assert np.isnan(tape_ct[c, t])
+            tape_ct[c, t] = u
+    out = {
+        'config_file': np.str_(config), 'seed': np.int64(seed),
+        'overrides': np.str_(json.dumps(overrides or {}, sort_keys=True)),
+        'num_cameras': np.int64(Nc), 'num_targets': np.int64(Nt), 'num_obstacles': np.int64(No),
+        'transmittance': np.float64(env.obstacle_transmittance), 'max_episode_steps': np.int64(env.max_episode_steps),
+        'sparse_reward': np.bool_(env._sparse_reward), 'freight_scale': np.float64(env.freight_scale),
+        'bounty_scale': np.float64(env.bounty_scale), 'reward_scale': np.float64(env.reward_scale),
+        'max_target_team_episode_reward': np.float64(env.max_target_team_episode_reward),
+        'target_step_size': np.float64(env.target_step_size),
+        'tape': tape, 'tape_ct': tape_ct,
+    }
+    for k, v in snapshot_static(env).items():
+        if not k.startswith('lut_outer'):
+            out['static/' + k] = v
+    for k, v in snapshot_dynamic(env).items():
+        out['reset/' + k] = v
+    out['reset/cam_obs'] = cam_obs
+    out['reset/tgt_obs'] = tgt_obs
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    minimal = ((Nc + Nt + No - 3 if env.shuffle_entities else 0) + (env.num_high_capacity_targets if env.shuffle_entities else 0)
+               + 4 * Nc + 3 * No + 2 * Nt + 2 * env.num_cargoes_per_target * Nt)
+    print(f'{name}: {len(tape)} draws ({len(tape) - minimal} beyond the retry-free minimum without goal draws), '
+          f'{int(np.isfinite(tape_ct).sum())} in-sector pairs, zero-radius obstacles={int((out["static/obs_xyr"][:, 2] == 0).sum()) if No else 0}, '
+          f'{os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def xform_fixture(trace_name, steps):
     """Reference outputs of the observation post-processing wrappers (RelativeCoordinates =
     agents/utils.py:40-94 `convert_coordinates`, RescaledObservation = :97-137 `rescale_observation`) applied
@@ -681,6 +815,21 @@ def main():
                    aux_rewards=({'soft_coverage_score': 1.0, 'real_coverage_rate': 1.0, 'baseline': -0.5}, 'mean'))
         make_trace('softcov_4v2-9_s10', 'MATE-4v2-9.yaml', 10, 'random', 48,
                    aux_rewards=({'soft_coverage_score': 1.0, 'mean_transport_rate': 3.0}, 'max'))
+        return
+    if sys.argv[1:] == ['reset']:
+        for cfg_name, tag in (('MATE-4v2-9.yaml', '4v2-9'), ('MATE-4v8-9.yaml', '4v8-9'), ('MATE-8v8-9.yaml', '8v8-9'),
+                              ('MATE-4v8-0.yaml', '4v8-0'), ('MATE-Navigation.yaml', 'nav')):
+            for seed in (0, 1, 2):
+                reset_fixture(f'reset_{tag}_s{seed}', cfg_name, seed)
+        # the branches the shipped scenarios do not take
+        reset_fixture('reset_4v8-9_noshuffle_s3', 'MATE-4v8-9.yaml', 3, {'shuffle_entities': False})
+        reset_fixture('reset_4v8-9_nocargo_s4', 'MATE-4v8-9.yaml', 4, {'targets_start_with_cargoes': False, 'high_capacity_target_split': 0.25})
+        reset_fixture('reset_8v8-9_crowded_s5', 'MATE-8v8-9.yaml', 5, {'num_cargoes_per_target': 4, 'high_capacity_target_split': 1.0,
+                                                                       'obstacle': {'radius_random_range': [90.0, 100.0]}})
+        reset_fixture('reset_2v4-9_s6', 'MATE-2v4-9.yaml', 6, {'high_capacity_target_split': 0.0})
+        # two obstacles pinned to the same spot: the second exhausts its 500 retries and gets radius 0 (environment.py:734-736)
+        reset_fixture('reset_4v2-3_stacked_s7', 'MATE-4v2-9.yaml', 7,
+                      {'obstacle': {'location_random_range': [[0, 0, 0, 0], [0, 0, 0, 0], [300, 320, 300, 320]], 'radius_random_range': [50.0, 60.0]}})
         return
     if sys.argv[1:] == ['xform']:
         xform_fixture('trace_4v8-9_greedy_s2', 48)

@@ -24,6 +24,32 @@ def trace_files():
     return sorted(glob.glob(os.path.join(GOLDEN_DIR, 'trace_*.npz')))
 
 
+def reset_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, 'reset_*.npz')))
+
+
+def config_of_reset_fixture(fx):
+    """The validated scenario mapping a reset fixture was recorded with (scenario file + keyword overrides)."""
+    import json
+    from mate_amd.config import read_config
+    return read_config(str(fx['config_file']), **json.loads(str(fx['overrides'])))
+
+
+# state a reset() determines, by the names of Engine.state_dict() / the oracle's fields: exact in tape mode
+RESET_EXACT = ['cam_x', 'cam_y', 'obs_x', 'obs_y', 'obs_radius', 'tgt_capacity', 'cam_phi', 'cam_theta', 'tgt_x', 'tgt_y',
+               'tgt_colliding', 'tgt_empty_bits', 'tgt_goal_bits', 'tgt_goals', 'freights', 'bounties', 'target_steps',
+               'tracked_steps', 'remaining_cargoes', 'awaiting_cargo_counts', 'num_delivered_cargoes', 'episode_reward',
+               'delayed_episode_reward', 'episode_step', 'camera_obstacle_view_mask']
+
+
+def reset_expectation(fx):
+    """name -> array the reference's reset() produced (fixture reset_*.npz)."""
+    st, dyn = static_of(fx), dynamic_of(fx)
+    out = {k: np.asarray(st[k], dtype=np.float64) for k in RESET_EXACT if k in st}
+    out.update({k: np.asarray(dyn[k], dtype=np.float64) for k in RESET_EXACT if k in dyn})
+    return out
+
+
 def load(name):
     path = name if os.path.isabs(name) else os.path.join(GOLDEN_DIR, name)
     return dict(np.load(path))

@@ -154,10 +154,13 @@ def _reset_and_rollout_vs_oracle(config, n, oracle_lib, steps=40):
         for c in range(Nc):
             gp, gr = eng.lut_read(e, c)
             oe.set_lut(c, gp, gr)
-    # reset observations
+    # reset observations: the first observation of the episode (view drawn from the reset-view stream) on both sides
+    batch.update_view_reset()
     oc, ot = batch.observe()
-    # first observation after reset uses the reset-view draws
     co, to = eng.camera_obs.cpu().numpy(), eng.target_obs.cpu().numpy()
+    assert rel_close(to, ot, 1e-5), ('reset target obs', np.abs(to - ot).max())
+    if Nc:
+        assert rel_close(co, oc, 1e-5), ('reset camera obs', np.abs(co - oc).max())
     # (3) rollout
     for s in range(steps):
         eng.step_random(auto_reset=False, want_masks=True)
@@ -176,9 +179,9 @@ def _reset_and_rollout_vs_oracle(config, n, oracle_lib, steps=40):
         assert np.abs(sdg['tgt_y'] - batch.gather('tgt_y')).max() < 1e-9, s
     oc, ot = batch.observe()
     co, to = eng.camera_obs.cpu().numpy(), eng.target_obs.cpu().numpy()
-    assert np.abs(to - ot).max() < 2e-4   # oracle batch observations are f32
+    assert rel_close(to, ot, 1e-5), np.abs(to - ot).max()   # oracle batch observations are f32: 1e-5 relative, the north-star bar
     if Nc:
-        assert np.abs(co - oc).max() < 2e-4
+        assert rel_close(co, oc, 1e-5), np.abs(co - oc).max()
     sc = eng.scalars.cpu().numpy()
     assert np.array_equal(sc[:, 1], batch.gather('reward_tgt').astype(np.float32))
 

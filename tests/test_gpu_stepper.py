@@ -1,0 +1,160 @@
+"""GPU (-m gpu): the graph-replayed learner-in-the-loop flow, fused rollouts over already finished environments,
+and the batch-scale census against the oracle (oracle-built occlusion tables on the oracle's side)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gpu_util as U
+
+pytestmark = pytest.mark.gpu
+
+MASKS = ['camera_target_view_mask', 'target_camera_view_mask', 'target_obstacle_view_mask', 'target_target_view_mask', 'camera_camera_view_mask']
+INTS = ['tgt_colliding', 'tgt_goals', 'freights', 'bounties', 'remaining_cargoes', 'awaiting_cargo_counts', 'num_delivered_cargoes', 'episode_step']
+
+
+@pytest.mark.parametrize('workload,n', [('MATE-4v8-9.yaml', 130), ('MATE-Navigation.yaml', 64)])
+def test_graph_replayed_steps_equal_direct_steps(workload, n):
+    """K (policy kernel, step, idle/real auto-reset) iterations captured in ONE HIP graph with the step counter on the
+    device (mate_engine_device_tick) == the same iterations launched one by one with the host counting: every output
+    and the whole state bit for bit, across episode ends (time limit 7 steps, so resets happen inside the graph)."""
+    from mate_amd._native import EngineError
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config(workload, max_episode_steps=7)
+    outs = []
+    for graph_steps in (0, 6):
+        eng = Engine(cfg, n, seed=21)
+        eng.reset()
+        eng.step_random(auto_reset=True)      # an odd host tick before the counter moves to the device
+        gen = torch.Generator(device='cuda').manual_seed(3)
+        cam = (torch.rand((n, eng.num_cameras, 2), device='cuda', generator=gen) * 2 - 1) * 6
+        tgt = (torch.rand((n, eng.num_targets, 2), device='cuda', generator=gen) * 2 - 1) * 25
+
+        def policy():
+            cam.mul_(-1.0).add_(0.125)
+            tgt.mul_(-1.0).add_(0.25)
+
+        stepper = eng.make_stepper(cam, tgt, auto_reset=True, graph_steps=graph_steps, between=policy)
+        rec = []
+        if graph_steps:
+            stepper.run(1)                    # what the constructor's warm-up iteration did, on the direct side
+        else:
+            stepper.run(1)
+            stepper.run(1)
+        for chunk in (12, 5, 6):              # full graph replays and a remainder of direct launches
+            stepper.run(chunk)
+            torch.cuda.synchronize()
+            rec.append([t.clone() for t in (eng.camera_obs, eng.target_obs, eng.scalars, eng.masks)])
+        if graph_steps:
+            with pytest.raises(EngineError):
+                eng.rollout_random(4)          # host-counted flows are refused while the counter is on the device
+        stepper.close()
+        eng.step_random(auto_reset=True)      # and the host-counted flow continues seamlessly afterwards
+        ro = eng.rollout_random(5, auto_reset=True)
+        rec.append([t.clone() for t in ro if t.numel()])
+        rec.append([eng.export_state().clone()])
+        outs.append(rec)
+        del stepper, eng
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+
+
+@pytest.mark.parametrize('policy', ['random', 'greedy'])
+def test_rollout_restarts_environment_finished_before_the_launch(policy):
+    """An episode that ended under auto_reset=False (or arrived with done = 1 through import_state) is skipped by every
+    step of a later fused rollout; the launch must still list it for the reset behind it."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=5)
+    eng = Engine(cfg, 9, seed=4)
+    if policy == 'greedy':
+        eng.enable_policies()
+    rollout = eng.rollout_greedy if policy == 'greedy' else eng.rollout_random
+    eng.reset()
+    rollout(8, auto_reset=False)                   # time limit: every episode ends at step 6 and stays finished
+    sd = eng.state_dict()
+    assert (sd['done'] == 1).all() and (sd['episode'] == 1).all()
+    idle0 = eng.idle_steps()
+    _, _, sc = rollout(4, auto_reset=True)         # nothing steps, but the finished environments are listed and reset
+    assert (sc[:, :, 2] == 2).all() and eng.idle_steps() - idle0 == 4 * 9
+    sd = eng.state_dict()
+    assert (sd['done'] == 0).all() and (sd['episode'] == 2).all() and (sd['episode_step'] == 0).all()
+    _, _, sc = rollout(3, auto_reset=True)
+    assert (sc[:, :, 2] == 0).all() and (eng.state_dict()['episode_step'] == 3).all()
+
+
+def _census(workload, n, steps, fused, own_tables, oracle_lib, seed=99, first=12345):
+    """Native reset + Philox random-policy rollout next to the oracle on the same streams; returns the environments
+    that ever differed in a mask bit or an integer, the worst position error of the others, and the final f32
+    observation error / reward equality of the others."""
+    O = oracle_lib
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    threads = min(32, len(os.sched_getaffinity(0)))
+    cfg = read_config(workload)
+    eng = Engine(cfg, n, seed=seed, first_env_index=first, obs_dtype=torch.float32)
+    eng.reset()
+    torch.cuda.synchronize()
+    batch = O.OracleBatch(U.oracle_proto_from_config(cfg, O), n, seed=seed, first_env_index=first)
+    batch.reset(threads=threads)
+    sd = eng.state_dict()
+    for k in U.STATE_KEYS:
+        ref = batch.gather(k)
+        assert np.array_equal(sd[k].reshape(ref.shape), ref), ('reset', k)
+    if not own_tables:
+        for e in range(n):
+            for c in range(eng.num_cameras):
+                batch.env(e).set_lut(c, *eng.lut_read(e, c))
+    bad = np.zeros(n, dtype=bool)
+    worst = 0.0
+    rows = None
+    for s in range(steps):
+        if fused > 1:
+            if s % fused == 0:
+                rows = eng.rollout_random(min(fused, steps - s), auto_reset=False, want_masks=True)
+            masks = eng.unpack_masks(eng._rollout['masks'][s % fused])
+        else:
+            eng.step_random(auto_reset=False, want_masks=True)
+            masks = eng.unpack_masks()
+        batch.step(auto_reset=False, threads=threads)
+        for m in MASKS:
+            ref = batch.gather(m) != 0
+            bad |= (masks[m].reshape(ref.shape) != ref).reshape(n, -1).any(axis=1)
+        if (fused > 1 and (s % fused == fused - 1 or s == steps - 1)) or fused == 1:
+            sdg = eng.state_dict()
+            for k in INTS:
+                ref = batch.gather(k)
+                bad |= (sdg[k].reshape(ref.shape) != ref).reshape(n, -1).any(axis=1)
+            good = ~bad
+            worst = max(worst, float(np.abs(sdg['tgt_x'] - batch.gather('tgt_x'))[good].max()), float(np.abs(sdg['tgt_y'] - batch.gather('tgt_y'))[good].max()))
+    _, ot = batch.observe(threads=threads)
+    to = (rows[1][(steps - 1) % fused] if fused > 1 else eng.target_obs).cpu().numpy()
+    sc = (rows[2][(steps - 1) % fused] if fused > 1 else eng.scalars).cpu().numpy()
+    good = ~bad
+    obs_ok = bool(np.all(np.abs(to - ot)[good] <= 1e-5 * np.maximum(1.0, np.abs(ot))[good]))
+    rew_ok = bool(np.array_equal(sc[:, 1][good], batch.gather('reward_tgt').astype(np.float32)[good]))
+    return int(bad.sum()), worst, obs_ok, rew_ok
+
+
+@pytest.mark.parametrize('workload,n,steps,fused', [('MATE-4v8-9.yaml', 4096, 32, 16), ('MATE-8v8-9.yaml', 1024, 24, 1), ('MATE-Navigation.yaml', 2048, 32, 32)])
+def test_batch_scale_census_vs_oracle(workload, n, steps, fused, oracle_lib):
+    """The soak of tests/soak_vs_oracle.py at a driver-runnable size: with identical occlusion tables on both sides no
+    environment may ever differ from the oracle in a mask bit or an integer; positions to 1e-9, f32 observations to
+    1e-5 relative, rewards equal."""
+    diverged, worst, obs_ok, rew_ok = _census(workload, n, steps, fused, False, oracle_lib)
+    assert diverged == 0 and worst < 1e-9 and obs_ok and rew_ok, (diverged, worst, obs_ok, rew_ok)
+
+
+@pytest.mark.parametrize('workload,n', [('MATE-4v8-9.yaml', 1024), ('MATE-8v8-9.yaml', 512)])
+def test_step_masks_with_independently_built_tables(workload, n, oracle_lib):
+    """The same census with the oracle keeping the occlusion tables IT built (nothing copied from the device), so that a
+    table divergence would surface as a mask disagreement.  The two builders differ only where the reference itself is
+    a coin flip -- rays exactly tangent to an obstacle, clipped or not by the last bit of asin / atan2 (DESIGN.md
+    section 4), at most two knots per obstacle and table -- and a target has to stand within a hundredth of a degree
+    of such a ray, behind the obstacle, inside the sector, to notice: at most 1 environment in 256 may diverge, and all
+    the others must agree with the oracle exactly."""
+    diverged, worst, obs_ok, rew_ok = _census(workload, n, 40, 1, True, oracle_lib)
+    assert diverged <= max(1, n // 256) and worst < 1e-9 and obs_ok and rew_ok, (diverged, worst, obs_ok, rew_ok)

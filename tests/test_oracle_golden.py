@@ -95,6 +95,46 @@ def test_trace_parity(path):
             np.testing.assert_allclose(env.get(key), fx['step/' + key][s], rtol=0, atol=F64_TOL)
 
 
+@pytest.mark.parametrize('path', G.reset_files(), ids=lambda p: os.path.basename(p)[6:-4])
+def test_reset_tape_parity(path):
+    """reset() (environment.py:679-834) pinned to the reference: the oracle consumes the uniforms the reference's RNG
+    proxies logged (shuffles, capacities, rejection-sampled placement, cargo matrix, initial goals) and must arrive
+    at the state the reference arrived at -- placements and integers exact, occlusion tables knot for knot."""
+    import gpu_util as U
+    fx = G.load(path)
+    cfg = G.config_of_reset_fixture(fx)
+    env = U.oracle_proto_from_config(cfg, O)
+    used = env.reset_tape(fx['tape'], fx['tape_ct'])
+    assert used == len(fx['tape']), (used, len(fx['tape']))
+    want = G.reset_expectation(fx)
+    for key, ref in want.items():
+        got = np.asarray(env.get(key), dtype=np.float64)
+        assert np.array_equal(got.reshape(ref.shape), ref), (key, got, ref)
+    Nc, No = int(fx['num_cameras']), int(fx['num_obstacles'])
+    if Nc:
+        assert np.array_equal(env.get('cam_sight'), fx['reset/cam_sight'])
+    flips = 0
+    for c, (phis, rhos) in enumerate(G.luts_of(fx)):
+        p2, r2 = env.get_lut(c)
+        assert len(p2) == len(phis), (c, len(p2), len(phis))
+        np.testing.assert_allclose(p2, phis, rtol=0, atol=1e-10)
+        bad = np.abs(r2 - rhos) > 1e-8
+        assert bad.sum() <= 2 * No      # tangent-ray coin flips of the reference itself (DESIGN.md section 4)
+        flips += int(bad.sum())
+    for m in G.MASK_FIELDS:
+        assert np.array_equal(np.asarray(env.get(m)) != 0, fx['reset/' + m].astype(bool)), m
+    co, to = env.observe()
+    if co.size:
+        np.testing.assert_allclose(co, fx['reset/cam_obs'], rtol=0, atol=F64_TOL)
+    np.testing.assert_allclose(to, fx['reset/tgt_obs'], rtol=0, atol=F64_TOL)
+    np.testing.assert_allclose(env.state(), fx['reset/state'], rtol=0, atol=F64_TOL)
+    for k in ('coverage_rate', 'real_coverage_rate', 'mean_transport_rate'):
+        assert env.get(k) == fx['reset/' + k], k
+    # a tape that is one draw short is reported, not read past
+    if len(fx['tape']) > 1:
+        assert U.oracle_proto_from_config(cfg, O).reset_tape(fx['tape'][:-1], fx['tape_ct']) == -1
+
+
 def test_trace_parity_with_own_lut():
     """Same replay, but the occlusion LUT comes from the oracle's own builder (a10)."""
     fx = G.load('trace_4v8-9_greedy_s2.npz')
