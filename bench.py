@@ -47,7 +47,6 @@ import argparse
 import json
 import os
 import socket
-import statistics
 import subprocess
 import sys
 import time
@@ -175,34 +174,32 @@ def launch_ranks(args):
 
 
 class StatsGather:
-    """Episode statistics of the finished rollout, all-gathered OFF the critical path: the reduction of the rollout's
-    scalar rows is enqueued on the launch stream (it reads buffers the next launch overwrites), the collective on a
-    side stream behind an event."""
+    """Episode statistics all-gathered OFF the critical path.  The engine accumulates the record of
+    every finished episode on the device (Engine.episode_stats: count, return, length, coverage, delivered); a gather is
+    an event on the launch stream, and behind it on a SIDE stream a 40-byte copy of the accumulators and the RCCL
+    all-gather of the copy.  Nothing is enqueued on the launch stream but the event."""
 
-    def __init__(self, torch, dist, distributed, device):
-        self.torch, self.dist, self.distributed = torch, dist, distributed
-        self.side = torch.cuda.Stream(device=device)
-        self.slots = [torch.zeros(5, dtype=torch.float64, device=device) for _ in range(2)]
-        self.gathered = [[torch.zeros(5, dtype=torch.float64, device=device) for _ in range(dist.get_world_size() if distributed else 1)] for _ in range(2)]
-        self.turn = 0
+    def __init__(self, torch, dist, distributed, eng):
+        self.torch, self.dist, self.distributed, self.eng = torch, dist, distributed, eng
+        self.side = torch.cuda.Stream(device=eng.device)
+        world = dist.get_world_size() if distributed else 1
+        self.slots = [torch.zeros(5, dtype=torch.float64, device=eng.device) for _ in range(2)]
+        self.gathered = [[torch.zeros(5, dtype=torch.float64, device=eng.device) for _ in range(world)] for _ in range(2)]
+        self.events = [torch.cuda.Event() for _ in range(2)]
+        self.turn = self.last = 0
         self.count = 0
 
-    def submit(self, scalars):
-        """`scalars`: [T, N, 8] (or [N, 8]) of the launch that was just enqueued."""
+    def submit(self):
         torch = self.torch
-        s = scalars.reshape(-1, 8)
-        done = (s[:, 2] == 1.0).to(torch.float64)
-        slot = self.slots[self.turn]
-        torch.stack([done.sum(), s[:, 1].sum(dtype=torch.float64), (done * s[:, 3]).sum(), (done * s[:, 6]).sum(),
-                     torch.tensor(float(s.shape[0]), dtype=torch.float64, device=s.device)], out=slot)
-        ready = torch.cuda.Event()
+        ready = self.events[self.turn]
         ready.record()
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
+            self.slots[self.turn].copy_(self.eng.episode_stats, non_blocking=True)
             if self.distributed:
-                self.dist.all_gather(self.gathered[self.turn], slot)
+                self.dist.all_gather(self.gathered[self.turn], self.slots[self.turn])
             else:
-                self.gathered[self.turn][0].copy_(slot)
+                self.gathered[self.turn][0].copy_(self.slots[self.turn], non_blocking=True)
         self.last = self.turn
         self.turn ^= 1
         self.count += 1
@@ -213,8 +210,8 @@ class StatsGather:
             return None
         total = self.torch.stack(self.gathered[self.last]).sum(dim=0).tolist()
         episodes = max(total[0], 1.0)
-        return {'gathers_in_timed_loop': self.count, 'episodes_finished_last_window': total[0], 'mean_step_reward': total[1] / max(total[4], 1.0),
-                'mean_final_coverage_rate': total[2] / episodes, 'mean_delivered': total[3] / episodes}
+        return {'gathers_in_timed_loops': self.count, 'episodes_finished': total[0], 'mean_episode_return': total[1] / episodes,
+                'mean_episode_length': total[2] / episodes, 'mean_final_coverage_rate': total[3] / episodes, 'mean_delivered': total[4] / episodes}
 
 
 def dry_run(args, world, rank):
@@ -283,27 +280,25 @@ def main():
     else:
         step = lambda: eng.step_random(auto_reset=True)     # noqa: E731
     rollout = eng.rollout_greedy if args.policy == 'greedy' else eng.rollout_random
-    gather = StatsGather(torch, dist, distributed, torch.device('cuda', local_rank)) if args.stats_interval > 0 else None
+    gather = StatsGather(torch, dist, distributed, eng) if args.stats_interval > 0 else None
 
     def run(steps, timed=False):
         """exactly `steps` env.step()s of the whole batch"""
         if external is not None:
             external.run(steps)
             if timed and gather is not None:
-                gather.submit(eng.scalars)
+                gather.submit()
         elif R > 0:
             lengths = [R] * (steps // R) + ([steps % R] if steps % R else [])
             for i, n in enumerate(lengths):
-                out = rollout(n, auto_reset=True)
+                rollout(n, auto_reset=True)
                 if timed and gather is not None and (i + 1) % args.stats_interval == 0:
-                    gather.submit(out[2])
-            if timed and gather is not None and len(lengths) < args.stats_interval:
-                gather.submit(out[2])          # short timed regions: one gather per repetition
+                    gather.submit()
         else:
             for i in range(steps):
                 step()
                 if timed and gather is not None and (i + 1) % (args.stats_interval * 128) == 0:
-                    gather.submit(eng.scalars)
+                    gather.submit()
 
     eng.reset()
     if R > 0:
@@ -314,6 +309,10 @@ def main():
         run(R + (args.steps % R))
     elif external is not None:
         external.run(min(args.steps, max(args.graph_steps, 1) + args.steps % max(args.graph_steps, 1)))
+    if gather is not None:
+        gather.submit()              # side stream, copies and (N > 1) the RCCL communicator warmed outside the timed region
+        gather.result()
+        gather.count = 0
 
     def barrier():
         torch.cuda.synchronize()
@@ -333,7 +332,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         executed = args.batch * args.steps - (eng.idle_steps() - idle0)   # env-steps actually simulated by this rank
-        assert gather is not None or torch.cuda.memory_allocated() <= allocated0, 'allocation inside the timed region'
+        assert torch.cuda.memory_allocated() <= allocated0, 'allocation inside the timed region'
         kernel_times.append(eng.kernel_time(enable=False))
         stats = eng.scalars[:, [1, 3, 6]].mean(dim=0)    # reward, coverage, delivered: logging only
         elapsed, executed, stats = reduce_job(elapsed, executed, stats, device='cuda')   # MAX time, SUM env-steps, gathered stats
@@ -438,14 +437,16 @@ class ExternalActions:
         N, Nc, Nt = eng.num_envs, eng.num_cameras, eng.num_targets
         gen = torch.Generator(device=eng.device)
         gen.manual_seed(1234)
-        self.cam = (torch.rand((N, Nc, 2), device=eng.device, generator=gen) * 2 - 1) * torch.tensor([5.0, 2.5], device=eng.device)
-        self.tgt = (torch.rand((N, Nt, 2), device=eng.device, generator=gen) * 2 - 1) * 20.0
+        self.flat = torch.rand(N * (Nc + Nt) * 2, device=eng.device, generator=gen) * 2 - 1      # one buffer, two views
+        self.cam = self.flat[:N * Nc * 2].view(N, Nc, 2)
+        self.tgt = self.flat[N * Nc * 2:].view(N, Nt, 2)
+        self.cam.mul_(torch.tensor([5.0, 2.5], device=eng.device))
+        self.tgt.mul_(20.0)
         self.stepper = eng.make_stepper(self.cam, self.tgt, auto_reset=True, graph_steps=self.graph_steps, between=self.policy)
 
     def policy(self):
-        # a new joint action every step, produced on the device by "someone else's" kernels
-        self.cam.mul_(-1.0)
-        self.tgt.mul_(-1.0)
+        # a new joint action every step, produced on the device by "someone else's" kernel
+        self.flat.mul_(-1.0)
 
     def step(self):
         self.stepper.run(1)

@@ -130,6 +130,13 @@ int mate_engine_reset_tape(mate_engine *engine, const uint8_t *env_mask_dev, con
  * build) when episodes end every step somewhere in the batch.  auto_reset == 0: the caller resets. */
 int mate_engine_step(mate_engine *engine, const mate_step_io *io, int32_t auto_reset, void *stream);
 
+/* Episode statistics for logging: `stats_dev` = 5 doubles in caller-owned device memory (or NULL to stop), to which
+ * every later step / rollout launch adds, for each episode that ends in it: 1, the target team's episode reward
+ * (environment.py:624), the episode length (:629), the final coverage_rate (:966) and num_delivered_cargoes.  This is
+ * the record the sharded job all-gathers over RCCL; the engine only accumulates it, with a
+ * handful of atomics per finished episode.  The caller zeroes / reads the buffer on its own streams. */
+int mate_engine_set_episode_stats(mate_engine *engine, double *stats_dev);
+
 /* Graph-replayable stepping (the learner-in-the-loop flow: policy kernels write the joint actions into caller
  * buffers, step() consumes them, K such iterations are captured once in a HIP graph and replayed).  A step() launch
  * normally carries the step counter (the Philox tick) and the ping-pong index of the finished-episode lists as launch

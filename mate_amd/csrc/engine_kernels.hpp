@@ -142,6 +142,7 @@ struct Ptrs {
     const double *reset_tape;     // tape mode of reset (mate_engine_reset_tape): [N][reset_tape_len] uniforms, or NULL = Philox
     int32_t reset_tape_len;
     int32_t *reset_draws;         // optional [N]: uniforms each reset consumed (-1: the tape ran out)
+    double *ep_stats;             // optional [5] accumulators over finished episodes: count, return, length, coverage, delivered
     uint32_t *dev_tick_ptr;       // &Params::dev_tick of the device-resident parameter block (advanced by the auto-reset launch)
     int32_t *ctrl;                // [0]: list parity the last step launch used (device-resident step counter mode)
     long long *phase_clocks;      // [N][16] s_memtime stamps (debug builds with -DMATE_PHASE_CLOCKS)
@@ -927,6 +928,11 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
         if (done && c.g.done_count) {
             const int slot = atomicAdd(c.g.done_count + c.parity, 1);
             c.g.done_list[(int64_t)c.parity * c.g.N + slot] = (int32_t)c.env;
+        }
+        if (done && c.g.ep_stats) {      // episode statistics for logging (the record SURVEY.md 8e all-gathers); rare
+            double *es = c.g.ep_stats;
+            atomicAdd(es + 0, 1.0); atomicAdd(es + 1, epr); atomicAdd(es + 2, (double)ep_step);
+            atomicAdd(es + 3, coverage); atomicAdd(es + 4, (double)delivered);
         }
     }
     wave_sync();

@@ -567,6 +567,12 @@ extern "C" int mate_engine_rebuild_luts(mate_engine *e, void *stream) {
     return launch_reset(e, g, RESET_ALL, PH_LUT, (hipStream_t)stream);
 }
 
+extern "C" int mate_engine_set_episode_stats(mate_engine *e, double *stats_dev) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    e->g.ep_stats = stats_dev;
+    return MATE_OK;
+}
+
 // Device-resident step counter: see Params::dev_tick.  enable: the host's tick goes to the device and stays there;
 // disable: the stream is drained and the counter comes back.
 extern "C" int mate_engine_device_tick(mate_engine *e, int32_t enable, void *stream_) {

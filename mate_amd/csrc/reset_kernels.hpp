@@ -138,6 +138,7 @@ __device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][
         for (int s = 0; s < 4; ++s) all = all && row_any(remaining + 4 * s);
         for (int g = 0; g < 4; ++g) c.ei(EI_AWAITING + g) = remaining[g] + remaining[4 + g] + remaining[8 + g] + remaining[12 + g];
         if (all) break;
+        if (rng.tape && rng.n > rng.tape_len) break;      // an exhausted tape yields zeros for ever: reported through reset_draws, not looped on
     }
     for (int t = 0; t < Nt; ++t) {                                                          // environment.py:777-783
         c.ti(t, TI_BOUNTY) = 0; c.ti(t, TI_FREIGHT) = 0; c.ti(t, TI_GW) = 0; c.ti(t, TI_TSTEPS) = 0; c.ti(t, TI_TRSTEPS) = 0;

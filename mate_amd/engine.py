@@ -99,6 +99,9 @@ class Engine:
             self.target_obs = torch.zeros((N, Nt, layout.target_obs_dim), dtype=obs_dtype, device=self.device)
             self.scalars = torch.zeros((N, 8), dtype=torch.float32, device=self.device)
             self.masks = torch.zeros((N, layout.mask_words), dtype=torch.int32, device=self.device)
+            # running sums over finished episodes (mate_amd.distributed.EpisodeStats.FIELDS): count, return, length, coverage, delivered
+            self.episode_stats = torch.zeros(5, dtype=torch.float64, device=self.device)
+        check(self.lib.mate_engine_set_episode_stats(self._h, ctypes.c_void_p(self.episode_stats.data_ptr())))
 
     def close(self):
         if getattr(self, '_h', None):

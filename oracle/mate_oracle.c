@@ -1223,6 +1223,7 @@ static void reset_impl(mo_env *e, const double *tape_ct) {
         int all = 1;
         for (int s = 0; s < MO_NW; ++s) all &= row_any(e->remaining[s]);
         if (all) break;
+        if (e->reset_tape_overrun) break;            /* an exhausted tape yields zeros for ever: reported by mo_reset_tape */
     }
     for (int t = 0; t < Nt; ++t) {                                               /* :777-783 */
         e->goals[t] = -1; e->target_steps[t] = e->tracked_steps[t] = 0; e->freights[t] = e->bounties[t] = 0;
@@ -1280,6 +1281,13 @@ void mo_batch_destroy(mo_batch *b) {
     free(b->envs); free(b);
 }
 mo_env *mo_batch_env(mo_batch *b, int i) { return b->envs[i]; }
+
+/* one field of every environment: out[i * n .. i * n + n) = mo_get(env i, field, n) */
+int mo_batch_get(const mo_batch *b, const char *field, double *out, int n) {
+    for (int i = 0; i < b->n; ++i)
+        if (mo_get(b->envs[i], field, out + (size_t)i * (size_t)n, n) != n) return -1;
+    return b->n;
+}
 
 void mo_batch_reset(mo_batch *b, int threads) {
     (void)threads;

@@ -82,6 +82,7 @@ typedef struct mo_batch mo_batch;
 mo_batch *mo_batch_create(const mo_env *prototype, int n, uint64_t seed, uint64_t first_env_index);
 void mo_batch_destroy(mo_batch *b);
 mo_env *mo_batch_env(mo_batch *b, int i);
+int mo_batch_get(const mo_batch *b, const char *field, double *out, int n);   /* mo_get of every environment, [envs][n] */
 void mo_batch_reset(mo_batch *b, int threads);
 /* Steps every env once with the on-the-fly uniform random policy,
  * auto-resetting finished episodes.  Actions may be NULL (= Philox policy). */

@@ -83,6 +83,8 @@ def _load():
     lib.mo_batch_destroy.argtypes = [P]
     lib.mo_batch_env.restype = P
     lib.mo_batch_env.argtypes = [P, I]
+    lib.mo_batch_get.restype = I
+    lib.mo_batch_get.argtypes = [P, ctypes.c_char_p, c_double_p, I]
     lib.mo_batch_reset.argtypes = [P, I]
     lib.mo_batch_step.argtypes = [P, c_float_p, c_float_p, I, I]
     lib.mo_batch_observe.argtypes = [P, c_float_p, c_float_p, I]
@@ -390,4 +392,17 @@ class OracleBatch:
             lib.mo_update_view_reset(lib.mo_batch_env(self._h, i))
 
     def gather(self, field):
-        return np.stack([self.env(i).get(field) for i in range(self.n)])
+        """`field` of every environment, stacked: [n, ...] (same values as env(i).get(field))."""
+        p = self.proto
+        if field in _PADDED:
+            stride, shape = _PADDED[field]
+            rows, cols = shape(p)
+            buf = np.zeros((self.n, max(rows * stride, 1)))
+            if rows:
+                assert lib.mo_batch_get(self._h, field.encode(), _dp(buf), rows * stride) == self.n, field
+            return buf[:, :rows * stride].reshape(self.n, rows, stride)[:, :, :cols].copy()
+        count = p._count(_VECTORS[field]) if field in _VECTORS else 1
+        buf = np.zeros((self.n, max(count, 1)))
+        if count:
+            assert lib.mo_batch_get(self._h, field.encode(), _dp(buf), count) == self.n, field
+        return buf[:, :count].copy() if field in _VECTORS else buf[:, 0].copy()

@@ -53,3 +53,28 @@ def test_gather_episode_stats_two_ranks():
     assert total['mean_length'] == pytest.approx(100 + 4)
     assert parts[0][0] == 3 and parts[1][0] == 2
     assert job[0] == 2.0 and job[1] == 3000.0 and job[2] == [0.5, 5.0, 1.0]
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` outside torchrun starts two ranks itself (torch.distributed.run child, rendezvous on
+    127.0.0.1) and the line rank 0 prints carries the process group's world size; `--dry-run` swaps RCCL for gloo and
+    the engine for fabricated timings, so the launch path and the job-level reduction run on CPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    done = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '10', '--warmup', '1'],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [json.loads(l) for l in done.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                      # rank 0 only
+    line = lines[0]
+    assert line['n_gpus'] == 2 and line['ranks'] == 2 and line['data'] == 'dry-run'
+    assert line['config']['global_batch'] == 2 * 4096
+    # MAX over ranks of the (fabricated) times 1.0 s and 1.25 s, SUM of the env-steps of both shards
+    assert line['ms_per_step'] == pytest.approx(1250.0 / 10) and line['value'] == pytest.approx(2 * 4096 * 10 / 1.25)
+    assert line['shard_first_env_mean'] == pytest.approx(2048.0)
+    # a rank count that contradicts the torchrun environment is refused, not silently benchmarked on one GPU
+    env_bad = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=env_bad,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=120)
+    assert bad.returncode != 0 and 'WORLD_SIZE=1' in bad.stderr

@@ -133,6 +133,7 @@ def test_reset_tape_parity(path):
     # a tape that is one draw short is reported, not read past
     if len(fx['tape']) > 1:
         assert U.oracle_proto_from_config(cfg, O).reset_tape(fx['tape'][:-1], fx['tape_ct']) == -1
+        assert U.oracle_proto_from_config(cfg, O).reset_tape(fx['tape'][:30], fx['tape_ct']) == -1      # and terminates
 
 
 def test_trace_parity_with_own_lut():
