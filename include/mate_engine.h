@@ -104,7 +104,10 @@ int mate_engine_create(const mate_config *config, int64_t num_envs, int32_t devi
                        uint64_t first_env_index, mate_engine **out);
 int mate_engine_destroy(mate_engine *engine);                               /* close(), environment.py:1192 */
 int mate_engine_get_layout(const mate_engine *engine, mate_layout *out);
-int mate_engine_seed(mate_engine *engine, uint64_t seed);                   /* seed(), environment.py:1203-1227 */
+/* seed() (environment.py:1203-1227): installs the Philox key AND rewinds every counter that enters a counter word
+ * (per-environment episode number, step tick), as the reference re-creates its RandomStates: after seed(s) the next
+ * reset() and everything that follows depend on (s, global environment index) only, whatever ran before. */
+int mate_engine_seed(mate_engine *engine, uint64_t seed);
 
 /* reset() (environment.py:679-834) of every environment (env_mask_dev == NULL) or of those with a
  * non-zero byte in env_mask_dev[N].  Writes the initial observations/masks like a step does. */

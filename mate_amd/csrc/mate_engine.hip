@@ -488,6 +488,12 @@ extern "C" int mate_engine_seed(mate_engine *e, uint64_t seed) {
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice));
+    // the reference re-creates its generators (environment.py:1219-1225): the same seed gives the same episodes again,
+    // whatever ran before.  Here: the key, and every counter that enters a Philox counter word (episode, tick) rewound.
+    hipLaunchKernelGGL(rewind_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t) nullptr, (const Params *)e->d_params, (const Ptrs)e->g);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    e->tick = 0;
     return MATE_OK;
 }
 

@@ -468,6 +468,16 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
     }
 }
 
+// seed(): every counter that enters a Philox counter word goes back to zero, so that (seed, environment index) alone
+// determines the next reset() and everything after it (environment.py:1203-1227 re-creates its RandomStates).
+__global__ void rewind_kernel(const Params *__restrict__ pp, const Ptrs g) {
+    const Params &p = *pp;
+    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= g.N) return;
+    int32_t *e = reinterpret_cast<int32_t *>(g.dyn + env * p.DW + p.DF) + p.Nt * TI_STRIDE;
+    e[EI_EPISODE] = 0; e[EI_TICK] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // canonical f64 export / import (one lane per environment; not on the hot path)
 struct Exporter {

@@ -372,7 +372,13 @@ class MultiAgentTracking(_ScenarioMixin, _EnvBase, metaclass=EnvMeta):
 
     # ------------------------------------------------------------------ gym API
     def seed(self, seed=None):
-        """Seed the host RNG handed to callers and the engine's counter-based streams."""
+        """Seed the host RNG handed to callers and the engine's counter-based streams (environment.py:1203-1227).
+
+        Returns the main seed followed by one seed per entity (cameras, targets, obstacles), drawn from the fresh main
+        generator exactly as the reference draws them (`np_random.randint(int_max)` per entity), so `len(env.seed())`
+        and the position of `env.np_random` afterwards match.  The engine itself needs one key: its streams are
+        Philox counters keyed by (seed, environment, episode, tick), and seeding rewinds those counters, so the same
+        seed always produces the same episodes -- like the reference, whose `__init__` also ends with `seed(0)`."""
         if seed is None:
             seed = int(np.random.SeedSequence().entropy % (2 ** 31))
         if not (isinstance(seed, (int, np.integer)) and seed >= 0):
@@ -380,15 +386,27 @@ class MultiAgentTracking(_ScenarioMixin, _EnvBase, metaclass=EnvMeta):
         self._seed_value = int(seed)
         self._np_random = np.random.RandomState(self._seed_value % (2 ** 32))
         self.engine.seed(self._seed_value)
-        return [self._seed_value]
+        int_max = np.iinfo(int).max
+        entities = self.num_cameras + self.num_targets + self.num_obstacles
+        return [self._seed_value] + [int(self._np_random.randint(int_max)) for _ in range(entities)]
 
     def _collect(self):
+        """Fresh observations + the metrics of joint_observation (environment.py:966-979), computed here in f64 from the
+        exported state and masks as the reference computes them (the engine's own scalar record is f32: the batched
+        product dtype)."""
         self._cache = self._masks = None
         cam = self.engine.camera_obs[0].to(torch.float64).cpu().numpy() if self.num_cameras else np.zeros((0, self.camera_observation_dim))
         tgt = self.engine.target_obs[0].to(torch.float64).cpu().numpy()
         scalars = self.engine.scalars[0].cpu().numpy()
-        self.coverage_rate, self.real_coverage_rate = float(scalars[3]), float(scalars[4])
-        self.mean_transport_rate, self.num_delivered_cargoes = float(scalars[5]), int(scalars[6])
+        f = self._fields()
+        tracked = self.tracked_bits.astype(bool)
+        with_bounty = f['bounties'] > 0
+        self.coverage_rate = tracked.sum() / self.num_targets
+        self.real_coverage_rate = float(np.logical_and(tracked, with_bounty).sum() / max(1, with_bounty.sum())) if with_bounty.any() else 0.0
+        self.coverage_rate = float(self.coverage_rate)
+        self.num_delivered_cargoes = int(f['num_delivered_cargoes'])
+        self.mean_transport_rate = (float(f['delayed_episode_reward']) / (self.reward_scale * self.num_delivered_cargoes)
+                                    if self.num_delivered_cargoes > 0 else 0.0)
         return cam, tgt, scalars
 
     def reset(self, *, seed=None):
@@ -399,8 +417,39 @@ class MultiAgentTracking(_ScenarioMixin, _EnvBase, metaclass=EnvMeta):
         cam, tgt, _ = self._collect()
         self.target_dones = np.zeros(self.num_targets, dtype=bool)
         self._last_goals = self.target_goals.copy()
+        self._last_episode_rewards = (self.target_team_episode_reward, self.delayed_target_team_episode_reward)
         self.episode_step = 0
         return cam, tgt
+
+    #: parity hook: {'camera_target': [Nc, Nt] uniforms, 'goal': [Nt] uniforms} consumed by the NEXT step() instead of the
+    #: engine's Philox draws (how the golden traces recorded from the reference are replayed through this API)
+    step_tape = None
+
+    def _tapes(self):
+        tape, self.step_tape = self.step_tape, None
+        if not tape:
+            return None, None
+        dev = self.engine.device
+        ct = tape.get('camera_target')
+        goal = tape.get('goal')
+        ct = None if ct is None else torch.from_numpy(np.nan_to_num(np.asarray(ct, dtype=np.float64), nan=0.0)[None].copy()).to(dev)
+        goal = None if goal is None else torch.from_numpy(np.nan_to_num(np.asarray(goal, dtype=np.float64), nan=0.0)[None].copy()).to(dev)
+        return ct, goal
+
+    def enable_greedy_policies(self):
+        """Let the engine play GreedyCameraAgent vs GreedyTargetAgent itself (`step_greedy`); call before the reset()
+        whose observations the agents first act on."""
+        self.engine.enable_policies()
+        self._greedy = True
+
+    def step_greedy(self):
+        """`env.step(mate.group_step(...))` of both teams with the reference's Greedy agents computed on the device
+        (mate/agents/greedy.py through Engine.step_greedy); same return value as step()."""
+        if not getattr(self, '_greedy', False):
+            raise RuntimeError('enable_greedy_policies() must precede the reset() the agents first act on')
+        tape_ct, tape_goal = self._tapes()
+        self.engine.step_greedy(tape_ct=tape_ct, tape_goal=tape_goal, auto_reset=False)
+        return self._finish_step()
 
     def step(self, action):
         camera_joint_action, target_joint_action = action
@@ -409,13 +458,23 @@ class MultiAgentTracking(_ScenarioMixin, _EnvBase, metaclass=EnvMeta):
         assert np.isfinite(cam_act).all(), f'Got unexpected joint action {cam_act}.'
         assert np.isfinite(tgt_act).all(), f'Got unexpected joint action {tgt_act}.'
         dev = self.engine.device
-        self.engine.step(torch.from_numpy(cam_act[None]).to(dev), torch.from_numpy(tgt_act[None]).to(dev), auto_reset=False)
+        tape_ct, tape_goal = self._tapes()
+        self.engine.step(torch.from_numpy(cam_act[None]).to(dev), torch.from_numpy(tgt_act[None]).to(dev), tape_ct=tape_ct, tape_goal=tape_goal,
+                         auto_reset=False)
+        return self._finish_step()
+
+    def _finish_step(self):
         cam, tgt, scalars = self._collect()
         goals = self.target_goals
         self.target_dones = (goals != self._last_goals) & (self._last_goals >= 0)
         self._last_goals = goals.copy()
         self.episode_step += 1
-        r_tgt = float(scalars[1])
+        # the step's team reward in f64: the increment of the episode sums (integers: exact), environment.py:618-624
+        sums = (self.target_team_episode_reward, self.delayed_target_team_episode_reward)
+        r_tgt = float(sums[1] - self._last_episode_rewards[1]) if self._sparse_reward else float(sums[0] - self._last_episode_rewards[0])
+        self._last_step_rewards = (float(sums[0] - self._last_episode_rewards[0]), float(sums[1] - self._last_episode_rewards[1]))
+        self._last_episode_rewards = sums
+        assert np.float32(r_tgt) == scalars[1]
         r_cam = -r_tgt
         done = bool(scalars[2])
         norm = r_tgt / self.max_target_team_episode_reward
@@ -431,6 +490,32 @@ class MultiAgentTracking(_ScenarioMixin, _EnvBase, metaclass=EnvMeta):
                         for t in range(self.num_targets)]
         self._clear_messages(totals=False)
         return (cam, tgt), (r_cam, r_tgt), done, (camera_infos, target_infos)
+
+    def snapshot(self):
+        """Everything a caller of the reference class can read after reset() / step(), as one dict of NumPy values keyed
+        like the golden fixtures (tests/golden): the backend protocol of mate_amd.reference_adapter."""
+        f = self._fields()
+        Nc, Nt, No = self.num_cameras, self.num_targets, self.num_obstacles
+        area = self.config['camera']['min_viewing_angle'] * self.config['camera']['max_sight_range'] ** 2 if Nc else 0.0
+        last = getattr(self, '_last_step_rewards', (0.0, 0.0))
+        snap = {
+            'cam_xy': np.stack([f['cam_x'], f['cam_y']], axis=-1).reshape(Nc, 2), 'cam_phi': f['cam_phi'].copy(), 'cam_theta': f['cam_theta'].copy(),
+            'cam_sight': np.sqrt(area / f['cam_theta']) if Nc else np.zeros(0),
+            'obs_xyr': np.stack([f['obs_x'], f['obs_y'], f['obs_radius']], axis=-1).reshape(No, 3),
+            'tgt_xy': np.stack([f['tgt_x'], f['tgt_y']], axis=-1).reshape(Nt, 2), 'tgt_capacity': f['tgt_capacity'].astype(np.int64),
+            'tgt_colliding': f['tgt_colliding'].astype(bool), 'tgt_empty_bits': f['tgt_empty_bits'].astype(bool),
+            'tgt_goal_bits': f['tgt_goal_bits'].astype(np.int64), 'tgt_goals': self.target_goals, 'freights': self.freights, 'bounties': self.bounties,
+            'target_steps': self.target_steps, 'tracked_steps': self.tracked_steps, 'remaining_cargoes': self.remaining_cargoes,
+            'awaiting_cargo_counts': self.awaiting_cargo_counts, 'num_delivered_cargoes': int(f['num_delivered_cargoes']),
+            'target_warehouse_distances': self.target_warehouse_distances, 'target_dones': np.asarray(self.target_dones, dtype=bool),
+            'coverage_rate': self.coverage_rate, 'real_coverage_rate': self.real_coverage_rate, 'mean_transport_rate': self.mean_transport_rate,
+            'reward_dense': last[0], 'reward_delayed': last[1],
+            'luts': [self.engine.lut_read(0, c) for c in range(Nc)],
+        }
+        for name in ('camera_target_view_mask', 'target_camera_view_mask', 'target_obstacle_view_mask', 'target_target_view_mask',
+                     'camera_camera_view_mask', 'camera_obstacle_view_mask', 'tracked_bits'):
+            snap[name] = self._mask(name).copy()
+        return snap
 
     def joint_observation(self):
         self.engine.observe()

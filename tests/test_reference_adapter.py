@@ -1,0 +1,137 @@
+"""The wrapper drop-in, proven in the build container (CPU, needs /root/reference: skipped where it is absent).
+
+`mate_amd.reference_adapter.hip_environment_class` derives, from the REFERENCE's own `MultiAgentTracking`, the subclass
+whose hot path runs on a backend.  There is no GPU here, so the backend replays a golden
+trace recorded from the reference -- everything above it is the reference's unmodified code: its constructor, its
+`step()` bookkeeping and info dictionaries, and its wrappers, whose `isinstance(env.unwrapped, MultiAgentTracking)`
+assertions (mate/wrappers/typing.py:59-66) and attribute reads now hit the adapter.  Outputs are checked against
+fixtures the reference's wrappers produced on the original environment (xform_*, discrete_*)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import golden_util as G
+
+REFERENCE = os.environ.get('MATE_REFERENCE', '/root/reference')
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, 'mate')), reason='the upstream reference is only present in the build container')
+
+
+@pytest.fixture(scope='module')
+def mate():
+    sys.path.insert(0, os.path.join(G.GOLDEN_DIR, 'gymshim'))
+    sys.path.insert(0, REFERENCE)
+    if not hasattr(np, 'bool8'):
+        np.bool8 = np.bool_
+    import mate as reference
+    yield reference
+    sys.path.remove(REFERENCE)
+    sys.path.remove(os.path.join(G.GOLDEN_DIR, 'gymshim'))
+
+
+class ReplayBackend:
+    """Serves a golden trace through the backend protocol (reset / step / snapshot); checks the actions it is handed."""
+
+    def __init__(self, fx, expect_actions=True):
+        self.fx, self.s, self.expect_actions = fx, -1, expect_actions
+
+    def _pick(self, key):
+        return self.fx['reset/' + key] if self.s < 0 else self.fx['step/' + key][self.s]
+
+    def reset(self, seed=None):
+        self.s = -1
+        return self.fx['reset/cam_obs'], self.fx['reset/tgt_obs']
+
+    def step(self, action):
+        self.s += 1
+        if self.expect_actions:          # what the wrappers decoded / passed down == what the reference's env.step received
+            np.testing.assert_allclose(action[0], self.fx['step/cam_act'][self.s], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(action[1], self.fx['step/tgt_act'][self.s], rtol=0, atol=1e-12)
+        r = float(self.fx['step/reward_tgt'][self.s])
+        return (self.fx['step/cam_obs'][self.s], self.fx['step/tgt_obs'][self.s]), (-r, r), bool(self.fx['step/done'][self.s]), None
+
+    def snapshot(self):
+        fx, st = self.fx, 'static/'
+        snap = {k: self._pick(k) for k in ('cam_phi', 'cam_theta', 'cam_sight', 'tgt_xy', 'tgt_colliding', 'tgt_empty_bits', 'tgt_goal_bits', 'tgt_goals',
+                                           'freights', 'bounties', 'target_steps', 'tracked_steps', 'remaining_cargoes', 'awaiting_cargo_counts',
+                                           'num_delivered_cargoes', 'target_warehouse_distances', 'target_dones', 'coverage_rate', 'real_coverage_rate',
+                                           'mean_transport_rate', 'camera_target_view_mask', 'target_camera_view_mask', 'target_obstacle_view_mask',
+                                           'target_target_view_mask', 'camera_camera_view_mask', 'tracked_bits')}
+        snap.update(cam_xy=fx[st + 'cam_xy'], obs_xyr=fx[st + 'obs_xyr'], tgt_capacity=fx[st + 'tgt_capacity'],
+                    camera_obstacle_view_mask=fx[st + 'camera_obstacle_view_mask'], luts=G.luts_of(fx))
+        if self.s >= 0:
+            prev = (fx['step/episode_reward'][self.s - 1], fx['step/delayed_episode_reward'][self.s - 1]) if self.s > 0 else (0.0, 0.0)
+            snap['reward_dense'] = fx['step/episode_reward'][self.s] - prev[0]
+            snap['reward_delayed'] = fx['step/delayed_episode_reward'][self.s] - prev[1]
+        return snap
+
+
+def _adapter(mate, fx, **kw):
+    from mate_amd.reference_adapter import hip_environment_class
+    cls = hip_environment_class(mate.environment)
+    return cls(str(fx['config_file']), backend=ReplayBackend(fx, **kw))
+
+
+def test_adapter_is_the_reference_class_and_replays_its_trace(mate):
+    fx = G.load('trace_4v8-9_greedy_s2.npz')
+    env = _adapter(mate, fx)
+    assert isinstance(env, mate.MultiAgentTracking) and isinstance(env.unwrapped, mate.environment.MultiAgentTracking)
+    assert len(env.seed(3)) == 1 + 4 + 8 + 9                         # the reference's own seed() (environment.py:1203-1227)
+    cam_obs, tgt_obs = env.reset()
+    assert np.array_equal(cam_obs, fx['reset/cam_obs']) and np.array_equal(tgt_obs, fx['reset/tgt_obs'])
+    np.testing.assert_allclose(env.state(), fx['reset/state'], rtol=0, atol=1e-9)      # the reference's state() over the mirrored entities
+    for s in range(64):
+        (cam_obs, tgt_obs), (r_cam, r_tgt), done, (cam_infos, tgt_infos) = env.step((fx['step/cam_act'][s], fx['step/tgt_act'][s]))
+        assert np.array_equal(tgt_obs, fx['step/tgt_obs'][s]) and r_tgt == fx['step/reward_tgt'][s] and r_cam == -r_tgt
+        assert done == bool(fx['step/done'][s]) and env.episode_step == s + 1
+        assert tgt_infos[0]['normalized_raw_reward'] == fx['step/normalized_reward_tgt'][s]
+        assert cam_infos[0]['coverage_rate'] == fx['step/coverage_rate'][s] and env.mean_transport_rate == fx['step/mean_transport_rate'][s]
+        for key in ('target_steps', 'tracked_steps', 'bounties', 'freights', 'remaining_cargoes', 'awaiting_cargo_counts'):
+            assert np.array_equal(getattr(env, key), fx['step/' + key][s]), (key, s)
+        assert np.array_equal(env.target_goals, fx['step/tgt_goals'][s]) and np.array_equal(env.target_dones, fx['step/target_dones'][s])
+        assert env.target_team_episode_reward == fx['step/episode_reward'][s]
+        assert np.array_equal(env.camera_target_view_mask, fx['step/camera_target_view_mask'][s])
+        np.testing.assert_allclose(env.state(), fx['step/state'][s], rtol=0, atol=1e-9)
+        assert env.targets[3].is_colliding == bool(fx['step/tgt_colliding'][s][3])
+        assert env.cameras[1].orientation == fx['step/cam_phi'][s][1]
+    # entity objects answer the geometric queries wrappers make (auxiliary_camera_rewards.py:206)
+    left = env.cameras[0].orientation - 0.5 * env.cameras[0].viewing_angle
+    angles, norms = env.cameras[0].boundary_between(left, left + env.cameras[0].viewing_angle)
+    assert len(angles) == len(norms) > 2 and np.all(norms <= env.cameras[0].max_sight_range * (1 + 1e-9))
+
+
+def test_reference_observation_wrappers_run_on_the_adapter(mate):
+    """RepeatedRewardIndividualDone o RescaledObservation o RelativeCoordinates of the reference over the adapter ==
+    the fixtures those functions produced on the reference's own observations (xform_*.npz)."""
+    fx, xf = G.load('trace_4v8-9_greedy_s2.npz'), G.load('xform_4v8-9_greedy_s2.npz')
+    env = mate.RepeatedRewardIndividualDone(mate.RescaledObservation(mate.RelativeCoordinates(_adapter(mate, fx))))
+    assert isinstance(env, mate.MultiAgentTracking)                  # EnvMeta: wrappers of the class count as the class
+    env.reset()
+    for s in range(int(xf['steps'])):
+        (cam_obs, tgt_obs), (cam_rewards, tgt_rewards), (cam_dones, tgt_dones), _ = env.step((fx['step/cam_act'][s], fx['step/tgt_act'][s]))
+        assert np.allclose(cam_obs, xf['cam_obs_relative_rescaled'][s], rtol=0, atol=1e-6)       # fixture stored as f32
+        assert np.allclose(tgt_obs, xf['tgt_obs_relative_rescaled'][s], rtol=0, atol=1e-6)
+        assert list(tgt_rewards) == [fx['step/reward_tgt'][s]] * 8 and list(cam_rewards) == [-fx['step/reward_tgt'][s]] * 4
+        assert list(cam_dones) == [bool(fx['step/done'][s])] * 4
+
+
+def test_reference_discrete_and_single_team_wrappers_run_on_the_adapter(mate):
+    """DiscreteTarget o DiscreteCamera: the recorded grid indices go in, the backend checks that what reaches
+    env.step() is what the reference decoded when the trace was recorded (discrete_*.npz).  Then the single-team
+    wrapper MultiCamera with a Greedy target agent of the reference on top of the adapter."""
+    fx = G.load('discrete_4v8-9_s6.npz')
+    levels = [int(v) for v in fx['discrete_levels']]
+    env = mate.DiscreteTarget(mate.DiscreteCamera(_adapter(mate, fx), levels=levels[0]), levels=levels[1])
+    env.reset()
+    assert env.camera_action_space.n == levels[0] ** 2 and env.target_action_space.n == levels[1] ** 2
+    for s in range(len(fx['step/done'])):
+        (cam_obs, tgt_obs), _, done, _ = env.step((fx['step/cam_idx'][s], fx['step/tgt_idx'][s]))
+        assert np.array_equal(cam_obs, fx['step/cam_obs'][s])
+    trace = G.load('trace_4v8-9_greedy_s2.npz')
+    single = mate.MultiCamera(_adapter(mate, trace, expect_actions=False), target_agent=mate.GreedyTargetAgent(seed=1))
+    cam_obs = single.reset()
+    assert cam_obs.shape == (4, 126)
+    for s in range(5):
+        cam_obs, reward, done, infos = single.step(trace['step/cam_act'][s])
+        assert np.array_equal(cam_obs, trace['step/cam_obs'][s]) and reward == -trace['step/reward_tgt'][s] and len(infos) == 4
