@@ -309,6 +309,14 @@ def main():
         run(R + (args.steps % R))
     elif external is not None:
         external.run(min(args.steps, max(args.graph_steps, 1) + args.steps % max(args.graph_steps, 1)))
+    # ... and, whatever W is, at least ~50 ms of the timed region's own launches: the GPU raises its clocks under load, and a
+    # 20-step region lasts 0.2 ms (reported as `warmup_extra_steps`; W itself is honoured above)
+    extra_steps = 0
+    t_warm = time.perf_counter()
+    while time.perf_counter() - t_warm < 0.05:
+        run(R if R > 0 else 64)
+        extra_steps += R if R > 0 else 64
+        torch.cuda.synchronize()
     if gather is not None:
         gather.submit()              # side stream, copies and (N > 1) the RCCL communicator warmed outside the timed region
         gather.result()
@@ -398,6 +406,7 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'reps': len(rep_ms), 'rep_ms': [round(v, 4) for v in rep_ms], 'timing': 'median repetition of the K-step timed region',
+            'warmup_extra_steps': extra_steps,
             'config': {'workload': f'{args.workload} batch={args.batch} envs per GPU, ' + policy_text
                                    + (f'fused {R}-step rollout launches, auto-reset after each launch' if R > 0 else 'one launch per step, auto-reset'),
                        'global_batch': total_envs, 'parallelism': f'env-shard x{world}', 'steps_per_launch': R if R > 0 else 1},
