@@ -167,6 +167,28 @@ __device__ __forceinline__ void sincos_deg(double deg, double &sn, double &cs) {
     cs = ((q + 1) & 2) ? -ca : ca;
 }
 
+// sin and cos of an angle given in degrees (|deg| <= 720) to f32: the Cody-Waite reduction of sincos_deg in f64 (the
+// argument's ABSOLUTE accuracy matters: a component near zero must keep its relative precision), then Taylor
+// polynomials of the reduced argument in f32.  Relative error of either result < 3e-7.
+__device__ __forceinline__ void sincos_deg_f32(double deg, float &sn, float &cs) {
+    const double x = deg * kDeg2Rad;
+    const double k = rint(x * 0.63661977236758134308);
+    double rd = fma(-k, 1.57079632679489655800e+00, x);
+    rd = fma(-k, 6.12323399573676603587e-17, rd);
+    const float r = (float)rd;
+    const float z = r * r;
+    float ps = 2.75573192239858906526e-06f;                       // 1/9!
+    ps = fmaf(ps, z, -1.98412698412698412698e-04f); ps = fmaf(ps, z, 8.33333333333333333333e-03f); ps = fmaf(ps, z, -1.66666666666666666667e-01f);
+    const float s0 = fmaf(r * z, ps, r);
+    float pc = 2.48015873015873015873e-05f;                       // 1/8!
+    pc = fmaf(pc, z, -1.38888888888888888889e-03f); pc = fmaf(pc, z, 4.16666666666666666667e-02f); pc = fmaf(pc, z, -0.5f);
+    const float c0 = fmaf(z, pc, 1.0f);
+    const int q = (int)k & 3;
+    const float sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
+    sn = (q & 2) ? -sa : sa;
+    cs = ((q + 1) & 2) ? -ca : ca;
+}
+
 // Obstacle.obstruct(ray, keep_tangential=True) (entities.py:158-184) on a step kept in cartesian form.
 // The reference shortens the ray through its polar form (new_norm * (cos a, sin a), a = atan2(v)); that
 // is v * (new_norm / |v|) up to last-place rounding, which is how it is done here (no atan2/sincos).

@@ -284,7 +284,7 @@ struct Ctx {
     __device__ int32_t &ti(int t, int f) { return di[t * TI_STRIDE + f]; }
     __device__ int32_t &ei(int f) { return di[p.Nt * TI_STRIDE + f]; }
     // temporaries
-    __device__ double &sight(int c) { return tmp[c]; }
+    __device__ double &sight2(int c) { return tmp[c]; }          // a camera's SQUARED sight range: area / viewing angle
     __device__ double &svx(int t) { return tmp[p.Nc + t]; }
     __device__ double &svy(int t) { return tmp[p.Nc + p.Nt + t]; }
     __device__ double &snorm(int t) { return tmp[p.Nc + 2 * p.Nt + t]; }
@@ -440,13 +440,25 @@ __device__ __forceinline__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &
             th = clipd(th + dz, p.theta_min, kMaxViewingAngle);
             c.phi(lane) = ph; c.theta(lane) = th;
         }
-        const double sr = sqrt_pos(div_nz(p.area, th));      // entities.py:360
-        c.sight(lane) = sr;
-        double sn, cs;
-        sincos_deg(ph, sn, cs);                    // Camera.state: polar2cartesian(sight_range, orientation), entities.py:318
+        // sight_range = sqrt(area / viewing_angle) (entities.py:360).  The visibility phase compares SQUARED distances with
+        // the quotient and takes square roots only inside the rounding rim (sector_eval), so the f64 root is needed for
+        // the f64 observation mirror only; f32 observations take an f32 root of the quotient (relative error 1e-7).
+        const double sr2 = div_nz(p.area, th);
+        c.sight2(lane) = sr2;
         ObsT *sc = c.scratch + p.sc_cam + lane * 10;
         if (!c.statics_done) { sc[0] = (ObsT)c.cam_x(lane); sc[1] = (ObsT)c.cam_y(lane); }
-        sc[3] = (ObsT)(sr * cs); sc[4] = (ObsT)(sr * sn); sc[5] = (ObsT)th;
+        // Camera.state: polar2cartesian(sight_range, orientation), entities.py:318
+        if constexpr (sizeof(ObsT) == 4) {         // f32 observations: f64 argument reduction, f32 polynomials (+8 % on the fused rollout:
+            float sn, cs;                          // the camera lanes' f64 sincos was the longest dependent chain of the phase)
+            sincos_deg_f32(ph, sn, cs);
+            const float srf = __builtin_sqrtf((float)sr2);
+            sc[3] = srf * cs; sc[4] = srf * sn; sc[5] = (float)th;
+        } else {
+            const double sr = sqrt_pos(sr2);
+            double sn, cs;
+            sincos_deg(ph, sn, cs);
+            sc[3] = (ObsT)(sr * cs); sc[4] = (ObsT)(sr * sn); sc[5] = (ObsT)th;
+        }
     }
 }
 
@@ -599,7 +611,7 @@ __device__ __forceinline__ double degree_interp(const double2 (&w)[kDegSlots], d
 }
 
 // Phase B: _update_view (environment.py:1356-1388).
-struct SectorEval { bool seen, need; double rn, x; int64_t lc; };
+struct SectorEval { bool seen, need; double rn, x; int64_t lc; };      // rn: the SQUARED distance camera -> other
 
 // What a lane's range tests look like is the same at every step: which (target, other) pair it holds in each round,
 // whether that is the diagonal, and the squared limit (sight + the other's radius)^2 -- all static inside an episode.
@@ -653,8 +665,10 @@ __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t 
     if (!is_target && cam == other) { e.seen = true; return e; }                   // environment.py:1383-1384
     const int oj = is_target ? c.tgt_slot(other) : other;
     const double rx = c.ex[oj] - c.ex[cam], ry = c.ey[oj] - c.ey[cam];
-    const double rn = norm2(rx, ry);
-    if (rn > c.sight(cam)) return e;
+    // `relative.norm > self.sight_range` (entities.py:495-496) on squares; inside the rounding rim, on the roots themselves
+    const double d2 = fma(ry, ry, rx * rx), s2 = c.sight2(cam);
+    if (d2 > s2 * (1.0 + 1e-14)) return e;
+    if (!(d2 < s2 * (1.0 - 1e-14)) && sqrt_pos(d2) > sqrt_pos(s2)) return e;
     const double ang = atan2_deg(ry, rx);
     double ra = fabs(c.phi(cam) - ang);
     const double alt = 360.0 - ra;
@@ -668,7 +682,7 @@ __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t 
         else u = c.draw(tick, stream, (uint32_t)pair);
         if ((p.tau <= 0.5) ? (u > 1.0 - p.tau) : (u <= p.tau)) { e.seen = true; return e; }
     }
-    e.need = true; e.rn = rn; e.x = normalize_angle(ang); e.lc = c.env * p.Nc + cam;
+    e.need = true; e.rn = d2; e.x = normalize_angle(ang); e.lc = c.env * p.Nc + cam;
     return e;
 }
 
@@ -702,7 +716,11 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorE
             limit = lut_lookup(knots, c.g.lut_bucket + e.lc * c.p.nbucket, c.g.lut_count[e.lc], e.x);
         }
     }
-    return e.rn <= limit * (1.0 + 1e-6);                                           // entities.py:505
+    // `relative.norm <= sight_range_at(angle) * (1 + 1e-6)` (entities.py:505) on squares, the root inside the rounding rim
+    const double lim = limit * (1.0 + 1e-6), lim2 = lim * lim;
+    if (e.rn < lim2 * (1.0 - 1e-14)) return lim > 0.0;
+    if (e.rn > lim2 * (1.0 + 1e-14)) return false;
+    return sqrt_pos(e.rn) <= lim;
 }
 
 template <bool HELD, typename ObsT>
@@ -1375,19 +1393,23 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
 #define ROLL_STAMP(i) do { } while (0)
 #endif
         ROLL_STAMP(7);         // loop overhead: from the end of the previous step to here
-        const StepDraws draws = step_draws(c, tick);
+#ifndef MATE_ABLATE            // experiment builds (tools/ablate_rollout.sh): a phase compiled out, to weigh it
+#define MATE_ABLATE 0
+#endif
+        StepDraws draws{0.0, 0.0};
+        if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick);
         ROLL_STAMP(0);
-        simulate_cameras(c, draws, true);
+        if (!(MATE_ABLATE & 2)) simulate_cameras(c, draws, true);
         ROLL_STAMP(1);
-        simulate_targets(c, draws);
+        if (!(MATE_ABLATE & 4)) simulate_targets(c, draws);
         ROLL_STAMP(2);
-        update_view<Shape::kHoldRoles>(c, tick, S_TRANSMIT, true, roles);
+        if (!(MATE_ABLATE & 8)) update_view<Shape::kHoldRoles>(c, tick, S_TRANSMIT, true, roles);
         ROLL_STAMP(3);
-        assign_and_score(c, tick, g.scalars);
+        if (!(MATE_ABLATE & 16)) assign_and_score(c, tick, g.scalars);
         ROLL_STAMP(4);
-        fill_scratch(c, last_gw);
+        if (!(MATE_ABLATE & 32)) fill_scratch(c, last_gw);
         ROLL_STAMP(5);
-        pack_observations<true>(c, held);
+        if (!(MATE_ABLATE & 64)) pack_observations<true>(c, held);
         wave_sync();
         stepped = true;
         ROLL_STAMP(6);
