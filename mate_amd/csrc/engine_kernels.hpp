@@ -91,7 +91,7 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
     p.off_mask = off; off += shape_round_up(p.MW * 4, 16);
     p.off_misc = off; off += shape_round_up((4 * Nt + 8) * 4, 16);
     p.off_flags = off; off += shape_round_up(p.nflags * obs_size, 16);
-    p.off_ent = off; off += shape_round_up(3 * p.NJ * 8, 16);
+    p.off_ent = off; off += shape_round_up(3 * p.NJ * 8 + 3 * p.NJ * 4, 16);   // f64 table + its f32 shadow
     p.lds_wave_bytes = off;
 }
 
@@ -229,6 +229,8 @@ struct Ctx {
     const uint32_t *table;
     unsigned char *base;
     double *ex, *ey, *er;         // unified entity table [cameras | obstacles | targets]: x, y, radius
+    float *exf, *eyf, *erf;       // ... rounded to f32: the screens that only have to be conservative, or that fall back to
+                                  // the f64 table inside an explicit error rim, read these (an f64 operation costs two f32 issue slots)
     const double *act_cam = nullptr, *act_tgt = nullptr;   // FLOW_GREEDY: this step's joint actions in LDS ([Nc][2], [Nt][2])
     int32_t parity;               // which of the two finished-episode lists this launch appends to
     bool statics_done = false;    // fused rollouts, steps after the first: what never changes inside an episode (static
@@ -246,6 +248,7 @@ struct Ctx {
         table = g_.desc;   // read through L1: every wave on the CU gathers through the same 6 KB table
         base = wave_base;
         ex = reinterpret_cast<double *>(wave_base + p.off_ent); ey = ex + p.NJ; er = ey + p.NJ;
+        exf = reinterpret_cast<float *>(er + p.NJ); eyf = exf + p.NJ; erf = eyf + p.NJ;
     }
     // launch switches (constants in the specialised flows)
     __device__ __forceinline__ int mode() const { return flow == FLOW_RANDOM ? (int)MODE_STEP_RANDOM : (flow == FLOW_ACT_F32 || flow == FLOW_GREEDY) ? (int)MODE_STEP : g.mode; }
@@ -375,6 +378,7 @@ __device__ __forceinline__ void build_entities(Ctx<ObsT> &c) {
         else if (j < p.Nc + p.No) { const int o = j - p.Nc; x = c.obs_x(o); y = c.obs_y(o); r = c.obs_r(o); }
         else { const int t = j - p.Nc - p.No; x = c.tx(t); y = c.ty(t); r = 0.0; }
         c.ex[j] = x; c.ey[j] = y; c.er[j] = r;
+        c.exf[j] = (float)x; c.eyf[j] = (float)y; c.erf[j] = (float)r;
     }
 }
 
@@ -514,15 +518,16 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
         if (q < npairs) {
             const int tt = (int)(((float)q + 0.5f) * p.inv_NK);
             const int k = q - tt * p.NK;
-            double cx, cy, cr;
-            c.circle(k, cx, cy, cr);
-            const double dx = cx - c.ex[c.tgt_slot(tt)], dy = cy - c.ey[c.tgt_slot(tt)];
-            const double d2 = fma(dy, dy, dx * dx);
-            const double nn = c.snorm(tt);
-            const double reach = nn + cr;
-            // far for sure  <=>  d2 comfortably above reach^2 (d >= reach then also holds after rounding)
-            const bool far = d2 > reach * reach * (1.0 + 1e-12);
-            if (nn != 0.0 && !far) atomicOr(&c.near(k < 32 ? tt : p.Nt + tt), 1 << (k & 31));
+            // a SCREEN: it only has to keep every circle the step can touch, so f32 with an absolute margin does (positions
+            // rounded to f32 are off by <= 3.1e-5, the distance by <= 1.3e-4, the f32 arithmetic by <= 1e-5: 1e-3 covers it
+            // eight times); the walk below repeats the test exactly
+            const int j = k < p.No ? p.Nc + k : k - p.No, tj = c.tgt_slot(tt);
+            const float dx = c.exf[j] - c.exf[tj], dy = c.eyf[j] - c.eyf[tj];
+            const float d2 = fmaf(dy, dy, dx * dx);
+            const float nn = (float)c.snorm(tt);
+            const float reach = nn + c.erf[j] + 1e-3f;
+            const bool far = d2 > reach * reach;
+            if (nn != 0.0f && !far) atomicOr(&c.near(k < 32 ? tt : p.Nt + tt), 1 << (k & 31));
         }
     }
     wave_sync();
@@ -547,6 +552,7 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
         const bool colliding = (fabs(nx - desx) > 1e-6) || (fabs(ny - desy) > 1e-6);  // entities.py:668
         c.tx(t) = nx; c.ty(t) = ny;
         c.ex[c.tgt_slot(t)] = nx; c.ey[c.tgt_slot(t)] = ny;
+        c.exf[c.tgt_slot(t)] = (float)nx; c.eyf[c.tgt_slot(t)] = (float)ny;
         int gw = c.ti(t, TI_GW) & ~(1 << 24);
         c.ti(t, TI_GW) = gw | ((int)colliding << 24);
     }
@@ -618,9 +624,24 @@ struct SectorEval { bool seen, need; double rn, x; int64_t lc; };      // rn: th
 // The fused rollout, which is VALU-bound, computes them once per launch and keeps them in registers (`HELD`); the
 // single-step kernel derives them in place.
 constexpr int kRoleRounds = 3;
+// Sensor.perceive (entities.py:229-232), `distance <= sight_range + radius`, is first tried on the f32 shadow of the entity
+// table: with positions rounded to f32 the distance is off by at most 1.3e-4 and the squared distance by at most
+// 2 * lim * 1.3e-4 + 3e-7 * lim^2 near the limit; outside a band of 2e-3 * lim + 2e-5 * lim^2 (eight times that) the f32
+// comparison IS the verdict, inside it the f64 test below decides (a pair in 10^5).
+__device__ __forceinline__ float range_rim(float lim) { return lim * (lim * 2e-5f + 2e-3f); }
+template <typename ObsT>
+__device__ __forceinline__ bool range_exact(const Ctx<ObsT> &c, int tj, int j) {
+    const double dx = c.ex[tj] - c.ex[j], dy = c.ey[tj] - c.ey[j];
+    const double d2 = fma(dy, dy, dx * dx);
+    const double lim = c.p.tgt_sight + c.er[j], lim2 = lim * lim;
+    if (d2 < lim2 * (1.0 - 1e-14)) return true;        // decided on squares unless within rounding of the rim
+    if (d2 > lim2 * (1.0 + 1e-14)) return false;
+    return sqrt_pos(d2) <= lim;
+}
 struct RangeRoles {
     int32_t pair[kRoleRounds];       // entity slot of the target | entity slot of the other << 16
-    double lim2[kRoleRounds];        // (target sight range + other's radius)^2
+    float lim2[kRoleRounds];         // (target sight range + other's radius)^2, f32
+    float rim[kRoleRounds];          // ... and the half-width of the band around it inside which the f64 test decides
     uint32_t diag_bits, valid_bits;  // bit `round`: the pair is (t, t) / the lane holds a pair in this round
     int32_t sector;                  // sector_role of the lane's pair in the last sector round
 };
@@ -636,9 +657,10 @@ __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &role
         const int t = (int)(((float)qq + 0.5f) * p.inv_NJ);
         const int j = qq - t * p.NJ;
         const int tj = c.tgt_slot(t);
-        const double lim = p.tgt_sight + c.er[j];
+        const float lim = (float)(p.tgt_sight + c.er[j]);
         roles.pair[round] = tj | (j << 16);
         roles.lim2[round] = lim * lim;
+        roles.rim[round] = range_rim(lim);
         roles.diag_bits |= (uint32_t)(j == tj) << round;
         roles.valid_bits |= (uint32_t)(q < p.n_range && round < p.range_rounds) << round;
     }
@@ -756,14 +778,12 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
             if (round < p.range_rounds) {
                 const int tj = held.pair[round] & 0xffff, j = held.pair[round] >> 16;
                 const bool diag = (held.diag_bits >> round) & 1u;
-                const double dx = c.ex[tj] - c.ex[j], dy = c.ey[tj] - c.ey[j];
-                const double d2 = fma(dy, dy, dx * dx);
-                const double lim2 = held.lim2[round];
-                bool seen;
-                if (d2 < lim2 * (1.0 - 1e-14)) seen = true;
-                else if (d2 > lim2 * (1.0 + 1e-14)) seen = diag;
-                else seen = diag || (sqrt_pos(d2) <= p.tgt_sight + c.er[j]);
-                seen_bits |= (uint32_t)(seen && ((held.valid_bits >> round) & 1u)) << round;
+                const float dx = c.exf[tj] - c.exf[j], dy = c.eyf[tj] - c.eyf[j];
+                const float d2 = fmaf(dy, dy, dx * dx);
+                const float lim2 = held.lim2[round], rim = held.rim[round];
+                bool seen = d2 < lim2 - rim;
+                if (!seen && !(d2 > lim2 + rim)) seen = range_exact(c, tj, j);
+                seen_bits |= (uint32_t)((seen || diag) && ((held.valid_bits >> round) & 1u)) << round;
             }
         }
     } else {
@@ -775,16 +795,12 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         const int j = qq - t * p.NJ;
         const int tj = c.tgt_slot(t);
         const bool diag = (j == tj);
-        const double orad = c.er[j];
-        // distance <= sight + radius (entities.py:232): decided on squares unless within rounding of the rim
-        const double dx = c.ex[tj] - c.ex[j], dy = c.ey[tj] - c.ey[j];
-        const double d2 = fma(dy, dy, dx * dx);
-        const double lim = p.tgt_sight + orad, lim2 = lim * lim;
-        bool seen;
-        if (d2 < lim2 * (1.0 - 1e-14)) seen = true;
-        else if (d2 > lim2 * (1.0 + 1e-14)) seen = diag;
-        else seen = diag || (sqrt_pos(d2) <= lim);
-        seen_bits |= (uint32_t)(seen && q < p.n_range) << round;
+        const float dx = c.exf[tj] - c.exf[j], dy = c.eyf[tj] - c.eyf[j];
+        const float d2 = fmaf(dy, dy, dx * dx);
+        const float lim = (float)p.tgt_sight + c.erf[j], lim2 = lim * lim, rim = range_rim(lim);
+        bool seen = d2 < lim2 - rim;
+        if (!seen && !(d2 > lim2 + rim)) seen = range_exact(c, tj, j);
+        seen_bits |= (uint32_t)((seen || diag) && q < p.n_range) << round;
     }
     }
     for (int round = 0; round < p.range_rounds; ++round) {
