@@ -137,7 +137,10 @@ def parse_args(argv=None):
     ap.add_argument('--policy', choices=['random', 'greedy', 'external'], default='random',
                     help='on-device policy: uniform random (headline), GreedyCamera vs GreedyTarget (BASELINE config 3), or '
                          'external = step(actions) with the joint actions in a caller-owned device buffer (learner in the loop)')
-    ap.add_argument('--reset-interval', type=int, default=32, help='greedy policy: batched auto-reset every k steps (1 = immediate)')
+    ap.add_argument('--reset-interval', type=int, default=32, help='greedy policy, one launch per step: batched auto-reset every k steps (1 = immediate)')
+    ap.add_argument('--rollout-reset-interval', type=int, default=-1,
+                    help='fused rollouts: restart finished environments after every k-th launch (1 = after every launch; default 1 for the '
+                         'random policy, 4 for Greedy vs Greedy, whose ~1.2k-step episodes end somewhere in the batch at every step)')
     ap.add_argument('--rollout', type=int, default=-1,
                     help='steps fused per launch (rollout_kernel / rollout_greedy_kernel); 0 = one launch per step; -1 (default) = 128 '
                          '(random) / 32 (greedy) while the batch is at most 64 / 32 environment-waves per CU, else 0 (the fused '
@@ -279,7 +282,9 @@ def main():
         step = external.step
     else:
         step = lambda: eng.step_random(auto_reset=True)     # noqa: E731
-    rollout = eng.rollout_greedy if args.policy == 'greedy' else eng.rollout_random
+    rollout_fn = eng.rollout_greedy if args.policy == 'greedy' else eng.rollout_random
+    rollout_resets = args.rollout_reset_interval if args.rollout_reset_interval > 0 else (4 if args.policy == 'greedy' else 1)
+    rollout = lambda n, auto_reset=True: rollout_fn(n, auto_reset=rollout_resets)     # noqa: E731
     gather = StatsGather(torch, dist, distributed, eng) if args.stats_interval > 0 else None
 
     def run(steps, timed=False):
@@ -408,7 +413,8 @@ def main():
             'reps': len(rep_ms), 'rep_ms': [round(v, 4) for v in rep_ms], 'timing': 'median repetition of the K-step timed region',
             'warmup_extra_steps': extra_steps,
             'config': {'workload': f'{args.workload} batch={args.batch} envs per GPU, ' + policy_text
-                                   + (f'fused {R}-step rollout launches, auto-reset after each launch' if R > 0 else 'one launch per step, auto-reset'),
+                                   + (f'fused {R}-step rollout launches, auto-reset after ' + ('each launch' if rollout_resets == 1 else f'every {rollout_resets} launches')
+                                      if R > 0 else 'one launch per step, auto-reset'),
                        'global_batch': total_envs, 'parallelism': f'env-shard x{world}', 'steps_per_launch': R if R > 0 else 1},
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

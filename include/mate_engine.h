@@ -162,7 +162,10 @@ int mate_engine_step_random(mate_engine *engine, const mate_step_io *io, int32_t
  * buffer is rollout-shaped: [steps][N][...] (row r*N + i = step r of environment i).  An environment
  * whose episode ends at step r stops there: its scalar rows of later steps carry done = 2 and its
  * observation rows are left untouched; with auto_reset it starts a new episode before the next call.
- * Those skipped slots are added to mate_engine_idle_steps.  This is the fastest way to step: the records stay in LDS
+ * Those skipped slots are added to mate_engine_idle_steps.  auto_reset == k > 1 batches the restarts as step() does: a
+ * finished environment idles through the following launches until every k-th call restarts all finished environments in
+ * one reset launch (episodes that end every few steps somewhere in the batch, e.g. Greedy vs Greedy, otherwise pay one
+ * latency-bound reset launch per rollout launch).  This is the fastest way to step: the records stay in LDS
  * for the whole launch and the waves of a SIMD take turns in issue priority (MATE_ROLLOUT_ROTATE=0 turns that off). */
 int mate_engine_rollout_random(mate_engine *engine, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream);
 

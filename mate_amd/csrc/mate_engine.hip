@@ -677,7 +677,7 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
     g.mode = MODE_STEP_RANDOM; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick; g.rollout_steps = steps;
     g.tape_ct = nullptr; g.tape_goal = nullptr;
     { const char *rv = getenv("MATE_ROLLOUT_ROTATE"); g.rotate_prio = rv ? atoi(rv) : 1; }
-    if (!auto_reset) g.done_count = nullptr;
+    if (auto_reset != 1) g.done_count = nullptr;     // no list: nothing restarts (0), or a batched reset finds the finished ones by their flag (k > 1)
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e->timing > 0 && (e->timing_tick++ % e->timing) == 0) {
@@ -694,12 +694,18 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
     hipExtLaunchKernelGGL(e->rollout_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
     HIP_TRY(hipGetLastError());
     e->tick += (uint32_t)steps;
-    if (auto_reset) {
+    if (auto_reset == 1) {
         Ptrs r = e->g;
         apply_io(r, nullptr);     // state only: the next rollout observes the fresh episode on its first step
         int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT, stream);
         if (rc != MATE_OK) return rc;
         e->parity ^= 1;
+    } else if (auto_reset > 1 && ++e->steps_since_reset >= auto_reset) {      // batched: every k-th launch restarts all finished environments
+        e->steps_since_reset = 0;
+        Ptrs r = e->g;
+        apply_io(r, nullptr);
+        int rc = launch_reset(e, r, RESET_FLAGGED, PH_PLACE | PH_LUT, stream);
+        if (rc != MATE_OK) return rc;
     }
     return MATE_OK;
 }
@@ -782,7 +788,7 @@ extern "C" int mate_engine_rollout_greedy(mate_engine *e, const mate_step_io *io
     g.mode = MODE_STEP; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick; g.rollout_steps = steps;
     g.tape_ct = nullptr; g.tape_goal = nullptr; g.freeze_done = 0;
     { const char *rv = getenv("MATE_ROLLOUT_ROTATE"); g.rotate_prio = rv ? atoi(rv) : 1; }
-    if (!auto_reset) g.done_count = nullptr;
+    if (auto_reset != 1) g.done_count = nullptr;
     PolicyPtrs q = e->q;
     std::memset(&q.tape, 0, sizeof(q.tape));
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
@@ -799,12 +805,18 @@ extern "C" int mate_engine_rollout_greedy(mate_engine *e, const mate_step_io *io
     hipExtLaunchKernelGGL(e->rollout_greedy_fn, dim3(blocks), dim3(256), lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g, (const PolicyPtrs)q);
     HIP_TRY(hipGetLastError());
     e->tick += (uint32_t)steps;
-    if (auto_reset) {
+    if (auto_reset == 1) {
         Ptrs r = e->g;
         apply_io(r, nullptr);     // state and the engine's own masks: the agents of the next rollout act on the fresh view
         int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream);
         if (rc != MATE_OK) return rc;
         e->parity ^= 1;
+    } else if (auto_reset > 1 && ++e->steps_since_reset >= auto_reset) {
+        e->steps_since_reset = 0;
+        Ptrs r = e->g;
+        apply_io(r, nullptr);
+        int rc = launch_reset(e, r, RESET_FLAGGED, PH_PLACE | PH_LUT | PH_VIEW, stream);
+        if (rc != MATE_OK) return rc;
     }
     return MATE_OK;
 }

@@ -613,7 +613,7 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
                  relative_coordinates=False, rescaled_observation=False, enhanced_observation=None, shared_field_of_view=None,
                  discrete_camera_levels=None, discrete_target_levels=None, **kwargs):
         self._setup_scenario(config, kwargs)
-        self.num_envs, self.auto_reset = int(num_envs), bool(auto_reset)
+        self.num_envs, self.auto_reset = int(num_envs), int(auto_reset)   # 0 / False: never; 1 / True: immediately; k > 1: batched, every k-th call
         self.engine = Engine(self.config, self.num_envs, device=device, seed=seed, first_env_index=first_env_index, obs_dtype=obs_dtype)
         self.num_cameras, self.num_targets, self.num_obstacles = self.engine.num_cameras, self.engine.num_targets, self.engine.num_obstacles
         self._setup_spaces()
@@ -667,14 +667,14 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
     def rollout_random(self, steps):
         """`steps` env.step(random action) iterations in ONE launch (the fastest flow): every tensor of
         step()'s result with a leading [steps] axis.  Finished episodes restart after the launch."""
-        return self._rollout_result(self.engine.rollout_random(steps, auto_reset=bool(self.auto_reset)))
+        return self._rollout_result(self.engine.rollout_random(steps, auto_reset=int(self.auto_reset)))
 
     def rollout_greedy(self, steps):
         """`steps` iterations of mate.group_step with the reference's Greedy camera / target agents + env.step in ONE
         launch (agents on the device)."""
         if not getattr(self, '_policies_on', False):
             raise RuntimeError('enable_greedy_policies() must precede the reset() the agents first act on')
-        return self._rollout_result(self.engine.rollout_greedy(steps, auto_reset=bool(self.auto_reset)))
+        return self._rollout_result(self.engine.rollout_greedy(steps, auto_reset=int(self.auto_reset)))
 
     def enable_greedy_policies(self):
         self.engine.enable_policies()

@@ -158,3 +158,30 @@ def test_step_masks_with_independently_built_tables(workload, n, oracle_lib):
     the others must agree with the oracle exactly."""
     diverged, worst, obs_ok, rew_ok = _census(workload, n, 40, 1, True, oracle_lib)
     assert diverged <= max(1, n // 256) and worst < 1e-9 and obs_ok and rew_ok, (diverged, worst, obs_ok, rew_ok)
+
+
+@pytest.mark.parametrize('policy', ['random', 'greedy'])
+def test_rollouts_with_batched_resets(policy):
+    """auto_reset = k > 1 on the fused rollouts: finished environments idle through the following launches and all
+    restart together after every k-th call; executed steps + idle slots account for every slot, nothing is lost."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=9)
+    n = 21
+    eng = Engine(cfg, n, seed=8)
+    if policy == 'greedy':
+        eng.enable_policies()
+    rollout = eng.rollout_greedy if policy == 'greedy' else eng.rollout_random
+    eng.reset()
+    episodes = []
+    for call in range(9):
+        _, _, sc = rollout(4, auto_reset=3)
+        sd = eng.state_dict()
+        episodes.append(sd['episode'].copy())
+        if call % 3 != 2:           # between batched resets a finished environment stays finished
+            assert ((sd['done'] != 0) == (sd['episode_step'] >= 10)).all()
+        else:                       # the third call restarted everything that had finished
+            assert (sd['done'] == 0).all()
+    # time limit 9 -> done on the 10th step: every environment finishes in call 2 (steps 9-12), idles, restarts after call 2, ...
+    assert (episodes[1] == 1).all() and (episodes[2] == 2).all() and (episodes[5] == 3).all() and (episodes[8] == 4).all()
+    assert eng.idle_steps() == n * 3 * 2          # per cycle of 12 slots: 10 executed steps, 2 idle
