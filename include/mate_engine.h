@@ -143,12 +143,13 @@ int mate_engine_set_episode_stats(mate_engine *engine, double *stats_dev);
 /* Graph-replayable stepping (the learner-in-the-loop flow: policy kernels write the joint actions into caller
  * buffers, step() consumes them, K such iterations are captured once in a HIP graph and replayed).  A step() launch
  * normally carries the step counter (the Philox tick) and the ping-pong index of the finished-episode lists as launch
- * arguments, which change at every step.  enable != 0 moves both to device memory: the step kernel reads them there
- * and the immediate auto-reset launch behind it advances them, so the (step, auto-reset) launch pair has identical
- * arguments at every step and may be captured (hipStreamBeginCapture on `stream`, or torch.cuda.graph) and replayed
- * any number of times.  Results are bit-identical to the host-counted flow.  While enabled only step() /
- * step_random() with auto_reset = 1, observe() and reset() are accepted (MATE_ESTATE otherwise).  enable == 0 drains
- * `stream` and takes the counter back to the host.  The reference has no counterpart (environment.py:590 runs one
+ * arguments, which change at every step.  enable = k >= 1 moves both to device memory: the step kernels read them there
+ * and the auto-reset launch that closes every interval of k steps advances them, so a whole interval (k step launches +
+ * one auto-reset launch; k = 1: a (step, auto-reset) pair) has identical arguments every time and any number of
+ * intervals may be captured (hipStreamBeginCapture on `stream`, or torch.cuda.graph) and replayed.  Results are
+ * bit-identical to the host-counted flow with the same auto_reset.  While enabled only step() / step_random() with
+ * auto_reset = k, observe() and reset() are accepted (MATE_ESTATE otherwise).  enable == 0 (at an interval boundary)
+ * drains `stream` and takes the counter back to the host.  The reference has no counterpart (environment.py:590 runs one
  * Python call per step); this is how its `for t in range(T): env.step(policy(obs))` loop is enqueued on a GPU. */
 int mate_engine_device_tick(mate_engine *engine, int32_t enable, void *stream);
 

@@ -47,6 +47,7 @@ struct Params {
     // the auto-reset launch that follows every step advances it -- a (step, auto-reset) pair then has the same
     // arguments at every step and a captured HIP graph of K pairs can be replayed.
     uint32_t dev_tick;            // written only by the auto-reset launch, through Ptrs::dev_tick_ptr
+    uint32_t dev_group;           // auto-reset launches so far (its low bit is the list parity); follows dev_tick in memory
     int32_t dev_tick_on;
 };
 
@@ -151,7 +152,9 @@ struct Ptrs {
     int32_t mode, act_f64, parity, reset_kind;
     int32_t rollout_steps;        // steps per launch of rollout_kernel
     int32_t freeze_done;          // batched auto-reset: finished environments idle (scalar done = 2) until the next reset launch
-    uint32_t tick;                // host step counter: Philox tick of this launch (all environments step together)
+    uint32_t tick;                // host step counter: Philox tick of this launch (all environments step together); with a
+                                  // device-resident counter: this launch's offset from it (steps since the last auto-reset launch)
+    uint32_t tick_advance;        // device-resident counter: what the auto-reset launch adds to it (steps per reset interval)
     int32_t stagger;              // per-phase wave priorities (see phase_prio)
     const double2 *cam_grid, *tgt_grid;   // normalised discrete-action grids (or NULL)
     int32_t n_cam_grid, n_tgt_grid;
@@ -259,7 +262,7 @@ struct Ctx {
     __device__ __forceinline__ const double *tape_goal() const { return flow != FLOW_ANY ? nullptr : g.tape_goal; }
     __device__ __forceinline__ int obs_mode() const { return flow != FLOW_ANY ? 0 : g.obs_mode; }
     __device__ __forceinline__ const uint2 *xdesc() const { return flow != FLOW_ANY ? nullptr : g.xdesc; }
-    __device__ __forceinline__ bool freeze_done() const { return flow != FLOW_ANY ? false : g.freeze_done != 0; }
+    __device__ __forceinline__ bool freeze_done() const { return flow == FLOW_GREEDY ? false : g.freeze_done != 0; }
     __device__ __forceinline__ bool has_scratch_init() const { return flow != FLOW_ANY ? true : g.scratch_init != nullptr; }
     __device__ __forceinline__ bool has_cam_obs() const { return flow != FLOW_ANY ? true : g.cam_obs != nullptr; }
     __device__ __forceinline__ bool has_tgt_obs() const { return flow != FLOW_ANY ? true : g.tgt_obs != nullptr; }
@@ -952,7 +955,8 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
         c.ei(EI_EPSTEP) = ep_step;
         const bool awaiting = c.ei(EI_AWAITING) || c.ei(EI_AWAITING + 1) || c.ei(EI_AWAITING + 2) || c.ei(EI_AWAITING + 3);
         const int done = !(ep_step <= p.max_episode_steps && awaiting);
-        c.ei(EI_DONE) = done;
+        // 1 = finished; 3 = finished AND on the list of the next batched reset (so that nobody lists it twice)
+        c.ei(EI_DONE) = done ? ((c.g.done_count && c.freeze_done()) ? 3 : 1) : 0;
         c.ei(EI_TICK) = (int)(tick + 1u);
         if (c.has_scalars() && scalars_out) {
             float *o = scalars_out + c.out * 8;
@@ -984,7 +988,7 @@ __device__ __forceinline__ void score_only(Ctx<ObsT> &c, float *scalars_out) {
     if (c.lane == 0 && scalars_out) {
         float *o = scalars_out + c.out * 8;
         const int delivered = c.ei(EI_DELIVERED);
-        o[0] = 0.f; o[1] = 0.f; o[2] = (float)c.ei(EI_DONE); o[3] = (float)((double)n_tracked / (double)p.Nt);
+        o[0] = 0.f; o[1] = 0.f; o[2] = c.ei(EI_DONE) != 0 ? 1.f : 0.f; o[3] = (float)((double)n_tracked / (double)p.Nt);
         o[4] = n_bounty > 0 ? (float)((double)n_both / (double)n_bounty) : 0.f;
         o[5] = delivered > 0 ? (float)(c.ep_delayed() / (p.reward_scale * (double)delivered)) : 0.f;
         o[6] = (float)delivered; o[7] = 0.f;
@@ -1239,8 +1243,8 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();   // constant 100 MHz: calibrates the s_memtime ticks
 #endif
     // tick and list parity: launch arguments, or the device-resident counter (graph-replayable launches, see Params)
-    const uint32_t tick = p.dev_tick_on ? p.dev_tick : g.tick;
-    const int32_t parity = p.dev_tick_on ? (int32_t)(tick & 1u) : g.parity;
+    const uint32_t tick = p.dev_tick_on ? p.dev_tick + g.tick : g.tick;
+    const int32_t parity = p.dev_tick_on ? (int32_t)(p.dev_group & 1u) : g.parity;
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) {
         g.done_count[parity ^ 1] = 0;  // next step's counter
         if (p.dev_tick_on) g.ctrl[0] = parity;
@@ -1275,6 +1279,11 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
         if (c.ei(EI_DONE) != 0) {     // waiting for the next batched reset: no step, no new observation
             if (lane == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; }
             if (lane == 0 && g.idle_steps) g.idle_steps[env] += 1;
+            if (lane == 0 && g.done_count && c.ei(EI_DONE) == 1) {      // finished under auto_reset = 0 earlier: not on the list yet
+                const int slot = atomicAdd(g.done_count + parity, 1);
+                g.done_list[(int64_t)parity * g.N + slot] = (int32_t)env;
+                reinterpret_cast<int32_t *>(g.dyn + env * p.DW + p.DF)[p.Nt * TI_STRIDE + EI_DONE] = 3;
+            }
             return;
         }
     }
@@ -1313,7 +1322,7 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
 // launch never runs: list it here, or it would idle forever.
 template <typename ObsT>
 __device__ __forceinline__ void list_finished_at_entry(Ctx<ObsT> &c) {
-    if (c.lane == 0 && c.g.done_count && c.ei(EI_DONE) != 0) {
+    if (c.lane == 0 && c.g.done_count && c.ei(EI_DONE) == 1) {     // (3: a batched-reset step listed it already)
         const int slot = atomicAdd(c.g.done_count + c.parity, 1);
         c.g.done_list[(int64_t)c.parity * c.g.N + slot] = (int32_t)c.env;
     }

@@ -85,6 +85,8 @@ struct mate_engine {
     int64_t steps_since_reset = 0;   // batched auto-reset bookkeeping
     bool was_reset = false;
     bool dev_tick = false;     // mate_engine_device_tick: the step counter lives on the device (graph-replayable launches)
+    int dev_interval = 1;      // ... and the auto-reset interval every step() must then use
+    int pending_interval = 0;  // auto_reset value of the batched-reset interval in progress (steps_since_reset > 0)
     size_t step_lds = 0, reset_lds = 0;
     PolicyFn policy_fn = nullptr, rollout_greedy_fn = nullptr;
     StepFn step_fn[3] = {nullptr, nullptr, nullptr}, rollout_fn[2] = {nullptr, nullptr};   // kernels chosen at create: shape-specialised when compiled for these counts; step_fn[flow]
@@ -545,7 +547,13 @@ extern "C" int mate_engine_reset(mate_engine *e, const uint8_t *env_mask_dev, co
     g.tape_ct = nullptr; g.tape_goal = nullptr;
     g.reset_mask = env_mask_dev;
     int rc = launch_reset(e, g, env_mask_dev ? RESET_MASK : RESET_ALL, PH_PLACE | PH_LUT | PH_VIEW, (hipStream_t)stream);
-    if (rc == MATE_OK && !env_mask_dev) e->was_reset = true;
+    if (rc == MATE_OK && !env_mask_dev) {
+        e->was_reset = true;
+        if (!e->dev_tick) {      // nothing is finished any more: the lists of a batched-reset interval in progress are void
+            HIP_TRY(hipMemsetAsync(e->g.done_count, 0, 2 * sizeof(int32_t), (hipStream_t)stream));
+            e->steps_since_reset = 0; e->pending_interval = 0;
+        }
+    }
     return rc;
 }
 
@@ -579,23 +587,44 @@ extern "C" int mate_engine_set_episode_stats(mate_engine *e, double *stats_dev) 
     return MATE_OK;
 }
 
-// Device-resident step counter: see Params::dev_tick.  enable: the host's tick goes to the device and stays there;
-// disable: the stream is drained and the counter comes back.
+static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream);
+
+// A batched-reset interval (auto_reset = k > 1) is in progress and the caller changes the mode: restart what has finished
+// so far now, by flag, and forget the lists.
+// `key`: auto_reset of the call that is about to run, tagged with its flow (kStepFlow / kRolloutFlow) when it batches.
+constexpr int kStepFlow = 0x10000, kRolloutFlow = 0x20000;
+static int flush_pending(mate_engine *e, int key, hipStream_t stream) {
+    if (e->steps_since_reset == 0 || key == e->pending_interval) return MATE_OK;
+    if (e->dev_tick) return fail(MATE_ESTATE, "auto_reset changed inside a reset interval while the step counter is device-resident");
+    Ptrs r = e->g;
+    r.cam_act = r.tgt_act = nullptr; r.tape_ct = r.tape_goal = nullptr; r.cam_obs = r.tgt_obs = nullptr; r.scalars = nullptr; r.masks = nullptr;
+    int rc = launch_reset(e, r, RESET_FLAGGED, PH_PLACE | PH_LUT | PH_VIEW, stream);
+    if (rc != MATE_OK) return rc;
+    HIP_TRY(hipMemsetAsync(e->g.done_count, 0, 2 * sizeof(int32_t), stream));
+    e->steps_since_reset = 0; e->pending_interval = 0;
+    return MATE_OK;
+}
+
+// Device-resident step counter: see Params::dev_tick.  enable = k >= 1: the host's tick goes to the device and stays there,
+// every step() must use auto_reset = k; disable: the stream is drained and the counter comes back.
 extern "C" int mate_engine_device_tick(mate_engine *e, int32_t enable, void *stream_) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
-    if ((enable != 0) == e->dev_tick) return MATE_OK;
+    if ((enable != 0) == e->dev_tick && (!enable || enable == e->dev_interval)) return MATE_OK;
+    if (enable && e->dev_tick) return fail(MATE_ESTATE, "device_tick: already enabled with interval %d", e->dev_interval);
+    int rc = flush_pending(e, 0, stream);
+    if (rc != MATE_OK) return rc;
     HIP_TRY(hipStreamSynchronize(stream));
     if (enable) {
-        // on the device the list parity is tick & 1; both finished-episode lists are consumed between two calls
-        HIP_TRY(hipMemsetAsync(e->g.done_count, 0, 2 * sizeof(int32_t), stream));
-        e->p.dev_tick = e->tick; e->p.dev_tick_on = 1;
+        e->p.dev_tick = e->tick; e->p.dev_group = (uint32_t)e->parity; e->p.dev_tick_on = 1;
+        e->dev_interval = enable;
     } else {
-        uint32_t tick = 0;
-        HIP_TRY(hipMemcpy(&tick, reinterpret_cast<const char *>(e->d_params) + offsetof(Params, dev_tick), sizeof(tick), hipMemcpyDeviceToHost));
-        e->tick = tick; e->parity = (int)(tick & 1u);
-        e->p.dev_tick = tick; e->p.dev_tick_on = 0;
+        if (e->steps_since_reset != 0) return fail(MATE_ESTATE, "device_tick: %d step(s) into a reset interval of %d; finish it first", (int)e->steps_since_reset, e->dev_interval);
+        uint32_t words[2] = {0, 0};
+        HIP_TRY(hipMemcpy(words, reinterpret_cast<const char *>(e->d_params) + offsetof(Params, dev_tick), sizeof(words), hipMemcpyDeviceToHost));
+        e->tick = words[0]; e->parity = (int)(words[1] & 1u);
+        e->p.dev_tick = words[0]; e->p.dev_group = words[1]; e->p.dev_tick_on = 0;
     }
     HIP_TRY(hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice));
     e->dev_tick = enable != 0;
@@ -605,18 +634,20 @@ extern "C" int mate_engine_device_tick(mate_engine *e, int32_t enable, void *str
 static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int auto_reset, hipStream_t stream) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (!e->was_reset) return fail(MATE_ESTATE, "step()/observe() called before reset() (or import_state)");
-    if (e->dev_tick && mode != MODE_OBSERVE && auto_reset != 1)
-        return fail(MATE_ESTATE, "with a device-resident step counter (mate_engine_device_tick) step() needs auto_reset = 1: the auto-reset launch advances it");
+    if (e->dev_tick && mode != MODE_OBSERVE && auto_reset != e->dev_interval)
+        return fail(MATE_ESTATE, "with a device-resident step counter (mate_engine_device_tick) step() needs auto_reset = %d: the auto-reset launch advances it", e->dev_interval);
     HIP_TRY(hipSetDevice(e->device));
+    if (mode != MODE_OBSERVE) { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | kStepFlow) : auto_reset, stream); if (rc != MATE_OK) return rc; }
     Ptrs g = e->g;
     apply_io(g, io);
     if (mode == MODE_STEP && ((e->p.Nc > 0 && !g.cam_act) || !g.tgt_act)) return fail(MATE_EINVAL, "step() needs camera and target joint actions");
     if (mode == MODE_STEP && (((g.act_discrete & 1) && !g.cam_grid) || ((g.act_discrete & 2) && !g.tgt_grid)))
         return fail(MATE_ESTATE, "discrete actions passed before mate_engine_set_action_grids");
-    g.mode = mode; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick;
-    // auto_reset = 1: finished environments restart inside this call; k > 1: they idle and restart together every k-th call
+    g.mode = mode; g.parity = e->parity; g.reset_kind = -1;
+    g.tick = e->dev_tick ? (uint32_t)e->steps_since_reset : e->tick;     // device-resident counter: the offset inside the reset interval
+    // auto_reset = 1: finished environments restart inside this call; k > 1: they idle (listed for it) and restart together every k-th call
     g.freeze_done = auto_reset > 1;
-    if (mode == MODE_OBSERVE || auto_reset != 1) g.done_count = nullptr;
+    if (mode == MODE_OBSERVE || auto_reset == 0) g.done_count = nullptr;
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e->timing > 0 && !e->dev_tick && mode != MODE_OBSERVE && (e->timing_tick++ % e->timing) == 0) {
@@ -631,7 +662,7 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     // kernel's own begin->end, without the marker-packet latency separate hipEventRecord calls would add
     // the kernel compiled for this launch's switches (enum Flow), when they are the common ones
     int flow = FLOW_ANY;
-    if (!e->flow_generic && !g.tape_ct && !g.tape_goal && !g.act_discrete && g.obs_mode == 0 && !g.xdesc && !g.xab && !g.freeze_done &&
+    if (!e->flow_generic && !g.tape_ct && !g.tape_goal && !g.act_discrete && g.obs_mode == 0 && !g.xdesc && !g.xab &&
         g.scratch_init && (g.cam_obs || e->p.Nc == 0) && g.tgt_obs && g.scalars) {
         if (mode == MODE_STEP_RANDOM) flow = FLOW_RANDOM;
         else if (mode == MODE_STEP && !g.act_f64) flow = FLOW_ACT_F32;
@@ -645,16 +676,22 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
         Ptrs r = e->g;
         apply_io(r, io);
         r.scalars = nullptr; r.tape_ct = nullptr; r.tape_goal = nullptr;   // keep the finished step's reward/done
+        r.tick_advance = 1u;
         int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream);
         if (rc != MATE_OK) return rc;
         if (!e->dev_tick) e->parity ^= 1;
-    } else if (mode != MODE_OBSERVE && auto_reset > 1 && ++e->steps_since_reset >= auto_reset) {
-        e->steps_since_reset = 0;
-        Ptrs r = e->g;
-        apply_io(r, io);
-        r.scalars = nullptr; r.tape_ct = nullptr; r.tape_goal = nullptr;
-        int rc = launch_reset(e, r, RESET_FLAGGED, PH_PLACE | PH_LUT | PH_VIEW, stream);
-        if (rc != MATE_OK) return rc;
+    } else if (mode != MODE_OBSERVE && auto_reset > 1) {
+        e->pending_interval = auto_reset | kStepFlow;
+        if (++e->steps_since_reset >= auto_reset) {       // the interval's one reset launch: everything its steps listed
+            e->steps_since_reset = 0; e->pending_interval = 0;
+            Ptrs r = e->g;
+            apply_io(r, io);
+            r.scalars = nullptr; r.tape_ct = nullptr; r.tape_goal = nullptr;
+            r.tick_advance = (uint32_t)auto_reset;
+            int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream);
+            if (rc != MATE_OK) return rc;
+            if (!e->dev_tick) e->parity ^= 1;
+        }
     }
     return MATE_OK;
 }
@@ -672,6 +709,7 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
     if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
+    { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | kRolloutFlow) : auto_reset, stream); if (rc != MATE_OK) return rc; }
     Ptrs g = e->g;
     apply_io(g, io);
     g.mode = MODE_STEP_RANDOM; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick; g.rollout_steps = steps;
@@ -700,8 +738,8 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
         int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT, stream);
         if (rc != MATE_OK) return rc;
         e->parity ^= 1;
-    } else if (auto_reset > 1 && ++e->steps_since_reset >= auto_reset) {      // batched: every k-th launch restarts all finished environments
-        e->steps_since_reset = 0;
+    } else if (auto_reset > 1 && (e->pending_interval = auto_reset | kRolloutFlow, ++e->steps_since_reset >= auto_reset)) {      // batched: every k-th launch restarts all finished environments
+        e->steps_since_reset = 0; e->pending_interval = 0;
         Ptrs r = e->g;
         apply_io(r, nullptr);
         int rc = launch_reset(e, r, RESET_FLAGGED, PH_PLACE | PH_LUT, stream);
@@ -779,6 +817,7 @@ extern "C" int mate_engine_rollout_greedy(mate_engine *e, const mate_step_io *io
     if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
+    { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | kRolloutFlow) : auto_reset, stream); if (rc != MATE_OK) return rc; }
     Ptrs g = e->g;
     apply_io(g, io);
     if ((e->p.Nc > 0 && !g.cam_obs) || !g.tgt_obs || !g.scalars) return fail(MATE_EINVAL, "rollout_greedy needs the observation and scalar outputs");
@@ -811,8 +850,8 @@ extern "C" int mate_engine_rollout_greedy(mate_engine *e, const mate_step_io *io
         int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream);
         if (rc != MATE_OK) return rc;
         e->parity ^= 1;
-    } else if (auto_reset > 1 && ++e->steps_since_reset >= auto_reset) {
-        e->steps_since_reset = 0;
+    } else if (auto_reset > 1 && (e->pending_interval = auto_reset | kRolloutFlow, ++e->steps_since_reset >= auto_reset)) {
+        e->steps_since_reset = 0; e->pending_interval = 0;
         Ptrs r = e->g;
         apply_io(r, nullptr);
         int rc = launch_reset(e, r, RESET_FLAGGED, PH_PLACE | PH_LUT | PH_VIEW, stream);

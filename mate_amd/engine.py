@@ -298,8 +298,9 @@ class Engine:
 
     def device_tick(self, enable=True):
         """Keep the step counter on the device (mate_engine_device_tick): step()/step_random() launches with
-        auto_reset=True then carry identical arguments at every step and can be captured in a HIP graph."""
-        check(self.lib.mate_engine_device_tick(self._h, int(bool(enable)), self._stream()))
+        auto_reset = `enable` (True = 1: immediate; k > 1: batched, one reset launch per k steps) then carry identical
+        arguments in every reset interval and can be captured in a HIP graph.  False / 0 gives the counter back."""
+        check(self.lib.mate_engine_device_tick(self._h, int(enable), self._stream()))
 
     def make_stepper(self, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None):
         """A replayable `for _ in range(n): between(); step((cam_act, tgt_act))` loop over caller-owned action tensors
@@ -460,17 +461,20 @@ class Stepper:
 
     def __init__(self, eng, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None):
         self.eng, self.between, self.graph_steps = eng, between, int(graph_steps)
-        self.auto_reset = int(bool(auto_reset))
+        self.auto_reset = int(auto_reset)        # True / 1: immediate; k > 1: batched (finished environments idle up to k - 1 steps)
         self.io, self.keep = eng._io(cam_act, tgt_act)
         # _io may have made contiguous copies: the stepper must read the caller's own storage
         assert self.keep[0].data_ptr() == tgt_act.data_ptr() and (eng.num_cameras == 0 or self.keep[1].data_ptr() == cam_act.data_ptr()), \
             'action tensors must be contiguous f32/f64 (or int32 grid indices) on the engine device'
         self.ref = ctypes.byref(self.io)
         self.graph = None
+        self._phase = 0                                   # steps into the current reset interval (graphs hold whole intervals)
         if self.graph_steps > 0:
-            assert self.auto_reset == 1, 'graph replay needs auto_reset=True (the auto-reset launch advances the device step counter)'
-            eng.device_tick(True)
-            self._one()                                   # code objects loaded before the capture
+            assert self.auto_reset >= 1 and self.graph_steps % self.auto_reset == 0, \
+                'graph replay needs auto_reset >= 1 (the auto-reset launch advances the device step counter) and whole reset intervals per graph'
+            eng.device_tick(self.auto_reset)
+            for _ in range(self.auto_reset):
+                self._one()                               # code objects loaded before the capture (one whole reset interval)
             torch.cuda.synchronize(eng.device)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
@@ -488,9 +492,14 @@ class Stepper:
     def run(self, steps):
         steps = int(steps)
         if self.graph is not None:
-            for _ in range(steps // self.graph_steps):
+            while steps > 0 and self._phase != 0:         # finish a reset interval a previous call stopped in, launch by launch
+                self._one()
+                self._phase = (self._phase + 1) % self.auto_reset
+                steps -= 1
+            while steps >= self.graph_steps:              # whole graphs (whole reset intervals)
                 self.graph.replay()
-            steps %= self.graph_steps
+                steps -= self.graph_steps
+            self._phase = steps % self.auto_reset
         for _ in range(steps):
             self._one()
         eng = self.eng

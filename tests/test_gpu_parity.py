@@ -312,6 +312,13 @@ def test_flow_specialised_kernel_equals_generic(workload, generic_shape, policy,
                 eng.step(ca, ta, auto_reset=True)
             assert eng.last_flow == (0 if generic == '1' else (1 if policy == 'random' else 2))
             rec.append([t.clone() for t in (getattr(eng, 'camera_obs', None), eng.target_obs, eng.scalars, eng.masks) if t is not None])
+        for _ in range(8):      # batched auto-reset (finished environments idle, one reset launch per 4 steps) runs the folded flows too
+            if policy == 'random':
+                eng.step_random(auto_reset=4, want_masks=True)
+            else:
+                eng.step(ca, ta, auto_reset=4)
+            assert eng.last_flow == (0 if generic == '1' else (1 if policy == 'random' else 2))
+            rec.append([t.clone() for t in (getattr(eng, 'camera_obs', None), eng.target_obs, eng.scalars, eng.masks) if t is not None])
         if policy == 'random':  # the fused K-step rollout has the same two compilations
             ro = eng.rollout_random(6, auto_reset=True)
             assert eng.last_flow == (0 if generic == '1' else 1)
@@ -324,8 +331,6 @@ def test_flow_specialised_kernel_equals_generic(workload, generic_shape, policy,
             eng.step(ca, ta, auto_reset=False)
             assert eng.last_flow == 0
             eng.step(ca.float(), ta.float(), tape_goal=torch.zeros((64, eng.num_targets), dtype=torch.float64, device='cuda'), auto_reset=False)
-            assert eng.last_flow == 0
-            eng.step_random(auto_reset=4)
             assert eng.last_flow == 0
         del eng
     for a, b in zip(*outs):

@@ -14,11 +14,12 @@ MASKS = ['camera_target_view_mask', 'target_camera_view_mask', 'target_obstacle_
 INTS = ['tgt_colliding', 'tgt_goals', 'freights', 'bounties', 'remaining_cargoes', 'awaiting_cargo_counts', 'num_delivered_cargoes', 'episode_step']
 
 
-@pytest.mark.parametrize('workload,n', [('MATE-4v8-9.yaml', 130), ('MATE-Navigation.yaml', 64)])
-def test_graph_replayed_steps_equal_direct_steps(workload, n):
+@pytest.mark.parametrize('workload,n,interval', [('MATE-4v8-9.yaml', 130, 1), ('MATE-Navigation.yaml', 64, 1), ('MATE-4v8-9.yaml', 67, 3)])
+def test_graph_replayed_steps_equal_direct_steps(workload, n, interval):
     """K (policy kernel, step, idle/real auto-reset) iterations captured in ONE HIP graph with the step counter on the
     device (mate_engine_device_tick) == the same iterations launched one by one with the host counting: every output
-    and the whole state bit for bit, across episode ends (time limit 7 steps, so resets happen inside the graph)."""
+    and the whole state bit for bit, across episode ends (time limit 7 steps, so resets happen inside the graph).
+    `interval` > 1: batched resets, one reset launch per `interval` steps (the graph then holds whole intervals)."""
     from mate_amd._native import EngineError
     from mate_amd.config import read_config
     from mate_amd.engine import Engine
@@ -36,14 +37,11 @@ def test_graph_replayed_steps_equal_direct_steps(workload, n):
             cam.mul_(-1.0).add_(0.125)
             tgt.mul_(-1.0).add_(0.25)
 
-        stepper = eng.make_stepper(cam, tgt, auto_reset=True, graph_steps=graph_steps, between=policy)
+        stepper = eng.make_stepper(cam, tgt, auto_reset=interval, graph_steps=graph_steps, between=policy)
         rec = []
-        if graph_steps:
-            stepper.run(1)                    # what the constructor's warm-up iteration did, on the direct side
-        else:
-            stepper.run(1)
-            stepper.run(1)
-        for chunk in (12, 5, 6):              # full graph replays and a remainder of direct launches
+        if not graph_steps:
+            stepper.run(interval)             # what the constructor's warm-up (one reset interval) did on the graph side
+        for chunk in (12, 5, 7):              # full graph replays, remainders of direct launches, a call that starts inside an interval
             stepper.run(chunk)
             torch.cuda.synchronize()
             rec.append([t.clone() for t in (eng.camera_obs, eng.target_obs, eng.scalars, eng.masks)])
@@ -185,3 +183,41 @@ def test_rollouts_with_batched_resets(policy):
     # time limit 9 -> done on the 10th step: every environment finishes in call 2 (steps 9-12), idles, restarts after call 2, ...
     assert (episodes[1] == 1).all() and (episodes[2] == 2).all() and (episodes[5] == 3).all() and (episodes[8] == 4).all()
     assert eng.idle_steps() == n * 3 * 2          # per cycle of 12 slots: 10 executed steps, 2 idle
+
+
+def test_batched_step_resets_list_once_and_survive_mode_changes():
+    """auto_reset = k on step(): a finished environment idles (done = 2 rows) and is listed exactly once for the reset
+    launch that closes the interval, whatever happened before: episodes that ended under auto_reset = 0, a change of k or
+    of the flow inside an interval (the pending interval is flushed), and the specialised flows run it
+    (no fall-back to the generic kernel)."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=6)
+    n = 33
+    eng = Engine(cfg, n, seed=12)
+    eng.reset()
+    for _ in range(8):
+        eng.step_random(auto_reset=False)                 # every episode ends at step 7 and stays finished, unlisted
+    assert (eng.state_dict()['done'] == 1).all()
+    eng.step_random(auto_reset=4)                         # 1st of the interval: all idle, all listed now
+    assert eng.last_flow == 1 and (eng.scalars[:, 2] == 2).all()
+    assert (eng.state_dict()['done'] == 3).all()
+    for _ in range(3):
+        eng.step_random(auto_reset=4)                     # ... 4th: the interval's reset launch restarts all of them once
+    sd = eng.state_dict()
+    assert (sd['done'] == 0).all() and (sd['episode'] == 2).all() and (sd['episode_step'] == 0).all()
+    for _ in range(9):                                    # 7 steps to the time limit, then idle; interval boundaries at 4, 8
+        eng.step_random(auto_reset=4)
+    sd = eng.state_dict()
+    assert (sd['episode'] == 3).all() and (sd['episode_step'] == 1).all()
+    # a change of mode inside an interval restarts what has finished so far and forgets the lists
+    eng2 = Engine(cfg, n, seed=12)
+    eng2.reset()
+    for _ in range(7):
+        eng2.step_random(auto_reset=8)                    # finished at the 7th step, listed, interval not over
+    assert (eng2.state_dict()['done'] == 3).all()
+    eng2.rollout_random(3, auto_reset=True)               # flushes: everything restarted before the rollout runs
+    sd = eng2.state_dict()
+    assert (sd['done'] == 0).all() and (sd['episode'] == 2).all() and (sd['episode_step'] == 3).all()
+    eng2.step_random(auto_reset=True)
+    assert (eng2.state_dict()['episode_step'] == 4).all()
