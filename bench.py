@@ -145,6 +145,9 @@ def parse_args(argv=None):
                     help='steps fused per launch (rollout_kernel / rollout_greedy_kernel); 0 = one launch per step; -1 (default) = 128 '
                          '(random) / 32 (greedy) while the batch is at most 64 / 32 environment-waves per CU, else 0 (the fused '
                          'kernels trade occupancy for registers and LDS); capped so that the [R][N][...] buffers stay under 4 GiB')
+    ap.add_argument('--step-reset-interval', type=int, default=8,
+                    help='one launch per step (per_step_launch / external_actions / --rollout 0 with the random policy): restart finished '
+                         'environments with one reset launch per k steps (1 = a reset launch behind every step); a finished environment idles at most k - 1 steps')
     ap.add_argument('--stats-interval', type=int, default=8, help='launches between two episode-statistics gathers inside the timed loop (0 = none)')
     ap.add_argument('--graph-steps', type=int, default=64, help='external policy: step + auto-reset pairs captured per HIP graph (0 = direct launches)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -278,10 +281,10 @@ def main():
         eng.enable_policies()
         step = lambda: eng.step_greedy(auto_reset=args.reset_interval)     # noqa: E731
     elif args.policy == 'external':
-        external = ExternalActions(torch, eng, args.graph_steps)
+        external = ExternalActions(torch, eng, args.graph_steps, args.step_reset_interval)
         step = external.step
     else:
-        step = lambda: eng.step_random(auto_reset=True)     # noqa: E731
+        step = lambda: eng.step_random(auto_reset=args.step_reset_interval)     # noqa: E731
     rollout_fn = eng.rollout_greedy if args.policy == 'greedy' else eng.rollout_random
     rollout_resets = args.rollout_reset_interval if args.rollout_reset_interval > 0 else (4 if args.policy == 'greedy' else 1)
     rollout = lambda n, auto_reset=True: rollout_fn(n, auto_reset=rollout_resets)     # noqa: E731
@@ -314,11 +317,11 @@ def main():
         run(R + (args.steps % R))
     elif external is not None:
         external.run(min(args.steps, max(args.graph_steps, 1) + args.steps % max(args.graph_steps, 1)))
-    # ... and, whatever W is, at least ~50 ms of the timed region's own launches: the GPU raises its clocks under load, and a
+    # ... and, whatever W is, at least ~0.25 s of the timed region's own launches: the GPU raises its clocks under load, and a
     # 20-step region lasts 0.2 ms (reported as `warmup_extra_steps`; W itself is honoured above)
     extra_steps = 0
     t_warm = time.perf_counter()
-    while time.perf_counter() - t_warm < 0.05:
+    while time.perf_counter() - t_warm < 0.25:
         run(R if R > 0 else 64)
         extra_steps += R if R > 0 else 64
         torch.cuda.synchronize()
@@ -362,9 +365,10 @@ def main():
     if not args.no_extras and args.policy == 'random' and R > 0:
         # the same workload with one step_kernel launch per step, and with externally supplied actions (learner in the loop)
         k2 = min(max(args.steps, 256), 1024)
+        k2 -= k2 % 64                            # whole reset intervals and whole graphs
         for name in ('per_step_launch', 'external_actions'):
             if name == 'external_actions':
-                ext = ExternalActions(torch, eng, args.graph_steps)
+                ext = ExternalActions(torch, eng, args.graph_steps, args.step_reset_interval)
                 runner = ext.run
             else:
                 runner = lambda n: [step() for _ in range(n)]     # noqa: E731
@@ -386,9 +390,14 @@ def main():
                             'kernel': 'step_kernel', 'kernel_avg_us': km2 * 1e3,
                             'roofline_frac': (b_alg * args.batch / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS) if km2 > 0 else 0.0,
                             'end_to_end_frac': b_alg * ex2 / e2 / 1e9 / HBM_PEAK_GBS}
+            extras[name]['reset_interval'] = args.step_reset_interval
+            if km2 <= 0:                         # launches replayed from a graph carry no dispatch events
+                del extras[name]['kernel_avg_us'], extras[name]['roofline_frac']
             if name == 'external_actions':
-                extras[name]['flow'] = (f'step(actions): f32 joint actions read from a caller-owned device buffer, {args.graph_steps} step + auto-reset '
-                                        'launch pairs per HIP graph replay') if args.graph_steps > 0 else 'step(actions), direct launches'
+                extras[name]['flow'] = ((f'step(actions): f32 joint actions rewritten by a policy kernel in a caller-owned device buffer before every step; '
+                                         f'{ext.graph_steps} (policy kernel, step) pairs + one reset launch per {args.step_reset_interval} steps per HIP graph replay')
+                                        if args.graph_steps > 0 else 'step(actions), direct launches')
+                ext.stepper.close()
 
     if rank == 0:
         total_envs = args.batch * world
@@ -447,8 +456,9 @@ class ExternalActions:
     that refreshes the buffers in place (a stand-in for a network's output layer), so the environment really consumes
     new externally produced actions at every step."""
 
-    def __init__(self, torch, eng, graph_steps):
+    def __init__(self, torch, eng, graph_steps, reset_interval=1):
         self.torch, self.eng, self.graph_steps = torch, eng, int(graph_steps)
+        self.graph_steps -= self.graph_steps % max(1, reset_interval)      # a graph holds whole reset intervals
         N, Nc, Nt = eng.num_envs, eng.num_cameras, eng.num_targets
         gen = torch.Generator(device=eng.device)
         gen.manual_seed(1234)
@@ -457,7 +467,7 @@ class ExternalActions:
         self.tgt = self.flat[N * Nc * 2:].view(N, Nt, 2)
         self.cam.mul_(torch.tensor([5.0, 2.5], device=eng.device))
         self.tgt.mul_(20.0)
-        self.stepper = eng.make_stepper(self.cam, self.tgt, auto_reset=True, graph_steps=self.graph_steps, between=self.policy)
+        self.stepper = eng.make_stepper(self.cam, self.tgt, auto_reset=max(1, reset_interval), graph_steps=self.graph_steps, between=self.policy)
 
     def policy(self):
         # a new joint action every step, produced on the device by "someone else's" kernel
