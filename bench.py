@@ -322,8 +322,9 @@ def main():
     extra_steps = 0
     t_warm = time.perf_counter()
     while time.perf_counter() - t_warm < 0.25:
-        run(R if R > 0 else 64)
-        extra_steps += R if R > 0 else 64
+        chunk = min(args.steps, 8 * R) if R > 0 else 64      # back to back like the timed region (sustained, not boost, clocks)
+        run(chunk)
+        extra_steps += chunk
         torch.cuda.synchronize()
     if gather is not None:
         gather.submit()              # side stream, copies and (N > 1) the RCCL communicator warmed outside the timed region
