@@ -235,12 +235,12 @@ struct Ctx {
     float *exf, *eyf, *erf;       // ... rounded to f32: the screens that only have to be conservative, or that fall back to
                                   // the f64 table inside an explicit error rim, read these (an f64 operation costs two f32 issue slots)
     const double *act_cam = nullptr, *act_tgt = nullptr;   // FLOW_GREEDY: this step's joint actions in LDS ([Nc][2], [Nt][2])
-    int32_t parity;               // which of the two finished-episode lists this launch appends to
+
     bool statics_done = false;    // fused rollouts, steps after the first: what never changes inside an episode (static
                                   // mask words and flags, obstacle / capacity slots of the scratch) is in LDS already
 
     __device__ Ctx(const Params &p_, const Ptrs &g_, unsigned char *wave_base, int lane_, int64_t env_, int flow_ = FLOW_ANY)
-        : p(p_), g(g_), flow(flow_), lane(lane_), env(env_), out(env_), parity(g_.parity) {
+        : p(p_), g(g_), flow(flow_), lane(lane_), env(env_), out(env_) {
         st = reinterpret_cast<double *>(wave_base + p.off_st);
         dy = reinterpret_cast<double *>(wave_base + p.off_dy);
         di = reinterpret_cast<int32_t *>(dy + p.DF);
@@ -253,6 +253,11 @@ struct Ctx {
         ex = reinterpret_cast<double *>(wave_base + p.off_ent); ey = ex + p.NJ; er = ey + p.NJ;
         exf = reinterpret_cast<float *>(er + p.NJ); eyf = exf + p.NJ; erf = eyf + p.NJ;
     }
+    // which of the two finished-episode lists this launch appends to: a launch argument, or the low bit of the device-resident
+    // reset-launch counter (Params::dev_group).  Re-derived where it is used (an episode ends: rare) instead of held in an
+    // SGPR for the whole kernel -- the step kernels live at the 96-SGPR limit of full occupancy.
+    // (one of the two summands is always zero: the host keeps dev_group = 0 while it counts itself and passes parity = 0 otherwise)
+    __device__ __forceinline__ int32_t list_parity() const { return (int32_t)((p.dev_group + (uint32_t)g.parity) & 1u); }
     // launch switches (constants in the specialised flows)
     __device__ __forceinline__ int mode() const { return flow == FLOW_RANDOM ? (int)MODE_STEP_RANDOM : (flow == FLOW_ACT_F32 || flow == FLOW_GREEDY) ? (int)MODE_STEP : g.mode; }
     __device__ __forceinline__ bool act_from_lds() const { return flow == FLOW_GREEDY; }
@@ -955,8 +960,8 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
         c.ei(EI_EPSTEP) = ep_step;
         const bool awaiting = c.ei(EI_AWAITING) || c.ei(EI_AWAITING + 1) || c.ei(EI_AWAITING + 2) || c.ei(EI_AWAITING + 3);
         const int done = !(ep_step <= p.max_episode_steps && awaiting);
-        // 1 = finished; 3 = finished AND on the list of the next batched reset (so that nobody lists it twice)
-        c.ei(EI_DONE) = done ? ((c.g.done_count && c.freeze_done()) ? 3 : 1) : 0;
+        // 1 = finished; 3 = finished AND on the list of the next reset launch (so that nobody lists it twice)
+        c.ei(EI_DONE) = done ? (c.g.done_count ? 3 : 1) : 0;
         c.ei(EI_TICK) = (int)(tick + 1u);
         if (c.has_scalars() && scalars_out) {
             float *o = scalars_out + c.out * 8;
@@ -964,8 +969,9 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
             o[4] = (float)real_cov; o[5] = (float)transport; o[6] = (float)delivered; o[7] = (float)div_nz(r, p.max_team_reward);
         }
         if (done && c.g.done_count) {
-            const int slot = atomicAdd(c.g.done_count + c.parity, 1);
-            c.g.done_list[(int64_t)c.parity * c.g.N + slot] = (int32_t)c.env;
+            const int parity = c.list_parity();
+            const int slot = atomicAdd(c.g.done_count + parity, 1);
+            c.g.done_list[(int64_t)parity * c.g.N + slot] = (int32_t)c.env;
         }
         if (done && c.g.ep_stats) {      // episode statistics for logging (the record SURVEY.md 8e all-gathers); rare
             double *es = c.g.ep_stats;
@@ -1243,12 +1249,14 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();   // constant 100 MHz: calibrates the s_memtime ticks
 #endif
     // tick and list parity: launch arguments, or the device-resident counter (graph-replayable launches, see Params)
-    const uint32_t tick = p.dev_tick_on ? p.dev_tick + g.tick : g.tick;
-    const int32_t parity = p.dev_tick_on ? (int32_t)(p.dev_group & 1u) : g.parity;
+    // (no select: the host keeps dev_tick = dev_group = 0 in the device parameters while it counts itself, and passes
+    // parity = 0 and tick = the offset inside the reset interval while the device counts)
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) {
+        const int32_t parity = (int32_t)((p.dev_group + (uint32_t)g.parity) & 1u);
         g.done_count[parity ^ 1] = 0;  // next step's counter
-        if (p.dev_tick_on) g.ctrl[0] = parity;
+        g.ctrl[0] = parity;            // read by the auto-reset launch behind a device-counted interval
     }
+    const uint32_t tick = p.dev_tick + g.tick;
     // wave-uniform by construction; readfirstlane lets the compiler keep everything derived from it in SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t env = (int64_t)blockIdx.x * 4 + wave;
@@ -1260,7 +1268,6 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     const Ptrs &gk = kernarg_ptrs(g);
     // the four waves of a workgroup never synchronise: each owns one environment and its LDS slice
     Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
-    c.parity = parity;
 #ifdef MATE_PHASE_CLOCKS
     if (lane == 0 && g.phase_clocks) {
         g.phase_clocks[env * 16 + 0] = t_begin;
@@ -1280,6 +1287,7 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
             if (lane == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; }
             if (lane == 0 && g.idle_steps) g.idle_steps[env] += 1;
             if (lane == 0 && g.done_count && c.ei(EI_DONE) == 1) {      // finished under auto_reset = 0 earlier: not on the list yet
+                const int parity = c.list_parity();
                 const int slot = atomicAdd(g.done_count + parity, 1);
                 g.done_list[(int64_t)parity * g.N + slot] = (int32_t)env;
                 reinterpret_cast<int32_t *>(g.dyn + env * p.DW + p.DF)[p.Nt * TI_STRIDE + EI_DONE] = 3;
@@ -1323,8 +1331,9 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
 template <typename ObsT>
 __device__ __forceinline__ void list_finished_at_entry(Ctx<ObsT> &c) {
     if (c.lane == 0 && c.g.done_count && c.ei(EI_DONE) == 1) {     // (3: a batched-reset step listed it already)
-        const int slot = atomicAdd(c.g.done_count + c.parity, 1);
-        c.g.done_list[(int64_t)c.parity * c.g.N + slot] = (int32_t)c.env;
+        const int parity = c.list_parity();
+        const int slot = atomicAdd(c.g.done_count + parity, 1);
+        c.g.done_list[(int64_t)parity * c.g.N + slot] = (int32_t)c.env;
     }
 }
 

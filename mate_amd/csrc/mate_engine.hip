@@ -624,7 +624,7 @@ extern "C" int mate_engine_device_tick(mate_engine *e, int32_t enable, void *str
         uint32_t words[2] = {0, 0};
         HIP_TRY(hipMemcpy(words, reinterpret_cast<const char *>(e->d_params) + offsetof(Params, dev_tick), sizeof(words), hipMemcpyDeviceToHost));
         e->tick = words[0]; e->parity = (int)(words[1] & 1u);
-        e->p.dev_tick = words[0]; e->p.dev_group = words[1]; e->p.dev_tick_on = 0;
+        e->p.dev_tick = 0; e->p.dev_group = 0; e->p.dev_tick_on = 0;      // zero while the host counts (the kernels ADD them to the launch arguments)
     }
     HIP_TRY(hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice));
     e->dev_tick = enable != 0;
@@ -643,7 +643,7 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     if (mode == MODE_STEP && ((e->p.Nc > 0 && !g.cam_act) || !g.tgt_act)) return fail(MATE_EINVAL, "step() needs camera and target joint actions");
     if (mode == MODE_STEP && (((g.act_discrete & 1) && !g.cam_grid) || ((g.act_discrete & 2) && !g.tgt_grid)))
         return fail(MATE_ESTATE, "discrete actions passed before mate_engine_set_action_grids");
-    g.mode = mode; g.parity = e->parity; g.reset_kind = -1;
+    g.mode = mode; g.parity = e->dev_tick ? 0 : e->parity; g.reset_kind = -1;
     g.tick = e->dev_tick ? (uint32_t)e->steps_since_reset : e->tick;     // device-resident counter: the offset inside the reset interval
     // auto_reset = 1: finished environments restart inside this call; k > 1: they idle (listed for it) and restart together every k-th call
     g.freeze_done = auto_reset > 1;
