@@ -97,9 +97,10 @@ int mate_engine_abi_version(void);
 /* MultiAgentTracking.__init__ (environment.py:330-562) for N environments on HIP device `device`.
  * RNG streams are keyed by (seed, first_env_index + i), so results do not depend on how a
  * global batch is sharded over GPUs.
- * Limits (MATE_EINVAL beyond them, never a silent fallback): at most 16 cameras, 16 targets, 64 obstacles;
- * with cameras present the occlusion-table build sorts 360 + 185 * obstacles rays inside the 160 KiB LDS, which
- * holds up to 20 obstacles (the reference's scenarios use 0 or 9; MATE-Navigation has 32 obstacles and no camera). */
+ * Limits (MATE_EINVAL beyond them, never a silent fallback): at most 16 cameras, 16 targets, 64 obstacles (bit widths of
+ * the packed records).  The occlusion-table build sorts 360 + 185 * obstacles rays per camera: in the 160 KiB LDS up
+ * to 20 obstacles, in an HBM scratch slice per workgroup beyond (same code, slower resets; the reference's scenarios
+ * use 0 or 9 obstacles with cameras, MATE-Navigation has 32 and no camera). */
 int mate_engine_create(const mate_config *config, int64_t num_envs, int32_t device, uint64_t seed,
                        uint64_t first_env_index, mate_engine **out);
 int mate_engine_destroy(mate_engine *engine);                               /* close(), environment.py:1192 */
@@ -244,7 +245,7 @@ int mate_engine_lut_read(mate_engine *engine, int64_t env, int32_t camera, doubl
 /* The outer occlusion boundary, Camera.boundary_outer / sight_range_outer_func (entities.py:419-448, 479), read by
  * boundary_between(outer=True) (entities.py:513-543: AuxiliaryCameraRewards' soft coverage score and the renderer).
  * Off by default; once enabled every reset / rebuild_luts builds it next to the inner table (`*capacity` = knots
- * per camera to provide to lut_read_outer).  Needs at most 16 obstacles (360 + 223 * obstacles rays in the LDS sort). */
+ * per camera to provide to lut_read_outer).  360 + 223 * obstacles rays per table: sorted in the LDS up to 16 obstacles, in HBM scratch beyond. */
 int mate_engine_enable_outer_boundary(mate_engine *engine, int32_t *capacity);
 int mate_engine_lut_read_outer(mate_engine *engine, int64_t env, int32_t camera, double *phis, double *rhos,
                                int32_t capacity, int32_t *count);

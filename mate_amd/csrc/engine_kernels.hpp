@@ -144,6 +144,7 @@ struct Ptrs {
     int32_t reset_tape_len;
     int32_t *reset_draws;         // optional [N]: uniforms each reset consumed (-1: the tape ran out)
     double *ep_stats;             // optional [5] accumulators over finished episodes: count, return, length, coverage, delivered
+    double *sort_scratch;         // occlusion-table sort arrays of scenarios too large for the LDS (ResetLds::sort_in_hbm)
     uint32_t *dev_tick_ptr;       // &Params::dev_tick of the device-resident parameter block (advanced by the auto-reset launch)
     int32_t *ctrl;                // [0]: list parity the last step launch used (device-resident step counter mode)
     long long *phase_clocks;      // [N][16] s_memtime stamps (debug builds with -DMATE_PHASE_CLOCKS)

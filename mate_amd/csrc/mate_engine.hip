@@ -114,7 +114,30 @@ extern "C" const char *mate_engine_last_error(void) { return g_error.c_str(); }
 extern "C" int mate_engine_abi_version(void) { return MATE_ABI_VERSION; }
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+constexpr int kSortGridCap = 1024;     // workgroups of a table-build launch when the sort arrays live in HBM (one scratch slice each)
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// LDS carve of the reset kernel behind the wave-0 context: the four sort arrays of the occlusion-table build (keys, values,
+// compacted keys, compacted values: 4 x sort_cap doubles), the per-degree index, per-obstacle ray metadata, a scan buffer.
+// Up to 20 obstacles per camera table (360 + 185 * obstacles rays) the sort runs in the 160 KiB LDS; beyond, the same code
+// sorts in an HBM scratch slice per workgroup (slower: every pass of the bitonic network is a global round trip).
+static void layout_reset_lds(const Params &p, ResetLds &rl, int sort_cap) {
+    rl.sort_cap = sort_cap;
+    const int fixed = 368 * 2 + round_up(8 * p.No * 8 + (2 * p.No + 4) * 4, 16) + 256 * 4;
+    rl.sort_in_hbm = (size_t)p.lds_wave_bytes + (size_t)4 * sort_cap * 8 + fixed > 160 * 1024;
+    const int in_lds = rl.sort_in_hbm ? 0 : sort_cap * 8;
+    // (the placement phase borrows the start of the sort region for its list of placed circles: keep that much in the LDS)
+    const int place_bytes = round_up(5 * (4 + p.Nc + p.No + p.Nt) * 8 + (p.Nc + p.No + 2 * p.Nt) * 4 + 64, 16);
+    int roff = p.lds_wave_bytes;
+    rl.off_keys = roff; roff += rl.sort_in_hbm ? place_bytes : in_lds;
+    rl.off_vals = roff; roff += in_lds;
+    rl.off_okeys = roff; roff += in_lds;
+    rl.off_ovals = roff; roff += in_lds;
+    rl.off_bucket = roff; roff += 368 * 2;
+    rl.off_meta = roff; roff += round_up(8 * p.No * 8 + (2 * p.No + 4) * 4, 16);
+    rl.off_scan = roff; roff += 256 * 4;
+    rl.total_bytes = roff;
+}
 
 template <typename T>
 static int dev_alloc(mate_engine *e, T **out, size_t count, bool zero = true) {
@@ -249,17 +272,8 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     { const char *fg = getenv("MATE_FLOW_GENERIC"); e->flow_generic = fg && atoi(fg) != 0; }
     if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }
     ResetLds &rl = e->rl;
-    rl.sort_cap = std::max(512, next_pow2(Nc > 0 ? 360 + No * 185 + 1 : 1));
-    int roff = p.lds_wave_bytes;
-    rl.off_keys = roff; roff += rl.sort_cap * 8;
-    rl.off_vals = roff; roff += rl.sort_cap * 8;
-    rl.off_okeys = roff; roff += rl.sort_cap * 8;
-    rl.off_ovals = roff; roff += rl.sort_cap * 8;
-    rl.off_bucket = roff; roff += 368 * 2;
-    rl.off_meta = roff; roff += round_up(8 * No * 8 + (2 * No + 4) * 4, 16);
-    rl.off_scan = roff; roff += 256 * 4;
-    rl.total_bytes = roff;
-    e->reset_lds = (size_t)roff;
+    layout_reset_lds(p, rl, std::max(512, next_pow2(Nc > 0 ? 360 + No * 185 + 1 : 1)));
+    e->reset_lds = (size_t)rl.total_bytes;
     if (e->step_lds > 160 * 1024 || e->reset_lds > 160 * 1024) {
         const size_t a = e->step_lds, b = e->reset_lds;
         delete e;
@@ -298,6 +312,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         if ((rc = dev_alloc(e, &g.flag_list, N))) break;
         if ((rc = dev_alloc(e, &g.idle_steps, N))) break;
         if ((rc = dev_alloc(e, &g.ctrl, (size_t)4))) break;
+        if (rl.sort_in_hbm && (rc = dev_alloc(e, &g.sort_scratch, (size_t)kSortGridCap * 4 * rl.sort_cap, false))) break;
         std::vector<uint32_t> desc;
         build_descriptors(p, desc);
         uint32_t *d_desc = nullptr;
@@ -513,7 +528,8 @@ static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_
     g.mode = MODE_OBSERVE; g.reset_kind = kind; g.parity = e->parity; g.freeze_done = 0;
     const Params &p = e->p;
     auto launch = [&](int ph, int fan, unsigned threads, size_t lds) {
-        const int64_t items = ((g.reset_kind == RESET_DONE || g.reset_kind == RESET_LIST) ? std::min<int64_t>(e->N, 256) : e->N) * fan;
+        int64_t items = ((g.reset_kind == RESET_DONE || g.reset_kind == RESET_LIST) ? std::min<int64_t>(e->N, 256) : e->N) * fan;
+        if (e->rl.sort_in_hbm && (ph & PH_LUT)) items = std::min<int64_t>(items, kSortGridCap);     // grid-stride loop; one scratch slice per workgroup
         if (p.obs_f64) hipLaunchKernelGGL(reset_kernel<double>, dim3((unsigned)items), dim3(threads), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const ResetLds)e->rl, (const int32_t)ph);
         else hipLaunchKernelGGL(reset_kernel<float>, dim3((unsigned)items), dim3(threads), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const ResetLds)e->rl, (const int32_t)ph);
     };
@@ -943,17 +959,14 @@ extern "C" int mate_engine_enable_outer_boundary(mate_engine *e, int32_t *capaci
     // 360 + per obstacle (arc <= 181 rays + two 21-point flanks) rays are sorted in LDS
     const int rays = 360 + p.No * (181 + 42) + 1;
     ResetLds rl = e->rl;
-    rl.sort_cap = std::max(rl.sort_cap, next_pow2(rays));
-    int roff = p.lds_wave_bytes;
-    rl.off_keys = roff; roff += rl.sort_cap * 8;
-    rl.off_vals = roff; roff += rl.sort_cap * 8;
-    rl.off_okeys = roff; roff += rl.sort_cap * 8;
-    rl.off_ovals = roff; roff += rl.sort_cap * 8;
-    rl.off_bucket = roff; roff += 368 * 2;
-    rl.off_meta = roff; roff += round_up(8 * p.No * 8 + (2 * p.No + 4) * 4, 16);
-    rl.off_scan = roff; roff += 256 * 4;
-    rl.total_bytes = roff;
-    if ((size_t)roff > 160 * 1024) return fail(MATE_EINVAL, "outer boundary: %d rays do not fit the 160 KiB LDS sort (at most 16 obstacles)", rays);
+    layout_reset_lds(p, rl, std::max(rl.sort_cap, next_pow2(rays)));
+    const int roff = rl.total_bytes;
+    if (rl.sort_in_hbm && (!e->g.sort_scratch || rl.sort_cap != e->rl.sort_cap)) {      // the larger sort needs (larger) HBM scratch
+        double *scratch = nullptr;
+        int rc0 = dev_alloc(e, &scratch, (size_t)kSortGridCap * 4 * rl.sort_cap, false);
+        if (rc0 != MATE_OK) return rc0;
+        e->g.sort_scratch = scratch;
+    }
     const int kmax_outer = round_up(rays + 2, 8);
     double2 *knots = nullptr; int32_t *counts = nullptr;
     int rc = dev_alloc(e, &knots, (size_t)e->N * p.Nc * kmax_outer);

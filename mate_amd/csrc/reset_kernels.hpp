@@ -17,6 +17,8 @@ enum ResetPhase : int32_t { PH_PLACE = 1, PH_LUT = 2, PH_VIEW = 4, PH_PER_CAMERA
 
 struct ResetLds {   // byte offsets inside the workgroup's dynamic LDS, after the wave-0 context
     int32_t off_keys, off_vals, off_okeys, off_ovals, off_bucket, off_meta, off_scan, sort_cap, total_bytes;
+    int32_t sort_in_hbm;   // the four sort arrays (4 x sort_cap doubles) do not fit the 160 KiB LDS next to the rest: they live in
+                           // Ptrs::sort_scratch, one slice per workgroup of a capped grid (scenarios beyond 20 obstacles per camera table)
 };
 
 // The reset stream: uniforms in the reference's call order (oracle/mate_oracle.c above reset_impl states how each
@@ -400,6 +402,11 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
     double *vals = reinterpret_cast<double *>(smem + rl.off_vals);
     double *okeys = reinterpret_cast<double *>(smem + rl.off_okeys);
     double *ovals = reinterpret_cast<double *>(smem + rl.off_ovals);
+    double *place_scratch = keys;     // reset_place's list of placed circles: always in the LDS
+    if (rl.sort_in_hbm) {      // same code on global memory: __syncthreads orders a workgroup's global accesses as well
+        keys = g.sort_scratch + (int64_t)blockIdx.x * 4 * rl.sort_cap;
+        vals = keys + rl.sort_cap; okeys = vals + rl.sort_cap; ovals = okeys + rl.sort_cap;
+    }
     uint16_t *lbucket = reinterpret_cast<uint16_t *>(smem + rl.off_bucket);
     double *meta = reinterpret_cast<double *>(smem + rl.off_meta);
     int32_t *scan = reinterpret_cast<int32_t *>(smem + rl.off_scan);
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
             load_records(c);
             wave_sync();
             if ((phases & PH_PLACE) && lane == 0) {
-                reset_place(c, keys, 4 + p.Nc + p.No + p.Nt);
+                reset_place(c, place_scratch, 4 + p.Nc + p.No + p.Nt);
                 if ((g.reset_kind == RESET_FLAGGED || g.reset_kind == RESET_MASK) && (phases & PH_MORE)) g.flag_list[atomicAdd(g.flag_count, 1)] = (int32_t)env;
             }
             wave_sync();

@@ -3,7 +3,7 @@
 The scenario numbers are restated programmatically: quadrant / edge / centre
 location ranges are generated from their symmetry instead of being listed, and
 `scenario(name)` returns the same nested mapping `yaml.safe_load` gives for the
-corresponding upstream file (checked in tests/test_config.py against the
+corresponding upstream file (checked in tests/test_host_logic.py::test_scenarios_match_reference_assets against the
 reference when it is present).
 """
 import copy

@@ -95,9 +95,10 @@ def test_reset_and_rollout_vs_oracle(config, n, oracle_lib):
 
 
 def test_largest_supported_scenario_vs_oracle(oracle_lib):
-    """A scenario at the engine's limits (16 cameras, 16 targets, 20 obstacles: 8 sector rounds, 13 range rounds,
-    4k-knot occlusion tables in a 160 KiB-LDS sort, generic kernels) goes through the same reset + rollout parity;
-    one obstacle more per camera table than the LDS sort can hold is refused loudly."""
+    """A scenario at the limit of the LDS sort (16 cameras, 16 targets, 20 obstacles: 8 sector rounds, 13 range rounds,
+    4k-knot occlusion tables in a 160 KiB-LDS sort, generic kernels) goes through the same reset + rollout parity, and so
+    does one beyond it (40 obstacles: 7.8k-knot tables sorted in an HBM scratch slice per workgroup); more entities than
+    the packed records can index are refused loudly."""
     from mate_amd._native import EngineError
     from mate_amd.engine import Engine
     from mate_amd.config import read_config
@@ -112,9 +113,13 @@ def test_largest_supported_scenario_vs_oracle(oracle_lib):
     cfg['obstacle']['radius_random_range'] = [10.0, 40.0]
     _reset_and_rollout_vs_oracle(cfg, 9, oracle_lib, steps=12)
     import copy
+    bigger = copy.deepcopy(cfg)
+    bigger['name'] = 'MultiAgentTracking(16v16, 40)'
+    bigger['obstacle']['location_random_range'] = (obs * 5)[:40]
+    _reset_and_rollout_vs_oracle(bigger, 5, oracle_lib, steps=8)
     too_big = copy.deepcopy(cfg)
-    too_big['obstacle']['location_random_range'] = (obs * 5)[:40]
-    with pytest.raises(EngineError, match='too large'):
+    too_big['obstacle']['location_random_range'] = (obs * 8)[:65]
+    with pytest.raises(EngineError, match='unsupported entity counts'):
         Engine(too_big, 4)
 
 
