@@ -72,7 +72,9 @@ __device__ __forceinline__ double div_nz(double a, double b) {
     return fma(fma(-b, q, a), r, q);
 }
 __device__ __forceinline__ double norm2(double x, double y) { return sqrt_pos(fma(y, y, x * x)); }
-__device__ __forceinline__ double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// np.clip on finite operands with lo <= hi, neither bound a zero (action limits, viewing-angle limits, the terrain): two
+// v_max / v_min instead of two compares and four selects.
+__device__ __forceinline__ double clipd(double v, double lo, double hi) { return __builtin_fmin(__builtin_fmax(v, lo), hi); }
 
 // Python float `%` with a positive divisor (utils.py:158 uses it with 360.0).
 __device__ __forceinline__ double pymod_pos(double a, double b) {
