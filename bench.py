@@ -20,8 +20,8 @@ caller-owned device buffer, the step + auto-reset launch pairs replayed from one
 
 Timing: W untimed warm-up steps (plus one untimed launch of every launch shape of the timed region, so that no
 buffer is allocated and no kernel is first loaded inside it), then the timed region of EXACTLY K steps, bracketed by a
-barrier + torch.cuda.synchronize() on both sides, is run `--reps` times (default 5) and the MEDIAN is reported
-(`ms_per_step` x `steps` = the median repetition; every repetition is listed in `rep_ms`).
+barrier + torch.cuda.synchronize() on both sides, is run `--rep-warmup` (3) untimed + `--reps` (5) timed times and the MEDIAN
+of the timed ones is reported (`ms_per_step` x `steps` = the median repetition; every timed repetition is listed in `rep_ms`).
 
 `--gpus N` (N > 1) started without a torchrun environment launches the N ranks itself (a `torch.distributed.run`
 child process, started before this process touches the GPU) and exits with its status; under torchrun WORLD_SIZE must
@@ -132,6 +132,9 @@ def parse_args(argv=None):
     ap.add_argument('--steps', type=int, default=2048)
     ap.add_argument('--warmup', type=int, default=128)
     ap.add_argument('--reps', type=int, default=5, help='repetitions of the timed region; the median is reported')
+    ap.add_argument('--rep-warmup', type=int, default=3,
+                    help='untimed repetitions of the whole measuring loop (region + its bookkeeping) before the timed ones: the first '
+                         'passes through that loop are slower than its steady state (clocks, lazily loaded code), whatever ran before')
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='environments per GPU')
     ap.add_argument('--workload', default=WORKLOAD)
     ap.add_argument('--policy', choices=['random', 'greedy', 'external'], default='random',
@@ -320,12 +323,14 @@ def main():
     # ... and, whatever W is, at least ~0.25 s of the timed region's own launches: the GPU raises its clocks under load, and a
     # 20-step region lasts 0.2 ms (reported as `warmup_extra_steps`; W itself is honoured above)
     extra_steps = 0
+    eng.kernel_time(enable=1 if R > 0 else 16)     # ... with the dispatch-event launch path of the timed region (events created, runtime warmed)
     t_warm = time.perf_counter()
     while time.perf_counter() - t_warm < 0.25:
         chunk = min(args.steps, 8 * R) if R > 0 else 64      # back to back like the timed region (sustained, not boost, clocks)
         run(chunk)
         extra_steps += chunk
         torch.cuda.synchronize()
+    eng.kernel_time(enable=False)
     if gather is not None:
         gather.submit()              # side stream, copies and (N > 1) the RCCL communicator warmed outside the timed region
         gather.result()
@@ -339,7 +344,7 @@ def main():
 
     from mate_amd.distributed import reduce_job
     rep_ms, rep_executed, kernel_times = [], [], []
-    for _ in range(max(1, args.reps)):
+    for rep in range(max(0, args.rep_warmup) + max(1, args.reps)):
         eng.kernel_time(enable=1 if R > 0 else 16)   # HIP-event pair around (every 16th) launch of the dominant kernel
         barrier()
         idle0 = eng.idle_steps()
@@ -353,6 +358,11 @@ def main():
         kernel_times.append(eng.kernel_time(enable=False))
         stats = eng.scalars[:, [1, 3, 6]].mean(dim=0)    # reward, coverage, delivered: logging only
         elapsed, executed, stats = reduce_job(elapsed, executed, stats, device='cuda')   # MAX time, SUM env-steps, gathered stats
+        if rep < max(0, args.rep_warmup):
+            kernel_times.pop()
+            if gather is not None:
+                gather.count = 0
+            continue                                  # an untimed pass through the measuring loop
         rep_ms.append(elapsed * 1e3)
         rep_executed.append(executed)
     order = sorted(range(len(rep_ms)), key=lambda i: rep_ms[i])
@@ -421,7 +431,7 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'reps': len(rep_ms), 'rep_ms': [round(v, 4) for v in rep_ms], 'timing': 'median repetition of the K-step timed region',
-            'warmup_extra_steps': extra_steps,
+            'warmup_extra_steps': extra_steps, 'rep_warmup': max(0, args.rep_warmup),
             'config': {'workload': f'{args.workload} batch={args.batch} envs per GPU, ' + policy_text
                                    + (f'fused {R}-step rollout launches, auto-reset after ' + ('each launch' if rollout_resets == 1 else f'every {rollout_resets} launches')
                                       if R > 0 else 'one launch per step, auto-reset'),

@@ -288,13 +288,21 @@ class Engine:
     def _run_rollout(self, entry_point, steps, auto_reset, want_masks):
         steps = int(steps)
         buf = self.reserve_rollout(steps, want_masks)
-        io = MateStepIO()
-        io.camera_obs_dev = buf['camera_obs'].data_ptr() if self.num_cameras else None
-        io.target_obs_dev = buf['target_obs'].data_ptr()
-        io.scalars_dev = buf['scalars'].data_ptr()
-        io.masks_dev = buf['masks'].data_ptr() if want_masks else None
-        check(entry_point(self._h, ctypes.byref(io), steps, int(auto_reset), self._stream()))
-        return buf['camera_obs'][:steps], buf['target_obs'][:steps], buf['scalars'][:steps]
+        # the argument block and the returned views of a (launch length, masks) combination never change while the buffers
+        # live: built once -- a 20-step launch lasts 0.18 ms, and this call is what the GPU waits for before it starts
+        cache = buf.setdefault('_calls', {})
+        call = cache.get((steps, bool(want_masks)))
+        if call is None:
+            io = MateStepIO()
+            io.camera_obs_dev = buf['camera_obs'].data_ptr() if self.num_cameras else None
+            io.target_obs_dev = buf['target_obs'].data_ptr()
+            io.scalars_dev = buf['scalars'].data_ptr()
+            io.masks_dev = buf['masks'].data_ptr() if want_masks else None
+            call = cache[(steps, bool(want_masks))] = (io, ctypes.byref(io), (buf['camera_obs'][:steps], buf['target_obs'][:steps], buf['scalars'][:steps]))
+        status = entry_point(self._h, call[1], steps, int(auto_reset), self._stream())
+        if status != 0:
+            check(status)
+        return call[2]
 
     def device_tick(self, enable=True):
         """Keep the step counter on the device (mate_engine_device_tick): step()/step_random() launches with
