@@ -41,47 +41,54 @@ def format_row(values):
     return '|'.join([''] + [f' {fmt(v)} ' for fmt, v in zip(COLUMNS.values(), values)] + [''])
 
 
+class _EpisodeLog:
+    """Running quantities behind one status row (mate/evaluate.py:129-139)."""
+
+    def __init__(self, env):
+        self.env = env
+        self.episode_reward = 0.0
+        self.coverage_sum = 0.0
+        self.steps = 0
+        self.started = time.perf_counter()
+
+    def row(self, step_reward):
+        env = self.env
+        self.steps += 1
+        self.episode_reward += step_reward
+        self.coverage_sum += env.coverage_rate
+        delivered = env.num_delivered_cargoes
+        return OrderedDict(zip(COLUMNS, (
+            env.episode_step, delivered, step_reward, self.episode_reward,
+            env.episode_step / delivered if delivered > 0 else np.nan,
+            env.mean_transport_rate, self.coverage_sum / self.steps,
+            self.episode_reward / env.max_target_team_episode_reward,
+            env.episode_step / (time.perf_counter() - self.started))))
+
+
 def evaluate(env, joint_policy=None, verbose=False, history=None):
     """One episode (mate/evaluate.py:85-167).  `joint_policy(env, (camera_obs, target_obs), (camera_infos, target_infos))`
     returns the joint action of both teams; None = the on-device Greedy agents of both teams
-    (`env.enable_greedy_policies()` must then precede this call).  Returns the reference's status dict; `history`
-    (a list) receives every step's row."""
-    status = {}
-    observations = env.reset()
-    infos = None
-    num_cargoes = 0
-    target_team_episode_reward = 0.0
-    time_start = time.perf_counter()
-    coverage_rates = []
+    (`env.enable_greedy_policies()` must then precede this call).  Returns the reference's status dict -- the row of
+    the last step once a cargo has been delivered or the episode is done, else empty; `history` (a list) receives
+    every step's row.  The loop ends at `max_episode_steps` like the reference's, one call before the environment's own
+    time-limit `done`."""
+    observations, infos, status = env.reset(), None, {}
+    log = _EpisodeLog(env)
     if verbose:
         print('|'.join([''] + [f' {name} ' for name in COLUMNS] + ['']))
-    while env.episode_step < env.max_episode_steps:
+    done = False
+    while not done and env.episode_step < env.max_episode_steps:
         if joint_policy is None:
-            observations, (_, target_team_reward), done, infos = env.step_greedy()
+            observations, rewards, done, infos = env.step_greedy()
         else:
-            observations, (_, target_team_reward), done, infos = env.step(joint_policy(env, observations, infos))
-        coverage_rates.append(env.coverage_rate)
-        num_cargoes = env.num_delivered_cargoes
-        target_team_episode_reward += target_team_reward
-        values = [
-            env.episode_step,
-            num_cargoes,
-            target_team_reward,
-            target_team_episode_reward,
-            env.episode_step / num_cargoes if num_cargoes > 0 else np.nan,
-            env.mean_transport_rate,
-            np.mean(coverage_rates),
-            target_team_episode_reward / env.max_target_team_episode_reward,
-            env.episode_step / (time.perf_counter() - time_start),
-        ]
-        if num_cargoes > 0 or done:
-            status = dict(zip(COLUMNS, values))
+            observations, rewards, done, infos = env.step(joint_policy(env, observations, infos))
+        row = log.row(rewards[1])                 # the target team's reward, as in the reference's single-team loop
+        if row['Cargo'] > 0 or done:
+            status = dict(row)
         if history is not None:
-            history.append(dict(zip(COLUMNS, values)))
+            history.append(dict(row))
         if verbose:
-            print(format_row(values))
-        if done:
-            break
+            print(format_row(list(row.values())))
     return status
 
 
