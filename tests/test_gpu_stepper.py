@@ -137,7 +137,8 @@ def _census(workload, n, steps, fused, own_tables, oracle_lib, seed=99, first=12
     return int(bad.sum()), worst, obs_ok, rew_ok
 
 
-@pytest.mark.parametrize('workload,n,steps,fused', [('MATE-4v8-9.yaml', 4096, 32, 16), ('MATE-8v8-9.yaml', 1024, 24, 1), ('MATE-Navigation.yaml', 2048, 32, 32)])
+@pytest.mark.parametrize('workload,n,steps,fused', [('MATE-4v8-9.yaml', 4096, 32, 16), ('MATE-8v8-9.yaml', 1024, 24, 1), ('MATE-Navigation.yaml', 2048, 32, 32),
+                                                    ('MATE-4v8-0.yaml', 2048, 32, 8), ('MATE-4v2-9.yaml', 1024, 32, 1)])
 def test_batch_scale_census_vs_oracle(workload, n, steps, fused, oracle_lib):
     """The soak of tests/soak_vs_oracle.py at a driver-runnable size: with identical occlusion tables on both sides no
     environment may ever differ from the oracle in a mask bit or an integer; positions to 1e-9, f32 observations to
