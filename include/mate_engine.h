@@ -190,6 +190,17 @@ typedef struct mate_policy_tape {
 int mate_engine_policy_enable(mate_engine *engine);
 int mate_engine_step_greedy(mate_engine *engine, const mate_step_io *io, const mate_policy_tape *tape,
                             int32_t auto_reset, void *stream);
+/* MultiCamera / MultiTarget (mate/wrappers/single_team.py:180-306, SingleTeamMultiAgent.step :245-264): the caller -- the
+ * learner of examples/ippo|mappo|qmix|... -- plays ONE team, the on-device greedy agents play the other:
+ * `group_step(env, opponent_agents, ...)` + `env.step((action, opponent_joint_action))` in two launches.  `team` is the
+ * CALLER's team; io->camera_actions_dev (MATE_TEAM_CAMERA) or io->target_actions_dev (MATE_TEAM_TARGET) holds its joint
+ * action in the encoding io->act_dtype names (f32 / f64 pairs, or grid indices with that team's *_DISCRETE bit); the other
+ * action pointer is ignored.  The opponents observe, exchange messages and act exactly as in mate_engine_step_greedy
+ * (their draws come from the same Philox streams / `tape`), so feeding the greedy agents' own recorded joint action for
+ * `team` reproduces the step_greedy trajectory bit for bit (tests/test_gpu_policies.py). */
+enum { MATE_TEAM_CAMERA = 0, MATE_TEAM_TARGET = 1 };           /* mate/utils.py Team */
+int mate_engine_step_versus_greedy(mate_engine *engine, int32_t team, const mate_step_io *io, const mate_policy_tape *tape,
+                                   int32_t auto_reset, void *stream);
 /* `steps` consecutive (agents act, environment steps) iterations of GreedyCameraAgent vs GreedyTargetAgent fused into ONE
  * launch: mate.group_step + env.step of the evaluation loop (mate/evaluate.py:104-139, agents/greedy.py), with the
  * environment records, the agents' memory and the view masks resident in LDS.  Outputs are rollout-shaped like
@@ -198,6 +209,14 @@ int mate_engine_step_greedy(mate_engine *engine, const mate_step_io *io, const m
  * episode before the next call.  Philox draws only (no policy tape).  Bit-identical to `steps` calls of
  * mate_engine_step_greedy. */
 int mate_engine_rollout_greedy(mate_engine *engine, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream);
+/* FrameSkip(frame_skip = steps) over MultiCamera / MultiTarget (examples/utils/wrappers.py:301-323: the same action for
+ * `frame_skip` env.step calls; every example trainer's make_env applies it last) in ONE launch: the caller's `team` repeats
+ * the joint action of io (as in mate_engine_step_versus_greedy) for `steps` frames, the greedy opponents act anew on every
+ * frame.  Outputs are rollout-shaped; the wrapper's summed reward is the column sum of the scalar rows (rows with
+ * done = 2 are zero), its observation the last row with done != 2.  Bit-identical to `steps` calls of
+ * mate_engine_step_versus_greedy with the same action. */
+int mate_engine_rollout_versus_greedy(mate_engine *engine, int32_t team, const mate_step_io *io, int32_t steps,
+                                      int32_t auto_reset, void *stream);
 
 /* copies the joint actions of the last step_greedy into caller buffers [N][Nc][2] / [N][Nt][2] f64 (either may be NULL) */
 int mate_engine_policy_actions(mate_engine *engine, double *camera_actions_dev, double *target_actions_dev, void *stream);

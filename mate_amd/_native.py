@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('MATE_ENGINE_LIB') or os.path.join(os.path.dirname(os.
 EXPORTED_SYMBOLS = (
     'mate_engine_last_error', 'mate_engine_abi_version', 'mate_engine_create', 'mate_engine_destroy',
     'mate_engine_get_layout', 'mate_engine_set_obs_transform', 'mate_engine_set_obs_mode', 'mate_engine_set_action_grids', 'mate_engine_seed', 'mate_engine_reset', 'mate_engine_reset_tape', 'mate_engine_step', 'mate_engine_device_tick', 'mate_engine_set_episode_stats', 'mate_engine_step_random',
-    'mate_engine_rollout_random', 'mate_engine_policy_enable', 'mate_engine_step_greedy', 'mate_engine_rollout_greedy', 'mate_engine_policy_actions',
+    'mate_engine_rollout_random', 'mate_engine_policy_enable', 'mate_engine_step_greedy', 'mate_engine_step_versus_greedy', 'mate_engine_rollout_greedy', 'mate_engine_rollout_versus_greedy', 'mate_engine_policy_actions',
     'mate_engine_observe', 'mate_engine_export_state', 'mate_engine_import_state', 'mate_engine_lut_read',
     'mate_engine_lut_write', 'mate_engine_enable_outer_boundary', 'mate_engine_lut_read_outer', 'mate_engine_lut_write_outer', 'mate_engine_soft_coverage', 'mate_engine_rebuild_luts', 'mate_engine_idle_steps', 'mate_engine_kernel_time', 'mate_engine_last_flow',
 )
@@ -105,8 +105,10 @@ def load():
     handle.mate_engine_rollout_random.argtypes = [P, ctypes.POINTER(MateStepIO), I32, I32, P]
     handle.mate_engine_policy_enable.argtypes = [P]
     handle.mate_engine_step_greedy.argtypes = [P, ctypes.POINTER(MateStepIO), ctypes.POINTER(MatePolicyTape), I32, P]
+    handle.mate_engine_step_versus_greedy.argtypes = [P, I32, ctypes.POINTER(MateStepIO), ctypes.POINTER(MatePolicyTape), I32, P]
     handle.mate_engine_policy_actions.argtypes = [P, P, P, P]
     handle.mate_engine_rollout_greedy.argtypes = [P, ctypes.POINTER(MateStepIO), I32, I32, P]
+    handle.mate_engine_rollout_versus_greedy.argtypes = [P, I32, ctypes.POINTER(MateStepIO), I32, I32, P]
     handle.mate_engine_observe.argtypes = [P, ctypes.POINTER(MateStepIO), P]
     handle.mate_engine_export_state.argtypes = [P, P, P]
     handle.mate_engine_import_state.argtypes = [P, P, P]

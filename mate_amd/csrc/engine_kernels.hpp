@@ -150,7 +150,7 @@ struct Ptrs {
     long long *phase_clocks;      // [N][16] s_memtime stamps (debug builds with -DMATE_PHASE_CLOCKS)
     int32_t debug_skip;           // phase-ablation mask (debug builds only)
     int64_t N;
-    int32_t mode, act_f64, parity, reset_kind;
+    int32_t mode, act_f64, parity, reset_kind;     // act_f64: bit 0 camera actions, bit 1 target actions are f64 (else f32)
     int32_t rollout_steps;        // steps per launch of rollout_kernel
     int32_t freeze_done;          // batched auto-reset: finished environments idle (scalar done = 2) until the next reset launch
     uint32_t tick;                // host step counter: Philox tick of this launch (all environments step together); with a
@@ -440,7 +440,7 @@ __device__ __forceinline__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &
                 idx = idx < 0 ? 0 : (idx >= c.g.n_cam_grid ? c.g.n_cam_grid - 1 : idx);
                 const double2 gxy = c.g.cam_grid[idx];
                 da = p.rot * gxy.x; dz = p.zoom * gxy.y;
-            } else if (c.act_f64()) {
+            } else if (c.act_f64() & 1) {
                 const double *a = reinterpret_cast<const double *>(c.g.cam_act) + (c.env * p.Nc + lane) * 2;
                 da = a[0]; dz = a[1];
             } else {
@@ -497,7 +497,7 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
             const double2 gxy = c.g.tgt_grid[idx];
             const double high = ((c.capword() >> t) & 1ull) ? p.tgt_step * 0.5 : p.tgt_step;
             ax = high * gxy.x; ay = high * gxy.y;
-        } else if (c.act_f64()) {
+        } else if (c.act_f64() & 2) {
             const double *a = reinterpret_cast<const double *>(c.g.tgt_act) + (c.env * p.Nt + t) * 2;
             ax = a[0]; ay = a[1];
         } else {

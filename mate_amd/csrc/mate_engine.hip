@@ -97,6 +97,7 @@ struct mate_engine {
     // on-device rule-based policies (mate_engine_step_greedy)
     bool policy_ready = false;
     PolicyPtrs q{};
+    int greedy_team_bits = 0;  // during mate_engine_step_greedy / _step_versus_greedy: teams whose joint action the policy kernel wrote
     // observation post-processing fused into the packer (set_obs_mode / set_obs_transform)
     int cam_mode = 0, tgt_mode = 0;
     bool xf_relative = false, xf_cam = false, xf_tgt = false;
@@ -518,7 +519,7 @@ static void apply_io(Ptrs &g, const mate_step_io *io) {
     g.cam_act = g.tgt_act = nullptr; g.tape_ct = g.tape_goal = nullptr;
     g.cam_obs = g.tgt_obs = nullptr; g.scalars = nullptr; g.masks = nullptr; g.act_f64 = 0; g.act_discrete = 0;
     if (!io) return;
-    g.cam_act = io->camera_actions_dev; g.tgt_act = io->target_actions_dev; g.act_f64 = (io->act_dtype & 0xff) == MATE_ACT_F64;
+    g.cam_act = io->camera_actions_dev; g.tgt_act = io->target_actions_dev; g.act_f64 = (io->act_dtype & 0xff) == MATE_ACT_F64 ? 3 : 0;
     g.act_discrete = ((io->act_dtype & MATE_ACT_CAMERA_DISCRETE) ? 1 : 0) | ((io->act_dtype & MATE_ACT_TARGET_DISCRETE) ? 2 : 0);
     g.tape_ct = io->tape_camera_target_dev; g.tape_goal = io->tape_goal_dev;
     g.cam_obs = io->camera_obs_dev; g.tgt_obs = io->target_obs_dev; g.scalars = io->scalars_dev; g.masks = io->masks_dev;
@@ -656,6 +657,7 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     if (mode != MODE_OBSERVE) { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | kStepFlow) : auto_reset, stream); if (rc != MATE_OK) return rc; }
     Ptrs g = e->g;
     apply_io(g, io);
+    if (e->greedy_team_bits) g.act_f64 |= e->greedy_team_bits;          // the on-device agents' team(s): f64 joint actions
     if (mode == MODE_STEP && ((e->p.Nc > 0 && !g.cam_act) || !g.tgt_act)) return fail(MATE_EINVAL, "step() needs camera and target joint actions");
     if (mode == MODE_STEP && (((g.act_discrete & 1) && !g.cam_grid) || ((g.act_discrete & 2) && !g.tgt_grid)))
         return fail(MATE_ESTATE, "discrete actions passed before mate_engine_set_action_grids");
@@ -798,12 +800,15 @@ extern "C" int mate_engine_policy_enable(mate_engine *e) {
     return policy_enable(e);
 }
 
-extern "C" int mate_engine_step_greedy(mate_engine *e, const mate_step_io *io, const mate_policy_tape *tape, int32_t auto_reset, void *stream_) {
+// team_caller: -1 = both teams are the on-device agents; 0 / 1 = the camera / target team's joint action is the caller's
+static int step_with_policies(mate_engine *e, int team_caller, const mate_step_io *io, const mate_policy_tape *tape, int32_t auto_reset, hipStream_t stream) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (!e->was_reset) return fail(MATE_ESTATE, "step_greedy called before reset() (or import_state)");
     if (e->dev_tick) return fail(MATE_ESTATE, "not available while the step counter is device-resident (mate_engine_device_tick)");
     if (!e->policy_ready) return fail(MATE_ESTATE, "call mate_engine_policy_enable() before the reset whose observations the policies act on");
-    hipStream_t stream = (hipStream_t)stream_;
+    if (team_caller == 0 && e->p.Nc == 0) return fail(MATE_EINVAL, "the scenario has no cameras to act for");
+    if (team_caller >= 0 && (!io || !(team_caller == 0 ? io->camera_actions_dev : io->target_actions_dev)))
+        return fail(MATE_EINVAL, "step_versus_greedy needs the %s team's joint action", team_caller == 0 ? "camera" : "target");
     HIP_TRY(hipSetDevice(e->device));
     PolicyPtrs q = e->q;
     std::memset(&q.tape, 0, sizeof(q.tape));
@@ -821,11 +826,25 @@ extern "C" int mate_engine_step_greedy(mate_engine *e, const mate_step_io *io, c
     HIP_TRY(hipGetLastError());
     mate_step_io io2;
     if (io) io2 = *io; else std::memset(&io2, 0, sizeof(io2));
-    io2.camera_actions_dev = q.cam_act; io2.target_actions_dev = q.tgt_act; io2.act_dtype = MATE_ACT_F64;
-    return launch_step(e, &io2, MODE_STEP, auto_reset, stream);
+    // the caller's team keeps its own pointer and encoding (f32 / f64 / grid indices); the agents' joint action is f64 pairs
+    if (team_caller != 0) { io2.camera_actions_dev = q.cam_act; io2.act_dtype &= ~MATE_ACT_CAMERA_DISCRETE; }
+    if (team_caller != 1) { io2.target_actions_dev = q.tgt_act; io2.act_dtype &= ~MATE_ACT_TARGET_DISCRETE; }
+    e->greedy_team_bits = team_caller < 0 ? 3 : (team_caller == 0 ? 2 : 1);
+    const int rc = launch_step(e, &io2, MODE_STEP, auto_reset, stream);
+    e->greedy_team_bits = 0;
+    return rc;
 }
 
-extern "C" int mate_engine_rollout_greedy(mate_engine *e, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_) {
+extern "C" int mate_engine_step_greedy(mate_engine *e, const mate_step_io *io, const mate_policy_tape *tape, int32_t auto_reset, void *stream) {
+    return step_with_policies(e, -1, io, tape, auto_reset, (hipStream_t)stream);
+}
+
+extern "C" int mate_engine_step_versus_greedy(mate_engine *e, int32_t team, const mate_step_io *io, const mate_policy_tape *tape, int32_t auto_reset, void *stream) {
+    if (team != MATE_TEAM_CAMERA && team != MATE_TEAM_TARGET) return fail(MATE_EINVAL, "team must be MATE_TEAM_CAMERA or MATE_TEAM_TARGET");
+    return step_with_policies(e, team, io, tape, auto_reset, (hipStream_t)stream);
+}
+
+static int rollout_with_policies(mate_engine *e, int team_caller, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (!e->was_reset) return fail(MATE_ESTATE, "rollout_greedy called before reset() (or import_state)");
     if (e->dev_tick) return fail(MATE_ESTATE, "not available while the step counter is device-resident (mate_engine_device_tick)");
@@ -838,6 +857,11 @@ extern "C" int mate_engine_rollout_greedy(mate_engine *e, const mate_step_io *io
     apply_io(g, io);
     if ((e->p.Nc > 0 && !g.cam_obs) || !g.tgt_obs || !g.scalars) return fail(MATE_EINVAL, "rollout_greedy needs the observation and scalar outputs");
     if (g.obs_mode != 0 || g.xdesc) return fail(MATE_EINVAL, "rollout_greedy packs plain observations (no fused transform / team mode)");
+    if (team_caller == 0 && e->p.Nc == 0) return fail(MATE_EINVAL, "the scenario has no cameras to act for");
+    if (team_caller >= 0 && !(team_caller == 0 ? g.cam_act : g.tgt_act))
+        return fail(MATE_EINVAL, "rollout_versus_greedy needs the %s team's joint action", team_caller == 0 ? "camera" : "target");
+    if (team_caller >= 0 && (((g.act_discrete & 1) && team_caller == 0 && !g.cam_grid) || ((g.act_discrete & 2) && team_caller == 1 && !g.tgt_grid)))
+        return fail(MATE_ESTATE, "discrete actions passed before mate_engine_set_action_grids");
     const size_t lds = 4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt) + 1024;
     if (lds > 160 * 1024) return fail(MATE_EINVAL, "rollout_greedy: %zu bytes of LDS per workgroup do not fit", lds);
     g.mode = MODE_STEP; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick; g.rollout_steps = steps;
@@ -846,6 +870,7 @@ extern "C" int mate_engine_rollout_greedy(mate_engine *e, const mate_step_io *io
     if (auto_reset != 1) g.done_count = nullptr;
     PolicyPtrs q = e->q;
     std::memset(&q.tape, 0, sizeof(q.tape));
+    q.caller_team = team_caller;
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e->timing > 0 && (e->timing_tick++ % e->timing) == 0) {
@@ -874,6 +899,15 @@ extern "C" int mate_engine_rollout_greedy(mate_engine *e, const mate_step_io *io
         if (rc != MATE_OK) return rc;
     }
     return MATE_OK;
+}
+
+extern "C" int mate_engine_rollout_greedy(mate_engine *e, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream) {
+    return rollout_with_policies(e, -1, io, steps, auto_reset, stream);
+}
+
+extern "C" int mate_engine_rollout_versus_greedy(mate_engine *e, int32_t team, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream) {
+    if (team != MATE_TEAM_CAMERA && team != MATE_TEAM_TARGET) return fail(MATE_EINVAL, "team must be MATE_TEAM_CAMERA or MATE_TEAM_TARGET");
+    return rollout_with_policies(e, team, io, steps, auto_reset, stream);
 }
 
 // Copy the joint actions the last mate_engine_step_greedy produced into caller buffers ([N][Nc][2], [N][Nt][2] f64).

@@ -42,6 +42,8 @@ struct PolicyPtrs {
     int32_t lds_bytes;         // per wave
     int32_t memory_period;     // 25 (greedy.py:21)
     double noise_scale;        // 0.5 (greedy.py:236)
+    int32_t caller_team;       // fused rollout: -1 both teams are the agents; 0 / 1 the camera / target team repeats the caller's
+                               // joint action (Ptrs::cam_act / tgt_act) for every step of the launch (FrameSkip over MultiCamera / MultiTarget)
 };
 
 // f64 part of the record
@@ -409,6 +411,49 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
 // agents' step on its stale data (no stores) and skips the environment's step.
 __host__ __device__ constexpr int policy_slice_bytes(int PW, int Nc, int Nt) { return shape_round_up((PW + Nc * Nc / 2 + 2 + 2 * (Nc + Nt)) * 8, 16); }
 
+// The caller's team of a fused rollout: its joint action, decoded as step() would (f32 / f64 pairs, or grid indices:
+// DiscreteCamera.action / DiscreteTarget.action, discrete_action_spaces.py:71-73, 177-179), over the agents' in LDS.
+template <typename ObsT>
+__device__ __forceinline__ void load_caller_actions(Ctx<ObsT> &c, int team, double *act_cam, double *act_tgt) {
+    const Params &p = c.p;
+    const Ptrs &g = c.g;
+    const int k = c.lane;
+    if (team == 0) {
+        if (k < p.Nc) {
+            double da, dz;
+            if (g.act_discrete & 1) {
+                int idx = reinterpret_cast<const int32_t *>(g.cam_act)[c.env * p.Nc + k];
+                idx = idx < 0 ? 0 : (idx >= g.n_cam_grid ? g.n_cam_grid - 1 : idx);
+                const double2 gxy = g.cam_grid[idx];
+                da = p.rot * gxy.x; dz = p.zoom * gxy.y;
+            } else if (g.act_f64 & 1) {
+                const double *a = reinterpret_cast<const double *>(g.cam_act) + (c.env * p.Nc + k) * 2;
+                da = a[0]; dz = a[1];
+            } else {
+                const float2 a = reinterpret_cast<const float2 *>(g.cam_act)[c.env * p.Nc + k];
+                da = (double)a.x; dz = (double)a.y;
+            }
+            act_cam[2 * k] = da; act_cam[2 * k + 1] = dz;
+        }
+    } else if (k < p.Nt) {
+        double ax, ay;
+        if (g.act_discrete & 2) {
+            int idx = reinterpret_cast<const int32_t *>(g.tgt_act)[c.env * p.Nt + k];
+            idx = idx < 0 ? 0 : (idx >= g.n_tgt_grid ? g.n_tgt_grid - 1 : idx);
+            const double2 gxy = g.tgt_grid[idx];
+            const double high = ((c.capword() >> k) & 1ull) ? p.tgt_step * 0.5 : p.tgt_step;   // loaded targets halve their step
+            ax = high * gxy.x; ay = high * gxy.y;
+        } else if (g.act_f64 & 2) {
+            const double *a = reinterpret_cast<const double *>(g.tgt_act) + (c.env * p.Nt + k) * 2;
+            ax = a[0]; ay = a[1];
+        } else {
+            const float2 a = reinterpret_cast<const float2 *>(g.tgt_act)[c.env * p.Nt + k];
+            ax = (double)a.x; ay = (double)a.y;
+        }
+        act_tgt[2 * k] = ax; act_tgt[2 * k + 1] = ay;
+    }
+}
+
 template <typename ObsT, typename Shape>
 __global__ __launch_bounds__(256, 4) void rollout_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q) {
     const Shape shape(pp);
@@ -478,6 +523,10 @@ __global__ __launch_bounds__(256, 4) void rollout_greedy_kernel(const Params *__
                 if (g.idle_steps) g.idle_steps[env_r] += 1;
             }
             continue;                                              // the next barrier is in the next step's agents
+        }
+        if (q.caller_team >= 0) {
+            load_caller_actions(c, q.caller_team, act_cam, act_tgt);
+            wave_sync();
         }
         const uint32_t tick = g.tick + (uint32_t)r;
         const StepDraws draws = step_draws(c, tick);               // see-through uniforms only (mode() is MODE_STEP)

@@ -117,34 +117,29 @@ class Engine:
     def _io(self, cam_act=None, tgt_act=None, tape_ct=None, tape_goal=None, want_masks=True):
         io = MateStepIO()
         keep = []
-        if tgt_act is not None:
-            # integer tensors are grid indices (set_action_grids): int32 [N, agents]; reals are [N, agents, 2]
+        if tgt_act is not None or cam_act is not None:
+            # integer tensors are grid indices (set_action_grids): int32 [N, agents]; reals are [N, agents, 2].
+            # One team alone = the caller's team of step_versus_greedy.
             ints = (torch.int32, torch.int64, torch.int16, torch.uint8)
-            tgt_discrete = tgt_act.dtype in ints
-            cam_discrete = self.num_cameras > 0 and cam_act is not None and cam_act.dtype in ints
-            reals = [a.dtype for a, d in ((tgt_act, tgt_discrete), (cam_act, cam_discrete)) if a is not None and not d]
+            if self.num_cameras == 0:
+                cam_act = None
+            teams = [(name, act, agents) for name, act, agents in (('camera', cam_act, self.num_cameras), ('target', tgt_act, self.num_targets))
+                     if act is not None]
+            reals = [act.dtype for _, act, _ in teams if act.dtype not in ints]
             act_dtype = reals[0] if reals else torch.float64
             assert act_dtype in (torch.float32, torch.float64)
-            io.act_dtype = (1 if act_dtype == torch.float64 else 0) | (0x100 if cam_discrete else 0) | (0x200 if tgt_discrete else 0)
-            if tgt_discrete:
-                assert getattr(self, 'target_action_grid', None) is not None, 'call set_action_grids(target_levels=...) first'
-                tgt_act = tgt_act.to(torch.int32).contiguous()
-                assert tgt_act.numel() == self.num_envs * self.num_targets and tgt_act.device == self.device
-            else:
-                tgt_act = tgt_act.to(act_dtype).contiguous()
-                assert tgt_act.numel() == self.num_envs * self.num_targets * 2 and tgt_act.device == self.device
-            io.target_actions_dev = tgt_act.data_ptr()
-            keep.append(tgt_act)
-            if self.num_cameras:
-                if cam_discrete:
-                    assert getattr(self, 'camera_action_grid', None) is not None, 'call set_action_grids(camera_levels=...) first'
-                    cam_act = cam_act.to(torch.int32).contiguous()
-                    assert cam_act.numel() == self.num_envs * self.num_cameras and cam_act.device == self.device
+            io.act_dtype = 1 if act_dtype == torch.float64 else 0
+            for name, act, agents in teams:
+                if act.dtype in ints:
+                    assert getattr(self, name + '_action_grid', None) is not None, f'call set_action_grids({name}_levels=...) first'
+                    act = act.to(torch.int32).contiguous()
+                    assert act.numel() == self.num_envs * agents and act.device == self.device
+                    io.act_dtype |= 0x100 if name == 'camera' else 0x200
                 else:
-                    cam_act = cam_act.to(act_dtype).contiguous()
-                    assert cam_act.numel() == self.num_envs * self.num_cameras * 2 and cam_act.device == self.device
-                io.camera_actions_dev = cam_act.data_ptr()
-                keep.append(cam_act)
+                    act = act.to(act_dtype).contiguous()
+                    assert act.numel() == self.num_envs * agents * 2 and act.device == self.device
+                setattr(io, name + '_actions_dev', act.data_ptr())
+                keep.append(act)
         if tape_ct is not None and self.num_cameras:
             tape_ct = tape_ct.to(torch.float64).contiguous()
             assert tape_ct.numel() == self.num_envs * self.num_cameras * self.num_targets
@@ -258,6 +253,22 @@ class Engine:
         first).  Same rollout-shaped tensors as rollout_random."""
         return self._run_rollout(self.lib.mate_engine_rollout_greedy, steps, auto_reset, want_masks)
 
+    def rollout_versus_greedy(self, team, joint_action, steps, auto_reset=True, want_masks=False):
+        """FrameSkip(frame_skip=steps) over MultiCamera / MultiTarget (examples/utils/wrappers.py:301-323 over
+        mate/wrappers/single_team.py:245-264) in ONE launch: the caller's `team` repeats `joint_action` for `steps` frames while
+        the on-device greedy opponents act anew on every frame.  Rollout-shaped tensors; the caller sums the reward rows."""
+        team = {'camera': 0, 'target': 1}.get(team, team)
+        assert team in (0, 1)
+        steps = int(steps)
+        buf = self.reserve_rollout(steps, want_masks)
+        io, keep = self._io(cam_act=joint_action if team == 0 else None, tgt_act=joint_action if team == 1 else None)
+        io.camera_obs_dev = buf['camera_obs'].data_ptr() if self.num_cameras else None
+        io.target_obs_dev = buf['target_obs'].data_ptr()
+        io.scalars_dev = buf['scalars'].data_ptr()
+        io.masks_dev = buf['masks'].data_ptr() if want_masks else None
+        check(self.lib.mate_engine_rollout_versus_greedy(self._h, team, ctypes.byref(io), steps, int(auto_reset), self._stream()))
+        return buf['camera_obs'][:steps], buf['target_obs'][:steps], buf['scalars'][:steps]
+
     def rollout_random(self, steps, auto_reset=True, want_masks=False):
         """`steps` fused steps under the on-device random policy.  Returns rollout-shaped tensors
         (camera_obs [T,N,Nc,Dc], target_obs [T,N,Nt,Dt], scalars [T,N,8]); scalars[..., 2] == 2 marks
@@ -319,23 +330,37 @@ class Engine:
         """Allocate the on-device policy state (call before the reset whose observations the agents act on)."""
         check(self.lib.mate_engine_policy_enable(self._h))
 
+    def _policy_tape(self, policy_tape, keep):
+        if policy_tape is None:
+            return None
+        tape = MatePolicyTape()
+        for name, dtype in (('camera_resample_u', torch.float64), ('camera_sample_u', torch.float64), ('camera_delay', torch.int32),
+                            ('target_choice_u', torch.float64), ('target_resample_u', torch.float64), ('target_sample_u', torch.float64),
+                            ('target_reset_sample_u', torch.float64)):
+            value = policy_tape.get(name)
+            if value is not None:
+                value = value.to(device=self.device, dtype=dtype).contiguous()
+                keep.append(value)
+                setattr(tape, name + '_dev', value.data_ptr())
+        return ctypes.byref(tape)
+
     def step_greedy(self, policy_tape=None, tape_ct=None, tape_goal=None, auto_reset=True):
         """One step with GreedyCameraAgent vs GreedyTargetAgent computed on the device.  `policy_tape`:
         dict of recorded agent draws (tensors) for parity runs.  Returns (camera_obs, target_obs, scalars)."""
         io, keep = self._io(tape_ct=tape_ct, tape_goal=tape_goal)
-        tape_ptr = None
-        if policy_tape is not None:
-            tape = MatePolicyTape()
-            for name, dtype in (('camera_resample_u', torch.float64), ('camera_sample_u', torch.float64), ('camera_delay', torch.int32),
-                                ('target_choice_u', torch.float64), ('target_resample_u', torch.float64), ('target_sample_u', torch.float64),
-                                ('target_reset_sample_u', torch.float64)):
-                value = policy_tape.get(name)
-                if value is not None:
-                    value = value.to(device=self.device, dtype=dtype).contiguous()
-                    keep.append(value)
-                    setattr(tape, name + '_dev', value.data_ptr())
-            tape_ptr = ctypes.byref(tape)
-        check(self.lib.mate_engine_step_greedy(self._h, ctypes.byref(io), tape_ptr, int(auto_reset), self._stream()))
+        check(self.lib.mate_engine_step_greedy(self._h, ctypes.byref(io), self._policy_tape(policy_tape, keep), int(auto_reset), self._stream()))
+        return self.camera_obs, self.target_obs, self.scalars
+
+    def step_versus_greedy(self, team, joint_action, policy_tape=None, tape_ct=None, tape_goal=None, auto_reset=True):
+        """MultiCamera (team = 'camera' / 0) or MultiTarget (team = 'target' / 1), mate/wrappers/single_team.py:245-264:
+        `joint_action` is the caller's team ([N, agents, 2] reals or [N, agents] grid indices), the opponents are the
+        on-device greedy agents.  Returns (camera_obs, target_obs, scalars)."""
+        team = {'camera': 0, 'target': 1}.get(team, team)
+        assert team in (0, 1)
+        io, keep = self._io(cam_act=joint_action if team == 0 else None, tgt_act=joint_action if team == 1 else None,
+                            tape_ct=tape_ct, tape_goal=tape_goal)
+        check(self.lib.mate_engine_step_versus_greedy(self._h, team, ctypes.byref(io), self._policy_tape(policy_tape, keep),
+                                                      int(auto_reset), self._stream()))
         return self.camera_obs, self.target_obs, self.scalars
 
     def policy_actions(self):
@@ -472,7 +497,7 @@ class Stepper:
         self.auto_reset = int(auto_reset)        # True / 1: immediate; k > 1: batched (finished environments idle up to k - 1 steps)
         self.io, self.keep = eng._io(cam_act, tgt_act)
         # _io may have made contiguous copies: the stepper must read the caller's own storage
-        assert self.keep[0].data_ptr() == tgt_act.data_ptr() and (eng.num_cameras == 0 or self.keep[1].data_ptr() == cam_act.data_ptr()), \
+        assert self.io.target_actions_dev == tgt_act.data_ptr() and (eng.num_cameras == 0 or self.io.camera_actions_dev == cam_act.data_ptr()), \
             'action tensors must be contiguous f32/f64 (or int32 grid indices) on the engine device'
         self.ref = ctypes.byref(self.io)
         self.graph = None

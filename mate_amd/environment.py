@@ -639,7 +639,10 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
         return [int(seed)]
 
     def reset(self, env_mask=None):
-        return self.engine.reset(env_mask)
+        out = self.engine.reset(env_mask)
+        for shaper in self.__dict__.get('_target_shapers', {}).values():
+            shaper.observe_reset()
+        return out
 
     def _result(self):
         s = self.engine.scalars
@@ -680,6 +683,23 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
         self.engine.enable_policies()
         self._policies_on = True
 
+    def step_versus_greedy(self, team, joint_action):
+        """MultiCamera(env, target_agent=GreedyTargetAgent()) for team = 'camera', MultiTarget(env,
+        camera_agent=GreedyCameraAgent()) for team = 'target' (mate/wrappers/single_team.py:281-306): the caller acts for
+        `team`, the greedy agents of the other team act on the device.  step()'s full result (both teams' observations
+        and rewards; a single-team learner reads its own half)."""
+        if not getattr(self, '_policies_on', False):
+            raise RuntimeError('enable_greedy_policies() must precede the reset() the agents first act on')
+        self.engine.step_versus_greedy(team, joint_action, auto_reset=self.auto_reset)
+        return self._result()
+
+    def rollout_versus_greedy(self, team, joint_action, frame_skip):
+        """FrameSkip(MultiCamera | MultiTarget, frame_skip) in one launch (examples/utils/wrappers.py:301-323): rollout-shaped
+        result; `rewards.sum(0)` is the wrapper's reward, `done.any(0)` its done."""
+        if not getattr(self, '_policies_on', False):
+            raise RuntimeError('enable_greedy_policies() must precede the reset() the agents first act on')
+        return self._rollout_result(self.engine.rollout_versus_greedy(team, joint_action, frame_skip, auto_reset=int(self.auto_reset)))
+
     def masks(self):
         return self.engine.unpack_masks()
 
@@ -718,6 +738,18 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
             shared = {'mean': reward.mean(dim=1), 'sum': reward.sum(dim=1), 'max': reward.max(dim=1).values, 'min': reward.min(dim=1).values}[reduction]
             reward = shared[:, None].expand(N, Nc)
         return reward
+
+    def auxiliary_target_rewards(self, coefficients, reduction='none'):
+        """Per-target shaped rewards of the last step, the reference's AuxiliaryTargetRewards wrapper
+        (wrappers/auxiliary_target_rewards.py:118-216) with constant coefficients: [num_envs, num_targets] on the GPU.  Call
+        it after every step (its `sparse_delivery` term compares the goals with those of the previous call; see
+        mate_amd/auxiliary_rewards.py)."""
+        key = (tuple(sorted(coefficients.items())), reduction)
+        shapers = self.__dict__.setdefault('_target_shapers', {})
+        if key not in shapers:
+            from mate_amd.auxiliary_rewards import AuxiliaryTargetRewards
+            shapers[key] = AuxiliaryTargetRewards(self.engine, coefficients, reduction)
+        return shapers[key]()
 
     def state_dict(self):
         return self.engine.state_dict()

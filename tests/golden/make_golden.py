@@ -277,7 +277,7 @@ def drain_agent_log(cam_agents, tgt_agents):
 
 
 def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f64_obs_steps=None, record_agents=False,
-               extra_factory=None, discrete_levels=None, aux_rewards=None):
+               extra_factory=None, discrete_levels=None, aux_rewards=None, aux_target_rewards=None):
     env = mate.make('MultiAgentTracking-v0', config=config, **(overrides or {}))
     env.seed(seed)
     cam_obs, tgt_obs = env.reset()
@@ -330,6 +330,14 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
         out['aux_keys'] = np.asarray(list(aux_rewards[0].keys()))
         out['aux_coefficients'] = np.asarray(list(aux_rewards[0].values()), dtype=np.float64)
         out['aux_reduction'] = np.str_(aux_rewards[1])
+    auxt = None
+    if aux_target_rewards is not None:  # ... and AuxiliaryTargetRewards the target rewards (wrappers/auxiliary_target_rewards.py)
+        auxt = mate.AuxiliaryTargetRewards(mate.RepeatedRewardIndividualDone(env), coefficients=aux_target_rewards[0],
+                                           reduction=aux_target_rewards[1])
+        out['auxt_keys'] = np.asarray(list(aux_target_rewards[0].keys()))
+        out['auxt_coefficients'] = np.asarray(list(aux_target_rewards[0].values()), dtype=np.float64)
+        out['auxt_reduction'] = np.str_(aux_target_rewards[1])
+        assert aux is None
 
     rng = np.random.RandomState(seed + 1000)
     if policy == 'greedy':
@@ -378,7 +386,15 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
         else:
             cam_act, tgt_act = random_actions(env, rng, step)
         log.clear()
-        if aux is None:
+        if auxt is not None:
+            (cam_obs, tgt_obs), (r_cams, shaped), (_, tgt_dones), (cam_infos, tgt_infos) = auxt.step((cam_act, tgt_act))
+            r_tgt, done = tgt_infos[0]['raw_reward'], tgt_dones[0]
+            r_cam = r_cams[0] if len(r_cams) else -r_tgt
+            push('aux_reward_tgt', np.asarray(shaped, dtype=np.float64))
+            for key in mate.AuxiliaryTargetRewards.ACCEPTABLE_KEYS:       # every term, whatever its coefficient
+                if key in aux_target_rewards[0]:
+                    push('auxt_' + key, np.asarray([info['auxiliary_reward_' + key] for info in tgt_infos], dtype=np.float64))
+        elif aux is None:
             (cam_obs, tgt_obs), (r_cam, r_tgt), done, (cam_infos, tgt_infos) = env.step((cam_act, tgt_act))
         else:
             (cam_obs, tgt_obs), (shaped, r_tgts), (cam_dones, _), (cam_infos, tgt_infos) = aux.step((cam_act, tgt_act))
@@ -414,7 +430,7 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
     for k, v in per_step.items():
         arr = np.stack(v)
         out['step/' + k] = arr
-    if record_agents:   # observations are not needed to check a policy: keep these fixtures small
+    if record_agents or auxt is not None:   # observations are not needed to check a policy / a reward: keep these fixtures small
         for k in ('step/cam_obs', 'step/tgt_obs', 'step/state'):
             out.pop(k, None)
     path = os.path.join(HERE, name + '.npz')
@@ -815,6 +831,17 @@ def main():
                    aux_rewards=({'soft_coverage_score': 1.0, 'real_coverage_rate': 1.0, 'baseline': -0.5}, 'mean'))
         make_trace('softcov_4v2-9_s10', 'MATE-4v2-9.yaml', 10, 'random', 48,
                    aux_rewards=({'soft_coverage_score': 1.0, 'mean_transport_rate': 3.0}, 'max'))
+        return
+    if sys.argv[1:] == ['auxtarget']:
+        every = {'raw_reward': 1.0, 'coverage_rate': -0.5, 'real_coverage_rate': -0.25, 'mean_transport_rate': 2.0,
+                 'normalized_goal_distance': -1.5, 'sparse_delivery': 100.0, 'soft_coverage_score': -0.75, 'is_tracked': -0.125,
+                 'is_colliding': -3.0, 'baseline': 0.0625}
+        make_trace('auxtgt_4v8-9_s11', 'MATE-4v8-9.yaml', 11, 'greedy', 120, aux_target_rewards=(every, 'none'))
+        make_trace('auxtgt_8v8-9_s12', 'MATE-8v8-9.yaml', 12, 'greedy', 64, aux_target_rewards=(every, 'mean'))
+        make_trace('auxtgt_4v2-9_s13', 'MATE-4v2-9.yaml', 13, 'random', 64,
+                   aux_target_rewards=({k: every[k] for k in ('raw_reward', 'normalized_goal_distance', 'is_colliding', 'soft_coverage_score')}, 'max'))
+        make_trace('auxtgt_nav_s14', 'MATE-Navigation.yaml', 14, 'greedy', 48,
+                   aux_target_rewards=({k: every[k] for k in ('raw_reward', 'normalized_goal_distance', 'sparse_delivery', 'is_colliding')}, 'sum'))
         return
     if sys.argv[1:] == ['reset']:
         for cfg_name, tag in (('MATE-4v2-9.yaml', '4v2-9'), ('MATE-4v8-9.yaml', '4v8-9'), ('MATE-8v8-9.yaml', '8v8-9'),

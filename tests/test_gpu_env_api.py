@@ -192,6 +192,38 @@ def test_auxiliary_camera_rewards_and_wrapper_kwargs():
     env.close()
 
 
+def test_single_team_training_flow_of_the_examples():
+    """The call pattern of examples/ippo/target/config.py on the batch: MultiTarget(env, GreedyCameraAgent) ->
+    AuxiliaryTargetRewards -> FrameSkip, i.e. the learner plays the targets (grid indices here: DiscreteTarget), the greedy
+    cameras run on the device, shaped per-target rewards come from the state, and k frames fuse into one launch."""
+    import torch
+    from mate_amd.environment import BatchedMultiAgentTracking
+    N = 48
+    env = BatchedMultiAgentTracking('MATE-4v8-9.yaml', num_envs=N, seed=5, discrete_target_levels=5, auto_reset=4, max_episode_steps=40)
+    env.enable_greedy_policies()
+    env.reset()
+    coef = {'raw_reward': 1.0, 'normalized_goal_distance': -1.0, 'sparse_delivery': 10.0, 'is_tracked': -0.5, 'is_colliding': -1.0,
+            'soft_coverage_score': -0.25}
+    g = torch.Generator(device='cpu').manual_seed(1)
+    episodes_before = env.state_dict()['episode'].copy()
+    for it in range(60):
+        act = torch.randint(0, 25, (N, 8), generator=g, dtype=torch.int32).cuda()
+        (co, to), (rc, rt), done, info = env.step_versus_greedy('target', act)
+        shaped = env.auxiliary_target_rewards(coef)
+        assert shaped.shape == (N, 8) and bool(torch.isfinite(shaped).all())
+        terms = env._target_shapers[next(iter(env._target_shapers))].terms
+        assert bool(((terms['normalized_goal_distance'] >= 0) & (terms['normalized_goal_distance'] <= 2 ** 0.5)).all())
+        assert bool(((terms['soft_coverage_score'] >= -1 - 1e-9) & (terms['soft_coverage_score'] <= 4 + 1e-9)).all())   # [-1, Nc]
+        tracked = torch.from_numpy(env.masks()['tracked_bits']).cuda()
+        assert torch.equal(terms['is_tracked'] != 0, tracked)
+    assert (env.state_dict()['episode'] > episodes_before).all()          # time limit 40: every environment restarted (batched, every 4th call)
+    (co, to), (rc, rt), done, info = env.rollout_versus_greedy('target', act, 4)     # FrameSkip(4)
+    assert rt.shape == (4, N) and to.shape[:2] == (4, N)
+    with pytest.raises(RuntimeError):
+        BatchedMultiAgentTracking('MATE-4v8-9.yaml', num_envs=4).step_versus_greedy('camera', torch.zeros(4, 4, 2).cuda())
+    env.close()
+
+
 def test_boundary_between_inner_and_outer():
     """Camera.boundary_between of the N=1 API (entities.py:513-543) on the reference's geometry: the knots inside a
     sector from the device-built tables, inner and (lazily enabled) outer, follow the reference's own tables."""

@@ -86,6 +86,38 @@ def test_trace_parity(path, dtype):
         check_obs(co, to, fx['step/cam_obs'][s], fx['step/tgt_obs'][s], ('step', s))
 
 
+@pytest.mark.parametrize('name', ['auxtgt_4v8-9_s11', 'auxtgt_8v8-9_s12', 'auxtgt_4v2-9_s13', 'auxtgt_nav_s14'])
+def test_auxiliary_target_rewards_fixtures(name):
+    """mate_amd.auxiliary_rewards.AuxiliaryTargetRewards on traces the reference's AuxiliaryTargetRewards wrapper shaped
+    (wrappers/auxiliary_target_rewards.py:118-216): every term and the shaped reward of every target and step.  The
+    per-target terms come from the f64 state (1e-9); the shared ones from the f32 step record (1e-6)."""
+    from mate_amd.auxiliary_rewards import AuxiliaryTargetRewards
+    fx = G.load(name + '.npz')
+    N = 3
+    eng = U.engine_from_fixture(fx, N, obs_dtype=torch.float32)
+    keys, coef, reduction = [str(k) for k in fx['auxt_keys']], [float(c) for c in fx['auxt_coefficients']], str(fx['auxt_reduction'])
+    if 'soft_coverage_score' in keys:
+        eng.enable_outer_boundary()
+        for c, (phis, rhos) in enumerate(G.luts_of(fx, outer=True)):
+            for e in range(N):
+                eng.lut_write(e, c, phis, rhos, outer=True)
+    shaper = AuxiliaryTargetRewards(eng, dict(zip(keys, coef)), reduction)
+    seen_delivery = False
+    for s in range(len(fx['step/done'])):
+        _replay(eng, fx, s, N)
+        shaped = shaper().cpu().numpy()
+        for key in keys:
+            term = shaper.terms[key].cpu().numpy()
+            loose = key in ('raw_reward', 'coverage_rate', 'real_coverage_rate', 'mean_transport_rate')
+            for e in range(N):
+                np.testing.assert_allclose(term[e], fx['step/auxt_' + key][s], rtol=1e-6 if loose else 1e-9, atol=1e-6 if loose else 1e-9,
+                                           err_msg=f'{key} step {s}')
+        for e in range(N):
+            np.testing.assert_allclose(shaped[e], fx['step/aux_reward_tgt'][s], rtol=1e-6, atol=1e-5, err_msg=str(s))
+        seen_delivery |= bool(fx['step/auxt_sparse_delivery'][s].any()) if 'sparse_delivery' in keys else False
+    assert seen_delivery == (name in ('auxtgt_4v8-9_s11', 'auxtgt_8v8-9_s12'))     # the delivery term is exercised
+
+
 @pytest.mark.parametrize('config,n', [('MATE-4v8-9.yaml', 256), ('MATE-8v8-9.yaml', 65), ('MATE-4v8-0.yaml', 64),
                                        ('MATE-Navigation.yaml', 64), ('MATE-4v2-9.yaml', 33), ('MATE-2v4-9.yaml', 16),
                                        ('MATE-1v1-0.yaml', 7)])

@@ -58,6 +58,119 @@ def test_greedy_policies_closed_loop(name):
         assert sd['episode_reward'][0] == fx['step/episode_reward'][s]
 
 
+@pytest.mark.parametrize('team', ['camera', 'target'])
+@pytest.mark.parametrize('name,act_dtype', [('greedy_4v8-9_s5', torch.float64), ('greedy_8v8-9_s6', torch.float64),
+                                            ('greedy_4v8-9_s5', torch.float32)])
+def test_single_team_versus_greedy_closed_loop(name, act_dtype, team):
+    """MultiCamera / MultiTarget (mate/wrappers/single_team.py:245-264): the caller's team replays the joint action the
+    reference's own agents took (fixture), the opponents are the on-device agents on the recorded draws -> the
+    reference's trace.  With f32 caller actions the f64 trace is only reproduced up to the rounding of those actions."""
+    fx = G.load(name + '.npz')
+    N = 2
+    eng = U.engine_from_fixture(fx, N, obs_dtype=torch.float64)
+    eng.enable_policies()
+    dev = eng.device
+    tape0 = torch.from_numpy(np.where(fx['reset/camera_target_view_mask'], 1.0, 0.0)[None].repeat(N, 0)).to(dev)
+    eng.observe(tape_ct=tape0)
+
+    def bc(a, dtype=np.float64):
+        a = np.asarray(a)
+        return torch.from_numpy(np.broadcast_to(a, (N,) + a.shape).astype(dtype).copy()).to(dev)
+
+    exact = act_dtype == torch.float64
+    tol = 1e-8 if exact else 2e-3
+    T = len(fx['step/done']) if exact else 25          # rounded actions: compare while the trajectories cannot have forked yet
+    for s in range(T):
+        tape = {
+            'camera_resample_u': bc(np.nan_to_num(fx['step/agent_cam_binom_u'][s], nan=0.0)),
+            'camera_sample_u': bc(np.nan_to_num(fx['step/agent_cam_sample_u'][s], nan=0.0)),
+            'camera_delay': bc(fx['step/agent_cam_delay'][s], np.int32),
+            'target_choice_u': bc(np.nan_to_num(fx['step/agent_tgt_choice_u'][s], nan=0.0)),
+            'target_resample_u': bc(np.nan_to_num(fx['step/agent_tgt_binom_u'][s], nan=0.0)),
+            'target_sample_u': bc(np.nan_to_num(fx['step/agent_tgt_sample_u'][s], nan=0.0)),
+            'target_reset_sample_u': bc(fx['agent/tgt_reset_sample_u']),
+        }
+        mine = bc(fx['step/cam_act' if team == 'camera' else 'step/tgt_act'][s]).to(act_dtype)
+        eng.step_versus_greedy(team, mine, policy_tape=tape, tape_ct=bc(np.nan_to_num(fx['step/tape_ct'][s], nan=0.0)),
+                               tape_goal=bc(np.nan_to_num(fx['step/goal_u'][s], nan=0.0)), auto_reset=False)
+        assert eng.last_flow == 0                      # mixed encodings / tapes: the generic kernel
+        cam_act, tgt_act = eng.policy_actions()        # the opponents' joint action is the recorded one
+        theirs, key = (tgt_act, 'step/tgt_act') if team == 'camera' else (cam_act, 'step/cam_act')
+        assert np.abs(theirs[1].cpu().numpy() - fx[key][s]).max() < tol, (key, s)
+        sd = eng.state_dict()
+        assert np.abs(sd['tgt_x'][0] - fx['step/tgt_xy'][s][:, 0]).max() < tol, s
+        assert np.abs(sd['cam_phi'][1] - fx['step/cam_phi'][s]).max() < tol, s
+        if exact:
+            masks = eng.unpack_masks()
+            assert np.array_equal(masks['camera_target_view_mask'][0], fx['step/camera_target_view_mask'][s]), s
+            assert np.array_equal(sd['tgt_goals'][0], fx['step/tgt_goals'][s].astype(np.float64)), s
+            assert np.array_equal(sd['bounties'][1], fx['step/bounties'][s].astype(np.float64)), s
+            assert sd['episode_reward'][0] == fx['step/episode_reward'][s]
+
+
+def test_single_team_versus_greedy_matches_step_greedy_on_philox():
+    """On Philox draws: engine A steps both greedy teams; engine B is fed A's target joint action as the caller's team (f64)
+    and A's camera joint action as grid indices is not possible, so: B1 = caller plays targets, B2 = caller plays cameras.
+    All three must stay bit-identical, auto-resets included."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=60)
+    engines = [Engine(cfg, 96, seed=11) for _ in range(3)]
+    for e in engines:
+        e.enable_policies()
+        e.reset()
+    a, b1, b2 = engines
+    for s in range(150):
+        a.step_greedy(auto_reset=True)
+        cam_act, tgt_act = a.policy_actions()
+        b1.step_versus_greedy('target', tgt_act, auto_reset=True)
+        b2.step_versus_greedy('camera', cam_act, auto_reset=True)
+        for b in (b1, b2):
+            assert torch.equal(a.scalars, b.scalars), s
+            assert torch.equal(a.target_obs, b.target_obs), s
+            assert torch.equal(a.camera_obs, b.camera_obs), s
+    assert (a.state_dict()['episode'] >= 2).all()
+
+
+@pytest.mark.parametrize('team,encoding', [('camera', 'f32'), ('target', 'f64'), ('camera', 'grid'), ('target', 'grid')])
+def test_frame_skip_rollout_versus_greedy_is_the_per_step_flow(team, encoding):
+    """FrameSkip over MultiCamera / MultiTarget fused into one launch (mate_engine_rollout_versus_greedy) against
+    frame_skip calls of mate_engine_step_versus_greedy with the same action: bit-identical rows, states, restarts."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=50)
+    N, K = 70, 5
+    a, b = (Engine(cfg, N, seed=23, obs_dtype=torch.float32) for _ in range(2))
+    for e in (a, b):
+        e.enable_policies()
+        e.set_action_grids(5, 5)
+        e.reset()
+    agents = a.num_cameras if team == 'camera' else a.num_targets
+    gen = torch.Generator(device='cpu').manual_seed(3)
+    for it in range(24):
+        if encoding == 'grid':
+            act = torch.randint(0, 25, (N, agents), generator=gen, dtype=torch.int32).to(a.device)
+        else:
+            scale = 5.0 if team == 'camera' else 1000.0     # beyond the action box: clipping / step-size normalisation is exercised
+            act = ((torch.rand((N, agents, 2), generator=gen, dtype=torch.float64) * 2 - 1) * scale).to(a.device)
+            act = act.to(torch.float32 if encoding == 'f32' else torch.float64)
+        cam, tgt, sc = a.rollout_versus_greedy(team, act, K, auto_reset=True)
+        alive = torch.ones(N, dtype=torch.bool, device=a.device)
+        for r in range(K):
+            # batched auto-reset every K calls = the rollout's semantics: a finished environment idles (done = 2) until the
+            # K-th call restarts all finished environments together
+            b.step_versus_greedy(team, act, auto_reset=K)
+            assert torch.equal(sc[r][:, :3], b.scalars[:, :3]), (it, r)       # reward, reward, done (2 = idle) of every environment
+            assert torch.equal(sc[r][alive], b.scalars[alive]), (it, r)        # (an idle row keeps its last metrics in the per-step buffer)
+            assert torch.equal(tgt[r][alive], b.target_obs[alive]), (it, r)
+            assert torch.equal(cam[r][alive], b.camera_obs[alive]), (it, r)
+            alive &= b.scalars[:, 2] == 0
+        sa, sb = a.state_dict(), b.state_dict()
+        for key in ('tgt_x', 'tgt_y', 'cam_phi', 'cam_theta', 'episode', 'episode_reward'):
+            assert np.array_equal(sa[key], sb[key]), (it, key)
+    assert (a.state_dict()['episode'] >= 2).any()
+
+
 def test_greedy_rollout_on_philox_streams():
     """C3-style workload: 8v8 Greedy vs Greedy stays on the device; episodes finish and auto-reset."""
     from mate_amd.config import read_config
