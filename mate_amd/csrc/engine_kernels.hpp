@@ -39,7 +39,7 @@ struct Params {
     double freight_scale, bounty_scale, reward_scale, max_team_reward;
     double obs_r_lo, obs_r_hi;
     uint32_t seed_lo, seed_hi, first_env;
-    int32_t desc_table_bytes, lds_wave_bytes, off_st, off_dy, off_tmp, off_scratch, off_mask, off_misc, off_flags, off_ent;
+    int32_t desc_table_bytes, lds_wave_bytes, off_st, off_dy, off_tmp, off_scratch, off_mask, off_misc, off_flags, off_ent, off_list;
     float inv_No;
     int32_t export_width;
     // Device-resident step counter (mate_engine_device_tick): while `dev_tick_on` the step kernels take the Philox
@@ -93,6 +93,7 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
     p.off_misc = off; off += shape_round_up((4 * Nt + 8) * 4, 16);
     p.off_flags = off; off += shape_round_up(p.nflags * obs_size, 16);
     p.off_ent = off; off += shape_round_up(3 * p.NJ * 8 + 3 * p.NJ * 4, 16);   // f64 table + its f32 shadow
+    p.off_list = off; off += (p.sector_rounds >= 2 && p.n_sector <= 256) ? shape_round_up(p.n_sector, 16) : 0;   // compacted sector candidates, one byte each (update_view)
     p.lds_wave_bytes = off;
 }
 
@@ -100,6 +101,8 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
 // FixedShape<Nc, Nt, No> is compiled for one scenario shape (the host picks it when the counts match).
 struct AnyShape {
     static constexpr bool kHoldRoles = false;      // rollout kernel: lane roles in registers (needs compile-time round counts)
+    static constexpr int kGreedyBlocks = 4;        // rollout_greedy_kernel: workgroups per CU the register budget is set for
+    static constexpr bool kGreedyHeld = false;     // ... and whether it keeps the observation descriptors in registers across steps
     const Params *pp;
     __device__ __forceinline__ explicit AnyShape(const Params *q) : pp(q) {}
     __device__ __forceinline__ const Params &get() const { return *pp; }
@@ -108,6 +111,8 @@ constexpr int shape_range_rounds(int Nc, int Nt, int No) { return (Nt * (Nc + No
 template <int NC, int NT, int NO, bool F64>
 struct FixedShape {
     static constexpr bool kHoldRoles = shape_range_rounds(NC, NT, NO) <= 3;      // 9 more VGPRs: fits beside the held descriptors
+    static constexpr int kGreedyBlocks = 4;
+    static constexpr bool kGreedyHeld = true;
     Params local;
     __device__ __forceinline__ explicit FixedShape(const Params *q) : local(*q) { fill_shape(local, NC, NT, NO, F64); }
     __device__ __forceinline__ const Params &get() const { return local; }
@@ -685,7 +690,12 @@ __device__ __forceinline__ int sector_role(const Params &p, int q) {      // cam
 }
 // `role`: sector_role of the pair, or kNoRole = derive it here (the fused rollout holds the last round's in a register)
 constexpr int kNoRole = -2;
-template <typename ObsT>
+// `relative.norm > self.sight_range` (entities.py:495-496) on squares; inside the rounding rim, on the roots themselves
+__device__ __forceinline__ bool sector_out_of_range(double d2, double s2) {
+    if (d2 > s2 * (1.0 + 1e-14)) return true;
+    return !(d2 < s2 * (1.0 - 1e-14)) && sqrt_pos(d2) > sqrt_pos(s2);
+}
+template <bool RANGED = false, typename ObsT>
 __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t tick, uint32_t stream, bool predrawn, int role = kNoRole) {
     const Params &p = c.p;
     SectorEval e{false, false, 0.0, 0.0, 0};
@@ -696,10 +706,8 @@ __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t 
     if (!is_target && cam == other) { e.seen = true; return e; }                   // environment.py:1383-1384
     const int oj = is_target ? c.tgt_slot(other) : other;
     const double rx = c.ex[oj] - c.ex[cam], ry = c.ey[oj] - c.ey[cam];
-    // `relative.norm > self.sight_range` (entities.py:495-496) on squares; inside the rounding rim, on the roots themselves
-    const double d2 = fma(ry, ry, rx * rx), s2 = c.sight2(cam);
-    if (d2 > s2 * (1.0 + 1e-14)) return e;
-    if (!(d2 < s2 * (1.0 - 1e-14)) && sqrt_pos(d2) > sqrt_pos(s2)) return e;
+    const double d2 = fma(ry, ry, rx * rx);
+    if (!RANGED && sector_out_of_range(d2, c.sight2(cam))) return e;              // RANGED: the caller has made this test
     const double ang = atan2_deg(ry, rx);
     double ra = fabs(c.phi(cam) - ang);
     const double alt = 360.0 - ra;
@@ -754,31 +762,48 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorE
     return sqrt_pos(e.rn) <= lim;
 }
 
-template <bool HELD, typename ObsT>
+// COMPACT (the fused rollouts): shapes with two or more rounds of sector pairs run the long part of the sector test on a
+// compacted list of the pairs in sight range.  The single-step kernel keeps the round-by-round form: it lives on a 64-VGPR /
+// 96-SGPR budget where the list bookkeeping spills, and measured 3 % slower with it.
+template <bool HELD, bool COMPACT = false, typename ObsT>
 __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn, const RangeRoles &held) {
     const Params &p = c.p;
     const int lane = c.lane;
     double2 w[kDegSlots];
-    // ---- sector tests for camera->target and camera->camera; all rounds but the last resolve at once
-    for (int round = 0; round + 1 < p.sector_rounds; ++round) {
-        const SectorEval e = sector_eval(c, round * 64 + lane, tick, stream, predrawn);
-        sector_fetch(c, e, w);
-        const bool seen = sector_resolve(c, e, w);
-        if (round * 64 + lane < p.n_sector) set_flag(c, round * 64 + lane, seen);
-        const unsigned long long b = __ballot(seen);
-        if (lane == 0) { c.mask[2 * round] = (uint32_t)b; c.mask[2 * round + 1] = (uint32_t)(b >> 32); }
+    int n_cand = 0;
+    uint8_t *cand = c.base + p.off_list;
+    const bool compact = COMPACT && p.sector_rounds >= 2 && p.n_sector <= 256;
+    if (compact) {
+        // ---- two or more rounds of sector pairs (8 cameras: 128): most are out of sight range, and only the others need the
+        // long part of Camera.perceive (atan2, the transmittance draw, the occlusion lookup).  Pass 1 makes the range test
+        // for every pair, settles the pairs it decides (out of range: hidden; a camera and itself: seen) and compacts the
+        // rest into a list; pass 2 runs the long part on the list, 64 candidates at a time (usually once).
+        for (int round = 0; round < p.sector_rounds; ++round) {
+            const int q = round * 64 + lane;
+            const int role = sector_role(p, q);
+            bool diag = false, in_range = false;
+            if (role >= 0) {
+                const int cam = role & 0xff, other = (role >> 8) & 0xff;
+                const bool is_target = (role >> 16) & 1;
+                diag = !is_target && cam == other;
+                if (!diag) {
+                    const int oj = is_target ? c.tgt_slot(other) : other;
+                    const double rx = c.ex[oj] - c.ex[cam], ry = c.ey[oj] - c.ey[cam];
+                    in_range = !sector_out_of_range(fma(ry, ry, rx * rx), c.sight2(cam));
+                }
+                set_flag(c, q, diag);
+            }
+            const unsigned long long b = __ballot(diag), m = __ballot(in_range);
+            if (lane == 0) { c.mask[2 * round] = (uint32_t)b; c.mask[2 * round + 1] = (uint32_t)(b >> 32); }
+            if (in_range) cand[n_cand + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint8_t)q;
+            n_cand += __popcll(m);
+        }
+        wave_sync();
     }
-    // the last round's occlusion records travel while the range tests run
-    const int last = p.sector_rounds - 1;
-    SectorEval pending{false, false, 0.0, 0.0, 0};
-    if (last >= 0) {
-        pending = sector_eval(c, last * 64 + lane, tick, stream, predrawn, HELD ? held.sector : kNoRole);
-        sector_fetch(c, pending, w);
-    }
-    SUB_STAMP(c, 13);
     // ---- range tests: Sensor.perceive (entities.py:229-232) target -> camera / obstacle / target.
     // Two passes: (1) all rounds' LDS reads and arithmetic back to back (independent chains overlap their
     // latency), results collected in a per-lane bit set; (2) flags, ballots and mask words.
+    auto range_tests = [&]() {
     const int rbase = p.bit_range >> 5;
     uint32_t seen_bits = 0;
     if constexpr (HELD) {
@@ -819,11 +844,43 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         const unsigned long long b = __ballot(seen);
         if (lane == 0) { c.mask[rbase + 2 * round] = (uint32_t)b; c.mask[rbase + 2 * round + 1] = (uint32_t)(b >> 32); }
     }
-    if (last >= 0) {
-        const bool seen = sector_resolve(c, pending, w);
-        if (last * 64 + lane < p.n_sector) set_flag(c, last * 64 + lane, seen);
-        const unsigned long long b = __ballot(seen);
-        if (lane == 0) { c.mask[2 * last] = (uint32_t)b; c.mask[2 * last + 1] = (uint32_t)(b >> 32); }
+    };
+    if (compact) {
+        // pass 2: the long part on the compacted list, 64 candidates at a time (usually one chunk).  (Not overlapped with the
+        // range tests as the one-round path below is: the occlusion records held across them cost 20 VGPRs the fused
+        // rollouts of these shapes do not have.)
+        for (int k = lane; k < n_cand; k += 64) {
+            const int q = cand[k];
+            const SectorEval e = sector_eval<true>(c, q, tick, stream, predrawn);
+            sector_fetch(c, e, w);
+            if (sector_resolve(c, e, w)) { set_flag(c, q, true); atomicOr(&c.mask[q >> 5], 1u << (q & 31)); }
+        }
+        range_tests();
+    } else {
+        // ---- sector tests for camera->target and camera->camera; all rounds but the last resolve at once, the last round's
+        // occlusion records travel while the range tests run
+        for (int round = 0; round + 1 < p.sector_rounds; ++round) {
+            const SectorEval e = sector_eval(c, round * 64 + lane, tick, stream, predrawn);
+            sector_fetch(c, e, w);
+            const bool seen = sector_resolve(c, e, w);
+            if (round * 64 + lane < p.n_sector) set_flag(c, round * 64 + lane, seen);
+            const unsigned long long b = __ballot(seen);
+            if (lane == 0) { c.mask[2 * round] = (uint32_t)b; c.mask[2 * round + 1] = (uint32_t)(b >> 32); }
+        }
+        const int last = p.sector_rounds - 1;
+        SectorEval pending{false, false, 0.0, 0.0, 0};
+        if (last >= 0) {
+            pending = sector_eval(c, last * 64 + lane, tick, stream, predrawn, HELD ? held.sector : kNoRole);
+            sector_fetch(c, pending, w);
+        }
+        SUB_STAMP(c, 13);
+        range_tests();
+        if (last >= 0) {
+            const bool seen = sector_resolve(c, pending, w);
+            if (last * 64 + lane < p.n_sector) set_flag(c, last * 64 + lane, seen);
+            const unsigned long long b = __ballot(seen);
+            if (lane == 0) { c.mask[2 * last] = (uint32_t)b; c.mask[2 * last + 1] = (uint32_t)(b >> 32); }
+        }
     }
     SUB_STAMP(c, 14);
     // ---- static camera->obstacle bits (environment.py:752-755) and the always-true bit
@@ -1438,7 +1495,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         ROLL_STAMP(1);
         if (!(MATE_ABLATE & 4)) simulate_targets(c, draws);
         ROLL_STAMP(2);
-        if (!(MATE_ABLATE & 8)) update_view<Shape::kHoldRoles>(c, tick, S_TRANSMIT, true, roles);
+        if (!(MATE_ABLATE & 8)) update_view<Shape::kHoldRoles, true>(c, tick, S_TRANSMIT, true, roles);
         ROLL_STAMP(3);
         if (!(MATE_ABLATE & 16)) assign_and_score(c, tick, g.scalars);
         ROLL_STAMP(4);

@@ -775,7 +775,7 @@ static int policy_enable(mate_engine *e) {
     q.PW = q.PF + (q.PI + 1) / 2;
     q.memory_period = 25;      // greedy.py:21
     q.noise_scale = 0.5;       // greedy.py:236
-    q.lds_bytes = round_up((q.PW + p.Nc * p.Nc / 2 + 2 + p.SW + p.DW) * 8 + p.MW * 4, 16);
+    q.lds_bytes = round_up((q.PW + policy_staging_words(p.Nc, p.Nt) + p.SW + p.DW) * 8 + p.MW * 4 + 4, 16);   // (+ one mask word of slack: seen_mask reads two)
     int rc;
     if ((rc = dev_alloc(e, &q.pol, (size_t)e->N * q.PW))) return rc;
     if ((rc = dev_alloc(e, &q.cam_act, (size_t)e->N * std::max(p.Nc, 1) * 2))) return rc;

@@ -50,6 +50,10 @@ struct PolicyPtrs {
 //   mem[c][t][2] | prev_action[c][2] | tgt_prev_xy[t][2] | tgt_prev_noise[t][2]
 // i32 part
 //   t2f[c][t] | delay[s][c] | neighbor[c][s] | has_state[c] | tgt_goal[t] | tgt_nonempty[t] | tgt_need[t] | episode
+#ifndef MATE_ABLATE            // experiment builds (tools/ablate_rollout.sh)
+#define MATE_ABLATE 0
+#endif
+
 template <typename ObsT>
 struct PolCtx {
     const Params &p;
@@ -72,9 +76,13 @@ struct PolCtx {
     __device__ int32_t &tgt_nonempty(int t) { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + p.Nt + t]; }
     __device__ int32_t &tgt_need(int t) { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + 2 * p.Nt + t]; }
     __device__ int32_t &episode() { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + 3 * p.Nt]; }
-    // scratch past the record: message staging
+    // scratch past the record (policy_staging_words): message staging, per-camera masks, per-pair distances
     __device__ int32_t &send_bits(int s, int c) { return i[q.PI + s * p.Nc + c]; }      // bit 31: 'state', bits 0..Nt-1: targets
+    __device__ int32_t &near_bits(int c) { return i[q.PI + p.Nc * p.Nc + c]; }          // targets within 110 % of the range of camera c
+    __device__ double &pair_dist(int c, int t) { return f[q.PW + (p.Nc * p.Nc + p.Nc) / 2 + 2 + c * p.Nt + t]; }
 };
+// 8-byte words of that scratch: Nc*Nc + Nc ints (possibly starting in the upper half of the record's last word), Nc*Nt doubles
+__host__ __device__ constexpr int policy_staging_words(int Nc, int Nt) { return (Nc * Nc + Nc) / 2 + 2 + Nc * Nt; }
 
 // sin of an angle in degrees, 0 <= deg <= 90: Taylor series to x^21 on the un-reduced argument
 // (remainder (pi/2)^23 / 23! = 1.2e-18), a third of the instructions of sincos_deg.
@@ -94,6 +102,23 @@ __device__ __forceinline__ double sin_deg_0_90(double deg) {
     return fma(x * z, ps, x);
 }
 
+// The zoom solve of GreedyCameraAgent.act: b <- area_product / (distance (1 + sin(b/2)))^2, 20 times from 180 (greedy.py:139-145),
+// with Kc = area_product / distance^2.  The map is a contraction (|f'| <= 0.65), so last-place differences do not grow: the
+// quotient is taken as Kc * (1/(1+sin))^2 with a Newton-refined reciprocal.  (An Estrin-form polynomial -- half the dependent
+// depth -- was no faster: the solving wave shares its SIMD with three others and is issue-bound, not latency-bound.)
+__device__ __forceinline__ double zoom_fixed_point(double Kc) {
+    double b = 180.0;
+    for (int it = 0; it < ((MATE_ABLATE & 256) ? 1 : 20); ++it) {
+        const double half = b * 0.5;
+        const double y = 1.0 + sin_deg_0_90(half < 90.0 ? half : 90.0);
+        double r = __builtin_amdgcn_rcp(y);
+        r = fma(r, fma(-y, r, 1.0), r);
+        r = fma(r, fma(-y, r, 1.0), r);
+        b = Kc * (r * r);
+    }
+    return b;
+}
+
 // One step of both teams' agents of ONE environment on LDS-resident data: `a` the agents' memory record, `st` / `dy` /
 // `di` the static and dynamic records, `mk` the packed view masks of the previous step.  Called by every wave of the
 // workgroup together (two barriers around the shared zoom solve).  Joint actions go to q.cam_act / q.tgt_act when
@@ -101,7 +126,13 @@ __device__ __forceinline__ double sin_deg_0_90(double deg) {
 template <typename ObsT>
 __device__ __forceinline__ void greedy_policy_body(const Params &p, const PolicyPtrs &q, PolCtx<ObsT> &a, const double *st, const double *dy,
                                                    const int32_t *di, const uint32_t *mk, double *shared_K, double *shared_B,
-                                                   int wave, int lane, int64_t env, bool active, double *lds_cam_act, double *lds_tgt_act) {
+                                                   int wave, int lane, int64_t env, bool active, double *lds_cam_act, double *lds_tgt_act,
+                                                   long long *acc = nullptr, long long *t_prev = nullptr) {
+#ifdef MATE_PHASE_CLOCKS
+#define POL_STAMP(i) do { if (acc) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); acc[i] += t_now - *t_prev; *t_prev = t_now; } } while (0)
+#else
+#define POL_STAMP(i) do { } while (0)
+#endif
     const int Nc = p.Nc, Nt = p.Nt;
     auto cam_x = [&](int c) { return st[c]; };
     auto cam_y = [&](int c) { return st[Nc + c]; };
@@ -124,24 +155,30 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     const uint64_t capword = reinterpret_cast<const uint64_t *>(st)[3 * Nc + 3 * p.No];
 
     // ------------------------------------------------------------------ reset + observe
-    if (lane < Nc) {                                        // GreedyCameraAgent.reset / process_messages (greedy.py:43-61,100-113)
-        const int c = lane;
-        if (fresh) {
-            for (int t = 0; t < Nt; ++t) {
-                const bool s = sees(c, t);
-                a.mem(c, t, 0) = s ? tx(t) : 0.0; a.mem(c, t, 1) = s ? ty(t) : 0.0;   // hidden rows of the observation are zeros
-                a.t2f(c, t) = s ? q.memory_period : 0;
-            }
-            a.prev_action(c, 0) = 0.0; a.prev_action(c, 1) = 0.0;
-            for (int s = 0; s < Nc; ++s) { a.delay(c, s) = 0; a.neighbor(c, s) = 0; }
-            a.has_state(c) = 1;
-        }
-        for (int t = 0; t < Nt; ++t) {
-            int left = a.t2f(c, t) - 1;
-            if (left < 0) left = 0;
-            if (sees(c, t)) { left = q.memory_period; a.mem(c, t, 0) = tx(t); a.mem(c, t, 1) = ty(t); }
-            a.t2f(c, t) = left;
-        }
+    // The camera agents' bookkeeping runs on PAIR lanes (camera c, target t) -- Nc*Nt of them instead of Nc lanes looping over
+    // the targets -- and on (sender, recipient) lanes for the messages; per-camera lanes only scan what those left in LDS.
+    auto seen_mask = [&](int c) -> uint32_t {              // row c of camera_target_view_mask: bits [c Nt, c Nt + Nt) of the packed words
+        const int b = c * Nt;
+        const uint64_t w = (uint64_t)mk[b >> 5] | ((uint64_t)mk[(b >> 5) + 1] << 32);
+        return (uint32_t)(w >> (b & 31)) & ((1u << Nt) - 1u);
+    };
+    const double threshold = 1.1 * p.rmax;                  // filterout_beyond_range / the tracking reach: 110 % of the range
+    if (lane < Nc) a.near_bits(lane) = 0;
+    if (fresh) {                                            // GreedyCameraAgent.reset (greedy.py:43-61)
+        if (lane < Nc) { a.prev_action(lane, 0) = 0.0; a.prev_action(lane, 1) = 0.0; a.has_state(lane) = 1; }
+        for (int k = lane; k < Nc * Nc; k += 64) { a.i[Nc * Nt + k] = 0; a.i[Nc * Nt + Nc * Nc + k] = 0; }   // delay, neighbor
+    }
+    wave_sync();
+    for (int k = lane; k < Nc * Nt; k += 64) {              // process_messages of the observation (greedy.py:100-113)
+        const int c = (int)(((float)k + 0.5f) * p.inv_Nt), t = k - c * Nt;
+        const bool s = sees(c, t);
+        int left = 0;
+        if (fresh) { a.mem(c, t, 0) = 0.0; a.mem(c, t, 1) = 0.0; }      // hidden rows of the first observation are zeros
+        else { left = a.t2f(c, t) - 1; if (left < 0) left = 0; }
+        const double x = tx(t), y = ty(t);
+        if (s) { left = q.memory_period; a.mem(c, t, 0) = x; a.mem(c, t, 1) = y; }
+        a.t2f(c, t) = left;
+        if (norm2(x - cam_x(c), y - cam_y(c)) < threshold) atomicOr(&a.near_bits(c), 1 << t);
     }
     const int tl = lane - 32;
     if (tl >= 0 && tl < Nt) {                               // GreedyTargetAgent.reset / process_messages (greedy.py:262-283,326-332)
@@ -165,6 +202,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     }
     if (lane == 0 && fresh) a.episode() = env_i[EI_EPISODE];
     wave_sync();
+    POL_STAMP(8);
 
     // ------------------------------------------------------------------ communicate
     // cameras: send_responses (greedy.py:158-190), one lane per (sender, recipient)
@@ -174,19 +212,12 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         int d = a.delay(s, c) - 1;
         if (d < 0) d = 0;
         // message2send is non-empty iff it still holds 'state' or a target was seen this step
-        uint32_t seen_now = 0;
-        for (int t = 0; t < Nt; ++t) seen_now |= (uint32_t)sees(s, t) << t;
-        const bool has_content = a.has_state(s) || seen_now;
-        if (has_content && s != c && d == 0) {
-            uint32_t list = 0;
-            if (seen_now && a.neighbor(s, c)) {            // filterout_beyond_range: 110 % of the teammate's range
-                const double threshold = 1.1 * p.rmax;
-                for (uint32_t m = seen_now; m; m &= m - 1) {          // only the targets seen this step
-                    const int t = __ffs((int)m) - 1;
-                    if (norm2(tx(t) - cam_x(c), ty(t) - cam_y(c)) < threshold) list |= 1u << t;
-                }
-            }
-            bits = (int)list | (a.has_state(s) ? (int)0x80000000u : 0);
+        const uint32_t seen_now = seen_mask(s);
+        const bool has_state = a.has_state(s) != 0;
+        if ((has_state || seen_now) && s != c && d == 0) {
+            // filterout_beyond_range: of the targets seen this step, those within 110 % of the teammate's range
+            const uint32_t list = a.neighbor(s, c) ? (seen_now & (uint32_t)a.near_bits(c)) : 0u;
+            bits = (int)list | (has_state ? (int)0x80000000u : 0);
             if (bits) {
                 int v;
                 if (q.tape.cam_delay) v = q.tape.cam_delay[(env * Nc + s) * Nc + c];
@@ -195,28 +226,28 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
                 d = v;
             }
         }
-        if (has_content) a.delay(s, c) = d;                 // the decrement happens only inside `if len(message2send) > 0`... see note
-        else a.delay(s, c) = d;
+        a.delay(s, c) = d;
         a.send_bits(s, c) = bits;
-    }
+        if (bits < 0) a.neighbor(c, s) = 1;                 // receive_responses: the recipient learns its neighbour (greedy.py:192-226);
+    }                                                       // (every lane read neighbor(s, c) above before any lane writes here)
     wave_sync();
-    if (lane < Nc) {                                        // receive_responses (greedy.py:192-226) + message2send.clear()
-        const int c = lane;
-        for (int s = 0; s < Nc; ++s) {
-            const int bits = a.send_bits(s, c);
-            if (bits == 0) continue;
-            if (bits & (int)0x80000000u) a.neighbor(c, s) = 1;
-            for (uint32_t m = (uint32_t)bits & 0xffffu; m; m &= m - 1) {
-                const int t = __ffs((int)m) - 1;
-                a.mem(c, t, 0) = tx(t); a.mem(c, t, 1) = ty(t); a.t2f(c, t) = q.memory_period;
-            }
+    for (int k = lane; k < Nc * Nt; k += 64) {              // ... and the positions of the targets it was told about
+        const int c = (int)(((float)k + 0.5f) * p.inv_Nt), t = k - c * Nt;
+        int told = 0;
+        for (int s = 0; s < Nc; ++s) told |= a.send_bits(s, c);
+        if ((told >> t) & 1) { a.mem(c, t, 0) = tx(t); a.mem(c, t, 1) = ty(t); a.t2f(c, t) = q.memory_period; }
+    }
+    if (lane < Nc && (a.has_state(lane) || seen_mask(lane))) a.has_state(lane) = 0;   // message2send.clear()
+    wave_sync();
+    // the tracking candidates: distance camera -> remembered position, +inf when forgotten or out of reach (greedy.py:115-127)
+    for (int k = lane; k < Nc * Nt; k += 64) {
+        const int c = (int)(((float)k + 0.5f) * p.inv_Nt), t = k - c * Nt;
+        double dn = INFINITY;
+        if (a.t2f(c, t) > 0) {
+            const double dnorm = norm2(a.mem(c, t, 0) - cam_x(c), a.mem(c, t, 1) - cam_y(c));
+            if (dnorm < threshold) dn = dnorm;
         }
-    }
-    wave_sync();
-    if (lane < Nc) {
-        uint32_t seen_now = 0;
-        for (int t = 0; t < Nt; ++t) seen_now |= (uint32_t)sees(lane, t) << t;
-        if (a.has_state(lane) || seen_now) a.has_state(lane) = 0;   // message2send.clear()
+        a.pair_dist(c, t) = dn;
     }
     // targets: broadcast non-empty warehouse sets (greedy.py:334-358)
     if (tl >= 0 && tl < Nt) {
@@ -230,6 +261,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     }
     wave_sync();
 
+    POL_STAMP(11);
     // ------------------------------------------------------------------ act
     // GreedyCameraAgent.act (greedy.py:69-156), part 1: pick the target, decide which viewing-angle rule applies
     int best = -1;
@@ -246,15 +278,10 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         orientation = phi;
         const double q2 = div_nz(sight, p.rmax);
         min_va = theta * (q2 * q2);
-        const double threshold = 1.1 * p.rmax;
-        double best_d = 0.0;
-        uint32_t remembered = 0;
-        for (int t = 0; t < Nt; ++t) remembered |= (uint32_t)(a.t2f(c, t) > 0) << t;
-        for (uint32_t m = remembered; m; m &= m - 1) {               // ascending t, like the reference's loop
-            const int t = __ffs((int)m) - 1;
-            const double dnorm = norm2(a.mem(c, t, 0) - cam_x(c), a.mem(c, t, 1) - cam_y(c));
-            if (!(dnorm < threshold)) continue;
-            if (best < 0 || dnorm < best_d) { best = t; best_d = dnorm; }
+        double best_d = INFINITY;
+        for (int t = 0; t < Nt; ++t) {                               // ascending t, first minimum wins, like the reference's loop
+            const double dnorm = a.pair_dist(c, t);
+            if (dnorm < best_d) { best = t; best_d = dnorm; }
         }
         if (best >= 0) {
             const double rx = a.mem(c, best, 0) - cam_x(c), ry = a.mem(c, best, 1) - cam_y(c);
@@ -268,27 +295,17 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
             }
         }
     }
-    // The zoom solve: b <- area_product / (distance (1 + sin(b/2)))^2, 20 times from 180 (greedy.py:139-145), is the
-    // longest dependent chain of the kernel and runs on at most Nc lanes of a wave.  The four waves of the workgroup
-    // publish their cameras' K = area_product / distance^2 and ONE wave iterates all of them (4 x Nc lanes busy
-    // instead of Nc, a quarter of the issue slots).  The map is a contraction (|f'| <= 0.65), so last-place
-    // differences do not grow: the quotient is taken as K * (1/(1+sin))^2 with a Newton-refined reciprocal.
+    // The zoom solve is the longest dependent chain of the agents' step and runs on at most Nc lanes of a wave: the four waves
+    // of the workgroup publish their cameras' K = area_product / distance^2 and ONE wave iterates all of them (4 x Nc lanes
+    // busy instead of Nc, a quarter of the issue slots).  Measured alternatives, all slower or equal: every wave solving its
+    // own cameras without the barriers (the chain then costs each wave 6.6 k cycles of a 48 k-cycle step), the solving wave
+    // at top issue priority (-3 %), an Estrin-form polynomial.
     if (lane < 16) shared_K[wave * 16 + lane] = solve ? K : 1.0;
+    POL_STAMP(12);
     __syncthreads();
-    if (wave == 0) {
-        const double Kc = shared_K[lane];
-        double b = 180.0;
-        for (int it = 0; it < 20; ++it) {
-            const double half = b * 0.5;
-            const double y = 1.0 + sin_deg_0_90(half < 90.0 ? half : 90.0);
-            double r = __builtin_amdgcn_rcp(y);
-            r = fma(r, fma(-y, r, 1.0), r);
-            r = fma(r, fma(-y, r, 1.0), r);
-            b = Kc * (r * r);
-        }
-        shared_B[lane] = b;
-    }
+    if (wave == 0) shared_B[lane] = zoom_fixed_point(shared_K[lane]);
     __syncthreads();
+    POL_STAMP(9);
     if (lane < Nc) {                                        // part 2: the action
         const int c = lane;
         double a0, a1;
@@ -378,7 +395,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     double *shared_B = shared_K + 64;
     // LDS: [policy record + staging][static record][dynamic record][mask words]
     PolCtx<ObsT> a(p, q, base);
-    double *st = reinterpret_cast<double *>(base + (size_t)(q.PW + p.Nc * p.Nc / 2 + 2) * 8);
+    double *st = reinterpret_cast<double *>(base + (size_t)(q.PW + policy_staging_words(p.Nc, p.Nt)) * 8);
     double *dy = st + p.SW;
     int32_t *di = reinterpret_cast<int32_t *>(dy + p.DF);
     uint32_t *mk = reinterpret_cast<uint32_t *>(dy + p.DW);
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
 // bit (tested).  The four waves of a workgroup meet at the two barriers of the shared zoom solve in every step, so no
 // wave leaves the loop early: a wave past the end of the batch, or whose episode has ended, keeps running the
 // agents' step on its stale data (no stores) and skips the environment's step.
-__host__ __device__ constexpr int policy_slice_bytes(int PW, int Nc, int Nt) { return shape_round_up((PW + Nc * Nc / 2 + 2 + 2 * (Nc + Nt)) * 8, 16); }
+__host__ __device__ constexpr int policy_slice_bytes(int PW, int Nc, int Nt) { return shape_round_up((PW + policy_staging_words(Nc, Nt) + 2 * (Nc + Nt)) * 8, 16); }
 
 // The caller's team of a fused rollout: its joint action, decoded as step() would (f32 / f64 pairs, or grid indices:
 // DiscreteCamera.action / DiscreteTarget.action, discrete_action_spaces.py:71-73, 177-179), over the agents' in LDS.
@@ -455,7 +472,7 @@ __device__ __forceinline__ void load_caller_actions(Ctx<ObsT> &c, int team, doub
 }
 
 template <typename ObsT, typename Shape>
-__global__ __launch_bounds__(256, 4) void rollout_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q) {
+__global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q) {
     const Shape shape(pp);
     const Params &p = shape.get();
     extern __shared__ __align__(16) unsigned char smem[];
@@ -470,7 +487,7 @@ __global__ __launch_bounds__(256, 4) void rollout_greedy_kernel(const Params *__
     double *shared_K = reinterpret_cast<double *>(smem + 4 * p.lds_wave_bytes + 4 * pol_bytes);
     double *shared_B = shared_K + 64;
     PolCtx<ObsT> a(p, q, pol_base);
-    double *act_cam = a.f + (q.PW + p.Nc * p.Nc / 2 + 2), *act_tgt = act_cam + 2 * p.Nc;
+    double *act_cam = a.f + (q.PW + policy_staging_words(p.Nc, p.Nt)), *act_tgt = act_cam + 2 * p.Nc;
     {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
         load_records(c);
@@ -486,12 +503,22 @@ __global__ __launch_bounds__(256, 4) void rollout_greedy_kernel(const Params *__
     PackDescriptors held;
     {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
-        load_pack_descriptors(c, held);
+        if constexpr (Shape::kGreedyHeld) load_pack_descriptors(c, held);
     }
     uint32_t hw_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     const int wave_slot = (int)(hw_id & 15u);
     bool stepped = false;                                          // statics written (see Ctx::statics_done)
+#ifdef MATE_PHASE_CLOCKS
+    long long acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // 0-6 as in rollout_kernel, 7 loop, 8 agents observe, 11 communicate, 12 choose, 9 the zoom solve, 10 the actions
+    long long t_prev = (long long)__builtin_amdgcn_s_memtime();
+    const long long t_first = t_prev, r_first = (long long)__builtin_amdgcn_s_memrealtime();
+#define GREEDY_STAMP(i) do { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#define GREEDY_ACC acc, &t_prev
+#else
+#define GREEDY_STAMP(i) do { } while (0)
+#define GREEDY_ACC nullptr, nullptr
+#endif
 #pragma clang loop unroll(disable)
     for (int r = 0; r < g.rollout_steps; ++r) {
         int lane_r = lane, wave_r = wave;                          // opaque per iteration, see rollout_kernel
@@ -515,8 +542,10 @@ __global__ __launch_bounds__(256, 4) void rollout_greedy_kernel(const Params *__
             else if (turn == 2) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(3);
         }
-        greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, c.mask, shared_K, shared_B, wave_r, lane_r, env_r, active, act_cam, act_tgt);
+        GREEDY_STAMP(7);
+        if (!(MATE_ABLATE & 128)) greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, c.mask, shared_K, shared_B, wave_r, lane_r, env_r, active, act_cam, act_tgt, GREEDY_ACC);
         wave_sync();
+        GREEDY_STAMP(10);
         if (!active) {
             if (in_batch && lane_r == 0) {
                 if (g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
@@ -529,16 +558,34 @@ __global__ __launch_bounds__(256, 4) void rollout_greedy_kernel(const Params *__
             wave_sync();
         }
         const uint32_t tick = g.tick + (uint32_t)r;
-        const StepDraws draws = step_draws(c, tick);               // see-through uniforms only (mode() is MODE_STEP)
-        simulate_cameras(c, draws, true);
-        simulate_targets(c, draws);
-        update_view(c, tick, S_TRANSMIT, true);
-        assign_and_score(c, tick, g.scalars);
-        fill_scratch(c);
-        pack_observations<true>(c, held);
+        StepDraws draws{0.0, 0.0};
+        if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick);       // see-through uniforms only (mode() is MODE_STEP)
+        GREEDY_STAMP(0);
+        if (!(MATE_ABLATE & 2)) simulate_cameras(c, draws, true);
+        GREEDY_STAMP(1);
+        if (!(MATE_ABLATE & 4)) simulate_targets(c, draws);
+        GREEDY_STAMP(2);
+        if (!(MATE_ABLATE & 8)) { RangeRoles none; update_view<false, true>(c, tick, S_TRANSMIT, true, none); }
+        GREEDY_STAMP(3);
+        if (!(MATE_ABLATE & 16)) assign_and_score(c, tick, g.scalars);
+        GREEDY_STAMP(4);
+        if (!(MATE_ABLATE & 32)) fill_scratch(c);
+        GREEDY_STAMP(5);
+        if (!(MATE_ABLATE & 64)) {
+            if constexpr (Shape::kGreedyHeld) pack_observations<true>(c, held);
+            else { PackDescriptors now; pack_observations<false>(c, now); }
+        }
         wave_sync();
         stepped = true;
+        GREEDY_STAMP(6);
     }
+#ifdef MATE_PHASE_CLOCKS
+    if (in_batch && lane == 0 && g.phase_clocks) {
+        for (int i = 0; i < 13; ++i) g.phase_clocks[env * 16 + i] = acc[i];
+        g.phase_clocks[env * 16 + 14] = (long long)__builtin_amdgcn_s_memtime() - t_first;
+        g.phase_clocks[env * 16 + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_first;
+    }
+#endif
     if (in_batch) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
         store_dynamic(c);
