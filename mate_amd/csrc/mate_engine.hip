@@ -130,7 +130,8 @@ static void layout_reset_lds(const Params &p, ResetLds &rl, int sort_cap) {
     // (the placement phase borrows the start of the sort region for its list of placed circles: keep that much in the LDS)
     const int place_bytes = round_up(5 * (4 + p.Nc + p.No + p.Nt) * 8 + (p.Nc + p.No + 2 * p.Nt) * 4 + 64, 16);
     int roff = p.lds_wave_bytes;
-    rl.off_keys = roff; roff += rl.sort_in_hbm ? place_bytes : in_lds;
+    rl.off_pre = roff + place_bytes;                       // 256 precomputed placement uniforms behind the list of placed circles
+    rl.off_keys = roff; roff += std::max(rl.sort_in_hbm ? 0 : in_lds, place_bytes + 2048);
     rl.off_vals = roff; roff += in_lds;
     rl.off_okeys = roff; roff += in_lds;
     rl.off_ovals = roff; roff += in_lds;
@@ -540,7 +541,8 @@ static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_
     if ((phases & PH_LUT) && p.Nc > 1 && kind != RESET_DONE && !(mono && atoi(mono))) {
         // placement: one wave per environment; tables: one workgroup per (environment, camera); view: one wave
         // reset_place scratch behind the wave slice: 5 arrays of placed circles + the shuffle permutations
-        const size_t lds_place = (size_t)e->rl.off_keys + 5 * (size_t)(4 + p.Nc + p.No + p.Nt) * 8 + (size_t)(p.Nc + p.No + 2 * p.Nt) * 4 + 64;
+        // (+ the 256 precomputed uniforms of the reset stream behind them)
+        const size_t lds_place = (size_t)e->rl.off_pre + 2048;
         if (phases & PH_PLACE) {
             const bool selective = kind == RESET_FLAGGED || kind == RESET_MASK;
             if (selective) HIP_TRY(hipMemsetAsync(g.flag_count, 0, sizeof(int32_t), stream));

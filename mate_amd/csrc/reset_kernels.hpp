@@ -17,6 +17,7 @@ enum ResetPhase : int32_t { PH_PLACE = 1, PH_LUT = 2, PH_VIEW = 4, PH_PER_CAMERA
 
 struct ResetLds {   // byte offsets inside the workgroup's dynamic LDS, after the wave-0 context
     int32_t off_keys, off_vals, off_okeys, off_ovals, off_bucket, off_meta, off_scan, sort_cap, total_bytes;
+    int32_t off_pre;       // 256 uniforms of the placement's reset stream, drawn by the whole wave before one lane consumes them
     int32_t sort_in_hbm;   // the four sort arrays (4 x sort_cap doubles) do not fit the 160 KiB LDS next to the rest: they live in
                            // Ptrs::sort_scratch, one slice per workgroup of a capped grid (scenarios beyond 20 obstacles per camera table)
 };
@@ -28,9 +29,12 @@ struct ResetRng {
     uint32_t k0, k1, env, episode, n;
     const double *tape;      // this environment's row of the tape, or nullptr
     uint32_t tape_len;
+    const double *pre;       // the first `pre_count` draws of the Philox stream, precomputed by all lanes (reset_kernel)
+    uint32_t pre_count;
     __device__ double draw() {
         const uint32_t idx = n++;
         if (tape) return idx < tape_len ? tape[idx] : 0.0;      // an overrun shows in the returned draw count
+        if (idx < pre_count) return pre[idx];
         const U4 r = philox(k0, k1, env, episode, S_RESET, idx >> 1);
         return (idx & 1u) ? u53(r.z, r.w) : u53(r.x, r.y);
     }
@@ -50,13 +54,14 @@ __device__ __forceinline__ int pick_goal(const int32_t *row, double u) {  // np_
 
 // R1: runs on ONE lane; all state lives in the wave context's LDS records.
 template <typename ObsT>
-__device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][cap] x y r sight iscam */, int placed_cap) {
+__device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][cap] x y r sight iscam */, int placed_cap,
+                                            const double *pre = nullptr, uint32_t pre_count = 0) {
     const Params &p = c.p;
     const int Nc = p.Nc, Nt = p.Nt, No = p.No;
     const uint32_t episode = (uint32_t)c.ei(EI_EPISODE) + 1u;
     c.ei(EI_EPISODE) = (int32_t)episode;
     ResetRng rng{p.seed_lo, p.seed_hi, c.env_global(), episode, 0u,
-                 c.g.reset_tape ? c.g.reset_tape + c.env * (int64_t)c.g.reset_tape_len : nullptr, (uint32_t)c.g.reset_tape_len};
+                 c.g.reset_tape ? c.g.reset_tape + c.env * (int64_t)c.g.reset_tape_len : nullptr, (uint32_t)c.g.reset_tape_len, pre, pre_count};
     double *px = placed, *py = placed + placed_cap, *pr = placed + 2 * placed_cap, *ps = placed + 3 * placed_cap, *pk = placed + 4 * placed_cap;
     int32_t *perm = reinterpret_cast<int32_t *>(placed + 5 * placed_cap);   // [Nc + Nt + No]
     int32_t *perm_c = perm, *perm_t = perm + Nc, *perm_o = perm + Nc + Nt;
@@ -201,7 +206,7 @@ __device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][
 // R2: occlusion table of camera `cam` by the whole workgroup.
 template <typename ObsT>
 __device__ __forceinline__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, double *okeys, double *ovals, uint16_t *lbucket,
-                          double *meta, int32_t *scan, int sort_cap, bool outer = false) {
+                          double *meta, int32_t *scan, int sort_cap, bool outer = false, bool in_hbm = false) {
     const Params &p = c.p;
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int No = p.No;
@@ -269,7 +274,13 @@ __device__ __forceinline__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, d
     int P = 512;
     while (P < nr) P <<= 1;          // nr <= sort_cap by construction
     (void)sort_cap;
-    for (int i = tid; i < P; i += nthreads) {
+    // The 360 integer-degree rays are generated in angle order: only the obstacle rays (edge + arc rays, typically ~20 per
+    // obstacle in range) are sorted -- in okeys / ovals -- and then merged with the degree grid by rank.  (Sorting all
+    // 360 + 21 No rays bitonically was 55 % of a reset's GPU time.)
+    const int nobs = nr - 360;
+    int P2 = 64;
+    while (P2 < nobs) P2 <<= 1;
+    for (int i = tid; i < 360 + P2; i += nthreads) {
         double key = __longlong_as_double(0x7ff0000000000000ll), val = 0.0;
         if (i < nr) {
             double a, n0;
@@ -307,40 +318,89 @@ __device__ __forceinline__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, d
             }
             double sn, cs;
             sincos_deg(a, sn, cs);
-            for (int q = 0; q < No; ++q)                                          // entities.py:450-455
-                if (m_num[q] > 0) n0 = clip_polar(n0, cs, sn, m_relx[q], m_rely[q], m_rn[q], m_rad[q], outer);
+            for (int q = 0; q < No; ++q) {                                        // entities.py:450-455
+                if (m_num[q] <= 0) continue;
+                // a ray whose LINE passes the circle at more than its radius (+ 1e-6 relative and absolute: a million times the
+                // rounding of clip_polar's own perpendicular) is returned unchanged by Obstacle.obstruct: two fmas screen it out
+                const double relx = m_relx[q], rely = m_rely[q], rad = m_rad[q];
+                if (fabs(fma(relx, sn, -(rely * cs))) > fma(rad, 1e-6, rad) + 1e-6) continue;
+                n0 = clip_polar(n0, cs, sn, relx, rely, m_rn[q], rad, outer);
+            }
             key = a; val = n0;
         }
-        keys[i] = key; vals[i] = val;
+        if (i < 360) { keys[i] = key; vals[i] = val; } else { okeys[i - 360] = key; ovals[i - 360] = val; }
     }
     __syncthreads();
-    // bitonic sort by angle (entities.py:458); equal angles are merged below, so stability is moot
-    for (int k = 2; k <= P; k <<= 1) {
+    // bitonic sort of the obstacle rays by angle (entities.py:458); equal angles are merged below, so stability is moot
+    for (int k = 2; k <= P2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += nthreads) {
+            for (int i = tid; i < P2; i += nthreads) {
                 const int l = i ^ j;
                 if (l > i) {
-                    const double ki = keys[i], kl = keys[l];
+                    const double ki = okeys[i], kl = okeys[l];
                     const bool up = (i & k) == 0;
                     if ((ki > kl) == up && ki != kl) {
-                        keys[i] = kl; keys[l] = ki;
-                        const double vi = vals[i]; vals[i] = vals[l]; vals[l] = vi;
+                        okeys[i] = kl; okeys[l] = ki;
+                        const double vi = ovals[i]; ovals[i] = ovals[l]; ovals[l] = vi;
                     }
                 }
             }
-            __syncthreads();
+            // partners at a distance below 64 sit in the same wave (i = tid + n * nthreads): between two such stages no workgroup
+            // barrier is needed
+            const int next_j = j > 1 ? (j >> 1) : k;
+            if (j >= 64 || next_j >= 64 || in_hbm) __syncthreads(); else wave_sync();
         }
     }
+    __syncthreads();
+    // merge by rank into keys / vals: a degree ray goes behind the obstacle rays with a smaller angle, an obstacle ray behind the
+    // degree rays with an angle <= its own (ties: the degree ray first; both counts use exact comparisons, so the positions are
+    // a permutation)
+    {
+        double held[6];                                                   // this thread's degree rays leave keys / vals first
+#pragma unroll
+        for (int n = 0; n < 6; ++n) { const int d = tid + n * nthreads; held[n] = d < 360 ? vals[d] : 0.0; }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+            const int d = tid + n * nthreads;
+            if (d < 360) {
+                const double a = -180.0 + (double)d;
+                int lo = 0, hi = nobs;                                    // first obstacle ray with angle >= a
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (okeys[mid] < a) lo = mid + 1; else hi = mid; }
+                keys[d + lo] = a; vals[d + lo] = held[n];
+            }
+        }
+        for (int sidx = tid; sidx < nobs; sidx += nthreads) {
+            const double x = okeys[sidx];
+            int before = (int)floor(x + 180.0) + 1;                       // degree rays -180 .. with angle <= x (x is in [-180, 180))
+            before = before < 0 ? 0 : (before > 360 ? 360 : before);
+            if (before > 0 && (double)(before - 1) - 180.0 > x) --before;         // x + 180 rounded up across an integer
+            if (before < 360 && (double)before - 180.0 <= x) ++before;
+            keys[sidx + before] = x; vals[sidx + before] = ovals[sidx];
+        }
+    }
+    __syncthreads();
     // dedupe equal angles keeping the smaller norm (entities.py:460-466) + compaction
     const int per = (P + nthreads - 1) / nthreads;
     const int lo = tid * per, hi = (lo + per < nr) ? lo + per : nr;
     int local = 0;
     for (int i = lo; i < hi; ++i) local += (i == 0 || keys[i] != keys[i - 1]);
-    scan[tid] = local;
+    // exclusive prefix over the threads: inside each wave by shuffles, across the (at most 16) waves through `scan`
+    int incl = local;
+    {
+        const int ln = tid & 63;
+        for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(incl, off, 64); if (ln >= off) incl += up; }
+        if (ln == 63) scan[tid >> 6] = incl;
+    }
     __syncthreads();
-    if (tid == 0) { int acc = 0; for (int q = 0; q < nthreads; ++q) { const int v = scan[q]; scan[q] = acc; acc += v; } hdr[2] = acc; }
+    int pos = incl - local;
+    {
+        const int nw = (nthreads + 63) >> 6;
+        int total = 0;
+        for (int wv = 0; wv < nw; ++wv) { const int v = scan[wv]; if (wv < (tid >> 6)) pos += v; total += v; }
+        if (tid == 0) hdr[2] = total;
+    }
     __syncthreads();
-    int pos = scan[tid];
     for (int i = lo; i < hi; ++i) {
         if (i == 0 || keys[i] != keys[i - 1]) {
             const double a = keys[i];
@@ -403,6 +463,7 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
     double *okeys = reinterpret_cast<double *>(smem + rl.off_okeys);
     double *ovals = reinterpret_cast<double *>(smem + rl.off_ovals);
     double *place_scratch = keys;     // reset_place's list of placed circles: always in the LDS
+    double *pre_draws = reinterpret_cast<double *>(smem + rl.off_pre);
     if (rl.sort_in_hbm) {      // same code on global memory: __syncthreads orders a workgroup's global accesses as well
         keys = g.sort_scratch + (int64_t)blockIdx.x * 4 * rl.sort_cap;
         vals = keys + rl.sort_cap; okeys = vals + rl.sort_cap; ovals = okeys + rl.sort_cap;
@@ -430,8 +491,19 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
         if (wave == 0) {
             load_records(c);
             wave_sync();
+            constexpr int kPreDraws = 256;      // a reset of the shipped scenarios takes 130-220 draws; beyond, draw() falls back to one Philox call per draw
+            if ((phases & PH_PLACE) && !g.reset_tape) {
+                // one Philox-4x32-10 block gives two 53-bit uniforms: the 64 lanes draw the stream's first 256 at once (the single
+                // placing lane used to spend half of its time on one block per draw)
+                const uint32_t episode = (uint32_t)c.ei(EI_EPISODE) + 1u;
+                for (int b = lane; b < kPreDraws / 2; b += 64) {
+                    const U4 r = philox(p.seed_lo, p.seed_hi, c.env_global(), episode, S_RESET, (uint32_t)b);
+                    pre_draws[2 * b] = u53(r.x, r.y); pre_draws[2 * b + 1] = u53(r.z, r.w);
+                }
+                wave_sync();
+            }
             if ((phases & PH_PLACE) && lane == 0) {
-                reset_place(c, place_scratch, 4 + p.Nc + p.No + p.Nt);
+                reset_place(c, place_scratch, 4 + p.Nc + p.No + p.Nt, pre_draws, g.reset_tape ? 0u : (uint32_t)kPreDraws);
                 if ((g.reset_kind == RESET_FLAGGED || g.reset_kind == RESET_MASK) && (phases & PH_MORE)) g.flag_list[atomicAdd(g.flag_count, 1)] = (int32_t)env;
             }
             wave_sync();
@@ -439,8 +511,8 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
         __syncthreads();
         if (phases & PH_LUT) {
             if (per_camera) {
-                build_lut(c, only_cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap);
-                if (g.lut_knots_outer) build_lut(c, only_cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap, true);
+                build_lut(c, only_cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap, false, rl.sort_in_hbm != 0);
+                if (g.lut_knots_outer) build_lut(c, only_cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap, true, rl.sort_in_hbm != 0);
                 // this workgroup owns exactly one word of the static record: the camera's obstacle mask row
                 if (threadIdx.x == 0) {
                     const int w = 2 * p.Nc + 3 * p.No + only_cam;
@@ -449,8 +521,8 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
                 continue;
             }
             for (int cam = 0; cam < p.Nc; ++cam) {
-                build_lut(c, cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap);
-                if (g.lut_knots_outer) build_lut(c, cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap, true);
+                build_lut(c, cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap, false, rl.sort_in_hbm != 0);
+                if (g.lut_knots_outer) build_lut(c, cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap, true, rl.sort_in_hbm != 0);
             }
         }
         __syncthreads();
