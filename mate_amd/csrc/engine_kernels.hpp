@@ -312,9 +312,11 @@ struct Ctx {
     __device__ int32_t &xch(int i) { return misc[4 * p.Nt + i]; }
     __device__ bool mask_bit(int b) const { return (mask[b >> 5] >> (b & 31)) & 1u; }
     __device__ uint32_t env_global() const { return p.first_env + (uint32_t)env; }
+    // A tick-keyed draw.  One Philox-4x32 block holds two 64-bit draws: ticks 2k and 2k + 1 share the block with counter k and
+    // take its first / second half -- the fused rollouts compute a block once per TWO steps (DrawCarry).
     __device__ double draw(uint32_t tick, uint32_t stream, uint32_t sub) const {
-        const U4 r = philox(p.seed_lo, p.seed_hi, env_global(), tick, stream, sub);
-        return u53(r.x, r.y);
+        const U4 r = philox(p.seed_lo, p.seed_hi, env_global(), tick >> 1, stream, sub);
+        return (tick & 1u) ? u53(r.z, r.w) : u53(r.x, r.y);
     }
 };
 
@@ -346,7 +348,8 @@ __device__ __forceinline__ void load_records(Ctx<ObsT> &c) {
 // while they are in flight (all co-resident waves of a SIMD start together: without this they idle through the
 // HBM latency together and then contend for the VALU together), then the data is committed to LDS.
 struct StepDraws { double a0, a1; };
-template <typename ObsT> __device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick);
+struct DrawCarry { uint32_t z, w, block; };      // second half of the lane's Philox block of the even tick, for the odd tick behind it
+template <typename ObsT> __device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry = nullptr);
 
 template <typename ObsT>
 __device__ __forceinline__ StepDraws load_records_with_draws(Ctx<ObsT> &c, uint32_t tick, bool draw) {
@@ -407,7 +410,7 @@ __device__ __forceinline__ void store_dynamic(Ctx<ObsT> &c) {
 // actions, [Nc, Nc+Nt) target actions, the remaining lanes pre-draw the see-through uniforms of the
 // first camera->target pairs (cheaper than a second divergent Philox in the visibility phase).
 template <typename ObsT>
-__device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick) {
+__device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry) {
     const Params &p = c.p;
     const int lane = c.lane;
     StepDraws d{0.0, 0.0};
@@ -419,12 +422,21 @@ __device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick) {
     if (lane < p.Nc) { stream = S_ACT_CAM; sub = (uint32_t)lane; active = random_policy; }
     else if (lane < nact) { stream = S_ACT_TGT; sub = (uint32_t)(lane - p.Nc); active = random_policy; }
     else if (lane - nact < p.Nc * p.Nt) { stream = S_TRANSMIT; sub = (uint32_t)(lane - nact); active = need_draws; }
+    // (a lane's role -- stream, sub -- is the same at every step of a launch, so the words it carries are its own)
+    const uint32_t block = tick >> 1;
+    uint32_t w0 = 0, w1 = 0;
+    if (carry && (tick & 1u) && carry->block == block) { w0 = carry->z; w1 = carry->w; }        // wave-uniform: no Philox at all on this step
+    else if (active) {
+        const U4 r = philox(p.seed_lo, p.seed_hi, c.env_global(), block, stream, sub);
+        if (tick & 1u) { w0 = r.z; w1 = r.w; }
+        else { w0 = r.x; w1 = r.y; if (carry) { carry->z = r.z; carry->w = r.w; } }
+    }
+    if (carry && !(tick & 1u)) carry->block = block;
     if (active) {
-        const U4 r = philox(p.seed_lo, p.seed_hi, c.env_global(), tick, stream, sub);
         if (lane < nact) {                        // one instruction stream for both kinds of agent
             const double m0 = lane < p.Nc ? p.rot : p.tgt_step, m1 = lane < p.Nc ? p.zoom : p.tgt_step;
-            d.a0 = action_component(r.x, m0); d.a1 = action_component(r.y, m1);
-        } else c.udraw(lane - nact) = u53(r.x, r.y);
+            d.a0 = action_component(w0, m0); d.a1 = action_component(w1, m1);
+        } else c.udraw(lane - nact) = u53(w0, w1);
     }
     return d;
 }
@@ -1451,6 +1463,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
 #endif
     bool stepped = false;            // a full step has written the static mask words, flags and scratch slots
     int last_gw = -1;                // fill_scratch: the goal word behind the target's goal / cargo slots
+    DrawCarry carry{0u, 0u, 0xffffffffu};
 #pragma clang loop unroll(disable)
     for (int r = 0; r < g.rollout_steps; ++r) {
         // an opaque copy of the lane id per iteration keeps the compiler from hoisting every lane-role
@@ -1489,7 +1502,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
 #define MATE_ABLATE 0
 #endif
         StepDraws draws{0.0, 0.0};
-        if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick);
+        if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick, &carry);
         ROLL_STAMP(0);
         if (!(MATE_ABLATE & 2)) simulate_cameras(c, draws, true);
         ROLL_STAMP(1);

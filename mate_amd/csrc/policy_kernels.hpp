@@ -509,6 +509,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     const int wave_slot = (int)(hw_id & 15u);
     bool stepped = false;                                          // statics written (see Ctx::statics_done)
+    DrawCarry carry{0u, 0u, 0xffffffffu};
 #ifdef MATE_PHASE_CLOCKS
     long long acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // 0-6 as in rollout_kernel, 7 loop, 8 agents observe, 11 communicate, 12 choose, 9 the zoom solve, 10 the actions
     long long t_prev = (long long)__builtin_amdgcn_s_memtime();
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         }
         const uint32_t tick = g.tick + (uint32_t)r;
         StepDraws draws{0.0, 0.0};
-        if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick);       // see-through uniforms only (mode() is MODE_STEP)
+        if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick, &carry);       // see-through uniforms only (mode() is MODE_STEP)
         GREEDY_STAMP(0);
         if (!(MATE_ABLATE & 2)) simulate_cameras(c, draws, true);
         GREEDY_STAMP(1);

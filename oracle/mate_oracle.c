@@ -106,10 +106,12 @@ static inline double u53(uint32_t hi, uint32_t lo) {
     return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
 }
 
+/* A tick-keyed draw of the engine's Philox streams: ticks 2k and 2k + 1 share the block with counter k and take its first /
+ * second 64 bits (mate_amd/csrc/engine_kernels.hpp, Ctx::draw). */
 static double draw_stream(const mo_env *e, uint32_t tick, uint32_t stream, uint32_t sub) {
     uint32_t r[4];
-    mo_philox4x32((uint32_t)e->seed, (uint32_t)(e->seed >> 32), e->env_index, tick, stream, sub, r);
-    return u53(r[0], r[1]);
+    mo_philox4x32((uint32_t)e->seed, (uint32_t)(e->seed >> 32), e->env_index, tick >> 1, stream, sub, r);
+    return (tick & 1u) ? u53(r[2], r[3]) : u53(r[0], r[1]);
 }
 
 static double draw_reset(mo_env *e) {
@@ -131,15 +133,16 @@ static int randint_reset(mo_env *e, int n) {
 void mo_random_actions(uint64_t seed, uint64_t env_index, uint64_t tick, int Nc, int Nt, double rot_step,
                        double zoom_step, double step_size, float *cam_act, float *tgt_act) {
     uint32_t r[4];
+    const int h = ((uint32_t)tick & 1u) ? 2 : 0;      /* the half of the block this tick takes (draw_stream) */
     for (int c = 0; c < Nc; ++c) {
-        mo_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)env_index, (uint32_t)tick, S_ACT_CAM, (uint32_t)c, r);
-        cam_act[2 * c + 0] = (float)((double)(r[0] >> 8) * 5.9604644775390625e-08 * (2.0 * rot_step) - rot_step);
-        cam_act[2 * c + 1] = (float)((double)(r[1] >> 8) * 5.9604644775390625e-08 * (2.0 * zoom_step) - zoom_step);
+        mo_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)env_index, (uint32_t)tick >> 1, S_ACT_CAM, (uint32_t)c, r);
+        cam_act[2 * c + 0] = (float)((double)(r[h] >> 8) * 5.9604644775390625e-08 * (2.0 * rot_step) - rot_step);
+        cam_act[2 * c + 1] = (float)((double)(r[h + 1] >> 8) * 5.9604644775390625e-08 * (2.0 * zoom_step) - zoom_step);
     }
     for (int t = 0; t < Nt; ++t) {
-        mo_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)env_index, (uint32_t)tick, S_ACT_TGT, (uint32_t)t, r);
-        tgt_act[2 * t + 0] = (float)((double)(r[0] >> 8) * 5.9604644775390625e-08 * (2.0 * step_size) - step_size);
-        tgt_act[2 * t + 1] = (float)((double)(r[1] >> 8) * 5.9604644775390625e-08 * (2.0 * step_size) - step_size);
+        mo_philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)env_index, (uint32_t)tick >> 1, S_ACT_TGT, (uint32_t)t, r);
+        tgt_act[2 * t + 0] = (float)((double)(r[h] >> 8) * 5.9604644775390625e-08 * (2.0 * step_size) - step_size);
+        tgt_act[2 * t + 1] = (float)((double)(r[h + 1] >> 8) * 5.9604644775390625e-08 * (2.0 * step_size) - step_size);
     }
 }
 
