@@ -142,8 +142,9 @@ def parse_args(argv=None):
                          'external = step(actions) with the joint actions in a caller-owned device buffer (learner in the loop)')
     ap.add_argument('--reset-interval', type=int, default=32, help='greedy policy, one launch per step: batched auto-reset every k steps (1 = immediate)')
     ap.add_argument('--rollout-reset-interval', type=int, default=-1,
-                    help='fused rollouts: restart finished environments after every k-th launch (1 = after every launch; default 1 for the '
-                         'random policy, 4 for Greedy vs Greedy, whose ~1.2k-step episodes end somewhere in the batch at every step)')
+                    help='fused rollouts: restart finished environments after every k-th launch (1 = after every launch; default: about every '
+                         '128 steps for the random policy (k = 128 // launch length), 4 for Greedy vs Greedy, whose ~1.2k-step episodes end '
+                         'somewhere in the batch at every step)')
     ap.add_argument('--rollout', type=int, default=-1,
                     help='steps fused per launch (rollout_kernel / rollout_greedy_kernel); 0 = one launch per step; -1 (default) = 128 '
                          '(random) / 32 (greedy) while the batch is at most 64 / 32 environment-waves per CU, else 0 (the fused '
@@ -289,7 +290,10 @@ def main():
     else:
         step = lambda: eng.step_random(auto_reset=args.step_reset_interval)     # noqa: E731
     rollout_fn = eng.rollout_greedy if args.policy == 'greedy' else eng.rollout_random
-    rollout_resets = args.rollout_reset_interval if args.rollout_reset_interval > 0 else (4 if args.policy == 'greedy' else 1)
+    # default restart cadence of the fused flows: Greedy vs Greedy every 4 launches; random policy about every 128
+    # steps whatever the launch length (after each 128-step launch; after every 6th 20-step launch): a finished environment then idles
+    # ~64 of its 10^4 steps (idle slots are not counted in `value`) and short launches do not each drag an idle reset launch behind them
+    rollout_resets = args.rollout_reset_interval if args.rollout_reset_interval > 0 else (4 if args.policy == 'greedy' else max(1, 128 // max(R, 1)))
     rollout = lambda n, auto_reset=True: rollout_fn(n, auto_reset=rollout_resets)     # noqa: E731
     gather = StatsGather(torch, dist, distributed, eng) if args.stats_interval > 0 else None
 
