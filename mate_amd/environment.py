@@ -451,6 +451,23 @@ class MultiAgentTracking(_ScenarioMixin, _EnvBase, metaclass=EnvMeta):
         self.engine.step_greedy(tape_ct=tape_ct, tape_goal=tape_goal, auto_reset=False)
         return self._finish_step()
 
+    def step_versus_greedy(self, team, joint_action):
+        """`mate.MultiCamera(env, target_agent=GreedyTargetAgent()).step(joint_action)` for team = 'camera' (or mate_amd.Team.CAMERA),
+        `mate.MultiTarget(env, camera_agent=GreedyCameraAgent()).step(...)` for 'target' (mate/wrappers/single_team.py:245-264): the
+        caller's team acts, the greedy opponents act on the device.  Same return value as step() (both teams' halves)."""
+        if not getattr(self, '_greedy', False):
+            raise RuntimeError('enable_greedy_policies() must precede the reset() the agents first act on')
+        team = getattr(team, 'name', team)
+        team = team.lower() if isinstance(team, str) else ('camera', 'target')[int(team)]
+        assert team in ('camera', 'target'), f'Invalid team {team!r}.'
+        agents, dim = (self.num_cameras, consts.CAMERA_ACTION_DIM) if team == 'camera' else (self.num_targets, consts.TARGET_ACTION_DIM)
+        act = np.asarray(joint_action, dtype=np.float64).reshape(agents, dim)
+        assert np.isfinite(act).all(), f'Got unexpected joint action {act}.'
+        tape_ct, tape_goal = self._tapes()
+        self.engine.step_versus_greedy(team, torch.from_numpy(act[None]).to(self.engine.device), tape_ct=tape_ct, tape_goal=tape_goal,
+                                       auto_reset=False)
+        return self._finish_step()
+
     def step(self, action):
         camera_joint_action, target_joint_action = action
         cam_act = np.asarray(camera_joint_action, dtype=np.float64).reshape(self.num_cameras, consts.CAMERA_ACTION_DIM)

@@ -192,6 +192,28 @@ def test_auxiliary_camera_rewards_and_wrapper_kwargs():
     env.close()
 
 
+def test_single_env_versus_greedy_follows_step_greedy():
+    """N = 1 API: MultiTarget / MultiCamera with the greedy opponent on the device.  Two instances on the same seed, one stepping
+    both greedy teams, the other fed the first one's joint action for its own team: identical trajectories."""
+    import mate_amd
+    a, b, c = (mate_amd.make('MATE-4v8-9-v0') for _ in range(3))
+    for env in (a, b, c):
+        env.enable_greedy_policies()
+        env.reset(seed=21)
+    for _ in range(40):
+        (ca, ta), (rc, rt), done, _ = a.step_greedy()
+        cam_act, tgt_act = (x[0].cpu().numpy() for x in a.engine.policy_actions())
+        (cb, tb), (rcb, rtb), doneb, _ = b.step_versus_greedy('target', tgt_act)
+        (cc, tc), (rcc, rtc), donec, _ = c.step_versus_greedy(mate_amd.Team.CAMERA, cam_act)
+        for other_c, other_t, r in ((cb, tb, rtb), (cc, tc, rtc)):
+            assert np.array_equal(np.asarray(ca), np.asarray(other_c)) and np.array_equal(np.asarray(ta), np.asarray(other_t))
+            assert r == rt
+    with pytest.raises(RuntimeError):
+        mate_amd.make('MATE-4v8-9-v0').step_versus_greedy('camera', np.zeros((4, 2)))
+    for env in (a, b, c):
+        env.close()
+
+
 def test_single_team_training_flow_of_the_examples():
     """The call pattern of examples/ippo/target/config.py on the batch: MultiTarget(env, GreedyCameraAgent) ->
     AuxiliaryTargetRewards -> FrameSkip, i.e. the learner plays the targets (grid indices here: DiscreteTarget), the greedy
