@@ -145,10 +145,11 @@ def parse_args(argv=None):
                     help='fused rollouts: restart finished environments after every k-th launch (1 = after every launch; default: about every '
                          '128 steps for the random policy (k = 128 // launch length), 4 for Greedy vs Greedy, whose ~1.2k-step episodes end '
                          'somewhere in the batch at every step)')
+    ap.add_argument('--buffer-gib', type=float, default=8.0, help='cap of the rollout-shaped output buffers [R][N][...] (limits --rollout)')
     ap.add_argument('--rollout', type=int, default=-1,
-                    help='steps fused per launch (rollout_kernel / rollout_greedy_kernel); 0 = one launch per step; -1 (default) = 128 '
-                         '(random) / 32 (greedy) while the batch is at most 64 / 32 environment-waves per CU, else 0 (the fused '
-                         'kernels trade occupancy for registers and LDS); capped so that the [R][N][...] buffers stay under 4 GiB')
+                    help='steps fused per launch (rollout_kernel / rollout_greedy_kernel); 0 = one launch per step; -1 (default) = 256 '
+                         '(random) / 48 (greedy) while the batch is at most 64 / 32 environment-waves per CU, else 0 (the fused '
+                         'kernels trade occupancy for registers and LDS); capped so that the [R][N][...] buffers stay under --buffer-gib')
     ap.add_argument('--step-reset-interval', type=int, default=8,
                     help='one launch per step (per_step_launch / external_actions / --rollout 0 with the random policy): restart finished '
                          'environments with one reset launch per k steps (1 = a reset launch behind every step); a finished environment idles at most k - 1 steps')
@@ -277,9 +278,11 @@ def main():
         cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
         R = 32 if args.batch <= (64 if args.policy == 'random' else 32) * cus else 0
         if R and args.policy == 'random':       # longer launches while the timed region still holds eight of them
-            R = next((r for r in (128, 64) if args.steps // r >= 8), 32)
-    if R > 0:        # rollout buffers [R][N][...] capped at 4 GiB
-        R = max(1, min(R, args.steps, (4 << 30) // (args.batch * b_obs)))
+            R = next((r for r in (256, 128, 64) if args.steps // r >= 8), 32)
+        elif R:                                 # Greedy vs Greedy: 48 steps (longer launches lose more to the idle slots of finished
+            R = 48 if args.steps >= 8 * 48 else 32     # episodes than they save in launches; measured 16 .. 96)
+    if R > 0:        # rollout buffers [R][N][...] capped (default 8 GiB of the 288)
+        R = max(1, min(R, args.steps, (int(args.buffer_gib * (1 << 30))) // (args.batch * b_obs)))
     external = None
     if args.policy == 'greedy':
         eng.enable_policies()
