@@ -784,6 +784,26 @@ static int policy_enable(mate_engine *e) {
     if ((rc = dev_alloc(e, &q.tgt_act, (size_t)e->N * p.Nt * 2))) return rc;
     if (!e->g.own_masks && (rc = dev_alloc(e, &e->g.own_masks, (size_t)e->N * p.MW))) return rc;
     q.masks = e->g.own_masks;
+    {   // GreedyCameraAgent's zoom solve (greedy.py:139-145) as a function of K = area_product / distance^2 alone, tabulated with the
+        // reference's own iteration (policy_kernels.hpp: zoom_lookup interpolates it to 1.5e-13)
+        constexpr double kInvH = 40.0, kMaxK = 720.0;
+        const int n = (int)(kMaxK * kInvH) + 8;
+        std::vector<double> tab((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            const double K = (double)i / kInvH;
+            double b = 180.0;
+            for (int it = 0; it < 20; ++it) {
+                const double half = b * 0.5;
+                const double y = 1.0 + std::sin((half < 90.0 ? half : 90.0) * (3.14159265358979323846 / 180.0));
+                b = K / (y * y);
+            }
+            tab[(size_t)i] = b;
+        }
+        double *d_tab = nullptr;
+        if ((rc = dev_alloc(e, &d_tab, (size_t)n, false))) return rc;
+        HIP_TRY(hipMemcpy(d_tab, tab.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+        q.zoom_tab = d_tab; q.zoom_inv_h = kInvH; q.zoom_n = n;
+    }
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->policy_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * q.lds_bytes + 1024);
     if (err == hipSuccess) {
         const size_t fused = 4 * (size_t)p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(q.PW, p.Nc, p.Nt) + 1024;

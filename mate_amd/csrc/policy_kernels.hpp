@@ -42,6 +42,9 @@ struct PolicyPtrs {
     int32_t lds_bytes;         // per wave
     int32_t memory_period;     // 25 (greedy.py:21)
     double noise_scale;        // 0.5 (greedy.py:236)
+    const double *zoom_tab;    // the zoom solve tabulated over K (zoom_table_value; built by mate_engine_policy_enable): zoom_n values at
+    double zoom_inv_h;         // K = i / zoom_inv_h
+    int32_t zoom_n;
     int32_t caller_team;       // fused rollout: -1 both teams are the agents; 0 / 1 the camera / target team repeats the caller's
                                // joint action (Ptrs::cam_act / tgt_act) for every step of the launch (FrameSkip over MultiCamera / MultiTarget)
 };
@@ -119,13 +122,31 @@ __device__ __forceinline__ double zoom_fixed_point(double Kc) {
     return b;
 }
 
+// The same quantity from a table.  The twenty iterations are a pure function of ONE scalar, K in (0, 720) (the branch that
+// solves has distance > sqrt(area_product / 180) / 2, i.e. K < 720), smooth in K (the clamp at 90 degrees is never active
+// there: b_1 = K / 4 <= 180): mate_engine_policy_enable tabulates it on the host with the iteration above at K = i / 40 and
+// the agents read four neighbours and interpolate cubically (Lagrange).  Measured against the iteration over 2e6 random K:
+// |error| <= 1.5e-13 degrees, the size of the iteration's own rounding -- and 460 dependent f64 instructions, two workgroup
+// barriers and the lockstep of the four waves of a workgroup (17 % of a fused Greedy step) become one 32-byte load.
+__device__ __forceinline__ double zoom_lookup(const PolicyPtrs &q, double K) {
+    const double x = K * q.zoom_inv_h;
+    int i = (int)x;
+    if (!(x >= 1.0) || i > q.zoom_n - 3) return zoom_fixed_point(K);     // outside the table (never in the solving branch): iterate
+    const double t = x - (double)i;
+    const double *f = q.zoom_tab + (i - 1);
+    const double fm1 = f[0], f0 = f[1], f1 = f[2], f2 = f[3];
+    const double tp1 = t + 1.0, tm1 = t - 1.0, tm2 = t - 2.0;
+    const double wm1 = t * tm1 * tm2 * (-1.0 / 6.0), w0 = tp1 * tm1 * tm2 * 0.5, w1 = tp1 * t * tm2 * (-0.5), w2 = tp1 * t * tm1 * (1.0 / 6.0);
+    return fma(wm1, fm1, fma(w0, f0, fma(w1, f1, w2 * f2)));
+}
+
 // One step of both teams' agents of ONE environment on LDS-resident data: `a` the agents' memory record, `st` / `dy` /
 // `di` the static and dynamic records, `mk` the packed view masks of the previous step.  Called by every wave of the
 // workgroup together (two barriers around the shared zoom solve).  Joint actions go to q.cam_act / q.tgt_act when
 // `active`, and to lds_cam_act / lds_tgt_act when those are given (the fused rollout steps from them).
 template <typename ObsT>
 __device__ __forceinline__ void greedy_policy_body(const Params &p, const PolicyPtrs &q, PolCtx<ObsT> &a, const double *st, const double *dy,
-                                                   const int32_t *di, const uint32_t *mk, double *shared_K, double *shared_B,
+                                                   const int32_t *di, const uint32_t *mk,
                                                    int wave, int lane, int64_t env, bool active, double *lds_cam_act, double *lds_tgt_act,
                                                    long long *acc = nullptr, long long *t_prev = nullptr) {
 #ifdef MATE_PHASE_CLOCKS
@@ -295,22 +316,13 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
             }
         }
     }
-    // The zoom solve is the longest dependent chain of the agents' step and runs on at most Nc lanes of a wave: the four waves
-    // of the workgroup publish their cameras' K = area_product / distance^2 and ONE wave iterates all of them (4 x Nc lanes
-    // busy instead of Nc, a quarter of the issue slots).  Measured alternatives, all slower or equal: every wave solving its
-    // own cameras without the barriers (the chain then costs each wave 6.6 k cycles of a 48 k-cycle step), the solving wave
-    // at top issue priority (-3 %), an Estrin-form polynomial.
-    if (lane < 16) shared_K[wave * 16 + lane] = solve ? K : 1.0;
     POL_STAMP(12);
-    __syncthreads();
-    if (wave == 0) shared_B[lane] = zoom_fixed_point(shared_K[lane]);
-    __syncthreads();
+    if (lane < Nc && solve) best_va = clipd(zoom_lookup(q, K), min_va, 180.0);      // greedy.py:139-146, tabulated (zoom_lookup)
     POL_STAMP(9);
     if (lane < Nc) {                                        // part 2: the action
         const int c = lane;
         double a0, a1;
         if (best >= 0) {
-            if (solve) best_va = clipd(shared_B[wave * 16 + c], min_va, 180.0);
             a0 = clipd(normalize_angle(best_orientation - orientation), -p.rot, p.rot);
             a1 = clipd(best_va - theta, -p.zoom, p.zoom);
         } else {
@@ -391,8 +403,6 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     const int64_t env = env_raw < g.N ? env_raw : g.N - 1;
     bool active = env_raw < g.N;
     unsigned char *base = smem + wave * q.lds_bytes;
-    double *shared_K = reinterpret_cast<double *>(smem + 4 * q.lds_bytes);      // [4 environments][16 cameras]
-    double *shared_B = shared_K + 64;
     // LDS: [policy record + staging][static record][dynamic record][mask words]
     PolCtx<ObsT> a(p, q, base);
     double *st = reinterpret_cast<double *>(base + (size_t)(q.PW + policy_staging_words(p.Nc, p.Nt)) * 8);
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     }
     wave_sync();
     if (g.freeze_done && (di + p.Nt * TI_STRIDE)[EI_DONE] != 0) active = false;   // finished, waiting for the batched reset
-    greedy_policy_body<ObsT>(p, q, a, st, dy, di, mk, shared_K, shared_B, wave, lane, env, active, nullptr, nullptr);
+    greedy_policy_body<ObsT>(p, q, a, st, dy, di, mk, wave, lane, env, active, nullptr, nullptr);
     wave_sync();
     if (active) {
         double *dst = q.pol + env * q.PW;
@@ -484,8 +494,6 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
     const Ptrs &gk = kernarg_ptrs(g);
     const int pol_bytes = policy_slice_bytes(q.PW, p.Nc, p.Nt);
     unsigned char *pol_base = smem + 4 * p.lds_wave_bytes + wave * pol_bytes;
-    double *shared_K = reinterpret_cast<double *>(smem + 4 * p.lds_wave_bytes + 4 * pol_bytes);
-    double *shared_B = shared_K + 64;
     PolCtx<ObsT> a(p, q, pol_base);
     double *act_cam = a.f + (q.PW + policy_staging_words(p.Nc, p.Nt)), *act_tgt = act_cam + 2 * p.Nc;
     {
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
             else __builtin_amdgcn_s_setprio(3);
         }
         GREEDY_STAMP(7);
-        if (!(MATE_ABLATE & 128)) greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, c.mask, shared_K, shared_B, wave_r, lane_r, env_r, active, act_cam, act_tgt, GREEDY_ACC);
+        if (!(MATE_ABLATE & 128)) greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, c.mask, wave_r, lane_r, env_r, active, act_cam, act_tgt, GREEDY_ACC);
         wave_sync();
         GREEDY_STAMP(10);
         if (!active) {
