@@ -141,14 +141,14 @@ __device__ __forceinline__ double zoom_lookup(const PolicyPtrs &q, double K) {
 }
 
 // One step of both teams' agents of ONE environment on LDS-resident data: `a` the agents' memory record, `st` / `dy` /
-// `di` the static and dynamic records, `mk` the packed view masks of the previous step.  Called by every wave of the
-// workgroup together (two barriers around the shared zoom solve).  Joint actions go to q.cam_act / q.tgt_act when
-// `active`, and to lds_cam_act / lds_tgt_act when those are given (the fused rollout steps from them).
+// `di` the static and dynamic records, `mk` the packed view masks of the previous step.  One wave, one environment.  Joint
+// actions go to q.cam_act / q.tgt_act when `active` and `publish`, and to lds_cam_act / lds_tgt_act when those are given (the
+// fused rollout steps from them and publishes the last executed step's once per launch).
 template <typename ObsT>
 __device__ __forceinline__ void greedy_policy_body(const Params &p, const PolicyPtrs &q, PolCtx<ObsT> &a, const double *st, const double *dy,
                                                    const int32_t *di, const uint32_t *mk,
                                                    int wave, int lane, int64_t env, bool active, double *lds_cam_act, double *lds_tgt_act,
-                                                   long long *acc = nullptr, long long *t_prev = nullptr) {
+                                                   long long *acc = nullptr, long long *t_prev = nullptr, bool publish = true) {
 #ifdef MATE_PHASE_CLOCKS
 #define POL_STAMP(i) do { if (acc) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); acc[i] += t_now - *t_prev; *t_prev = t_now; } } while (0)
 #else
@@ -338,7 +338,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         }
         a.prev_action(c, 0) = a0; a.prev_action(c, 1) = a1;
         if (lds_cam_act) { lds_cam_act[2 * c] = a0; lds_cam_act[2 * c + 1] = a1; }
-        if (active) { q.cam_act[(env * Nc + c) * 2] = a0; q.cam_act[(env * Nc + c) * 2 + 1] = a1; }
+        if (active && publish) { q.cam_act[(env * Nc + c) * 2] = a0; q.cam_act[(env * Nc + c) * 2 + 1] = a1; }
     }
     if (tl >= 0 && tl < Nt) {                               // GreedyTargetAgent.act (greedy.py:285-324)
         const int t = tl;
@@ -387,7 +387,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         a.tgt_prev(t, 0) = x; a.tgt_prev(t, 1) = y;
         a.tgt_noise(t, 0) = nx; a.tgt_noise(t, 1) = ny;
         if (lds_tgt_act) { lds_tgt_act[2 * t] = outx; lds_tgt_act[2 * t + 1] = outy; }
-        if (active) { q.tgt_act[(env * Nt + t) * 2] = outx; q.tgt_act[(env * Nt + t) * 2 + 1] = outy; }
+        if (active && publish) { q.tgt_act[(env * Nt + t) * 2] = outx; q.tgt_act[(env * Nt + t) * 2 + 1] = outy; }
     }
 }
 
@@ -397,11 +397,9 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     const Params &p = shape.get();
     extern __shared__ __align__(16) unsigned char smem[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    // No wave leaves early: the four waves of a workgroup meet at two barriers around the shared zoom solve, so a wave
-    // past the end of the batch or on a frozen environment runs on (duplicate / stale data) and only skips its stores.
-    const int64_t env_raw = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t env = env_raw < g.N ? env_raw : g.N - 1;
-    bool active = env_raw < g.N;
+    // the four waves of a workgroup never synchronise: each owns one environment
+    const int64_t env = (int64_t)blockIdx.x * 4 + wave;
+    if (env >= g.N) return;
     unsigned char *base = smem + wave * q.lds_bytes;
     // LDS: [policy record + staging][static record][dynamic record][mask words]
     PolCtx<ObsT> a(p, q, base);
@@ -420,22 +418,20 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
         for (int k = lane; k < p.MW; k += 64) mk[k] = m[k];
     }
     wave_sync();
-    if (g.freeze_done && (di + p.Nt * TI_STRIDE)[EI_DONE] != 0) active = false;   // finished, waiting for the batched reset
-    greedy_policy_body<ObsT>(p, q, a, st, dy, di, mk, wave, lane, env, active, nullptr, nullptr);
+    if (g.freeze_done && (di + p.Nt * TI_STRIDE)[EI_DONE] != 0) return;          // finished, waiting for the batched reset
+    greedy_policy_body<ObsT>(p, q, a, st, dy, di, mk, wave, lane, env, true, nullptr, nullptr);
     wave_sync();
-    if (active) {
-        double *dst = q.pol + env * q.PW;
-        for (int k = lane; k < q.PW; k += 64) dst[k] = a.f[k];
-    }
+    double *dst = q.pol + env * q.PW;
+    for (int k = lane; k < q.PW; k += 64) dst[k] = a.f[k];
 }
 
 // =============================================================================================
 // K fused steps of Greedy cameras vs Greedy targets: the agents' step (greedy_policy_body) and the environment's step
 // in one loop, with the environment records, the agents' memory and the view masks resident in LDS for the whole
 // launch and the joint actions handed over in LDS.  Same results as K x (greedy_policy_kernel + step_kernel), bit for
-// bit (tested).  The four waves of a workgroup meet at the two barriers of the shared zoom solve in every step, so no
-// wave leaves the loop early: a wave past the end of the batch, or whose episode has ended, keeps running the
-// agents' step on its stale data (no stores) and skips the environment's step.
+// bit (tested).  No
+// wave of a workgroup depends on another (the agents' zoom solve is a table lookup, not a shared iteration any more): a wave
+// past the end of the batch, or whose episode has ended, skips agents and step alike.
 __host__ __device__ constexpr int policy_slice_bytes(int PW, int Nc, int Nt) { return shape_round_up((PW + policy_staging_words(Nc, Nt) + 2 * (Nc + Nt)) * 8, 16); }
 
 // The caller's team of a fused rollout: its joint action, decoded as step() would (f32 / f64 pairs, or grid indices:
@@ -552,16 +548,17 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
             else __builtin_amdgcn_s_setprio(3);
         }
         GREEDY_STAMP(7);
-        if (!(MATE_ABLATE & 128)) greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, c.mask, wave_r, lane_r, env_r, active, act_cam, act_tgt, GREEDY_ACC);
-        wave_sync();
-        GREEDY_STAMP(10);
-        if (!active) {
+        if (!active) {                                             // past the end of the batch, or the episode has ended: no agents, no step
             if (in_batch && lane_r == 0) {
                 if (g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
                 if (g.idle_steps) g.idle_steps[env_r] += 1;
             }
-            continue;                                              // the next barrier is in the next step's agents
+            continue;
         }
+        // (the joint actions stay in LDS; the last executed step's are published once, at the end of the launch)
+        if (!(MATE_ABLATE & 128)) greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, c.mask, wave_r, lane_r, env_r, true, act_cam, act_tgt, GREEDY_ACC, false);
+        wave_sync();
+        GREEDY_STAMP(10);
         if (q.caller_team >= 0) {
             load_caller_actions(c, q.caller_team, act_cam, act_tgt);
             wave_sync();
@@ -600,6 +597,10 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         store_dynamic(c);
         double *dst = q.pol + env * q.PW;
         for (int k = lane; k < q.PW; k += 64) dst[k] = a.f[k];
+        if (stepped) {                                             // what mate_engine_policy_actions reads: the last executed step's joint actions
+            for (int k = lane; k < 2 * p.Nc; k += 64) q.cam_act[env * 2 * p.Nc + k] = act_cam[k];
+            for (int k = lane; k < 2 * p.Nt; k += 64) q.tgt_act[env * 2 * p.Nt + k] = act_tgt[k];
+        }
     }
 }
 
