@@ -252,33 +252,30 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         if (bits < 0) a.neighbor(c, s) = 1;                 // receive_responses: the recipient learns its neighbour (greedy.py:192-226);
     }                                                       // (every lane read neighbor(s, c) above before any lane writes here)
     wave_sync();
-    for (int k = lane; k < Nc * Nt; k += 64) {              // ... and the positions of the targets it was told about
+    // ... and the positions of the targets it was told about; then the tracking candidates: distance camera -> remembered
+    // position, +inf when forgotten or out of reach (greedy.py:115-127)
+    for (int k = lane; k < Nc * Nt; k += 64) {
         const int c = (int)(((float)k + 0.5f) * p.inv_Nt), t = k - c * Nt;
         int told = 0;
         for (int s = 0; s < Nc; ++s) told |= a.send_bits(s, c);
-        if ((told >> t) & 1) { a.mem(c, t, 0) = tx(t); a.mem(c, t, 1) = ty(t); a.t2f(c, t) = q.memory_period; }
-    }
-    if (lane < Nc && (a.has_state(lane) || seen_mask(lane))) a.has_state(lane) = 0;   // message2send.clear()
-    wave_sync();
-    // the tracking candidates: distance camera -> remembered position, +inf when forgotten or out of reach (greedy.py:115-127)
-    for (int k = lane; k < Nc * Nt; k += 64) {
-        const int c = (int)(((float)k + 0.5f) * p.inv_Nt), t = k - c * Nt;
+        double mx = a.mem(c, t, 0), my = a.mem(c, t, 1);
+        int left = a.t2f(c, t);
+        if ((told >> t) & 1) { mx = tx(t); my = ty(t); left = q.memory_period; a.mem(c, t, 0) = mx; a.mem(c, t, 1) = my; a.t2f(c, t) = left; }
         double dn = INFINITY;
-        if (a.t2f(c, t) > 0) {
-            const double dnorm = norm2(a.mem(c, t, 0) - cam_x(c), a.mem(c, t, 1) - cam_y(c));
+        if (left > 0) {
+            const double dnorm = norm2(mx - cam_x(c), my - cam_y(c));
             if (dnorm < threshold) dn = dnorm;
         }
         a.pair_dist(c, t) = dn;
     }
-    // targets: broadcast non-empty warehouse sets (greedy.py:334-358)
+    if (lane < Nc && (a.has_state(lane) || seen_mask(lane))) a.has_state(lane) = 0;   // message2send.clear()
+    // targets: broadcast non-empty warehouse sets (greedy.py:334-358).  Every lane's reads precede every lane's writes: one wave,
+    // one instruction stream, LDS operations in order.
     if (tl >= 0 && tl < Nt) {
         int set = a.tgt_nonempty(tl);
         for (int s = 0; s < Nt; ++s) if (a.tgt_need(s)) set &= a.tgt_nonempty(s);
-        wave_sync();
         a.tgt_nonempty(tl) = set;
         a.tgt_need(tl) = 0;
-    } else {
-        wave_sync();
     }
     wave_sync();
 
