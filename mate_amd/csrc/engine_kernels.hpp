@@ -725,6 +725,9 @@ __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t 
     const double alt = 360.0 - ra;
     if (alt < ra) ra = alt;
     if (ra * 2.0 > c.theta(cam)) return e;
+    // no obstacles: every knot of the occlusion table is the full range, and the pair is inside the sight range already, so
+    // `norm <= sight_range_at(angle) (1 + 1e-6)` (entities.py:505) holds whatever the transmittance draw says
+    if (p.No == 0) { e.seen = true; return e; }
     if (is_target) {                                                               // np_random.binomial(1, tau), entities.py:503
         const int pair = cam * p.Nt + other;
         double u;
