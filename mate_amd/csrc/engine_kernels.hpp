@@ -416,7 +416,7 @@ __device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, Dra
     StepDraws d{0.0, 0.0};
     const int nact = p.Nc + p.Nt;
     const bool random_policy = c.mode() == MODE_STEP_RANDOM;
-    const bool need_draws = !c.tape_ct() && p.Nc > 0;
+    const bool need_draws = !c.tape_ct() && p.Nc > 0 && p.No > 0;      // (without obstacles nothing is ever seen THROUGH one)
     uint32_t stream = 0, sub = 0;
     bool active = false;
     if (lane < p.Nc) { stream = S_ACT_CAM; sub = (uint32_t)lane; active = random_policy; }
