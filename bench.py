@@ -143,7 +143,7 @@ def parse_args(argv=None):
     ap.add_argument('--reset-interval', type=int, default=32, help='greedy policy, one launch per step: batched auto-reset every k steps (1 = immediate)')
     ap.add_argument('--rollout-reset-interval', type=int, default=-1,
                     help='fused rollouts: restart finished environments after every k-th launch (1 = after every launch; default: about every '
-                         '128 steps for the random policy (k = 128 // launch length), 4 for Greedy vs Greedy, whose ~1.2k-step episodes end '
+                         '128 steps for the random policy (k = 128 // launch length), 2 for Greedy vs Greedy, whose ~1.2k-step episodes end '
                          'somewhere in the batch at every step)')
     ap.add_argument('--buffer-gib', type=float, default=8.0, help='cap of the rollout-shaped output buffers [R][N][...] (limits --rollout)')
     ap.add_argument('--rollout', type=int, default=-1,
@@ -293,10 +293,10 @@ def main():
     else:
         step = lambda: eng.step_random(auto_reset=args.step_reset_interval)     # noqa: E731
     rollout_fn = eng.rollout_greedy if args.policy == 'greedy' else eng.rollout_random
-    # default restart cadence of the fused flows: Greedy vs Greedy every 4 launches; random policy about every 128
+    # default restart cadence of the fused flows: Greedy vs Greedy every 2 launches (k = 2..4 are within 1.5 %); random policy about every 128
     # steps whatever the launch length (after each 128-step launch; after every 6th 20-step launch): a finished environment then idles
     # ~64 of its 10^4 steps (idle slots are not counted in `value`) and short launches do not each drag an idle reset launch behind them
-    rollout_resets = args.rollout_reset_interval if args.rollout_reset_interval > 0 else (4 if args.policy == 'greedy' else max(1, 128 // max(R, 1)))
+    rollout_resets = args.rollout_reset_interval if args.rollout_reset_interval > 0 else (2 if args.policy == 'greedy' else max(1, 128 // max(R, 1)))
     rollout = lambda n, auto_reset=True: rollout_fn(n, auto_reset=rollout_resets)     # noqa: E731
     gather = StatsGather(torch, dist, distributed, eng) if args.stats_interval > 0 else None
 

@@ -52,7 +52,10 @@ __device__ __forceinline__ int pick_goal(const int32_t *row, double u) {  // np_
     return pick;
 }
 
-// R1: runs on ONE lane; all state lives in the wave context's LDS records.
+// R1: the placement is sequential (every draw depends on how many the attempts before it took), so ALL 64 lanes run it
+// redundantly -- same draws, same values, same stores to the wave context's LDS records, every branch wave-uniform -- and
+// share only the one data-parallel part: the overlap test of a candidate against everything placed so far (one placed
+// circle per lane + a ballot instead of a loop of up to 29 square roots on one lane; it was 60 % of the placement's latency).
 template <typename ObsT>
 __device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][cap] x y r sight iscam */, int placed_cap,
                                             const double *pre = nullptr, uint32_t pre_count = 0) {
@@ -117,12 +120,17 @@ __device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][
                 theta = p.theta_min + (kMaxViewingAngle - p.theta_min) * rng.draw();
                 sight = sqrt(p.area / theta);
             }
-            ok = true;
-            for (int q = 0; q < np && ok; ++q) {                                            // entities.py:96-100, 484-489
-                const double d = norm2(x - px[q], y - py[q]);
-                if (d * (1.0 + 1e-6) < rad + pr[q] + min_distance) ok = false;
-                else if (kind == 0 && pk[q] != 0.0) { const double m = sight < ps[q] ? sight : ps[q]; if (d < 0.1 * m) ok = false; }
+            // overlap against everything placed so far (entities.py:96-100, 484-489): one placed circle per lane
+            bool bad = false;
+            for (int q0 = 0; q0 < np; q0 += 64) {
+                const int q = q0 + c.lane;
+                if (q < np) {
+                    const double d = norm2(x - px[q], y - py[q]);
+                    if (d * (1.0 + 1e-6) < rad + pr[q] + min_distance) bad = true;
+                    else if (kind == 0 && pk[q] != 0.0) { const double m = sight < ps[q] ? sight : ps[q]; if (d < 0.1 * m) bad = true; }
+                }
             }
+            ok = __ballot(bad) == 0ull;
         }
         if (!ok && kind == 1) rad = 0.0;                                                    // environment.py:735-736
         px[np] = x; py[np] = y; pr[np] = rad; ps[np] = sight; pk[np] = kind == 0 ? 1.0 : 0.0; ++np;
@@ -502,8 +510,8 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
                 }
                 wave_sync();
             }
+            if (phases & PH_PLACE) reset_place(c, place_scratch, 4 + p.Nc + p.No + p.Nt, pre_draws, g.reset_tape ? 0u : (uint32_t)kPreDraws);
             if ((phases & PH_PLACE) && lane == 0) {
-                reset_place(c, place_scratch, 4 + p.Nc + p.No + p.Nt, pre_draws, g.reset_tape ? 0u : (uint32_t)kPreDraws);
                 if ((g.reset_kind == RESET_FLAGGED || g.reset_kind == RESET_MASK) && (phases & PH_MORE)) g.flag_list[atomicAdd(g.flag_count, 1)] = (int32_t)env;
             }
             wave_sync();
