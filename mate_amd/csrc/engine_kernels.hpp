@@ -144,6 +144,8 @@ struct Ptrs {
     int32_t *done_list;           // [2][N]
     int32_t *flag_count;          // [1] environments selected by a batched (flagged) reset ...
     int32_t *flag_list;           // [N] ... and their indices
+    int32_t *lut_overflow;        // [1 + N Nc] count, then environment * Nc + camera of the occlusion tables a small-LDS table launch deferred
+    int32_t lut_defer_above;      // that launch: tables with more rays than this go on the list (0 = build everything here)
     const uint8_t *reset_mask;    // optional
     const double *reset_tape;     // tape mode of reset (mate_engine_reset_tape): [N][reset_tape_len] uniforms, or NULL = Philox
     int32_t reset_tape_len;

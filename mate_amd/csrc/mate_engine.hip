@@ -77,6 +77,7 @@ struct mate_engine {
     Params *d_params = nullptr;   // device copy read by the kernels
     Ptrs g{};
     ResetLds rl{};
+    ResetLds rl_small{};       // two-tier table launches (launch_reset): the layout with half-size sort arrays; sort_cap 0 = off
     mate_config cfg{};
     int device = 0;
     int64_t N = 0;
@@ -139,6 +140,19 @@ static void layout_reset_lds(const Params &p, ResetLds &rl, int sort_cap) {
     rl.off_meta = roff; roff += round_up(8 * p.No * 8 + (2 * p.No + 4) * 4, 16);
     rl.off_scan = roff; roff += 256 * 4;
     rl.total_bytes = roff;
+}
+
+// Two-tier table launches: the worst case (obstacles filling a camera's horizon: 185 rays each) sizes the sort arrays at
+// 4 x 2048 doubles = 64 KB, two workgroups per CU, while a table of the shipped scenarios has ~550 rays.  The per-camera
+// table launch therefore runs with half-size arrays (four workgroups per CU) and defers the rare larger table to a small
+// full-size launch behind it (RESET_PAIRS).  MATE_LUT_SMALL_CAP=<rays> overrides the small size (tests force deferrals with it).
+static void setup_two_tier(mate_engine *e) {
+    e->rl_small = ResetLds{};
+    if (e->rl.sort_in_hbm || e->rl.sort_cap < 1024) return;
+    int cap = e->rl.sort_cap / 2;
+    if (const char *v = getenv("MATE_LUT_SMALL_CAP")) cap = std::max(512, next_pow2(atoi(v)));
+    if (cap >= e->rl.sort_cap) return;
+    layout_reset_lds(e->p, e->rl_small, cap);
 }
 
 template <typename T>
@@ -276,6 +290,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     ResetLds &rl = e->rl;
     layout_reset_lds(p, rl, std::max(512, next_pow2(Nc > 0 ? 360 + No * 185 + 1 : 1)));
     e->reset_lds = (size_t)rl.total_bytes;
+    setup_two_tier(e);
     if (e->step_lds > 160 * 1024 || e->reset_lds > 160 * 1024) {
         const size_t a = e->step_lds, b = e->reset_lds;
         delete e;
@@ -312,6 +327,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         if ((rc = dev_alloc(e, &g.done_list, 2 * N))) break;
         if ((rc = dev_alloc(e, &g.flag_count, (size_t)4))) break;
         if ((rc = dev_alloc(e, &g.flag_list, N))) break;
+        if ((rc = dev_alloc(e, &g.lut_overflow, N * (size_t)std::max(Nc, 1) + 1))) break;
         if ((rc = dev_alloc(e, &g.idle_steps, N))) break;
         if ((rc = dev_alloc(e, &g.ctrl, (size_t)4))) break;
         if (rl.sort_in_hbm && (rc = dev_alloc(e, &g.sort_scratch, (size_t)kSortGridCap * 4 * rl.sort_cap, false))) break;
@@ -529,11 +545,13 @@ static void apply_io(Ptrs &g, const mate_step_io *io) {
 static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream) {
     g.mode = MODE_OBSERVE; g.reset_kind = kind; g.parity = e->parity; g.freeze_done = 0;
     const Params &p = e->p;
-    auto launch = [&](int ph, int fan, unsigned threads, size_t lds) {
+    auto launch = [&](int ph, int fan, unsigned threads, size_t lds, const ResetLds *layout = nullptr, int64_t grid = 0) {
         int64_t items = ((g.reset_kind == RESET_DONE || g.reset_kind == RESET_LIST) ? std::min<int64_t>(e->N, 256) : e->N) * fan;
         if (e->rl.sort_in_hbm && (ph & PH_LUT)) items = std::min<int64_t>(items, kSortGridCap);     // grid-stride loop; one scratch slice per workgroup
-        if (p.obs_f64) hipLaunchKernelGGL(reset_kernel<double>, dim3((unsigned)items), dim3(threads), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const ResetLds)e->rl, (const int32_t)ph);
-        else hipLaunchKernelGGL(reset_kernel<float>, dim3((unsigned)items), dim3(threads), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const ResetLds)e->rl, (const int32_t)ph);
+        if (grid > 0) items = grid;
+        const ResetLds rl = layout ? *layout : e->rl;
+        if (p.obs_f64) hipLaunchKernelGGL(reset_kernel<double>, dim3((unsigned)items), dim3(threads), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const ResetLds)rl, (const int32_t)ph);
+        else hipLaunchKernelGGL(reset_kernel<float>, dim3((unsigned)items), dim3(threads), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const ResetLds)rl, (const int32_t)ph);
     };
     const char *mono = getenv("MATE_RESET_MONOLITHIC");
     // The immediate auto-reset (RESET_DONE) is launched after EVERY step and is idle almost always: it stays one
@@ -549,7 +567,19 @@ static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_
             launch(PH_PLACE | PH_MORE, 1, 64, lds_place);
             if (selective) g.reset_kind = RESET_LIST;      // the placement launch listed what it reset
         }
-        launch(PH_LUT | PH_PER_CAMERA, p.Nc, 256, e->reset_lds);
+        if (e->rl_small.sort_cap > 0) {
+            // tables: small-LDS launch for (almost) all of them, then the full-size launch for what it deferred
+            HIP_TRY(hipMemsetAsync(g.lut_overflow, 0, sizeof(int32_t), stream));
+            g.lut_defer_above = e->rl_small.sort_cap;
+            launch(PH_LUT | PH_PER_CAMERA, p.Nc, 256, (size_t)e->rl_small.total_bytes, &e->rl_small);
+            g.lut_defer_above = 0;
+            const int kind_now = g.reset_kind;
+            g.reset_kind = RESET_PAIRS;
+            launch(PH_LUT | PH_PER_CAMERA, 1, 256, e->reset_lds, nullptr, 64);
+            g.reset_kind = kind_now;
+        } else {
+            launch(PH_LUT | PH_PER_CAMERA, p.Nc, 256, e->reset_lds);
+        }
         if (phases & PH_VIEW) launch(PH_VIEW, 1, 64, (size_t)p.lds_wave_bytes);
     } else {
         launch(phases, 1, 256, e->reset_lds);
@@ -1032,6 +1062,7 @@ extern "C" int mate_engine_enable_outer_boundary(mate_engine *e, int32_t *capaci
                                : hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, roff);
     if (err != hipSuccess) return fail(MATE_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
     e->rl = rl; e->reset_lds = (size_t)roff;
+    setup_two_tier(e);
     e->g.lut_knots_outer = knots; e->g.lut_count_outer = counts; e->g.kmax_outer = kmax_outer;
     if (capacity) *capacity = kmax_outer;
     return MATE_OK;

@@ -12,7 +12,8 @@
 
 namespace mate {
 
-enum ResetKind : int32_t { RESET_ALL = 0, RESET_MASK = 1, RESET_DONE = 2, RESET_FLAGGED = 3, RESET_LIST = 4 };
+enum ResetKind : int32_t { RESET_ALL = 0, RESET_MASK = 1, RESET_DONE = 2, RESET_FLAGGED = 3, RESET_LIST = 4,
+                           RESET_PAIRS = 5 };   // the (environment, camera) tables a small-LDS table launch deferred (Ptrs::lut_overflow)
 enum ResetPhase : int32_t { PH_PLACE = 1, PH_LUT = 2, PH_VIEW = 4, PH_PER_CAMERA = 8, PH_MORE = 16 };
 
 struct ResetLds {   // byte offsets inside the workgroup's dynamic LDS, after the wave-0 context
@@ -213,8 +214,8 @@ __device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][
 
 // R2: occlusion table of camera `cam` by the whole workgroup.
 template <typename ObsT>
-__device__ __forceinline__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, double *okeys, double *ovals, uint16_t *lbucket,
-                          double *meta, int32_t *scan, int sort_cap, bool outer = false, bool in_hbm = false) {
+__device__ __forceinline__ bool build_lut(Ctx<ObsT> &c, int cam, double *keys, double *vals, double *okeys, double *ovals, uint16_t *lbucket,
+                          double *meta, int32_t *scan, int sort_cap, bool outer = false, bool in_hbm = false, int defer_above = 0) {
     const Params &p = c.p;
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int No = p.No;
@@ -263,13 +264,21 @@ __device__ __forceinline__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, d
     }
     __syncthreads();
     const int nr = hdr[0];
+    // Two-tier launches: the sort arrays of this launch hold `defer_above` rays (half of the worst case, so that four
+    // workgroups fit a CU instead of two); a table with more -- obstacles filling most of a camera's horizon -- is put on a list
+    // and built by the full-size launch behind this one.
+    if (defer_above > 0 && nr >= defer_above) {            // (the closing knot takes slot nr)
+        if (tid == 0) { const int slot = atomicAdd(c.g.lut_overflow, 1); c.g.lut_overflow[1 + slot] = (int32_t)(c.env * p.Nc + cam); }
+        __syncthreads();
+        return true;
+    }
     const int64_t lc = c.env * p.Nc + cam;
     double2 *knots = outer ? c.g.lut_knots_outer + lc * c.g.kmax_outer : c.g.lut_knots + lc * p.kmax;
     int32_t *knot_count = outer ? c.g.lut_count_outer + lc : c.g.lut_count + lc;
     uint16_t *bucket = c.g.lut_bucket + lc * p.nbucket;
     if (hdr[1]) {   // fully blocked view
         if (tid == 0) { knots[0] = make_double2(-180.0, 0.0); knots[1] = make_double2(180.0, 0.0); *knot_count = 2; }
-        if (outer) { __syncthreads(); return; }
+        if (outer) { __syncthreads(); return false; }
         for (int d = tid; d < p.nbucket; d += nthreads) bucket[d] = d >= 360 ? 1 : 0;
         for (int d = tid; d < 360; d += nthreads) {
             double2 *rec = c.g.lut_deg + (lc * 360 + d) * kDegSlots;
@@ -277,7 +286,7 @@ __device__ __forceinline__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, d
             for (int i = 2; i < kDegSlots; ++i) rec[i] = make_double2(__longlong_as_double(0x7ff0000000000000ll), 0.0);
         }
         __syncthreads();
-        return;
+        return false;
     }
     int P = 512;
     while (P < nr) P <<= 1;          // nr <= sort_cap by construction
@@ -428,7 +437,7 @@ __device__ __forceinline__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, d
     }
     __syncthreads();
     for (int i = tid; i <= m; i += nthreads) knots[i] = make_double2(okeys[i], ovals[i]);
-    if (outer) { __syncthreads(); return; }                                // boundary_between(outer=True) only reads the knots
+    if (outer) { __syncthreads(); return false; }                          // boundary_between(outer=True) only reads the knots
     for (int d = tid; d < p.nbucket; d += nthreads) bucket[d] = d <= 361 ? lbucket[d] : (uint16_t)m;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     for (int d = tid; d < 360; d += nthreads) {       // per-degree records of the fast lookup path
@@ -445,6 +454,7 @@ __device__ __forceinline__ void build_lut(Ctx<ObsT> &c, int cam, double *keys, d
         }
     }
     __syncthreads();
+    return false;
 }
 
 // One launch can run all three phases for an environment in one workgroup, or the host splits them
@@ -464,6 +474,8 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
     if (p.dev_tick_on && g.reset_kind == RESET_DONE && blockIdx.x == 0 && threadIdx.x == 0) { g.dev_tick_ptr[0] += g.tick_advance; g.dev_tick_ptr[1] += 1u; }
     if (g.reset_kind == RESET_DONE && (int64_t)blockIdx.x >= (int64_t)g.done_count[parity] * ((phases & PH_PER_CAMERA) ? p.Nc : 1)) return;   // idle: nothing finished
     if (g.reset_kind == RESET_LIST && (int64_t)blockIdx.x >= (int64_t)g.flag_count[0] * ((phases & PH_PER_CAMERA) ? p.Nc : 1)) return;
+    const bool pairs = g.reset_kind == RESET_PAIRS;
+    if (pairs && (int)blockIdx.x >= g.lut_overflow[0]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned char *wave_base = smem;
     double *keys = reinterpret_cast<double *>(smem + rl.off_keys);
@@ -480,13 +492,15 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
     double *meta = reinterpret_cast<double *>(smem + rl.off_meta);
     int32_t *scan = reinterpret_cast<int32_t *>(smem + rl.off_scan);
     const bool per_camera = (phases & PH_PER_CAMERA) != 0;
-    const int fan = per_camera ? p.Nc : 1;
+    const int fan = (per_camera && !pairs) ? p.Nc : 1;
     int64_t count = g.N;
     if (g.reset_kind == RESET_DONE) count = g.done_count[parity];
     if (g.reset_kind == RESET_LIST) count = g.flag_count[0];
+    if (pairs) count = g.lut_overflow[0];
     for (int64_t v = blockIdx.x; v < count * fan; v += gridDim.x) {
-        const int64_t item = per_camera ? v / p.Nc : v;
-        const int only_cam = per_camera ? (int)(v - item * p.Nc) : -1;
+        int64_t item = per_camera ? v / p.Nc : v;
+        int only_cam = per_camera ? (int)(v - item * p.Nc) : -1;
+        if (pairs) { const int32_t entry = g.lut_overflow[1 + v]; item = entry / p.Nc; only_cam = entry - (int32_t)item * p.Nc; }
         const int64_t env = g.reset_kind == RESET_DONE ? (int64_t)g.done_list[(int64_t)parity * g.N + item]
                           : g.reset_kind == RESET_LIST ? (int64_t)g.flag_list[item] : item;
         if (g.reset_kind == RESET_MASK && !g.reset_mask[env]) continue;
@@ -519,8 +533,9 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
         __syncthreads();
         if (phases & PH_LUT) {
             if (per_camera) {
-                build_lut(c, only_cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap, false, rl.sort_in_hbm != 0);
-                if (g.lut_knots_outer) build_lut(c, only_cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap, true, rl.sort_in_hbm != 0);
+                const bool deferred = build_lut(c, only_cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap, false, rl.sort_in_hbm != 0, g.lut_defer_above);
+                if (g.lut_knots_outer && !deferred)       // (deferred here, with the inner table built: the full-size launch rebuilds both)
+                    build_lut(c, only_cam, keys, vals, okeys, ovals, lbucket, meta, scan, rl.sort_cap, true, rl.sort_in_hbm != 0, g.lut_defer_above);
                 // this workgroup owns exactly one word of the static record: the camera's obstacle mask row
                 if (threadIdx.x == 0) {
                     const int w = 2 * p.Nc + 3 * p.No + only_cam;

@@ -185,3 +185,37 @@ def test_kat_scalar_on_device():
     sd = eng.state_dict()
     got = np.concatenate([sd['tgt_x'], sd['tgt_y']], axis=1)
     assert np.abs(got - want).max() < 1e-12, np.abs(got - want).max()
+
+
+def test_two_tier_table_launches_build_the_same_tables(monkeypatch):
+    """The per-camera table launch runs with half-size sort arrays and defers larger tables to a full-size launch behind it
+    (mate_engine.hip: setup_two_tier).  MATE_LUT_SMALL_CAP=512 makes most tables of a 9-obstacle scenario take the deferred path
+    (they have ~550 rays, and the closing knot needs slot nr): tables, static masks and the first observations must be bit-identical
+    to the default build's."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-8v8-9.yaml')
+    n = 300
+    a = Engine(cfg, n, seed=41, first_env_index=9)
+    a.enable_outer_boundary()                # the outer tables (up to 59 rays per obstacle more) go through the same launches
+    monkeypatch.setenv('MATE_LUT_SMALL_CAP', '512')      # read when the reset layout is (re)computed: at creation and here
+    b = Engine(cfg, n, seed=41, first_env_index=9)
+    b.enable_outer_boundary()
+    monkeypatch.delenv('MATE_LUT_SMALL_CAP')
+    for eng in (a, b):
+        eng.reset()
+    torch.cuda.synchronize()
+    assert torch.equal(a.camera_obs, b.camera_obs) and torch.equal(a.target_obs, b.target_obs) and torch.equal(a.masks, b.masks)
+    deferred = 0
+    for e in range(0, n, 7):
+        for c in range(a.num_cameras):
+            pa, ra = a.lut_read(e, c)
+            pb, rb = b.lut_read(e, c)
+            assert np.array_equal(pa, pb) and np.array_equal(ra, rb), (e, c)
+            deferred += len(pa) >= 500
+            qa, sa = a.lut_read(e, c, outer=True)
+            qb, sb = b.lut_read(e, c, outer=True)
+            assert np.array_equal(qa, qb) and np.array_equal(sa, sb), (e, c, 'outer')
+    assert deferred > 20          # the deferred path was exercised
+    sa, sb = a.state_dict(), b.state_dict()
+    assert np.array_equal(sa['camera_obstacle_view_mask'], sb['camera_obstacle_view_mask'])
