@@ -160,3 +160,80 @@ def test_kernels_need_no_scratch_and_keep_full_occupancy():
         # (a couple of SGPRs parked in VGPR lanes are tolerated -- the 8v8-9 random-policy flow sits at the SGPR limit --
         # as long as nothing reaches scratch memory and the occupancy holds)
         assert r['TotalSGPRs'] <= 96 and r['VGPRs'] <= 64 and r['SGPRs Spill'] <= 8 and r['VGPRs Spill'] == 0 and r['Occupancy'] == 8, (name, r)
+
+
+def test_auxiliary_target_rewards_on_a_replayed_trace():
+    """mate_amd.auxiliary_rewards.AuxiliaryTargetRewards (the batched counterpart of the reference wrapper) on CPU tensors: a stand-in
+    engine serves the state, step record and masks of a trace the reference's AuxiliaryTargetRewards shaped; every term but the
+    soft coverage score (a device kernel, checked under -m gpu) and the shaped reward must match the wrapper's own numbers."""
+    import numpy as np
+    import torch
+    import golden_util as G
+    from mate_amd.auxiliary_rewards import AuxiliaryTargetRewards
+    from mate_amd.engine import export_layout
+
+    fx = G.load('auxtgt_4v8-9_s11.npz')
+    Nc, Nt, No = int(fx['num_cameras']), int(fx['num_targets']), int(fx['num_obstacles'])
+    N = 2
+
+    class Replay:
+        device = torch.device('cpu')
+        num_envs, num_cameras, num_targets = N, Nc, Nt
+
+        def __init__(self):
+            self.export_fields, self.width = export_layout(Nc, Nt, No)
+            self.step = -1
+
+        def _row(self):
+            row = np.zeros(self.width)
+            pre = 'reset/' if self.step < 0 else 'step/'
+            pick = (lambda k: fx[pre + k]) if self.step < 0 else (lambda k: fx[pre + k][self.step])
+
+            def put(name, value):
+                off, shape = self.export_fields[name]
+                n = int(np.prod(shape)) if shape else 1
+                row[off:off + n] = np.asarray(value, dtype=np.float64).reshape(n)
+            put('tgt_x', pick('tgt_xy')[:, 0]); put('tgt_y', pick('tgt_xy')[:, 1])
+            put('tgt_goals', pick('tgt_goals')); put('tgt_empty_bits', pick('tgt_empty_bits')); put('tgt_colliding', pick('tgt_colliding'))
+            put('episode', 1)
+            return row
+
+        def export_state(self):
+            return torch.from_numpy(np.broadcast_to(self._row(), (N, self.width)).copy())
+
+        @property
+        def scalars(self):
+            s = self.step
+            rec = [-fx['step/reward_tgt'][s], fx['step/reward_tgt'][s], 0.0, fx['step/coverage_rate'][s], fx['step/real_coverage_rate'][s],
+                   fx['step/mean_transport_rate'][s], fx['step/num_delivered_cargoes'][s], 0.0]
+            return torch.tensor([rec] * N, dtype=torch.float32)
+
+        @property
+        def masks(self):
+            bits = fx['step/camera_target_view_mask'][self.step].reshape(-1)
+            words = np.zeros((bits.size + 31) // 32 + 1, dtype=np.int64)
+            for b in np.flatnonzero(bits):
+                words[b >> 5] |= 1 << (b & 31)
+            return torch.from_numpy(np.broadcast_to(words.astype(np.uint32).view(np.int32), (N, words.size)).copy())
+
+    eng = Replay()
+    keys = [str(k) for k in fx['auxt_keys'] if str(k) != 'soft_coverage_score']
+    coef = dict(zip([str(k) for k in fx['auxt_keys']], [float(c) for c in fx['auxt_coefficients']]))
+    shaper = AuxiliaryTargetRewards(eng, {k: coef[k] for k in keys}, 'none')
+    soft = coef.get('soft_coverage_score', 0.0)
+    delivered = 0
+    for s in range(len(fx['step/done'])):
+        eng.step = s
+        shaped = shaper().numpy()
+        for key in keys:
+            loose = key in ('raw_reward', 'coverage_rate', 'real_coverage_rate', 'mean_transport_rate')
+            np.testing.assert_allclose(shaper.terms[key].numpy()[1], fx['step/auxt_' + key][s], rtol=1e-6 if loose else 1e-12,
+                                       atol=1e-6 if loose else 1e-12, err_msg=f'{key} step {s}')
+        want = fx['step/aux_reward_tgt'][s] - soft * fx['step/auxt_soft_coverage_score'][s]
+        np.testing.assert_allclose(shaped[0], want, rtol=1e-6, atol=1e-5, err_msg=str(s))
+        delivered += int(fx['step/auxt_sparse_delivery'][s].sum())
+    assert delivered == 4          # the trace delivers four cargoes: the delivery term was exercised
+    with pytest.raises(AssertionError):
+        AuxiliaryTargetRewards(eng, {'bogus': 1.0})
+    with pytest.raises(AssertionError):
+        AuxiliaryTargetRewards(eng, {'raw_reward': 1.0}, reduction='min')      # the reference's target wrapper has no 'min'
