@@ -177,7 +177,9 @@ int mate_engine_rollout_random(mate_engine *engine, const mate_step_io *io, int3
  * messages).  mate_engine_policy_enable() must precede the reset()/step() whose view they first act on.
  * mate_engine_step_greedy() = group_step of both teams (observe, two-phase message exchange, act;
  * mate/wrappers/single_team.py:79-92) + step().  `tape` (device arrays, any member NULL = Philox):
- * recorded draws of the agents, for parity runs. */
+ * recorded draws of the agents, for parity runs.  (mate_engine_policy_enable also tabulates the camera agents' 20-iteration
+ * zoom solve, greedy.py:139-145 -- a function of one scalar -- with the reference's own iteration: 225 KB, read with cubic
+ * interpolation to 1.5e-13 degrees; the agents' memory, joint actions and a copy of the view masks are allocated there too.) */
 typedef struct mate_policy_tape {
     const double *camera_resample_u_dev;     /* [N][Nc]      Bernoulli(0.1) uniform when no target is remembered (greedy.py:93) */
     const double *camera_sample_u_dev;       /* [N][Nc][2]   action_space.sample() uniforms (greedy.py:94) */
