@@ -220,7 +220,7 @@ __device__ __forceinline__ void wave_sync() {
 enum Flow : int {
     FLOW_ANY = 0,
     FLOW_RANDOM = 1,    // step_random: on-device uniform policy, Philox draws, plain observations, all outputs present
-    FLOW_ACT_F32 = 2,   // step: f32 continuous joint actions, Philox draws, plain observations, all outputs present
+    FLOW_ACT_F32 = 2,   // step: real-valued joint actions (f32 or f64, per team: Ptrs::act_f64), Philox draws, plain observations, all outputs present
     FLOW_GREEDY = 3,    // rollout_greedy_kernel: joint actions of the on-device Greedy agents, handed over in LDS
 };
 
@@ -269,7 +269,7 @@ struct Ctx {
     // launch switches (constants in the specialised flows)
     __device__ __forceinline__ int mode() const { return flow == FLOW_RANDOM ? (int)MODE_STEP_RANDOM : (flow == FLOW_ACT_F32 || flow == FLOW_GREEDY) ? (int)MODE_STEP : g.mode; }
     __device__ __forceinline__ bool act_from_lds() const { return flow == FLOW_GREEDY; }
-    __device__ __forceinline__ int act_f64() const { return flow == FLOW_ACT_F32 ? 0 : g.act_f64; }
+    __device__ __forceinline__ int act_f64() const { return g.act_f64; }     // (a launch argument in every flow: f32 and f64 joint actions, per team, run the specialised kernel)
     __device__ __forceinline__ int act_discrete() const { return flow != FLOW_ANY ? 0 : g.act_discrete; }
     __device__ __forceinline__ const double *tape_ct() const { return flow != FLOW_ANY ? nullptr : g.tape_ct; }
     __device__ __forceinline__ const double *tape_goal() const { return flow != FLOW_ANY ? nullptr : g.tape_goal; }

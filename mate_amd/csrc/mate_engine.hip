@@ -542,7 +542,7 @@ static void apply_io(Ptrs &g, const mate_step_io *io) {
     g.cam_obs = io->camera_obs_dev; g.tgt_obs = io->target_obs_dev; g.scalars = io->scalars_dev; g.masks = io->masks_dev;
 }
 
-static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream) {
+static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream, bool split_done = false) {
     g.mode = MODE_OBSERVE; g.reset_kind = kind; g.parity = e->parity; g.freeze_done = 0;
     const Params &p = e->p;
     auto launch = [&](int ph, int fan, unsigned threads, size_t lds, const ResetLds *layout = nullptr, int64_t grid = 0) {
@@ -555,8 +555,12 @@ static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_
     };
     const char *mono = getenv("MATE_RESET_MONOLITHIC");
     // The immediate auto-reset (RESET_DONE) is launched after EVERY step and is idle almost always: it stays one
-    // launch.  Whole-batch, masked and batched (flagged) resets are split:
-    if ((phases & PH_LUT) && p.Nc > 1 && kind != RESET_DONE && !(mono && atoi(mono))) {
+    // launch.  Whole-batch, masked and batched (flagged) resets are split -- and so are the list-driven resets of the
+    // flows with the on-device greedy agents (`split_done`), whose ~1.2 k-step episodes finish somewhere in the batch all the time:
+    // one workgroup per finished environment building its tables one after the other was 9 us per step of the learner-versus-greedy loop
+    const uint32_t advance = g.tick_advance;      // device-resident step counter: advanced by the LAST launch of the group
+    if ((phases & PH_LUT) && p.Nc > 1 && (kind != RESET_DONE || split_done) && !(mono && atoi(mono))) {
+        g.tick_advance = 0u;
         // placement: one wave per environment; tables: one workgroup per (environment, camera); view: one wave
         // reset_place scratch behind the wave slice: 5 arrays of placed circles + the shuffle permutations
         // (+ the 256 precomputed uniforms of the reset stream behind them)
@@ -580,6 +584,7 @@ static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_
         } else {
             launch(PH_LUT | PH_PER_CAMERA, p.Nc, 256, e->reset_lds);
         }
+        g.tick_advance = advance;
         if (phases & PH_VIEW) launch(PH_VIEW, 1, 64, (size_t)p.lds_wave_bytes);
     } else {
         launch(phases, 1, 256, e->reset_lds);
@@ -636,7 +641,7 @@ extern "C" int mate_engine_set_episode_stats(mate_engine *e, double *stats_dev) 
     return MATE_OK;
 }
 
-static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream);
+static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream, bool split_done);
 
 // A batched-reset interval (auto_reset = k > 1) is in progress and the caller changes the mode: restart what has finished
 // so far now, by flag, and forget the lists.
@@ -715,7 +720,7 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     if (!e->flow_generic && !g.tape_ct && !g.tape_goal && !g.act_discrete && g.obs_mode == 0 && !g.xdesc && !g.xab &&
         g.scratch_init && (g.cam_obs || e->p.Nc == 0) && g.tgt_obs && g.scalars) {
         if (mode == MODE_STEP_RANDOM) flow = FLOW_RANDOM;
-        else if (mode == MODE_STEP && !g.act_f64) flow = FLOW_ACT_F32;
+        else if (mode == MODE_STEP) flow = FLOW_ACT_F32;      // caller-supplied real-valued actions, f32 or f64 per team
     }
     e->last_flow = flow;
     if (ev0) hipExtLaunchKernelGGL(e->step_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
@@ -738,7 +743,7 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
             apply_io(r, io);
             r.scalars = nullptr; r.tape_ct = nullptr; r.tape_goal = nullptr;
             r.tick_advance = (uint32_t)auto_reset;
-            int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream);
+            int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream, e->greedy_team_bits != 0);
             if (rc != MATE_OK) return rc;
             if (!e->dev_tick) e->parity ^= 1;
         }
@@ -856,7 +861,8 @@ extern "C" int mate_engine_policy_enable(mate_engine *e) {
 static int step_with_policies(mate_engine *e, int team_caller, const mate_step_io *io, const mate_policy_tape *tape, int32_t auto_reset, hipStream_t stream) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (!e->was_reset) return fail(MATE_ESTATE, "step_greedy called before reset() (or import_state)");
-    if (e->dev_tick) return fail(MATE_ESTATE, "not available while the step counter is device-resident (mate_engine_device_tick)");
+    // (works with a device-resident step counter too -- the agents take their tick from the environment record -- so the
+    // learner-versus-greedy loop can be captured in a HIP graph like step(); launch_step checks the reset interval)
     if (!e->policy_ready) return fail(MATE_ESTATE, "call mate_engine_policy_enable() before the reset whose observations the policies act on");
     if (team_caller == 0 && e->p.Nc == 0) return fail(MATE_EINVAL, "the scenario has no cameras to act for");
     if (team_caller >= 0 && (!io || !(team_caller == 0 ? io->camera_actions_dev : io->target_actions_dev)))
@@ -940,7 +946,7 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     if (auto_reset == 1) {
         Ptrs r = e->g;
         apply_io(r, nullptr);     // state and the engine's own masks: the agents of the next rollout act on the fresh view
-        int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream);
+        int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream, true);
         if (rc != MATE_OK) return rc;
         e->parity ^= 1;
     } else if (auto_reset > 1 && (e->pending_interval = auto_reset | kRolloutFlow, ++e->steps_since_reset >= auto_reset)) {

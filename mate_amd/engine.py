@@ -321,10 +321,10 @@ class Engine:
         arguments in every reset interval and can be captured in a HIP graph.  False / 0 gives the counter back."""
         check(self.lib.mate_engine_device_tick(self._h, int(enable), self._stream()))
 
-    def make_stepper(self, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None):
+    def make_stepper(self, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None, versus=None):
         """A replayable `for _ in range(n): between(); step((cam_act, tgt_act))` loop over caller-owned action tensors
-        (see Stepper)."""
-        return Stepper(self, cam_act, tgt_act, auto_reset, graph_steps, between)
+        (see Stepper); versus = 'camera' / 'target': the caller plays that team only, the greedy agents the other."""
+        return Stepper(self, cam_act, tgt_act, auto_reset, graph_steps, between, versus)
 
     def enable_policies(self):
         """Allocate the on-device policy state (call before the reset whose observations the agents act on)."""
@@ -492,12 +492,21 @@ class Stepper:
     graph launch per K steps instead of two kernel launches through ctypes per step.  Bit-identical to calling
     Engine.step in a loop (tested).  `close()` gives the step counter back to the host."""
 
-    def __init__(self, eng, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None):
+    def __init__(self, eng, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None, versus=None):
         self.eng, self.between, self.graph_steps = eng, between, int(graph_steps)
         self.auto_reset = int(auto_reset)        # True / 1: immediate; k > 1: batched (finished environments idle up to k - 1 steps)
+        # versus = 'camera' / 'target': the caller's team (MultiCamera / MultiTarget); the other team is played by the on-device
+        # greedy agents (Engine.step_versus_greedy) and its tensor argument is ignored
+        self.versus = {'camera': 0, 'target': 1, None: None}.get(versus, versus)
+        assert self.versus in (None, 0, 1)
+        if self.versus == 0:
+            tgt_act = None
+        elif self.versus == 1:
+            cam_act = None
         self.io, self.keep = eng._io(cam_act, tgt_act)
         # _io may have made contiguous copies: the stepper must read the caller's own storage
-        assert self.io.target_actions_dev == tgt_act.data_ptr() and (eng.num_cameras == 0 or self.io.camera_actions_dev == cam_act.data_ptr()), \
+        assert (tgt_act is None or self.io.target_actions_dev == tgt_act.data_ptr()) and \
+            (cam_act is None or eng.num_cameras == 0 or self.io.camera_actions_dev == cam_act.data_ptr()), \
             'action tensors must be contiguous f32/f64 (or int32 grid indices) on the engine device'
         self.ref = ctypes.byref(self.io)
         self.graph = None
@@ -518,7 +527,10 @@ class Stepper:
         if self.between is not None:
             self.between()
         eng = self.eng
-        status = eng.lib.mate_engine_step(eng._h, self.ref, self.auto_reset, eng._stream())
+        if self.versus is None:
+            status = eng.lib.mate_engine_step(eng._h, self.ref, self.auto_reset, eng._stream())
+        else:
+            status = eng.lib.mate_engine_step_versus_greedy(eng._h, self.versus, self.ref, None, self.auto_reset, eng._stream())
         if status != 0:
             check(status)
 

@@ -159,6 +159,48 @@ def test_step_masks_with_independently_built_tables(workload, n, oracle_lib):
     assert diverged <= max(1, n // 256) and worst < 1e-9 and obs_ok and rew_ok, (diverged, worst, obs_ok, rew_ok)
 
 
+@pytest.mark.parametrize('team,interval', [('camera', 1), ('target', 2)])
+def test_graph_replayed_learner_versus_greedy(team, interval):
+    """The single-team training loop -- the learner's policy rewrites ITS team's joint action, the greedy opponents act on the
+    device, the environment steps (Engine.step_versus_greedy = MultiCamera / MultiTarget) -- captured in one HIP graph with the step
+    counter on the device == the same iterations launched one by one: outputs, state and the agents' joint actions bit for bit,
+    across episode ends (time limit 9)."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=9)
+    n = 70
+    outs = []
+    for graph_steps in (0, 6):
+        eng = Engine(cfg, n, seed=5)
+        eng.enable_policies()
+        eng.reset()
+        agents = eng.num_cameras if team == 'camera' else eng.num_targets
+        gen = torch.Generator(device='cuda').manual_seed(9)
+        mine = (torch.rand((n, agents, 2), device='cuda', generator=gen) * 2 - 1) * (6 if team == 'camera' else 25)
+
+        def policy():
+            mine.mul_(-1.0).add_(0.125)
+
+        stepper = eng.make_stepper(mine if team == 'camera' else None, mine if team == 'target' else None, auto_reset=interval,
+                                   graph_steps=graph_steps, between=policy, versus=team)
+        rec = []
+        if not graph_steps:
+            stepper.run(interval)
+        for chunk in (12, 5, 7):
+            stepper.run(chunk)
+            torch.cuda.synchronize()
+            rec.append([t.clone() for t in (eng.camera_obs, eng.target_obs, eng.scalars, eng.masks) + tuple(eng.policy_actions())])
+        stepper.close()
+        eng.step_greedy(auto_reset=True)      # the host-counted flow continues seamlessly afterwards
+        rec.append([eng.export_state().clone(), eng.scalars.clone()])
+        outs.append(rec)
+        del stepper, eng
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+    assert float(outs[0][-1][0][:, -2].min()) >= 2          # (export column `episode`) every environment restarted at least once
+
+
 @pytest.mark.parametrize('policy', ['random', 'greedy'])
 def test_rollouts_with_batched_resets(policy):
     """auto_reset = k > 1 on the fused rollouts: finished environments idle through the following launches and all
