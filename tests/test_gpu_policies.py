@@ -277,3 +277,19 @@ def test_fused_greedy_rollout_equals_single_steps(config, n, kw):
         for k in sa:
             assert np.array_equal(sa[k], sb[k]), (rnd, k)
     assert idled == bool(kw)         # the time-limit case did end episodes inside a rollout
+
+
+def test_policies_refuse_more_than_eight_cameras():
+    """The camera agents' message exchange runs one lane per (sender, recipient) pair: scenarios with more than 8 cameras are refused
+    loudly by mate_engine_policy_enable, not stepped wrongly (the environment itself takes up to 16)."""
+    from mate_amd._native import EngineError
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-8v8-9.yaml')
+    cfg['camera']['location_random_range'] = list(cfg['camera']['location_random_range']) + [[-300.0, -200.0, -300.0, -200.0]]
+    eng = Engine(cfg, 8, seed=1)
+    assert eng.num_cameras == 9
+    eng.reset()                                # nine cameras step fine ...
+    eng.step_random()
+    with pytest.raises(EngineError, match='at most 8 cameras'):
+        eng.enable_policies()                  # ... but not with the on-device greedy agents
