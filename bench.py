@@ -40,8 +40,18 @@ Rank 0 prints ONE JSON line (see the driver contract).  Extra objects:
   cpu_baseline  the CPU oracle (oracle/, a parity-checked port of the reference's step path)
                 stepping + packing f32 observations for the same workload on the host cores.
 
+  other_configs the other BASELINE.json configurations that fit one GPU, timed for about a second each after the
+                headline in the default N = 1 run: config 3 (MATE-8v8-9 x 8192, on-device Greedy vs Greedy, fused
+                48-step launches), the per-GPU shard of config 4 (MATE-4v8-0 x 8192) and of config 5
+                (MATE-Navigation x 4096), each with its dominant kernel's dispatch-event average and roofline fraction.
+
 `--dry-run` exercises the launcher and the job-level reduction without a GPU (gloo, fabricated timings; the line says
 `"data": "dry-run"`): it exists for the CPU test of the N-rank launch path and measures nothing.
+`--backend gloo` runs the REAL engine under N ranks that may share a GPU (rank r uses device r mod #devices): the
+sharded `Engine(first_env_index = rank * batch)`, the device-side statistics accumulators, `StatsGather` and the job-level
+reduction, with gloo instead of RCCL for the (CPU-staged) collectives -- the test of the multi-rank path on a one-GPU box.
+`--deterministic` replaces the time-based clock warm-up by a fixed number of steps and `--dump PATH` makes every rank save
+its final state (`PATH.rank<r>.pt`): a sharded run can then be compared with a single-process run of the whole batch.
 """
 import argparse
 import json
@@ -85,8 +95,24 @@ def measured_traffic(kernel, env_steps_per_launch):
         return None
 
 
+REFERENCE_NUMPY_PER_CORE = 391.0   # env-steps/s of the reference's own NumPy path on MATE-4v8-9, one core of the build container
+
+
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(seconds=10.0):
-    """Oracle (CPU port of the reference step path) on the host cores: step + f32 observation pack."""
+    """Oracle (CPU port of the reference step path) on the host cores: step + f32 observation pack, single thread and
+    OpenMP over environments.  About `seconds` of OpenMP work + ~3 s single-threaded + ~3 s of
+    thread-count selection."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from oracle import oracle as O
     import gpu_util as U
@@ -94,35 +120,38 @@ def cpu_baseline(seconds=10.0):
     cfg = read_config(WORKLOAD)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     proto = U.oracle_proto_from_config(cfg, O)
-    batch = O.OracleBatch(proto, BATCH_PER_GPU, seed=0, first_env_index=0)
-    batch.reset(threads=min(cores, 32))
-    # pick the thread count that is fastest on this box (containers often expose more CPUs than they may use)
-    best = (0.0, 1)
-    for threads in sorted({1, 8, 16, 32, 64, 128, cores}):
-        if threads > cores:
-            continue
+
+    def rate(batch, threads, min_seconds, min_steps=2):
         batch.step(auto_reset=True, threads=threads)
-        t0 = time.perf_counter()
-        for _ in range(2):
+        t0, steps = time.perf_counter(), 0
+        while steps < min_steps or time.perf_counter() - t0 < min_seconds:
             batch.step(auto_reset=True, threads=threads)
             batch.observe(threads=threads)
-        rate = 2 * BATCH_PER_GPU / (time.perf_counter() - t0)
-        if rate > best[0]:
-            best = (rate, threads)
-    cores = best[1]
-    t0 = time.perf_counter()
-    steps = 0
-    while True:
-        batch.step(auto_reset=True, threads=cores)
-        batch.observe(threads=cores)
-        steps += 1
-        if steps >= 20 and time.perf_counter() - t0 >= seconds:
-            break
-    dt = time.perf_counter() - t0
+            steps += 1
+        return batch.n * steps / (time.perf_counter() - t0), steps
+
+    # single thread: a 256-environment slice of the same batch (one core steps ~10^4 environments a second)
+    small = O.OracleBatch(proto, 256, seed=0, first_env_index=0)
+    small.reset(threads=1)
+    single, single_steps = rate(small, 1, 3.0)
+    batch = O.OracleBatch(proto, BATCH_PER_GPU, seed=0, first_env_index=0)
+    batch.reset(threads=min(cores, 32))
+    # the thread count that is fastest on this box (containers often expose more CPUs than they may use): >= 0.4 s each
+    scan = {}
+    for threads in sorted({8, 16, 32, 64, 128, cores}):
+        if threads <= cores:
+            scan[threads] = rate(batch, threads, 0.4)[0]
+    best = max(scan, key=scan.get) if scan else 1
+    value, steps = rate(batch, best, seconds, min_steps=10)
     return {
-        'value': BATCH_PER_GPU * steps / dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
-        'sample': f'{WORKLOAD} batch={BATCH_PER_GPU} x {steps} steps (random policy, f32 observation pack), '
-                  f'{dt:.1f} s, OpenMP over environments',
+        'value': value, 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
+        'sample': f'{WORKLOAD} batch={BATCH_PER_GPU} x {steps} steps (random policy, f32 observation pack), OpenMP over environments on '
+                  f'{best} threads (fastest of {sorted(scan)}); single thread: batch=256 x {single_steps} steps',
+        'single_thread': single, 'host_cpus': cores, 'cpu_model': cpu_model(),
+        'thread_scan': {str(k): round(v) for k, v in scan.items()},
+        'reference_numpy_per_core': REFERENCE_NUMPY_PER_CORE,
+        'reference_note': 'the reference\'s own NumPy step() on one core of the BUILD container (Intel Xeon 2.10 GHz; BASELINE.md section 2): '
+                          'it is pure Python and never travels to the GPU box',
     }
 
 
@@ -159,6 +188,14 @@ def parse_args(argv=None):
     ap.add_argument('--no-extras', action='store_true', help='skip the per_step_launch / external_actions side measurements')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
     ap.add_argument('--dry-run', action='store_true', help='launcher / reduction plumbing on CPU with gloo: measures nothing')
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
+                    help='process-group backend for N > 1: nccl (= RCCL, one GPU per rank) or gloo (ranks may share a GPU: the real engine '
+                         'under N ranks on a one-GPU box; statistics are staged through the host)')
+    ap.add_argument('--deterministic', action='store_true', help='fixed-length clock warm-up instead of the time-based one (reproducible final state)')
+    ap.add_argument('--dump', default='', help='every rank saves its final state and last outputs to <path>.rank<r>.pt')
+    ap.add_argument('--max-episode-steps', type=int, default=0, help='override the scenario\'s time limit (tests: episodes that end inside a short run)')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the BASELINE config 3 / 4-shard / 5-shard side measurements')
+    ap.add_argument('--other-seconds', type=float, default=1.0, help='timed seconds per entry of other_configs')
     return ap.parse_args(argv)
 
 
@@ -174,7 +211,7 @@ def launch_ranks(args):
     if not args.dry_run:
         import torch
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < (1 if args.backend == 'gloo' else args.gpus):     # (gloo: ranks may share a GPU)
             raise SystemExit(f'bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
@@ -188,14 +225,17 @@ class StatsGather:
     """Episode statistics all-gathered OFF the critical path.  The engine accumulates the record of
     every finished episode on the device (Engine.episode_stats: count, return, length, coverage, delivered); a gather is
     an event on the launch stream, and behind it on a SIDE stream a 40-byte copy of the accumulators and the RCCL
-    all-gather of the copy.  Nothing is enqueued on the launch stream but the event."""
+    all-gather of the copy.  Nothing is enqueued on the launch stream but the event.  With the gloo backend (ranks
+    sharing a GPU in the one-box test) the side stream copies into pinned host memory and the collective of the LAST
+    submitted copy runs on the host in result()."""
 
-    def __init__(self, torch, dist, distributed, eng):
-        self.torch, self.dist, self.distributed, self.eng = torch, dist, distributed, eng
+    def __init__(self, torch, dist, distributed, eng, host_staged=False):
+        self.torch, self.dist, self.distributed, self.eng, self.host_staged = torch, dist, distributed, eng, host_staged
         self.side = torch.cuda.Stream(device=eng.device)
         world = dist.get_world_size() if distributed else 1
         self.slots = [torch.zeros(5, dtype=torch.float64, device=eng.device) for _ in range(2)]
         self.gathered = [[torch.zeros(5, dtype=torch.float64, device=eng.device) for _ in range(world)] for _ in range(2)]
+        self.host = [torch.zeros(5, dtype=torch.float64).pin_memory() for _ in range(2)] if host_staged else None
         self.events = [torch.cuda.Event() for _ in range(2)]
         self.turn = self.last = 0
         self.count = 0
@@ -207,7 +247,9 @@ class StatsGather:
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
             self.slots[self.turn].copy_(self.eng.episode_stats, non_blocking=True)
-            if self.distributed:
+            if self.host_staged:
+                self.host[self.turn].copy_(self.slots[self.turn], non_blocking=True)
+            elif self.distributed:
                 self.dist.all_gather(self.gathered[self.turn], self.slots[self.turn])
             else:
                 self.gathered[self.turn][0].copy_(self.slots[self.turn], non_blocking=True)
@@ -219,10 +261,76 @@ class StatsGather:
         self.side.synchronize()
         if not self.count:
             return None
-        total = self.torch.stack(self.gathered[self.last]).sum(dim=0).tolist()
+        if self.host_staged:
+            mine = self.host[self.last].clone()
+            parts = [self.torch.zeros_like(mine) for _ in range(self.dist.get_world_size())] if self.distributed else [mine]
+            if self.distributed:
+                self.dist.all_gather(parts, mine)
+            total = self.torch.stack(parts).sum(dim=0).tolist()
+        else:
+            total = self.torch.stack(self.gathered[self.last]).sum(dim=0).tolist()
         episodes = max(total[0], 1.0)
         return {'gathers_in_timed_loops': self.count, 'episodes_finished': total[0], 'mean_episode_return': total[1] / episodes,
                 'mean_episode_length': total[2] / episodes, 'mean_final_coverage_rate': total[3] / episodes, 'mean_delivered': total[4] / episodes}
+
+
+def measure_other_config(torch, device_index, spec, seconds, buffer_gib):
+    """One entry of `other_configs`: a BASELINE.json configuration other than the headline, in its default flow (fused
+    launches; Greedy vs Greedy restarts finished episodes after every 2nd launch, the random policy about every 128
+    steps), timed for about `seconds` of back-to-back launches after an untimed pass and 0.25 s of clock warm-up."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    workload, batch, policy, label = spec
+    eng = Engine(read_config(workload), batch, device=device_index, seed=0, first_env_index=0)
+    b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
+    b_obs = 4 * (eng.num_cameras * eng.camera_obs_dim + eng.num_targets * eng.target_obs_dim) + 48
+    cap = int(buffer_gib * (1 << 30)) // (batch * b_obs)
+    if policy == 'greedy':
+        eng.enable_policies()
+        R, resets, fn, kernel = min(48, cap), 2, eng.rollout_greedy, 'rollout_greedy_kernel'
+    else:
+        R = next((r for r in (256, 128, 64, 32) if r <= cap), max(1, cap))
+        resets, fn, kernel = max(1, 128 // R), eng.rollout_random, 'rollout_kernel'
+    eng.reset()
+    eng.reserve_rollout(R)
+    for _ in range(2 * resets):
+        fn(R, auto_reset=resets)
+    torch.cuda.synchronize()
+    t0, n_warm = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 0.25:
+        for _ in range(resets):
+            fn(R, auto_reset=resets)
+        n_warm += resets
+        torch.cuda.synchronize()
+    per_launch = (time.perf_counter() - t0) / n_warm
+    launches = max(resets, int(seconds / per_launch) // resets * resets)
+    eng.kernel_time(enable=1)
+    torch.cuda.synchronize()
+    idle0, t0 = eng.idle_steps(), time.perf_counter()
+    for _ in range(launches):
+        fn(R, auto_reset=resets)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    executed = batch * R * launches - (eng.idle_steps() - idle0)
+    kernel_ms, timed = eng.kernel_time(enable=False)
+    value = executed / elapsed
+    out = {'config': label, 'workload': f'{workload} batch={batch} envs, {policy} policy, fused {R}-step launches, restarts every {resets} launch(es)',
+           'value': value, 'unit': 'env-steps/s (executed: idle slots of finished episodes excluded)', 'seconds': elapsed, 'launches': launches,
+           'kernel': kernel, 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': timed,
+           'algorithmic_bytes_per_env_step': b_alg,
+           'frac': (b_alg * batch * R / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms > 0 else 0.0,
+           'end_to_end_frac': b_alg * value / 1e9 / HBM_PEAK_GBS}
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
+OTHER_CONFIGS = (
+    ('MATE-8v8-9.yaml', 8192, 'greedy', 'BASELINE config 3'),
+    ('MATE-4v8-0.yaml', 8192, 'random', 'BASELINE config 4, the shard of one of its 8 GPUs'),
+    ('MATE-Navigation.yaml', 4096, 'random', 'BASELINE config 5, the shard of one of its 8 GPUs'),
+)
 
 
 def dry_run(args, world, rank):
@@ -264,11 +372,17 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
+    host_staged = args.backend == 'gloo'
+    if host_staged:
+        local_rank = local_rank % torch.cuda.device_count()      # ranks may share a GPU
     torch.cuda.set_device(local_rank)
     if distributed:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if host_staged:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
-    cfg = read_config(args.workload)
+    cfg = read_config(args.workload, **({'max_episode_steps': args.max_episode_steps} if args.max_episode_steps > 0 else {}))
     eng = Engine(cfg, args.batch, device=local_rank, seed=0, first_env_index=rank * args.batch)
     b_obs = 4 * (eng.num_cameras * eng.camera_obs_dim + eng.num_targets * eng.target_obs_dim) + 48   # written per env-step
     R = args.rollout
@@ -298,7 +412,7 @@ def main():
     # ~64 of its 10^4 steps (idle slots are not counted in `value`) and short launches do not each drag an idle reset launch behind them
     rollout_resets = args.rollout_reset_interval if args.rollout_reset_interval > 0 else (2 if args.policy == 'greedy' else max(1, 128 // max(R, 1)))
     rollout = lambda n, auto_reset=True: rollout_fn(n, auto_reset=rollout_resets)     # noqa: E731
-    gather = StatsGather(torch, dist, distributed, eng) if args.stats_interval > 0 else None
+    gather = StatsGather(torch, dist, distributed, eng, host_staged=host_staged) if args.stats_interval > 0 else None
 
     def run(steps, timed=False):
         """exactly `steps` env.step()s of the whole batch"""
@@ -308,14 +422,16 @@ def main():
                 gather.submit()
         elif R > 0:
             lengths = [R] * (steps // R) + ([steps % R] if steps % R else [])
+            # a gather every `stats_interval` launches -- and one behind the last launch of a region that holds fewer
             for i, n in enumerate(lengths):
                 rollout(n, auto_reset=True)
-                if timed and gather is not None and (i + 1) % args.stats_interval == 0:
+                if timed and gather is not None and ((i + 1) % args.stats_interval == 0 or (i + 1 == len(lengths) < args.stats_interval)):
                     gather.submit()
         else:
+            every = args.stats_interval * 128
             for i in range(steps):
                 step()
-                if timed and gather is not None and (i + 1) % (args.stats_interval * 128) == 0:
+                if timed and gather is not None and ((i + 1) % every == 0 or (i + 1 == steps < every)):
                     gather.submit()
 
     eng.reset()
@@ -332,7 +448,7 @@ def main():
     extra_steps = 0
     eng.kernel_time(enable=1 if R > 0 else 16)     # ... with the dispatch-event launch path of the timed region (events created, runtime warmed)
     t_warm = time.perf_counter()
-    while time.perf_counter() - t_warm < 0.25:
+    while (extra_steps < 4 * args.steps) if args.deterministic else (time.perf_counter() - t_warm < 0.25):
         chunk = min(args.steps, 8 * R) if R > 0 else 64      # back to back like the timed region (sustained, not boost, clocks)
         run(chunk)
         extra_steps += chunk
@@ -364,7 +480,9 @@ def main():
         assert torch.cuda.memory_allocated() <= allocated0, 'allocation inside the timed region'
         kernel_times.append(eng.kernel_time(enable=False))
         stats = eng.scalars[:, [1, 3, 6]].mean(dim=0)    # reward, coverage, delivered: logging only
-        elapsed, executed, stats = reduce_job(elapsed, executed, stats, device='cuda')   # MAX time, SUM env-steps, gathered stats
+        if host_staged:
+            stats = stats.cpu()
+        elapsed, executed, stats = reduce_job(elapsed, executed, stats, device='cpu' if host_staged else 'cuda')   # MAX time, SUM env-steps, gathered stats
         if rep < max(0, args.rep_warmup):
             kernel_times.pop()
             if gather is not None:
@@ -379,8 +497,14 @@ def main():
     flow = eng.last_flow
     gathered_stats = gather.result() if gather is not None else None
 
+    if args.dump:      # every rank: the final state and the last outputs of its shard (compared across shardings by the tests)
+        torch.cuda.synchronize()
+        torch.save({'rank': rank, 'world': world, 'first_env_index': rank * args.batch, 'state': eng.export_state().cpu(),
+                    'scalars': eng.scalars.cpu(), 'episode_stats': eng.episode_stats.cpu(), 'idle_steps': eng.idle_steps(),
+                    'last_rollout_scalars': (eng._rollout['scalars'].cpu() if getattr(eng, '_rollout', None) else None)},
+                   f'{args.dump}.rank{rank}.pt')
     extras = {}
-    if not args.no_extras and args.policy == 'random' and R > 0:
+    if not args.no_extras and args.policy == 'random' and R > 0 and not args.dump:
         # the same workload with one step_kernel launch per step, and with externally supplied actions (learner in the loop)
         k2 = min(max(args.steps, 256), 1024)
         k2 -= k2 % 64                            # whole reset intervals and whole graphs
@@ -461,6 +585,14 @@ def main():
                               'mean_delivered': float(stats[2]), 'gathered_in_loop': gathered_stats},
         }
         line.update(extras)
+        line['config']['backend'] = ('gloo (ranks may share a GPU; statistics staged through the host)' if host_staged else 'nccl (RCCL)') if distributed else 'single process'
+        default_case = world == 1 and args.policy == 'random' and args.workload == WORKLOAD and args.batch == BATCH_PER_GPU
+        if default_case and not args.no_other_configs and not args.dump:
+            # the other BASELINE configurations that fit one GPU, about a second each (the headline engine's buffers are released first)
+            eng.close()
+            eng._rollout = None
+            torch.cuda.empty_cache()
+            line['other_configs'] = [measure_other_config(torch, local_rank, spec, args.other_seconds, args.buffer_gib) for spec in OTHER_CONFIGS]
         if not args.no_cpu_baseline and world == 1 and args.policy == 'random' and args.workload == WORKLOAD:
             line['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -9,6 +9,29 @@
  * (NULL = the default stream); calls on one handle must be serialised by the caller.
  * Every function returns 0 on success or a negative MATE_E* code; the message is available
  * from mate_engine_last_error().  One handle drives N independent environments on one GPU.
+ *
+ * Synchronisation.  Launching entry points only enqueue on `stream`.  The host-side accessors without a stream
+ * argument (seed, lut_read / lut_write(_outer), set_obs_transform, set_obs_mode, set_action_grids,
+ * enable_outer_boundary, idle_steps, kernel_time) wait for the stream of the handle's MOST RECENT launch
+ * (hipStreamSynchronize), never for the whole device: other streams of the caller keep running.
+ *
+ * Environment switches.  All are read ONCE, in mate_engine_create(), and fixed for the life of the handle; none
+ * changes results (each selects between implementations the tests hold bit-identical, except MATE_ZOOM_ITERATE,
+ * see below).  They exist for tests and measurements:
+ *   MATE_GENERIC=1           run the generic kernels even for a (cameras, targets, obstacles) shape with a compiled
+ *                            specialisation (mate_layout.specialised reports which one runs)
+ *   MATE_FLOW_GENERIC=1      run the kernel that reads every launch switch at run time instead of the ones compiled
+ *                            for the common flows (mate_engine_last_flow)
+ *   MATE_STAGGER=<digits>    wave priorities of the single-step kernel at its five phase boundaries, one decimal digit
+ *                            (0-3) each; 0 = off; default 33210 while the batch is one resident generation, else off
+ *   MATE_ROLLOUT_ROTATE=0    no per-step rotation of the wave priorities in the fused rollout kernels (default 1)
+ *   MATE_RESET_MONOLITHIC=1  whole-batch / masked / batched resets as ONE launch instead of placement, per-camera
+ *                            occlusion tables and first view as separate launches
+ *   MATE_LUT_SMALL_CAP=<n>   ray capacity of the small-LDS occlusion-table launch (default: half of the worst case);
+ *                            tables with more rays are built by the full-size launch behind it
+ *   MATE_ZOOM_ITERATE=1      the on-device GreedyCameraAgent runs the reference's 20-iteration zoom solve
+ *                            (mate/agents/greedy.py:139-145) instead of reading its tabulation; the two differ by
+ *                            <= 1.5e-13 degrees in the viewing angle (parity runs that want the iteration itself)
  */
 #ifndef MATE_ENGINE_H
 #define MATE_ENGINE_H

@@ -104,17 +104,34 @@ struct AnyShape {
     static constexpr int kGreedyBlocks = 4;        // rollout_greedy_kernel: workgroups per CU the register budget is set for
     static constexpr bool kGreedyHeld = false;     // ... and whether it keeps the observation descriptors in registers across steps
     const Params *pp;
-    __device__ __forceinline__ explicit AnyShape(const Params *q) : pp(q) {}
+    __device__ __forceinline__ explicit AnyShape(const Params *q, bool /*through_constant*/ = false) : pp(q) {}
     __device__ __forceinline__ const Params &get() const { return *pp; }
 };
 constexpr int shape_range_rounds(int Nc, int Nt, int No) { return (Nt * (Nc + No + Nt) + 63) / 64; }
+struct ParamsWords { uint64_t w[sizeof(Params) / 8]; };
+static_assert(sizeof(ParamsWords) == sizeof(Params), "Params is a whole number of 8-byte words");
+__device__ __forceinline__ Params load_params_constant(const Params *q) {
+    const __attribute__((address_space(4))) uint64_t *src = (const __attribute__((address_space(4))) uint64_t *)q;
+    ParamsWords t;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(Params) / 8; ++i) t.w[i] = src[i];
+    return __builtin_bit_cast(Params, t);
+}
 template <int NC, int NT, int NO, bool F64>
 struct FixedShape {
     static constexpr bool kHoldRoles = shape_range_rounds(NC, NT, NO) <= 3;      // 9 more VGPRs: fits beside the held descriptors
     static constexpr int kGreedyBlocks = 4;
     static constexpr bool kGreedyHeld = true;
     Params local;
-    __device__ __forceinline__ explicit FixedShape(const Params *q) : local(*q) { fill_shape(local, NC, NT, NO, F64); }
+    // `through_constant` (the fused rollouts): the record is copied through the CONSTANT address space.  Nothing writes it
+    // while a kernel runs (the host between launches, the auto-reset launch's dev_tick for the next one), and only then
+    // may the compiler fetch its fields with scalar loads wherever the copy is made.  Through the generic pointer the copy
+    // inside the rollout loop -- behind the previous step's observation stores, which might alias -- was ten flat_load per
+    // step into 26 VGPRs, and their s_waitcnt vmcnt(0) made every wave wait for the HBM acknowledgement of those stores
+    // before its next step (rollout_kernel -1.5 %, rollout_greedy_kernel -3 %).  The single-step kernels copy at their
+    // top, where the compiler emits scalar loads anyway, and live at the 96-SGPR limit: they keep the plain copy.
+    __device__ __forceinline__ explicit FixedShape(const Params *q, bool through_constant = false)
+        : local(through_constant ? load_params_constant(q) : *q) { fill_shape(local, NC, NT, NO, F64); }
     __device__ __forceinline__ const Params &get() const { return local; }
 };
 
@@ -1421,7 +1438,7 @@ __device__ __forceinline__ void list_finished_at_entry(Ctx<ObsT> &c) {
 // scalar record) and is reset by the host-launched reset kernel after the rollout.
 template <typename ObsT, typename Shape, int FLOW = FLOW_ANY>
 __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restrict__ pp, const Ptrs g) {
-    const Shape shape(pp);
+    const Shape shape(pp, true);
     const Params &p = shape.get();
     extern __shared__ __align__(16) unsigned char smem[];
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;
@@ -1478,7 +1495,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         asm volatile("" : "+s"(wave_r));
         const Params *pr = pp;
         asm volatile("" : "+s"(pr));
-        const Shape shape_r(pr);
+        const Shape shape_r(pr, true);
         const Params &p = shape_r.get();
         const int64_t env_r = (int64_t)blockIdx.x * 4 + wave_r;
         Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW);
@@ -1499,6 +1516,8 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         }
 #ifdef MATE_PHASE_CLOCKS
 #define ROLL_STAMP(i) do { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#elif defined(MATE_ISA_MARKS)      // tools/isa_phases.py: phase boundaries as comments in the -S output (no instruction is emitted)
+#define ROLL_STAMP(i) asm volatile("; ==== MATE_PHASE_END " #i)
 #else
 #define ROLL_STAMP(i) do { } while (0)
 #endif

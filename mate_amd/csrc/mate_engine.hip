@@ -44,10 +44,9 @@ using PolicyFn = void (*)(const Params *, const Ptrs, const PolicyPtrs);
 
 // step[flow]: the launch-flag specialisations (enum Flow) exist for f32 observations, the product path; f64
 // observations (the parity mirror) run the generic flow everywhere.
-static void pick_kernels(int Nc, int Nt, int No, bool f64, StepFn *step, StepFn *rollout, PolicyFn *policy, PolicyFn *rollout_greedy, int *specialised) {
-    const char *gen = getenv("MATE_GENERIC");
+static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, StepFn *step, StepFn *rollout, PolicyFn *policy, PolicyFn *rollout_greedy, int *specialised) {
     *specialised = 0;
-    if (!(gen && atoi(gen) != 0)) {
+    if (!generic) {
 #define X(C, T, O)                                                                                                  \
     if (Nc == C && Nt == T && No == O) {                                                                            \
         *specialised = 1;                                                                                           \
@@ -72,7 +71,32 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, StepFn *step, StepFn 
     *rollout_greedy = f64 ? (PolicyFn)rollout_greedy_kernel<double, AnyShape> : (PolicyFn)rollout_greedy_kernel<float, AnyShape>;
 }
 
+// Environment switches (all read ONCE, in mate_engine_create; documented in include/mate_engine.h).
+struct Switches {
+    bool generic = false;          // MATE_GENERIC=1: generic (AnyShape) kernels even for a shape with a compiled specialisation
+    bool flow_generic = false;     // MATE_FLOW_GENERIC=1: every launch runs the FLOW_ANY kernel
+    int stagger = -1;              // MATE_STAGGER=<5 digits>: per-phase wave priorities of step_kernel (-1: by batch size)
+    int lut_small_cap = 0;         // MATE_LUT_SMALL_CAP=<rays>: sort-array size of the small-LDS table launch (0: half the full size)
+    bool reset_monolithic = false; // MATE_RESET_MONOLITHIC=1: resets as one launch instead of placement / tables / view
+    int rollout_rotate = 1;        // MATE_ROLLOUT_ROTATE=0: no wave-priority rotation in the fused rollouts
+    bool zoom_iterate = false;     // MATE_ZOOM_ITERATE=1: the greedy camera agents iterate the zoom solve (greedy.py:139-145) instead of reading its table
+};
+static Switches read_switches() {
+    Switches w;
+    auto flag = [](const char *name) { const char *v = getenv(name); return v && atoi(v) != 0; };
+    w.generic = flag("MATE_GENERIC");
+    w.flow_generic = flag("MATE_FLOW_GENERIC");
+    if (const char *v = getenv("MATE_STAGGER")) w.stagger = atoi(v);
+    if (const char *v = getenv("MATE_LUT_SMALL_CAP")) w.lut_small_cap = atoi(v);
+    w.reset_monolithic = flag("MATE_RESET_MONOLITHIC");
+    if (const char *v = getenv("MATE_ROLLOUT_ROTATE")) w.rollout_rotate = atoi(v);
+    w.zoom_iterate = flag("MATE_ZOOM_ITERATE");
+    return w;
+}
+
 struct mate_engine {
+    Switches sw{};
+    hipStream_t last_stream = nullptr;   // stream of the most recent launch: what the host-side accessors wait for
     Params p{};
     Params *d_params = nullptr;   // device copy read by the kernels
     Ptrs g{};
@@ -150,7 +174,7 @@ static void setup_two_tier(mate_engine *e) {
     e->rl_small = ResetLds{};
     if (e->rl.sort_in_hbm || e->rl.sort_cap < 1024) return;
     int cap = e->rl.sort_cap / 2;
-    if (const char *v = getenv("MATE_LUT_SMALL_CAP")) cap = std::max(512, next_pow2(atoi(v)));
+    if (e->sw.lut_small_cap > 0) cap = std::max(512, next_pow2(e->sw.lut_small_cap));
     if (cap >= e->rl.sort_cap) return;
     layout_reset_lds(e->p, e->rl_small, cap);
 }
@@ -284,8 +308,9 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     p.obs_r_lo = cfg->obstacle_radius_range[0]; p.obs_r_hi = cfg->obstacle_radius_range[1];
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.first_env = (uint32_t)first_env_index;
     e->step_lds = 4 * (size_t)p.lds_wave_bytes;
-    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->step_fn, e->rollout_fn, &e->policy_fn, &e->rollout_greedy_fn, &e->specialised);
-    { const char *fg = getenv("MATE_FLOW_GENERIC"); e->flow_generic = fg && atoi(fg) != 0; }
+    e->sw = read_switches();
+    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->sw.generic, e->step_fn, e->rollout_fn, &e->policy_fn, &e->rollout_greedy_fn, &e->specialised);
+    e->flow_generic = e->sw.flow_generic;
     if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }
     ResetLds &rl = e->rl;
     layout_reset_lds(p, rl, std::max(512, next_pow2(Nc > 0 ? 360 + No * 185 + 1 : 1)));
@@ -307,8 +332,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         // environments run 15-30 % faster without)
         hipDeviceProp_t prop;
         const int64_t cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
-        const char *sv = getenv("MATE_STAGGER");
-        const int digits = sv ? atoi(sv) : (((num_envs + 3) / 4 <= 4 * cus) ? 33210 : 0);
+        const int digits = e->sw.stagger >= 0 ? e->sw.stagger : (((num_envs + 3) / 4 <= 4 * cus) ? 33210 : 0);
         g.stagger = 0;
         if (digits > 0) {
             int d = digits;
@@ -463,7 +487,7 @@ extern "C" int mate_engine_set_obs_transform(mate_engine *e, int32_t relative, c
     if (!e) return fail(MATE_EINVAL, "null engine");
     if ((cam_scale && !cam_bias) || (tgt_scale && !tgt_bias)) return fail(MATE_EINVAL, "scale without bias");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
     const Params &p = e->p;
     e->xf_relative = relative != 0;
     e->xf_cam = cam_scale != nullptr; e->xf_tgt = tgt_scale != nullptr;
@@ -478,7 +502,7 @@ extern "C" int mate_engine_set_obs_mode(mate_engine *e, int32_t camera_mode, int
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (camera_mode < 0 || camera_mode > 2 || target_mode < 0 || target_mode > 2) return fail(MATE_EINVAL, "observation mode must be 0 (plain), 1 (enhanced) or 2 (shared field of view)");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
     e->cam_mode = camera_mode; e->tgt_mode = target_mode;
     return apply_obs_tables(e);
 }
@@ -487,7 +511,7 @@ extern "C" int mate_engine_set_action_grids(mate_engine *e, const double *camera
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (n_cam < 0 || n_tgt < 0 || (n_cam > 0 && !camera_grid) || (n_tgt > 0 && !target_grid)) return fail(MATE_EINVAL, "invalid action grid");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
     auto upload = [&](const double *src, int n, const double2 **dst, int32_t *count) -> int {
         *dst = nullptr; *count = 0;
         if (n == 0) return MATE_OK;
@@ -521,13 +545,13 @@ extern "C" int mate_engine_seed(mate_engine *e, uint64_t seed) {
     if (e->dev_tick) return fail(MATE_ESTATE, "seed() while the step counter is device-resident (mate_engine_device_tick)");
     e->p.seed_lo = (uint32_t)seed; e->p.seed_hi = (uint32_t)(seed >> 32);
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
     HIP_TRY(hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice));
     // the reference re-creates its generators (environment.py:1219-1225): the same seed gives the same episodes again,
     // whatever ran before.  Here: the key, and every counter that enters a Philox counter word (episode, tick) rewound.
-    hipLaunchKernelGGL(rewind_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t) nullptr, (const Params *)e->d_params, (const Ptrs)e->g);
+    hipLaunchKernelGGL(rewind_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, e->last_stream, (const Params *)e->d_params, (const Ptrs)e->g);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
     e->tick = 0;
     return MATE_OK;
 }
@@ -544,6 +568,7 @@ static void apply_io(Ptrs &g, const mate_step_io *io) {
 
 static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream, bool split_done = false) {
     g.mode = MODE_OBSERVE; g.reset_kind = kind; g.parity = e->parity; g.freeze_done = 0;
+    e->last_stream = stream;
     const Params &p = e->p;
     auto launch = [&](int ph, int fan, unsigned threads, size_t lds, const ResetLds *layout = nullptr, int64_t grid = 0) {
         int64_t items = ((g.reset_kind == RESET_DONE || g.reset_kind == RESET_LIST) ? std::min<int64_t>(e->N, 256) : e->N) * fan;
@@ -553,13 +578,12 @@ static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_
         if (p.obs_f64) hipLaunchKernelGGL(reset_kernel<double>, dim3((unsigned)items), dim3(threads), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const ResetLds)rl, (const int32_t)ph);
         else hipLaunchKernelGGL(reset_kernel<float>, dim3((unsigned)items), dim3(threads), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const ResetLds)rl, (const int32_t)ph);
     };
-    const char *mono = getenv("MATE_RESET_MONOLITHIC");
     // The immediate auto-reset (RESET_DONE) is launched after EVERY step and is idle almost always: it stays one
     // launch.  Whole-batch, masked and batched (flagged) resets are split -- and so are the list-driven resets of the
     // flows with the on-device greedy agents (`split_done`), whose ~1.2 k-step episodes finish somewhere in the batch all the time:
     // one workgroup per finished environment building its tables one after the other was 9 us per step of the learner-versus-greedy loop
     const uint32_t advance = g.tick_advance;      // device-resident step counter: advanced by the LAST launch of the group
-    if ((phases & PH_LUT) && p.Nc > 1 && (kind != RESET_DONE || split_done) && !(mono && atoi(mono))) {
+    if ((phases & PH_LUT) && p.Nc > 1 && (kind != RESET_DONE || split_done) && !e->sw.reset_monolithic) {
         g.tick_advance = 0u;
         // placement: one wave per environment; tables: one workgroup per (environment, camera); view: one wave
         // reset_place scratch behind the wave slice: 5 arrays of placed circles + the shuffle permutations
@@ -665,23 +689,26 @@ extern "C" int mate_engine_device_tick(mate_engine *e, int32_t enable, void *str
     if (!e) return fail(MATE_EINVAL, "null engine");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
+    e->last_stream = stream;
     if ((enable != 0) == e->dev_tick && (!enable || enable == e->dev_interval)) return MATE_OK;
     if (enable && e->dev_tick) return fail(MATE_ESTATE, "device_tick: already enabled with interval %d", e->dev_interval);
-    int rc = flush_pending(e, 0, stream);
-    if (rc != MATE_OK) return rc;
+    if (enable) { int rc = flush_pending(e, 0, stream); if (rc != MATE_OK) return rc; }
     HIP_TRY(hipStreamSynchronize(stream));
     if (enable) {
         e->p.dev_tick = e->tick; e->p.dev_group = (uint32_t)e->parity; e->p.dev_tick_on = 1;
         e->dev_interval = enable;
     } else {
-        if (e->steps_since_reset != 0) return fail(MATE_ESTATE, "device_tick: %d step(s) into a reset interval of %d; finish it first", (int)e->steps_since_reset, e->dev_interval);
+        // The device counter holds the tick of the interval's first step; the steps of an interval that is still open
+        // (the caller stopped between two reset launches) are added here, and what finished in it restarts now, by flag
+        // (flush_pending, once the host counts again) -- the same thing a change of auto_reset inside an interval does.
         uint32_t words[2] = {0, 0};
         HIP_TRY(hipMemcpy(words, reinterpret_cast<const char *>(e->d_params) + offsetof(Params, dev_tick), sizeof(words), hipMemcpyDeviceToHost));
-        e->tick = words[0]; e->parity = (int)(words[1] & 1u);
+        e->tick = words[0] + (uint32_t)e->steps_since_reset; e->parity = (int)(words[1] & 1u);
         e->p.dev_tick = 0; e->p.dev_group = 0; e->p.dev_tick_on = 0;      // zero while the host counts (the kernels ADD them to the launch arguments)
     }
     HIP_TRY(hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice));
     e->dev_tick = enable != 0;
+    if (!enable) return flush_pending(e, 0, stream);
     return MATE_OK;
 }
 
@@ -691,6 +718,7 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     if (e->dev_tick && mode != MODE_OBSERVE && auto_reset != e->dev_interval)
         return fail(MATE_ESTATE, "with a device-resident step counter (mate_engine_device_tick) step() needs auto_reset = %d: the auto-reset launch advances it", e->dev_interval);
     HIP_TRY(hipSetDevice(e->device));
+    e->last_stream = stream;
     if (mode != MODE_OBSERVE) { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | kStepFlow) : auto_reset, stream); if (rc != MATE_OK) return rc; }
     Ptrs g = e->g;
     apply_io(g, io);
@@ -764,12 +792,13 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
     if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
+    e->last_stream = stream;
     { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | kRolloutFlow) : auto_reset, stream); if (rc != MATE_OK) return rc; }
     Ptrs g = e->g;
     apply_io(g, io);
     g.mode = MODE_STEP_RANDOM; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick; g.rollout_steps = steps;
     g.tape_ct = nullptr; g.tape_goal = nullptr;
-    { const char *rv = getenv("MATE_ROLLOUT_ROTATE"); g.rotate_prio = rv ? atoi(rv) : 1; }
+    g.rotate_prio = e->sw.rollout_rotate;
     if (auto_reset != 1) g.done_count = nullptr;     // no list: nothing restarts (0), or a batched reset finds the finished ones by their flag (k > 1)
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -839,7 +868,7 @@ static int policy_enable(mate_engine *e) {
         double *d_tab = nullptr;
         if ((rc = dev_alloc(e, &d_tab, (size_t)n, false))) return rc;
         HIP_TRY(hipMemcpy(d_tab, tab.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-        q.zoom_tab = d_tab; q.zoom_inv_h = kInvH; q.zoom_n = n;
+        q.zoom_tab = d_tab; q.zoom_inv_h = kInvH; q.zoom_n = e->sw.zoom_iterate ? 0 : n;      // 0 entries: zoom_lookup iterates
     }
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->policy_fn), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * q.lds_bytes + 1024);
     if (err == hipSuccess) {
@@ -870,6 +899,7 @@ static int step_with_policies(mate_engine *e, int team_caller, const mate_step_i
     if (team_caller >= 0 && (!io || !(team_caller == 0 ? io->camera_actions_dev : io->target_actions_dev)))
         return fail(MATE_EINVAL, "step_versus_greedy needs the %s team's joint action", team_caller == 0 ? "camera" : "target");
     HIP_TRY(hipSetDevice(e->device));
+    e->last_stream = stream;
     PolicyPtrs q = e->q;
     std::memset(&q.tape, 0, sizeof(q.tape));
     if (tape) {
@@ -912,6 +942,7 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
+    e->last_stream = stream;
     { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | kRolloutFlow) : auto_reset, stream); if (rc != MATE_OK) return rc; }
     Ptrs g = e->g;
     apply_io(g, io);
@@ -926,7 +957,7 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     if (lds > 160 * 1024) return fail(MATE_EINVAL, "rollout_greedy: %zu bytes of LDS per workgroup do not fit", lds);
     g.mode = MODE_STEP; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick; g.rollout_steps = steps;
     g.tape_ct = nullptr; g.tape_goal = nullptr; g.freeze_done = 0;
-    { const char *rv = getenv("MATE_ROLLOUT_ROTATE"); g.rotate_prio = rv ? atoi(rv) : 1; }
+    g.rotate_prio = e->sw.rollout_rotate;
     if (auto_reset != 1) g.done_count = nullptr;
     PolicyPtrs q = e->q;
     std::memset(&q.tape, 0, sizeof(q.tape));
@@ -974,6 +1005,7 @@ extern "C" int mate_engine_rollout_versus_greedy(mate_engine *e, int32_t team, c
 extern "C" int mate_engine_policy_actions(mate_engine *e, double *camera_actions_dev, double *target_actions_dev, void *stream) {
     if (!e || !e->policy_ready) return fail(MATE_ESTATE, "policies are not enabled");
     HIP_TRY(hipSetDevice(e->device));
+    e->last_stream = (hipStream_t)stream;
     if (camera_actions_dev && e->p.Nc > 0)
         HIP_TRY(hipMemcpyAsync(camera_actions_dev, e->q.cam_act, sizeof(double) * 2 * e->p.Nc * (size_t)e->N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (target_actions_dev)
@@ -988,6 +1020,7 @@ extern "C" int mate_engine_observe(mate_engine *e, const mate_step_io *io, void 
 extern "C" int mate_engine_export_state(mate_engine *e, double *dst_dev, void *stream) {
     if (!e || !dst_dev) return fail(MATE_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(e->device));
+    e->last_stream = (hipStream_t)stream;
     hipLaunchKernelGGL(export_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->d_params, e->g, dst_dev);
     HIP_TRY(hipGetLastError());
     return MATE_OK;
@@ -997,6 +1030,7 @@ extern "C" int mate_engine_import_state(mate_engine *e, const double *src_dev, v
     if (!e || !src_dev) return fail(MATE_EINVAL, "null argument");
     if (e->dev_tick) return fail(MATE_ESTATE, "import_state while the step counter is device-resident (mate_engine_device_tick)");
     HIP_TRY(hipSetDevice(e->device));
+    e->last_stream = (hipStream_t)stream;
     hipLaunchKernelGGL(import_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->d_params, e->g, src_dev);
     HIP_TRY(hipGetLastError());
     // all environments step together, so they share one tick: adopt the imported one
@@ -1012,7 +1046,7 @@ extern "C" int mate_engine_lut_read(mate_engine *e, int64_t env, int32_t camera,
     if (!e || !phis || !rhos || !count) return fail(MATE_EINVAL, "null argument");
     if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_read: index out of range");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
     const int64_t lc = env * e->p.Nc + camera;
     int32_t n = 0;
     HIP_TRY(hipMemcpy(&n, e->g.lut_count + lc, sizeof(n), hipMemcpyDeviceToHost));
@@ -1029,7 +1063,7 @@ extern "C" int mate_engine_lut_read_outer(mate_engine *e, int64_t env, int32_t c
     if (!e->g.lut_knots_outer) return fail(MATE_ESTATE, "outer boundary not enabled (mate_engine_enable_outer_boundary)");
     if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_read_outer: index out of range");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
     const int64_t lc = env * e->p.Nc + camera;
     int32_t n = 0;
     HIP_TRY(hipMemcpy(&n, e->g.lut_count_outer + lc, sizeof(n), hipMemcpyDeviceToHost));
@@ -1049,7 +1083,7 @@ extern "C" int mate_engine_enable_outer_boundary(mate_engine *e, int32_t *capaci
     if (p.Nc == 0) return fail(MATE_EINVAL, "no cameras in this scenario");
     if (e->g.lut_knots_outer) { if (capacity) *capacity = e->g.kmax_outer; return MATE_OK; }
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
     // 360 + per obstacle (arc <= 181 rays + two 21-point flanks) rays are sorted in LDS
     const int rays = 360 + p.No * (181 + 42) + 1;
     ResetLds rl = e->rl;
@@ -1082,7 +1116,7 @@ extern "C" int mate_engine_lut_write_outer(mate_engine *e, int64_t env, int32_t 
     if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_write_outer: index out of range");
     if (n < 2 || n > e->g.kmax_outer) return fail(MATE_EINVAL, "lut_write_outer: %d knots do not fit (capacity %d)", n, e->g.kmax_outer);
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
     std::vector<double2> knots((size_t)n);
     for (int i = 0; i < n; ++i) { knots[i].x = phis[i]; knots[i].y = rhos[i]; }
     const int64_t lc = env * e->p.Nc + camera;
@@ -1100,6 +1134,7 @@ extern "C" int mate_engine_soft_coverage(mate_engine *e, const uint32_t *masks_d
     if (!e->was_reset) return fail(MATE_ESTATE, "soft_coverage called before reset() (or import_state)");
     HIP_TRY(hipSetDevice(e->device));
     const int64_t items = e->N * e->p.Nc;
+    e->last_stream = (hipStream_t)stream;
     hipLaunchKernelGGL(soft_coverage_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const Params *)e->d_params, (const Ptrs)e->g, masks_dev, matrix_dev, scores_dev);
     HIP_TRY(hipGetLastError());
@@ -1111,7 +1146,7 @@ extern "C" int mate_engine_lut_write(mate_engine *e, int64_t env, int32_t camera
     if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_write: index out of range");
     if (n < 2 || n > e->p.kmax) return fail(MATE_EINVAL, "lut_write: %d knots do not fit (capacity %d)", n, e->p.kmax);
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
     std::vector<double2> knots((size_t)n);
     std::vector<uint16_t> bucket((size_t)e->p.nbucket, 0);
     for (int i = 0; i < n; ++i) { knots[i].x = phis[i]; knots[i].y = rhos[i]; }
@@ -1165,7 +1200,7 @@ extern "C" int mate_engine_debug_skip(mate_engine *e, int32_t mask) {
 extern "C" int mate_engine_idle_steps(mate_engine *e, int64_t *total) {
     if (!e || !total) return fail(MATE_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
     std::vector<int32_t> host((size_t)e->N);
     HIP_TRY(hipMemcpy(host.data(), e->g.idle_steps, sizeof(int32_t) * host.size(), hipMemcpyDeviceToHost));
     int64_t sum = 0;
@@ -1182,7 +1217,7 @@ extern "C" int mate_engine_kernel_time(mate_engine *e, int32_t enable, double *a
     double total = 0.0;
     int64_t n = 0;
     if (e->events_used) {
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipStreamSynchronize(e->last_stream));
         for (size_t i = 0; i < e->events_used; ++i) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, e->events[i].first, e->events[i].second));

@@ -476,7 +476,7 @@ __device__ __forceinline__ void load_caller_actions(Ctx<ObsT> &c, int team, doub
 
 template <typename ObsT, typename Shape>
 __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q) {
-    const Shape shape(pp);
+    const Shape shape(pp, true);
     const Params &p = shape.get();
     extern __shared__ __align__(16) unsigned char smem[];
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         asm volatile("" : "+s"(wave_r));
         const Params *pr = pp;
         asm volatile("" : "+s"(pr));
-        const Shape shape_r(pr);
+        const Shape shape_r(pr, true);
         const Params &p = shape_r.get();
         const int64_t env_w = (int64_t)blockIdx.x * 4 + wave_r;
         const int64_t env_r = env_w < g.N ? env_w : g.N - 1;

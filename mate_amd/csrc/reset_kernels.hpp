@@ -505,6 +505,19 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
         const int64_t env = g.reset_kind == RESET_DONE ? (int64_t)g.done_list[(int64_t)parity * g.N + item]
                           : g.reset_kind == RESET_LIST ? (int64_t)g.flag_list[item] : item;
         if (g.reset_kind == RESET_MASK && !g.reset_mask[env]) continue;
+        if (g.reset_kind == RESET_DONE) {
+            // A listed environment that somebody else restarted since (reset(env_mask), reset_tape, a whole-batch reset under a
+            // device-resident step counter) is in the middle of a NEW episode: leave it alone.  The launch that places voids
+            // the list entry, so that the table / view launches of a split reset skip it too.
+            if (env < 0) continue;
+            if (phases & PH_PLACE) {
+                const int done = reinterpret_cast<const int32_t *>(g.dyn + env * p.DW + p.DF)[p.Nt * TI_STRIDE + EI_DONE];
+                if (done == 0) {
+                    if (threadIdx.x == 0) g.done_list[(int64_t)parity * g.N + item] = -1;
+                    continue;
+                }
+            }
+        }
         if (g.reset_kind == RESET_FLAGGED) {
             const int done = reinterpret_cast<const int32_t *>(g.dyn + env * p.DW + p.DF)[p.Nt * TI_STRIDE + EI_DONE];
             if (done == 0) continue;

@@ -323,7 +323,8 @@ class Engine:
 
     def make_stepper(self, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None, versus=None):
         """A replayable `for _ in range(n): between(); step((cam_act, tgt_act))` loop over caller-owned action tensors
-        (see Stepper); versus = 'camera' / 'target': the caller plays that team only, the greedy agents the other."""
+        (see Stepper); versus = 'camera' / 'target': the caller plays that team only, the greedy agents the other.
+        With graph_steps > 0 the constructor runs `auto_reset` REAL steps before it captures (Stepper.warmup_steps)."""
         return Stepper(self, cam_act, tgt_act, auto_reset, graph_steps, between, versus)
 
     def enable_policies(self):
@@ -490,7 +491,14 @@ class Stepper:
     iterations are captured once in a HIP graph (torch.cuda.CUDAGraph: the policy's kernels and the engine's launches
     in one graph); `run(n)` replays it n // K times and launches the remainder directly.  The host then spends one
     graph launch per K steps instead of two kernel launches through ctypes per step.  Bit-identical to calling
-    Engine.step in a loop (tested).  `close()` gives the step counter back to the host."""
+    Engine.step in a loop (tested).  `close()` gives the step counter back to the host; an open reset interval (run()
+    stopped between two reset launches) is closed there: what had finished in it restarts at once.
+
+    NOTE -- building a graph Stepper ADVANCES the environments: before the capture, one whole reset interval
+    (`auto_reset` real steps: `between()`, the greedy opponents of `versus`, the step) runs directly, so that every code
+    object is loaded and the device-resident counter sits on an interval boundary.  Those `warmup_steps` transitions are
+    real (outputs in the engine's tensors, episode statistics counted) and a learner that must see every transition
+    reads them like any other step; "bit-identical to Engine.step in a loop" means a loop that includes them."""
 
     def __init__(self, eng, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None, versus=None):
         self.eng, self.between, self.graph_steps = eng, between, int(graph_steps)
@@ -511,6 +519,7 @@ class Stepper:
         self.ref = ctypes.byref(self.io)
         self.graph = None
         self._phase = 0                                   # steps into the current reset interval (graphs hold whole intervals)
+        self.warmup_steps = self.auto_reset if self.graph_steps > 0 else 0      # real steps the constructor runs (see the class note)
         if self.graph_steps > 0:
             assert self.auto_reset >= 1 and self.graph_steps % self.auto_reset == 0, \
                 'graph replay needs auto_reset >= 1 (the auto-reset launch advances the device step counter) and whole reset intervals per graph'
@@ -554,10 +563,12 @@ class Stepper:
         if self.graph is not None:
             torch.cuda.synchronize(self.eng.device)
             self.graph = None
-            self.eng.device_tick(False)
+            self._phase = 0
+            self.eng.device_tick(False)                   # (closes an open reset interval: mate_engine_device_tick)
 
     def __del__(self):
         try:
             self.close()
-        except Exception:
-            pass
+        except Exception as exc:      # an engine left in device-tick mode refuses rollouts / seed / import_state: say so
+            import warnings
+            warnings.warn(f'Stepper.close() failed while the stepper was collected: {exc!r}; the engine may still count steps on the device', RuntimeWarning)

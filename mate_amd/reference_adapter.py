@@ -100,6 +100,7 @@ def hip_environment_class(reference_environment):
         # ---------------------------------------------------------------- the swapped internals
         def reset(self, *, seed=None):                                    # environment.py:679-834
             self._destroy()
+            self._step_record = None                                      # the previous episode's last step says nothing about the new one
             if seed is not None:
                 self.seed(seed)
             self.cameras, self.targets, self.obstacles = list(self.cameras_ordered), list(self.targets_ordered), list(self.obstacles_ordered)

@@ -123,3 +123,33 @@ def oracle_from_fixture(fx, use_golden_lut=True):
     for k, v in dynamic_of(fx).items():
         env.set(k, v)
     return env
+
+
+def assert_only_tangent_flips(phis, got, ref, cam_xy, rmax, obstacles_xyr, tol, where=None):
+    """The occlusion-table tolerance, as narrow as the reference's own indeterminacy.  A ray EXACTLY tangent to an obstacle
+    is clipped or not depending on the last bit of asin / atan2 (`radius > perpendicular`, entities.py:170), so a knot
+    of `Camera.sight_range_func` may differ from the reference's -- but only a knot whose angle is a tangent direction
+    `atan2(rel) +- asin(r / |rel|)` of an obstacle in range of that camera (entities.py:389-417: the arc's first / last
+    ray, with the +-0.01 degree edge rays beside it), and at most two of them per obstacle.  Everything else must agree
+    to `tol`."""
+    phis, got, ref = np.asarray(phis, dtype=np.float64), np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    bad = np.flatnonzero(np.abs(got - ref) > tol)
+    obstacles = np.asarray(obstacles_xyr, dtype=np.float64).reshape(-1, 3)
+    assert len(bad) <= 2 * len(obstacles), (where, 'mismatching knots', len(bad))
+    if not len(bad):
+        return 0
+    rel = obstacles[:, :2] - np.asarray(cam_xy, dtype=np.float64).reshape(1, 2)
+    dist = np.hypot(rel[:, 0], rel[:, 1])
+    in_range = (dist < rmax + obstacles[:, 2]) & (dist > obstacles[:, 2])          # Camera.add_obstacles, entities.py:365
+    centre = np.degrees(np.arctan2(rel[in_range, 1], rel[in_range, 0]))
+    half = np.degrees(np.arcsin(np.minimum(1.0, obstacles[in_range, 2] / dist[in_range])))
+    tangents = np.concatenate([centre - half, centre + half])
+    per_obstacle = np.zeros(int(in_range.sum()), dtype=int)
+    for i in bad:
+        off = np.abs((phis[i] - tangents + 180.0) % 360.0 - 180.0)
+        j = int(np.argmin(off)) if len(off) else -1
+        assert j >= 0 and off[j] <= 0.011, (where, 'knot', int(i), 'angle', float(phis[i]), 'differs by', float(abs(got[i] - ref[i])),
+                                            'and is', float(off[j]) if j >= 0 else None, 'degrees from the nearest tangent direction')
+        per_obstacle[j % len(per_obstacle)] += 1
+    assert per_obstacle.max() <= 2 + 2, (where, per_obstacle)      # the tangent ray and its +-0.01 degree edge rays, both sides
+    return len(bad)

@@ -1,0 +1,131 @@
+"""The one collective's payload and the multi-rank path on the REAL engine.
+
+* the device-side episode-statistics accumulators (assign_and_score: five atomicAdd per finished episode) against sums
+  computed from the per-step scalar records -- the counterpart of the reference's per-episode logging
+  (mate/evaluate.py:129-143, examples/utils/callbacks.py:146-233);
+* `bench.py --gpus 2 --backend gloo`: two processes (sharing cuda:0 on a one-GPU box) run the sharded
+  `Engine(first_env_index = rank * N)`, `StatsGather` inside the timed loops and the job-level reduction; the state each
+  rank ends with equals its half of a single-process run of the whole 2N batch, bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from mate_amd.config import read_config
+from mate_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('flow', ['step', 'rollout', 'greedy_rollout'])
+def test_device_episode_statistics_equal_sums_over_the_step_records(flow):
+    """max_episode_steps = 5 -> every episode ends at its 6th step (or earlier, by cargo); with auto-reset the batch runs
+    through several episodes.  Engine.episode_stats = (episodes, sum of returns, sum of lengths, sum of final coverage
+    rates, sum of delivered cargoes): count / length / delivered exact, the f64 sums to 1e-9 relative."""
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=5)
+    n = 64
+    eng = Engine(cfg, n, seed=21)
+    if flow == 'greedy_rollout':
+        eng.enable_policies()
+    eng.reset()
+    assert float(eng.episode_stats.abs().sum()) == 0.0
+    episodes = 0
+    returns = np.zeros(n)           # running return of the episode in progress (f64 sums of the f32 step rewards' exact values)
+    lengths = np.zeros(n, dtype=np.int64)
+    want = np.zeros(5)
+
+    def account(scalars):           # one step's record [n, 8]
+        nonlocal episodes
+        sc = scalars.double().cpu().numpy()
+        live = sc[:, 2] != 2
+        returns[live] += sc[live, 1]
+        lengths[live] += 1
+        done = sc[:, 2] == 1
+        want[0] += done.sum(); want[1] += returns[done].sum(); want[2] += lengths[done].sum()
+        want[3] += sc[done, 3].sum(); want[4] += sc[done, 6].sum()
+        returns[done] = 0.0; lengths[done] = 0
+
+    if flow == 'step':
+        for _ in range(40):
+            _, _, sc = eng.step_random(auto_reset=True)
+            account(sc)
+    else:
+        fn = eng.rollout_greedy if flow == 'greedy_rollout' else eng.rollout_random
+        for _ in range(8):
+            _, _, sc = fn(5, auto_reset=True)
+            for r in range(5):
+                account(sc[r])
+    got = eng.episode_stats.cpu().numpy()
+    assert want[0] >= 3 * n
+    assert got[0] == want[0] and got[2] == want[2] and got[4] == want[4]
+    # step rewards are integers (bounties, freights) at this scale and survive the f32 record exactly; coverage is k / 8
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(got[3], want[3], rtol=1e-9, atol=1e-9)
+    assert got[2] <= 6 * got[0]
+
+
+def _bench(args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # a CHILD process per run: this pytest process has initialised the GPU and must not be replaced by another program
+    done = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          universal_newlines=True, timeout=timeout)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [json.loads(l) for l in done.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, done.stdout[-2000:]
+    return lines[0]
+
+
+def test_two_ranks_on_one_gpu_run_the_real_engine_and_shard_bit_for_bit(tmp_path):
+    common = ['--steps', '20', '--warmup', '5', '--reps', '2', '--rep-warmup', '1', '--deterministic', '--no-cpu-baseline', '--no-extras',
+              '--no-other-configs', '--workload', 'MATE-4v8-9.yaml', '--max-episode-steps', '7', '--rollout-reset-interval', '1']
+    n = 96
+    sharded = _bench(common + ['--gpus', '2', '--backend', 'gloo', '--batch', str(n), '--dump', str(tmp_path / 'two')])
+    whole = _bench(common + ['--gpus', '1', '--batch', str(2 * n), '--dump', str(tmp_path / 'one')])
+    assert sharded['n_gpus'] == 2 and sharded['config']['global_batch'] == 2 * n and 'gloo' in sharded['config']['backend']
+    assert whole['n_gpus'] == 1 and whole['config']['global_batch'] == 2 * n
+    assert sharded['data'] == 'synthetic' and sharded['value'] > 0 and sharded['roofline']['kernel_avg_us'] > 0
+    # the statistics gather fired inside the timed loops of both runs (once per repetition: one 20-step launch each)
+    for line in (sharded, whole):
+        gathered = line['episode_stats']['gathered_in_loop']
+        assert gathered is not None and gathered['gathers_in_timed_loops'] >= 1
+    parts = [torch.load(str(tmp_path / f'two.rank{r}.pt')) for r in range(2)]
+    one = torch.load(str(tmp_path / 'one.rank0.pt'))
+    assert [p['first_env_index'] for p in parts] == [0, n] and [p['world'] for p in parts] == [2, 2]
+    state = torch.cat([p['state'] for p in parts], dim=0)
+    assert torch.equal(state.view(torch.uint8), one['state'].view(torch.uint8))                 # every environment, every field
+    assert torch.equal(torch.cat([p['scalars'] for p in parts]).view(torch.uint8), one['scalars'].view(torch.uint8))
+    rows = torch.cat([p['last_rollout_scalars'] for p in parts], dim=1)
+    assert torch.equal(rows.view(torch.uint8), one['last_rollout_scalars'].view(torch.uint8))
+    # the accumulators the collective carries: per-rank sums add up to the whole batch's (sums of f64 in a different order: 1e-9)
+    total = parts[0]['episode_stats'] + parts[1]['episode_stats']
+    assert total[0] >= 2 * n * 3                                     # time limit 7: several episodes per environment ended inside the run
+    assert sharded['episode_stats']['gathered_in_loop']['episodes_finished'] >= 2 * n
+    assert total[0] == one['episode_stats'][0] and total[2] == one['episode_stats'][2] and total[4] == one['episode_stats'][4]
+    assert torch.allclose(total, one['episode_stats'], rtol=1e-9, atol=1e-9)
+    assert parts[0]['idle_steps'] + parts[1]['idle_steps'] == one['idle_steps']
+
+
+def test_time_limited_episodes_reach_the_gathered_statistics(tmp_path):
+    """With episodes that end inside the run the gathered record is not empty: max_episode_steps is a config override the
+    bench does not expose, so this drives StatsGather itself on a short-episode engine (one rank)."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=5)
+    eng = Engine(cfg, 64, seed=3)
+    eng.reset()
+    gather = bench.StatsGather(torch, dist, False, eng)
+    for i in range(6):
+        eng.rollout_random(4, auto_reset=True)
+        if i % 2 == 1:
+            gather.submit()
+    out = gather.result()
+    torch.cuda.synchronize()
+    assert out['gathers_in_timed_loops'] == 3 and out['episodes_finished'] == float(eng.episode_stats[0]) >= 64 * 3
+    assert 1.0 <= out['mean_episode_length'] <= 6.0

@@ -45,7 +45,8 @@ def test_reset_tape_parity(path, dtype):
         gp, gr = eng.lut_read(1, c)
         assert len(gp) == len(phis), (c, len(gp), len(phis))
         assert np.abs(gp - phis).max() < 1e-9
-        assert (np.abs(gr - rhos) > 1e-6).sum() <= 2 * No     # tangent-ray coin flips of the reference
+        # ... except the reference's own tangent-ray coin flips: only knots AT a tangent direction of an obstacle in range may differ
+        G.assert_only_tangent_flips(phis, gr, rhos, fx['static/cam_xy'][c], float(fx['static/cam_max_sight_range'][c]), fx['static/obs_xyr'], 1e-6, (path, c))
     masks = eng.unpack_masks()
     for m in G.MASK_FIELDS:
         for e in range(N):
@@ -219,3 +220,48 @@ def test_two_tier_table_launches_build_the_same_tables(monkeypatch):
     assert deferred > 20          # the deferred path was exercised
     sa, sb = a.state_dict(), b.state_dict()
     assert np.array_equal(sa['camera_obstacle_view_mask'], sb['camera_obstacle_view_mask'])
+
+
+@pytest.mark.parametrize('rmax', [150.0, 1500.0])
+def test_kat_obstruct_geometries_as_one_obstacle_tables(rmax, oracle_lib):
+    """The NON-tangential variants of Obstacle.obstruct (entities.py:158-184: near crossing = the inner table, far crossing
+    = `outer`) are what the occlusion-table builder applies to every ray (entities.py:450-455).  Every distinct (origin,
+    circle) geometry of the non-tangential kat_obstruct rows -- miss, tangent, grazing, head-on, exact touch -- becomes one
+    environment (one camera at the origin, that one obstacle): the device's tables against the oracle's builder, whose
+    `obstruct` the CPU suite pins to those rows' recorded outputs.  Inner table knot for knot (only a knot AT a tangent
+    direction may sit on the other side of the reference's coin flip); outer table as a piecewise-linear function (its
+    flank points may merge with the arc's end ray, as in test_outer_boundary_*)."""
+    O = oracle_lib
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    rows = G.load('kat_obstruct.npz')['rows']
+    geo = np.unique(rows[rows[:, 7] == 0][:, [0, 1, 4, 5, 6]], axis=0)
+    dist = np.hypot(geo[:, 2] - geo[:, 0], geo[:, 3] - geo[:, 1])
+    geo = geo[dist > geo[:, 4]]                     # (a camera never stands inside an obstacle: Camera.overlap, entities.py:484-489)
+    n = len(geo)
+    assert n > 1200
+    cfg = read_config('MATE-1v1-9.yaml', camera={'max_sight_range': float(rmax)}, obstacle={'location_random_range': [[-100, 100, -100, 100]]})
+    eng = Engine(cfg, n, seed=2, obs_dtype=torch.float64)
+    assert (eng.num_cameras, eng.num_targets, eng.num_obstacles) == (1, 1, 1)
+    eng.enable_outer_boundary()
+    eng.reset()
+    eng.load_state_dict({'cam_x': geo[:, 0:1], 'cam_y': geo[:, 1:2], 'obs_x': geo[:, 2:3], 'obs_y': geo[:, 3:4], 'obs_radius': geo[:, 4:5]})
+    eng.rebuild_luts()
+    torch.cuda.synchronize()
+    in_range = np.hypot(geo[:, 2] - geo[:, 0], geo[:, 3] - geo[:, 1]) < rmax + geo[:, 4]
+    assert np.array_equal(eng.state_dict()['camera_obstacle_view_mask'][:, 0, 0] != 0, in_range)        # entities.py:365, strict
+    grid = np.linspace(-180.0, 180.0, 7201)
+    flips = clipped = 0
+    for e in range(n):
+        obstacle = geo[e, 2:5].reshape(1, 3)
+        gp, gr = eng.lut_read(e, 0)
+        op, orr = O.build_lut(geo[e, 0:2], rmax, obstacle)
+        assert len(gp) == len(op) and np.abs(gp - op).max() < 1e-9, (e, len(gp), len(op))
+        flips += G.assert_only_tangent_flips(gp, gr, orr, geo[e, 0:2], rmax, obstacle, 1e-7, e)
+        clipped += int((orr < rmax * (1 - 1e-9)).any())
+        gp, gr = eng.lut_read(e, 0, outer=True)
+        op, orr = O.build_lut(geo[e, 0:2], rmax, obstacle, outer=True)
+        assert abs(len(gp) - len(op)) <= 2, (e, len(gp), len(op))
+        diff = np.abs(np.interp(grid, gp, gr) - np.interp(grid, op, orr))
+        assert (diff > 1e-6).mean() < 0.002, (e, (diff > 1e-6).sum(), diff.max())
+    assert clipped >= 0.9 * in_range.sum() and flips <= n // 50

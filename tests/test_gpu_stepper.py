@@ -264,3 +264,80 @@ def test_batched_step_resets_list_once_and_survive_mode_changes():
     assert (sd['done'] == 0).all() and (sd['episode'] == 2).all() and (sd['episode_step'] == 3).all()
     eng2.step_random(auto_reset=True)
     assert (eng2.state_dict()['episode_step'] == 4).all()
+
+
+@pytest.mark.parametrize('greedy', [False, True])
+def test_listed_environment_restarted_by_mask_is_not_restarted_again(greedy):
+    """auto_reset = k on step(): an environment on the interval's finished-episode list that the caller restarts itself
+    (reset(env_mask)) before the interval ends is in a NEW episode when the interval's reset launch runs -- that launch
+    must leave it alone (no second restart in mid-episode, no rewritten view), and still restart the others.  `greedy`:
+    the list-driven reset split into placement / table / view launches (the flows with the on-device agents).
+    A twin engine whose interval (k = 16) does not end at the 8th step is the reference for the restarted ones."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=4)
+    n = 19
+    mask = torch.zeros(n, dtype=torch.uint8)
+    mask[::3] = 1
+    picked = mask.numpy().astype(bool)
+    runs = []
+    for k in (8, 16):
+        eng = Engine(cfg, n, seed=5)
+        if greedy:
+            eng.enable_policies()
+        step = (lambda: eng.step_greedy(auto_reset=k)) if greedy else (lambda: eng.step_random(auto_reset=k))
+        eng.reset()
+        for _ in range(5):
+            step()                                        # time limit 4 -> done on the 5th step: all finished and listed
+        assert (eng.state_dict()['done'] == 3).all()
+        eng.reset(env_mask=mask)                          # the caller restarts a third of them inside the interval
+        sd = eng.state_dict()
+        assert (sd['done'][picked] == 0).all() and (sd['episode'][picked] == 2).all() and (sd['done'][~picked] == 3).all()
+        for _ in range(3):
+            step()                                        # 6th .. 8th: the restarted ones advance; k = 8: then the interval's reset launch
+        torch.cuda.synchronize()
+        runs.append((eng.state_dict(), eng.target_obs.clone(), eng.camera_obs.clone(), eng.scalars.clone(), eng))
+    sd, sd16 = runs[0][0], runs[1][0]
+    assert (sd['episode'][picked] == 2).all() and (sd['episode_step'][picked] == 3).all() and (sd['done'][picked] == 0).all()
+    assert (sd['episode'][~picked] == 2).all() and (sd['episode_step'][~picked] == 0).all() and (sd['done'][~picked] == 0).all()
+    assert (sd16['episode'][~picked] == 1).all() and (sd16['done'][~picked] == 3).all()          # the twin's interval is still open
+    for key in sd:                                        # state, last observations and step record of the restarted ones: untouched
+        assert np.array_equal(sd[key][picked], sd16[key][picked]), key
+    sel = torch.from_numpy(picked).cuda()
+    for a, b in zip(runs[0][1:4], runs[1][1:4]):
+        assert torch.equal(a[sel].view(torch.uint8), b[sel].view(torch.uint8))
+
+
+@pytest.mark.parametrize('policy', ['random', 'greedy'])
+def test_idle_rows_of_a_fused_rollout_are_marked_and_never_written(policy):
+    """The stale-row contract of the fused rollouts (Engine.reserve_rollout): a slot behind the end of an episode inside
+    the launch carries done = 2 and zeros in its scalar row and is NOT written in the observation / mask buffers -- those
+    rows keep what they held (here: a NaN / -1 sentinel), every executed row is fully written, and the batched API's
+    `info['skipped']` is exactly the done == 2 slots.  The reference never returns such rows (its loop stops at `done`):
+    a consumer drops them by that flag."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=5)
+    n, K = 13, 9
+    eng = Engine(cfg, n, seed=4)
+    if policy == 'greedy':
+        eng.enable_policies()
+    eng.reset()
+    buf = eng.reserve_rollout(K, want_masks=True)
+    buf['camera_obs'].fill_(float('nan')); buf['target_obs'].fill_(float('nan')); buf['masks'].fill_(-1)
+    fn = eng.rollout_greedy if policy == 'greedy' else eng.rollout_random
+    cam, tgt, sc = fn(K, auto_reset=True, want_masks=True)
+    torch.cuda.synchronize()
+    idle = sc[..., 2] == 2
+    assert idle[6:].all() and not idle[:5].any()             # time limit 5: the 6th step ends every episode still running
+    assert (sc[idle][:, [0, 1, 3, 4, 5, 6, 7]] == 0).all()
+    assert torch.isnan(cam[idle]).all() and torch.isnan(tgt[idle]).all() and (buf['masks'][:K][idle] == -1).all()
+    assert torch.isfinite(cam[~idle]).all() and torch.isfinite(tgt[~idle]).all() and (buf['masks'][:K][~idle][:, -1] == 1).all()
+    assert eng.idle_steps() == int(idle.sum())
+    from mate_amd.environment import BatchedMultiAgentTracking
+    env = BatchedMultiAgentTracking(cfg, n, seed=4)
+    if policy == 'greedy':
+        env.enable_greedy_policies()
+    env.reset()
+    _, _, done, info = env.rollout_greedy(K) if policy == 'greedy' else env.rollout_random(K)
+    assert torch.equal(info['skipped'], idle) and torch.equal(done, sc[..., 2] == 1)

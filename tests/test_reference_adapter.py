@@ -95,6 +95,15 @@ def test_adapter_is_the_reference_class_and_replays_its_trace(mate):
         np.testing.assert_allclose(env.state(), fx['step/state'][s], rtol=0, atol=1e-9)
         assert env.targets[3].is_colliding == bool(fx['step/tgt_colliding'][s][3])
         assert env.cameras[1].orientation == fx['step/cam_phi'][s][1]
+    # a reset AFTER stepping starts from the fresh snapshot's metrics, not from the last step's (reset, step, reset)
+    assert env.coverage_rate == fx['step/coverage_rate'][63] and fx['step/coverage_rate'][63] != fx['reset/coverage_rate']
+    cam_obs, tgt_obs = env.reset()
+    assert np.array_equal(cam_obs, fx['reset/cam_obs']) and env.episode_step == 0
+    for key in ('coverage_rate', 'real_coverage_rate', 'mean_transport_rate'):
+        assert getattr(env, key) == float(fx['reset/' + key]), key
+    assert env.target_team_episode_reward == 0.0 and not env.target_steps.any()
+    (cam_obs, tgt_obs), (r_cam, r_tgt), done, _ = env.step((fx['step/cam_act'][0], fx['step/tgt_act'][0]))
+    assert np.array_equal(tgt_obs, fx['step/tgt_obs'][0]) and r_tgt == fx['step/reward_tgt'][0] and env.coverage_rate == fx['step/coverage_rate'][0]
     # entity objects answer the geometric queries wrappers make (auxiliary_camera_rewards.py:206)
     left = env.cameras[0].orientation - 0.5 * env.cameras[0].viewing_angle
     angles, norms = env.cameras[0].boundary_between(left, left + env.cameras[0].viewing_angle)
