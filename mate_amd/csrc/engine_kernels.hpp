@@ -1426,6 +1426,7 @@ __device__ __forceinline__ void list_finished_at_entry(Ctx<ObsT> &c) {
         const int parity = c.list_parity();
         const int slot = atomicAdd(c.g.done_count + parity, 1);
         c.g.done_list[(int64_t)parity * c.g.N + slot] = (int32_t)c.env;
+        c.ei(EI_DONE) = 3;      // listed (stored with the record at the end of the launch): the one-step launches of a batched-reset interval meet it again
     }
 }
 

@@ -79,6 +79,7 @@ struct Switches {
     int lut_small_cap = 0;         // MATE_LUT_SMALL_CAP=<rays>: sort-array size of the small-LDS table launch (0: half the full size)
     bool reset_monolithic = false; // MATE_RESET_MONOLITHIC=1: resets as one launch instead of placement / tables / view
     int rollout_rotate = 1;        // MATE_ROLLOUT_ROTATE=0: no wave-priority rotation in the fused rollouts
+    bool policy_split = false;     // MATE_POLICY_SPLIT=1: step_greedy / step_versus_greedy as two launches (agents' kernel, step kernel) even when the fused one-launch form applies
     bool zoom_iterate = false;     // MATE_ZOOM_ITERATE=1: the greedy camera agents iterate the zoom solve (greedy.py:139-145) instead of reading its table
 };
 static Switches read_switches() {
@@ -91,6 +92,7 @@ static Switches read_switches() {
     w.reset_monolithic = flag("MATE_RESET_MONOLITHIC");
     if (const char *v = getenv("MATE_ROLLOUT_ROTATE")) w.rollout_rotate = atoi(v);
     w.zoom_iterate = flag("MATE_ZOOM_ITERATE");
+    w.policy_split = flag("MATE_POLICY_SPLIT");
     return w;
 }
 
@@ -888,9 +890,18 @@ extern "C" int mate_engine_policy_enable(mate_engine *e) {
     return policy_enable(e);
 }
 
+static int rollout_with_policies(mate_engine *e, int team_caller, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_, bool per_step = false);
+
 // team_caller: -1 = both teams are the on-device agents; 0 / 1 = the camera / target team's joint action is the caller's
 static int step_with_policies(mate_engine *e, int team_caller, const mate_step_io *io, const mate_policy_tape *tape, int32_t auto_reset, hipStream_t stream) {
     if (!e) return fail(MATE_EINVAL, "null engine");
+    // One launch (agents + step fused, rollout_greedy_kernel with one step) unless something needs the two-launch form: recorded
+    // agent draws, tapes of the step itself, fused observation post-processing, a missing output, a workgroup that does not fit
+    if (e->policy_ready && e->was_reset && !e->sw.policy_split && !tape && io && !io->tape_camera_target_dev && !io->tape_goal_dev &&
+        e->g.obs_mode == 0 && !e->g.xdesc && (io->camera_obs_dev || e->p.Nc == 0) && io->target_obs_dev && io->scalars_dev && !e->p.obs_f64 &&
+        4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt) + 1024 <= 160 * 1024 &&
+        (team_caller < 0 || (team_caller == 0 ? io->camera_actions_dev : io->target_actions_dev)))
+        return rollout_with_policies(e, team_caller, io, 1, auto_reset, (void *)stream, true);
     if (!e->was_reset) return fail(MATE_ESTATE, "step_greedy called before reset() (or import_state)");
     // (works with a device-resident step counter too -- the agents take their tick from the environment record -- so the
     // learner-versus-greedy loop can be captured in a HIP graph like step(); launch_step checks the reset interval)
@@ -934,16 +945,23 @@ extern "C" int mate_engine_step_versus_greedy(mate_engine *e, int32_t team, cons
     return step_with_policies(e, team, io, tape, auto_reset, (hipStream_t)stream);
 }
 
-static int rollout_with_policies(mate_engine *e, int team_caller, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_) {
+// `per_step`: ONE fused (agents act, environment steps) launch with the semantics of the per-step flows -- outputs in the
+// caller's [N][...] buffers, immediate (auto_reset = 1) or batched (k > 1: finished environments idle, listed, and restart
+// together behind every k-th call) list-driven resets that write the restarted environments' first observations, and the
+// device-resident step counter (graph replay).  It is what step_greedy / step_versus_greedy run when nothing asks for
+// the two-launch form (a policy tape, a fused observation transform or team mode, a missing output buffer).
+static int rollout_with_policies(mate_engine *e, int team_caller, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_, bool per_step) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (!e->was_reset) return fail(MATE_ESTATE, "rollout_greedy called before reset() (or import_state)");
-    if (e->dev_tick) return fail(MATE_ESTATE, "not available while the step counter is device-resident (mate_engine_device_tick)");
+    if (e->dev_tick && !per_step) return fail(MATE_ESTATE, "not available while the step counter is device-resident (mate_engine_device_tick)");
+    if (e->dev_tick && auto_reset != e->dev_interval)
+        return fail(MATE_ESTATE, "with a device-resident step counter (mate_engine_device_tick) step() needs auto_reset = %d: the auto-reset launch advances it", e->dev_interval);
     if (!e->policy_ready) return fail(MATE_ESTATE, "call mate_engine_policy_enable() before the reset whose observations the policies act on");
     if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
     e->last_stream = stream;
-    { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | kRolloutFlow) : auto_reset, stream); if (rc != MATE_OK) return rc; }
+    { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | (per_step ? kStepFlow : kRolloutFlow)) : auto_reset, stream); if (rc != MATE_OK) return rc; }
     Ptrs g = e->g;
     apply_io(g, io);
     if ((e->p.Nc > 0 && !g.cam_obs) || !g.tgt_obs || !g.scalars) return fail(MATE_EINVAL, "rollout_greedy needs the observation and scalar outputs");
@@ -955,16 +973,20 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
         return fail(MATE_ESTATE, "discrete actions passed before mate_engine_set_action_grids");
     const size_t lds = 4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt) + 1024;
     if (lds > 160 * 1024) return fail(MATE_EINVAL, "rollout_greedy: %zu bytes of LDS per workgroup do not fit", lds);
-    g.mode = MODE_STEP; g.parity = e->parity; g.reset_kind = -1; g.tick = e->tick; g.rollout_steps = steps;
+    g.mode = MODE_STEP; g.reset_kind = -1; g.rollout_steps = steps;
+    g.parity = e->dev_tick ? 0 : e->parity;
+    g.tick = e->dev_tick ? (uint32_t)e->steps_since_reset : e->tick;     // device-resident counter: the offset inside the reset interval
     g.tape_ct = nullptr; g.tape_goal = nullptr; g.freeze_done = 0;
     g.rotate_prio = e->sw.rollout_rotate;
-    if (auto_reset != 1) g.done_count = nullptr;
+    // the finished-episode list: the rollout flows keep it for the immediate restart only (a batched restart finds the finished
+    // ones by their flag); the per-step flow lists in both modes, like step()
+    if (per_step ? auto_reset == 0 : auto_reset != 1) g.done_count = nullptr;
     PolicyPtrs q = e->q;
     std::memset(&q.tape, 0, sizeof(q.tape));
     q.caller_team = team_caller;
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (e->timing > 0 && (e->timing_tick++ % e->timing) == 0) {
+    if (e->timing > 0 && !e->dev_tick && (e->timing_tick++ % e->timing) == 0) {
         if (e->events_used == e->events.size()) {
             hipEvent_t a, b;
             HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
@@ -973,9 +995,26 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
         ev0 = e->events[e->events_used].first; ev1 = e->events[e->events_used].second; ++e->events_used;
     }
     e->last_flow = FLOW_GREEDY;
-    hipExtLaunchKernelGGL(e->rollout_greedy_fn, dim3(blocks), dim3(256), lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g, (const PolicyPtrs)q);
+    if (ev0) hipExtLaunchKernelGGL(e->rollout_greedy_fn, dim3(blocks), dim3(256), lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g, (const PolicyPtrs)q);
+    else hipLaunchKernelGGL(e->rollout_greedy_fn, dim3(blocks), dim3(256), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const PolicyPtrs)q);   // (capturable)
     HIP_TRY(hipGetLastError());
-    e->tick += (uint32_t)steps;
+    if (!e->dev_tick) e->tick += (uint32_t)steps;
+    if (per_step) {
+        const bool now = auto_reset == 1 || (auto_reset > 1 && (e->pending_interval = auto_reset | kStepFlow, ++e->steps_since_reset >= auto_reset));
+        if (now) {
+            e->steps_since_reset = 0; e->pending_interval = 0;
+            Ptrs r = e->g;
+            apply_io(r, io);
+            r.cam_act = r.tgt_act = nullptr; r.act_f64 = 0; r.act_discrete = 0;
+            r.scalars = nullptr; r.tape_ct = nullptr; r.tape_goal = nullptr;   // keep the finished step's reward / done
+            r.tick_advance = (uint32_t)auto_reset;
+            // (the immediate restart, idle almost always, stays ONE launch; the interval's restart is split: placement / tables / view)
+            int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream, auto_reset > 1);
+            if (rc != MATE_OK) return rc;
+            if (!e->dev_tick) e->parity ^= 1;
+        }
+        return MATE_OK;
+    }
     if (auto_reset == 1) {
         Ptrs r = e->g;
         apply_io(r, nullptr);     // state and the engine's own masks: the agents of the next rollout act on the fresh view

@@ -479,7 +479,13 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
     const Shape shape(pp, true);
     const Params &p = shape.get();
     extern __shared__ __align__(16) unsigned char smem[];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;
+    // tick and list parity: launch arguments, or the device-resident counter (one-step launches replayed from a HIP graph:
+    // see step_kernel -- the host keeps dev_tick = dev_group = 0 in the record while it counts itself)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) {
+        const int32_t parity = (int32_t)((p.dev_group + (uint32_t)g.parity) & 1u);
+        g.done_count[parity ^ 1] = 0;
+        g.ctrl[0] = parity;
+    }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t env_raw = (int64_t)blockIdx.x * 4 + wave;
     const bool in_batch = env_raw < g.N;
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
             load_caller_actions(c, q.caller_team, act_cam, act_tgt);
             wave_sync();
         }
-        const uint32_t tick = g.tick + (uint32_t)r;
+        const uint32_t tick = p.dev_tick + g.tick + (uint32_t)r;
         StepDraws draws{0.0, 0.0};
         if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick, &carry);       // see-through uniforms only (mode() is MODE_STEP)
         GREEDY_STAMP(0);
