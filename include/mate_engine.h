@@ -29,6 +29,8 @@
  *                            occlusion tables and first view as separate launches
  *   MATE_LUT_SMALL_CAP=<n>   ray capacity of the small-LDS occlusion-table launch (default: half of the worst case);
  *                            tables with more rays are built by the full-size launch behind it
+ *   MATE_NO_IMAGE=1          the fused rollouts pack observations through the descriptor table even for a shape with a
+ *                            row-image compilation (same rows; tests compare the two)
  *   MATE_POLICY_SPLIT=1      mate_engine_step_greedy / _step_versus_greedy as two launches (the agents' kernel, then the step
  *                            kernel) even where the fused one-launch form applies (same results; tests compare the two)
  *   MATE_ZOOM_ITERATE=1      the on-device GreedyCameraAgent runs the reference's 20-iteration zoom solve

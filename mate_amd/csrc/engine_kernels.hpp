@@ -49,13 +49,17 @@ struct Params {
     uint32_t dev_tick;            // written only by the auto-reset launch, through Ptrs::dev_tick_ptr
     uint32_t dev_group;           // auto-reset launches so far (its low bit is the list parity); follows dev_tick in memory
     int32_t dev_tick_on;
+    // "Row image" mode of the fused rollouts (fill_shape(..., image = true), see image_statics): the observation rows of the
+    // environment live in LDS for the whole launch, next to a table of the entities' public states; there are no flag words,
+    // no gather scratch and no descriptors.
+    int32_t image, off_pub, off_img;
 };
 
 // Everything in Params that follows from the entity counts and the observation type alone.  Shared by the
 // host (mate_engine_create) and by the shape-specialised kernels, which overwrite the loaded record with
 // these compile-time values so that index arithmetic, loop bounds and LDS offsets fold to literals.
 __host__ __device__ constexpr int shape_round_up(int x, int m) { return (x + m - 1) / m * m; }
-__host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No, bool obs_f64) {
+__host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No, bool obs_f64, bool image = false) {
     p.Nc = Nc; p.Nt = Nt; p.No = No; p.NK = No + Nc; p.NJ = Nc + No + Nt;
     p.Dc = 13 + 9 + 5 * Nt + 4 * No + 7 * Nc;    // constants.py:267-282
     p.Dt = 13 + 14 + 7 * Nc + 4 * No + 5 * Nt;   // constants.py:285-300
@@ -88,18 +92,32 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
     p.off_st = off; off += shape_round_up(p.SW * 8, 16);
     p.off_dy = off; off += shape_round_up(p.DW * 8, 16);
     p.off_tmp = off; off += shape_round_up((Nc + 3 * Nt + 64) * 8, 16);
-    p.off_scratch = off; off += shape_round_up(p.nscratch * obs_size, 16);
+    p.off_scratch = off; off += image ? 0 : shape_round_up(p.nscratch * obs_size, 16);
     p.off_mask = off; off += shape_round_up(p.MW * 4, 16);
     p.off_misc = off; off += shape_round_up((4 * Nt + 8) * 4, 16);
-    p.off_flags = off; off += shape_round_up(p.nflags * obs_size, 16);
+    p.off_flags = off; off += image ? 0 : shape_round_up(p.nflags * obs_size, 16);
     p.off_ent = off; off += shape_round_up(3 * p.NJ * 8 + 3 * p.NJ * 4, 16);   // f64 table + its f32 shadow
     p.off_list = off; off += (p.sector_rounds >= 2 && p.n_sector <= 256) ? shape_round_up(p.n_sector, 16) : 0;   // compacted sector candidates, one byte each (update_view)
+    // row-image mode: public states [cameras 8 | targets 8 | obstacles 4 floats each] (+ 16 bytes a block read may overrun),
+    // then the environment's observation rows exactly as they lie in the output buffers (camera block, target block)
+    p.image = image ? 1 : 0;
+    p.off_pub = off; off += image ? (8 * Nc + 8 * Nt + 4 * No) * 4 + 16 : 0;
+    p.off_img = off; off += image ? (p.cam_elems + p.tgt_elems) * 4 : 0;
     p.lds_wave_bytes = off;
+}
+// Shapes the row-image mode is compiled for: f32 rows in whole 16-byte chunks, one round of sector pairs, at most three of
+// range pairs (the lane roles are held in registers), and 16 environments per CU still resident (160 KiB of LDS).
+constexpr bool image_fits(int Nc, int Nt, int No) {
+    Params p{};
+    fill_shape(p, Nc, Nt, No, false, true);
+    return Nc > 0 && p.cam_elems % 4 == 0 && p.tgt_elems % 4 == 0 && p.cam_elems <= 4 * 128 && p.tgt_elems <= 4 * 384 &&      // (image_store's unrolled rounds)
+           p.sector_rounds == 1 && p.range_rounds <= 3 && p.lds_wave_bytes <= 10 * 1024;
 }
 
 // Kernel shape policies: AnyShape reads every constant from the device-resident Params on demand;
 // FixedShape<Nc, Nt, No> is compiled for one scenario shape (the host picks it when the counts match).
 struct AnyShape {
+    static constexpr bool kImage = false;
     static constexpr bool kHoldRoles = false;      // rollout kernel: lane roles in registers (needs compile-time round counts)
     static constexpr int kGreedyBlocks = 4;        // rollout_greedy_kernel: workgroups per CU the register budget is set for
     static constexpr bool kGreedyHeld = false;     // ... and whether it keeps the observation descriptors in registers across steps
@@ -117,8 +135,10 @@ __device__ __forceinline__ Params load_params_constant(const Params *q) {
     for (unsigned i = 0; i < sizeof(Params) / 8; ++i) t.w[i] = src[i];
     return __builtin_bit_cast(Params, t);
 }
-template <int NC, int NT, int NO, bool F64>
+template <int NC, int NT, int NO, bool F64, bool IMAGE = false>
 struct FixedShape {
+    static constexpr bool kImage = IMAGE;
+    static_assert(!IMAGE || (!F64 && image_fits(NC, NT, NO)), "row-image mode: f32 observations of a shape that fits");
     static constexpr bool kHoldRoles = shape_range_rounds(NC, NT, NO) <= 3;      // 9 more VGPRs: fits beside the held descriptors
     static constexpr int kGreedyBlocks = 4;
     static constexpr bool kGreedyHeld = true;
@@ -131,7 +151,7 @@ struct FixedShape {
     // before its next step (rollout_kernel -1.5 %, rollout_greedy_kernel -3 %).  The single-step kernels copy at their
     // top, where the compiler emits scalar loads anyway, and live at the 96-SGPR limit: they keep the plain copy.
     __device__ __forceinline__ explicit FixedShape(const Params *q, bool through_constant = false)
-        : local(through_constant ? load_params_constant(q) : *q) { fill_shape(local, NC, NT, NO, F64); }
+        : local(through_constant ? load_params_constant(q) : *q) { fill_shape(local, NC, NT, NO, F64, IMAGE); }
     __device__ __forceinline__ const Params &get() const { return local; }
 };
 
@@ -260,6 +280,7 @@ struct Ctx {
     float *exf, *eyf, *erf;       // ... rounded to f32: the screens that only have to be conservative, or that fall back to
                                   // the f64 table inside an explicit error rim, read these (an f64 operation costs two f32 issue slots)
     const double *act_cam = nullptr, *act_tgt = nullptr;   // FLOW_GREEDY: this step's joint actions in LDS ([Nc][2], [Nt][2])
+    float *pub = nullptr, *img = nullptr;                  // row-image mode: public-state table, observation rows (Params::off_pub / off_img)
 
     bool statics_done = false;    // fused rollouts, steps after the first: what never changes inside an episode (static
                                   // mask words and flags, obstacle / capacity slots of the scratch) is in LDS already
@@ -277,7 +298,15 @@ struct Ctx {
         base = wave_base;
         ex = reinterpret_cast<double *>(wave_base + p.off_ent); ey = ex + p.NJ; er = ey + p.NJ;
         exf = reinterpret_cast<float *>(er + p.NJ); eyf = exf + p.NJ; erf = eyf + p.NJ;
+        pub = reinterpret_cast<float *>(wave_base + p.off_pub); img = reinterpret_cast<float *>(wave_base + p.off_img);
     }
+    // row-image mode (a compile-time constant of the shape-specialised fused rollouts; zero in the device record otherwise)
+    __device__ __forceinline__ bool image() const { return p.image != 0; }
+    __device__ __forceinline__ float *pub_cam(int c) const { return pub + 8 * c; }
+    __device__ __forceinline__ float *pub_tgt(int t) const { return pub + 8 * p.Nc + 8 * t; }
+    __device__ __forceinline__ float *pub_obs(int o) const { return pub + 8 * (p.Nc + p.Nt) + 4 * o; }
+    __device__ __forceinline__ float *img_cam_row(int c) const { return img + c * p.Dc; }
+    __device__ __forceinline__ float *img_tgt_row(int t) const { return img + p.cam_elems + t * p.Dt; }
     // which of the two finished-episode lists this launch appends to: a launch argument, or the low bit of the device-resident
     // reset-launch counter (Params::dev_group).  Re-derived where it is used (an episode ends: rare) instead of held in an
     // SGPR for the whole kernel -- the step kernels live at the 96-SGPR limit of full occupancy.
@@ -356,7 +385,7 @@ __device__ __forceinline__ void load_records(Ctx<ObsT> &c) {
     const double *d = c.g.dyn + c.env * c.p.DW;
     for (int i = c.lane; i < c.p.SW; i += 64) c.st[i] = s[i];
     for (int i = c.lane; i < c.p.DW; i += 64) c.dy[i] = d[i];
-    if (c.has_scratch_init()) {
+    if (c.has_scratch_init() && !c.image()) {
         const ObsT *si = reinterpret_cast<const ObsT *>(c.g.scratch_init);
         for (int i = c.lane; i < c.p.nscratch; i += 64) c.scratch[i] = si[i];
     }
@@ -495,13 +524,19 @@ __device__ __forceinline__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &
         const double sr2 = div_nz(p.area, th);
         c.sight2(lane) = sr2;
         ObsT *sc = c.scratch + p.sc_cam + lane * 10;
-        if (!c.statics_done) { sc[0] = (ObsT)c.cam_x(lane); sc[1] = (ObsT)c.cam_y(lane); }
+        if (!c.statics_done && !c.image()) { sc[0] = (ObsT)c.cam_x(lane); sc[1] = (ObsT)c.cam_y(lane); }
         // Camera.state: polar2cartesian(sight_range, orientation), entities.py:318
         if constexpr (sizeof(ObsT) == 4) {         // f32 observations: f64 argument reduction, f32 polynomials (+8 % on the fused rollout:
             float sn, cs;                          // the camera lanes' f64 sincos was the longest dependent chain of the phase)
             sincos_deg_f32(ph, sn, cs);
             const float srf = __builtin_sqrtf((float)sr2);
+            if (c.image()) {                       // the camera's public state (read by every block that shows it) and its own row
+                float *pc = c.pub_cam(lane), *row = c.img_cam_row(lane) + 13;
+                const float x = srf * cs, y = srf * sn, t = (float)th;
+                pc[3] = x; pc[4] = y; pc[5] = t; row[3] = x; row[4] = y; row[5] = t;
+            } else {
             sc[3] = srf * cs; sc[4] = srf * sn; sc[5] = (float)th;
+            }
         } else {
             const double sr = sqrt_pos(sr2);
             double sn, cs;
@@ -689,11 +724,30 @@ struct RangeRoles {
     float rim[kRoleRounds];          // ... and the half-width of the band around it inside which the f64 test decides
     uint32_t diag_bits, valid_bits;  // bit `round`: the pair is (t, t) / the lane holds a pair in this round
     int32_t sector;                  // sector_role of the lane's pair in the last sector round
+    // row-image mode: the (viewer, other) block each of the lane's pairs owns in the observation rows -- slot 0 the sector pair,
+    // slots 1.. the range rounds: LDS byte offset of the other's public state | of the block in the viewer's row << 16
+    uint32_t block[1 + kRoleRounds];
+    uint32_t block_bits;             // 2 bits per slot: 0 none, 1 = 4 floats (obstacle), 2 = 5 (target), 3 = 7 (camera)
 };
+// LDS byte offsets (inside the wave's slice) of an entity's public state and of its block in a viewer's row; width code as above
+__device__ __forceinline__ void image_block_of(const Params &p, bool viewer_is_camera, int viewer, int j, uint32_t &word, uint32_t &code) {
+    // j: entity slot, cameras | obstacles | targets (the order of the entity table)
+    int src, col;
+    if (j < p.Nc) { src = p.off_pub + 32 * j; code = 3u; }
+    else if (j < p.Nc + p.No) { src = p.off_pub + 32 * (p.Nc + p.Nt) + 16 * (j - p.Nc); code = 1u; }
+    else { src = p.off_pub + 32 * p.Nc + 32 * (j - p.Nc - p.No); code = 2u; }
+    if (viewer_is_camera) {                      // camera row: [preserved 13 | private 9 | targets 5 each | obstacles 4 each | cameras 7 each]
+        col = 22 + (j < p.Nc ? 5 * p.Nt + 4 * p.No + 7 * j : j < p.Nc + p.No ? 5 * p.Nt + 4 * (j - p.Nc) : 5 * (j - p.Nc - p.No));
+        word = (uint32_t)src | ((uint32_t)(p.off_img + 4 * (viewer * p.Dc + col)) << 16);
+    } else {                                     // target row: [preserved 13 | private 14 | cameras 7 each | obstacles 4 each | targets 5 each]
+        col = 27 + (j < p.Nc ? 7 * j : j < p.Nc + p.No ? 7 * p.Nc + 4 * (j - p.Nc) : 7 * p.Nc + 4 * p.No + 5 * (j - p.Nc - p.No));
+        word = (uint32_t)src | ((uint32_t)(p.off_img + 4 * (p.cam_elems + viewer * p.Dt + col)) << 16);
+    }
+}
 template <typename ObsT>
 __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &roles) {
     const Params &p = c.p;
-    roles.diag_bits = 0; roles.valid_bits = 0;
+    roles.diag_bits = 0; roles.valid_bits = 0; roles.block_bits = 0;
     roles.sector = sector_role(p, (p.sector_rounds - 1) * 64 + c.lane);
 #pragma unroll
     for (int round = 0; round < kRoleRounds; ++round) {
@@ -708,6 +762,20 @@ __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &role
         roles.rim[round] = range_rim(lim);
         roles.diag_bits |= (uint32_t)(j == tj) << round;
         roles.valid_bits |= (uint32_t)(q < p.n_range && round < p.range_rounds) << round;
+        roles.block[1 + round] = 0u;
+        if (c.image() && q < p.n_range && round < p.range_rounds) {
+            uint32_t code;
+            image_block_of(p, false, t, j, roles.block[1 + round], code);
+            roles.block_bits |= code << (2 * (1 + round));
+        }
+    }
+    roles.block[0] = 0u;
+    if (c.image() && roles.sector >= 0) {
+        const int cam = roles.sector & 0xff, other = (roles.sector >> 8) & 0xff;
+        const bool is_target = (roles.sector >> 16) & 1;
+        uint32_t code;
+        image_block_of(p, true, cam, is_target ? c.tgt_slot(other) : other, roles.block[0], code);
+        roles.block_bits |= code;
     }
 }
 
@@ -799,10 +867,13 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorE
 // COMPACT (the fused rollouts): shapes with two or more rounds of sector pairs run the long part of the sector test on a
 // compacted list of the pairs in sight range.  The single-step kernel keeps the round-by-round form: it lives on a 64-VGPR /
 // 96-SGPR budget where the list bookkeeping spills, and measured 3 % slower with it.
+// `seen_out` (row-image mode, which writes no flag words): bit 0 = the lane's sector pair is seen, bit 1 + r = its pair of
+// range round r (image_blocks turns them into the pair's block of the observation rows).
 template <bool HELD, bool COMPACT = false, typename ObsT>
-__device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn, const RangeRoles &held) {
+__device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn, const RangeRoles &held, uint32_t &seen_out) {
     const Params &p = c.p;
     const int lane = c.lane;
+    seen_out = 0u;
     double2 w[kDegSlots];
     int n_cand = 0;
     uint8_t *cand = c.base + p.off_list;
@@ -874,10 +945,11 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     for (int round = 0; round < p.range_rounds; ++round) {
         const int q = round * 64 + lane;
         const bool seen = (seen_bits >> round) & 1u;
-        if (q < p.n_range) set_flag(c, p.fs_range + q, seen);
+        if (!c.image() && q < p.n_range) set_flag(c, p.fs_range + q, seen);
         const unsigned long long b = __ballot(seen);
         if (lane == 0) { c.mask[rbase + 2 * round] = (uint32_t)b; c.mask[rbase + 2 * round + 1] = (uint32_t)(b >> 32); }
     }
+    seen_out |= seen_bits << 1;
     };
     if (compact) {
         // pass 2: the long part on the compacted list, 64 candidates at a time (usually one chunk).  (Not overlapped with the
@@ -911,7 +983,8 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         range_tests();
         if (last >= 0) {
             const bool seen = sector_resolve(c, pending, w);
-            if (last * 64 + lane < p.n_sector) set_flag(c, last * 64 + lane, seen);
+            if (!c.image() && last * 64 + lane < p.n_sector) set_flag(c, last * 64 + lane, seen);
+            seen_out |= (uint32_t)seen;
             const unsigned long long b = __ballot(seen);
             if (lane == 0) { c.mask[2 * last] = (uint32_t)b; c.mask[2 * last + 1] = (uint32_t)(b >> 32); }
         }
@@ -924,7 +997,8 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
             c.mask[(p.bit_camobs >> 5) + 2 * lane] = (uint32_t)m;
             c.mask[(p.bit_camobs >> 5) + 2 * lane + 1] = (uint32_t)(m >> 32);
         }
-        if (lane == 0) { c.mask[p.bit_always >> 5] = 1u; set_flag(c, p.fs_always, true); }
+        if (lane == 0) { c.mask[p.bit_always >> 5] = 1u; if (!c.image()) set_flag(c, p.fs_always, true); }
+        if (!c.image())
         for (int q = lane; q < p.Nc * p.No; q += 64) {
             const int cam = (int)(((float)q + 0.5f) * p.inv_No);
             const int o = q - cam * p.No;
@@ -949,6 +1023,11 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     wave_sync();
 }
 
+template <bool HELD, bool COMPACT = false, typename ObsT>
+__device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn, const RangeRoles &held) {
+    uint32_t seen;
+    update_view<HELD, COMPACT>(c, tick, stream, predrawn, held, seen);
+}
 template <typename ObsT>
 __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn) {
     RangeRoles none;
@@ -1296,6 +1375,19 @@ __device__ __forceinline__ bool packs_rows_f32(const Ctx<ObsT> &c) {
     return !c.xdesc() && sizeof(ObsT) == 4 && (p.cam_elems % 4) == 0 && (p.tgt_elems % 4) == 0 && c.has_tgt_obs() && (c.has_cam_obs() || p.cam_elems == 0);
 }
 
+template <typename ObsT>
+__device__ __forceinline__ void store_masks(const Ctx<ObsT> &c) {
+    const Params &p = c.p;
+    if (c.g.masks) {
+        uint32_t *m = c.g.masks + c.out * p.MW;
+        for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
+    }
+    if (c.g.own_masks) {
+        uint32_t *m = c.g.own_masks + c.env * p.MW;
+        for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
+    }
+}
+
 // HELD: the caller loaded this lane's descriptors before (the rollout kernel, once per launch); otherwise they are
 // loaded here.  A template switch, not a pointer: a nullable pointer to the register array would force it into memory.
 template <bool HELD, typename ObsT>
@@ -1317,13 +1409,139 @@ __device__ __forceinline__ void pack_observations(Ctx<ObsT> &c, PackDescriptors 
     if (c.has_tgt_obs())
         pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.tgt_obs) + c.out * p.tgt_elems, c.table + p.tgt_table_off, p.tgt_elems);
     }
-    if (c.g.masks) {
-        uint32_t *m = c.g.masks + c.out * p.MW;
-        for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
+    store_masks(c);
+}
+
+// =============================================================================================
+// Row-image mode of the fused rollouts (FixedShape<..., IMAGE = true>).
+//
+// joint_observation (environment.py:908-964) builds every row as [preserved | own private state | one block per other
+// entity: its public state and a 1.0, or zeros when the viewer does not see it].  The descriptor packer above gathers those
+// 1552 floats (MATE-4v8-9) element by element -- source slot, flag word, AND -- at every step: 13 vector instructions and 8 LDS
+// reads per 16-byte chunk, 130 of a step's ~780 vector instructions with the scratch and flag writes that feed it, although
+// a third of the elements never change inside an episode and every block shares ONE flag.  Here the environment's rows
+// live in LDS for the whole launch (6.2 KB next to 3 KB of state: sixteen environments per CU still fit), laid out
+// exactly as in the output buffers:
+//   * image_statics, once per launch: the preserved blocks, the static parts of the private states, the camera rows'
+//     obstacle blocks (camera_obstacle_view_mask is static), the static fields of the public-state table;
+//   * per step, the lanes that own the kinematics write the three / three-to-eleven floats of a camera's / target's private
+//     and public state that changed (simulate_cameras, image_targets);
+//   * per step, THE LANE THAT MADE A VISIBILITY TEST WRITES ITS BLOCK (image_blocks): the (viewer, other) pair's public state
+//     AND-ed with the verdict it holds in a register -- two 16-byte LDS reads, 4-7 ANDs, 2-4 LDS writes per pair, the block's
+//     address held in a register since the launch began;
+//   * image_store streams the rows out: one 16-byte LDS read and one non-temporal 16-byte store per chunk, no arithmetic.
+// Same values, bit for bit, as the descriptor packer (tested against it and against the oracle).
+template <typename ObsT>
+__device__ __forceinline__ void image_statics(Ctx<ObsT> &c) {
+    if constexpr (sizeof(ObsT) == 4) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    const float *si = reinterpret_cast<const float *>(c.g.scratch_init);        // [1] = 1, [2..4] counts, [5..12] warehouses, [13] = 75, [14 + i] = i
+    for (int i = lane; i < (p.Nc + p.Nt) * 13; i += 64) {                        // preserved block of every row (environment.py:499-501, 941)
+        const int row = (int)(((float)i + 0.5f) * (1.0f / 13.0f)), col = i - row * 13;
+        const int agent = row < p.Nc ? row : row - p.Nc;
+        const float v = si[col < 3 ? 2 + col : col == 3 ? 14 + agent : col + 1];
+        (row < p.Nc ? c.img_cam_row(row) : c.img_tgt_row(agent))[col] = v;
     }
-    if (c.g.own_masks) {
-        uint32_t *m = c.g.own_masks + c.env * p.MW;
-        for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
+    if (lane < p.Nc) {                                                           // Camera.state(private), entities.py:313-324
+        float *pc = c.pub_cam(lane), *row = c.img_cam_row(lane) + 13;
+        const float x = (float)c.cam_x(lane), y = (float)c.cam_y(lane), r = (float)p.cam_radius;
+        pc[0] = x; pc[1] = y; pc[2] = r; pc[6] = 1.0f; pc[7] = 0.0f;
+        row[0] = x; row[1] = y; row[2] = r; row[6] = (float)p.rmax; row[7] = (float)p.rot; row[8] = (float)p.zoom;
+    }
+    if (lane < p.Nt) {                                                           // Target.state(private), entities.py:631-637
+        float *pt = c.pub_tgt(lane), *row = c.img_tgt_row(lane) + 13;
+        const int cap = 1 + (int)((c.capword() >> lane) & 1ull);
+        pt[2] = (float)p.tgt_sight; pt[4] = 1.0f; pt[5] = 0.0f; pt[6] = 0.0f; pt[7] = 0.0f;
+        row[2] = (float)p.tgt_sight; row[4] = (float)(cap == 2 ? p.tgt_step * 0.5 : p.tgt_step); row[5] = (float)cap;
+    }
+    for (int o = lane; o < p.No; o += 64) {                                      // Obstacle.state, entities.py:147-148
+        float *po = c.pub_obs(o);
+        po[0] = (float)c.obs_x(o); po[1] = (float)c.obs_y(o); po[2] = (float)c.obs_r(o); po[3] = 1.0f;
+    }
+    if (lane < 4) c.pub_obs(p.No)[lane] = 0.0f;                                  // (what the second 16-byte read of the last obstacle's block sees)
+    wave_sync();
+    for (int q = lane; q < p.Nc * p.No; q += 64) {                               // camera rows: obstacle blocks, gated by the static mask
+        const int cam = (int)(((float)q + 0.5f) * p.inv_No), o = q - cam * p.No;
+        const uint32_t m = ((c.camobs(cam) >> o) & 1ull) ? ~0u : 0u;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(c.pub_obs(o));
+        uint32_t *dst = reinterpret_cast<uint32_t *>(c.img_cam_row(cam) + 22 + 5 * p.Nt + 4 * o);
+        dst[0] = src[0] & m; dst[1] = src[1] & m; dst[2] = src[2] & m; dst[3] = src[3] & m;
+    }
+    wave_sync();
+    }
+}
+
+// The targets' private and public state (the row-image counterpart of fill_scratch); `last_gw` as there.
+template <typename ObsT>
+__device__ __forceinline__ void image_targets(Ctx<ObsT> &c, int &last_gw) {
+    if constexpr (sizeof(ObsT) == 4) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    if (lane < p.Nt) {
+        float *pt = c.pub_tgt(lane), *row = c.img_tgt_row(lane) + 13;
+        const int gw = c.ti(lane, TI_GW) & 0xffffff;            // bit 24 (colliding) is not part of the observation
+        const float x = (float)c.tx(lane), y = (float)c.ty(lane);
+        pt[0] = x; pt[1] = y; row[0] = x; row[1] = y;
+        if (gw != last_gw) {
+            last_gw = gw;
+            const int goal = (gw & 0xff) - 1, weight = (gw >> 8) & 0xff, empty = (gw >> 16) & 0xf;
+            const float loaded = goal >= 0 && weight > 0 ? 1.0f : 0.0f;
+            pt[3] = loaded; row[3] = loaded;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                row[6 + w] = (float)(goal == w ? weight : 0);
+                row[10 + w] = (float)((empty >> w) & 1);
+            }
+        }
+    }
+    wave_sync();
+    }
+}
+
+// Every lane writes the blocks of the visibility pairs it tested (`seen`: update_view's seen_out).
+template <typename ObsT>
+__device__ __forceinline__ void image_blocks(Ctx<ObsT> &c, const RangeRoles &roles, uint32_t seen) {
+    const Params &p = c.p;
+#pragma unroll
+    for (int slot = 0; slot < 1 + kRoleRounds; ++slot) {
+        if (slot > p.range_rounds) break;
+        const uint32_t code = (roles.block_bits >> (2 * slot)) & 3u;
+        if (code != 0u) {
+            const uint32_t m = ((seen >> slot) & 1u) ? ~0u : 0u;
+            const uint4 *src = reinterpret_cast<const uint4 *>(c.base + (roles.block[slot] & 0xffffu));
+            uint32_t *dst = reinterpret_cast<uint32_t *>(c.base + (roles.block[slot] >> 16));
+            const uint4 a = src[0], b = src[1];
+            dst[0] = a.x & m; dst[1] = a.y & m; dst[2] = a.z & m; dst[3] = a.w & m;
+            if (code >= 2u) dst[4] = b.x & m;
+            if (code == 3u) { dst[5] = b.y & m; dst[6] = b.z & m; }
+        }
+    }
+    wave_sync();
+}
+
+// The rows as they lie in LDS, 16 bytes per lane and chunk, to the output buffers (write-once stream: non-temporal).
+template <typename ObsT>
+__device__ __forceinline__ void image_store(const Ctx<ObsT> &c) {
+    if constexpr (sizeof(ObsT) == 4) {
+    const Params &p = c.p;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int nvc = p.cam_elems / 4, nvt = p.tgt_elems / 4;
+    const f32x4 *src_c = reinterpret_cast<const f32x4 *>(c.img), *src_t = reinterpret_cast<const f32x4 *>(c.img + p.cam_elems);
+    f32x4 *cam = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.cam_obs) + c.out * p.cam_elems);
+    f32x4 *tgt = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems);
+    // all LDS reads of a block before its first store (a store issued between them would be waited for with them)
+    constexpr int GC = 2, GT = 6;       // (image_fits shapes: at most 128 camera chunks and 384 target chunks; asserted by the host)
+    const int lane = c.lane & 63;       // (the range, for the compiler: whole chunks rounds fold their bounds checks)
+    f32x4 vc[GC], vt[GT];
+#pragma unroll
+    for (int k = 0; k < GC; ++k) { const int s = lane + 64 * k; if (s < nvc) vc[k] = src_c[s]; }
+#pragma unroll
+    for (int k = 0; k < GT; ++k) { const int s = lane + 64 * k; if (s < nvt) vt[k] = src_t[s]; }
+#pragma unroll
+    for (int k = 0; k < GC; ++k) { const int s = lane + 64 * k; if (s < nvc) __builtin_nontemporal_store(vc[k], &cam[s]); }
+#pragma unroll
+    for (int k = 0; k < GT; ++k) { const int s = lane + 64 * k; if (s < nvt) __builtin_nontemporal_store(vt[k], &tgt[s]); }
     }
 }
 
@@ -1459,8 +1677,10 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     // The observation descriptors of this lane are the same for every step: loaded once and held in 32 VGPRs (the
     // headline batch runs 4 waves per SIMD, the register file has room), which takes the table's two global-load
     // round trips out of every step's pack phase.
+    constexpr bool IMAGE = Shape::kImage;   // row-image mode: the observation rows live in LDS (see image_statics)
+    static_assert(!IMAGE || (Shape::kHoldRoles && sizeof(ObsT) == 4 && FLOW != FLOW_ANY), "row-image mode: f32 rows, held lane roles, a folded flow");
     PackDescriptors held;
-    {
+    if constexpr (!IMAGE) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
         load_pack_descriptors(c, held);      // (indices clamped: harmless when another pack path runs)
     }
@@ -1468,6 +1688,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     if constexpr (Shape::kHoldRoles) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
         range_roles(c, roles);
+        if constexpr (IMAGE) image_statics(c);
     }
     // Fair shares of the SIMD.  Its arbiter serves the oldest resident wave first, and in a launch that lasts for
     // tens of steps the age order never changes: of the four environment-waves of a SIMD the oldest ran a step in
@@ -1533,13 +1754,20 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         ROLL_STAMP(1);
         if (!(MATE_ABLATE & 4)) simulate_targets(c, draws);
         ROLL_STAMP(2);
-        if (!(MATE_ABLATE & 8)) update_view<Shape::kHoldRoles, true>(c, tick, S_TRANSMIT, true, roles);
+        uint32_t seen = 0u;
+        if (!(MATE_ABLATE & 8)) update_view<Shape::kHoldRoles, true>(c, tick, S_TRANSMIT, true, roles, seen);
         ROLL_STAMP(3);
         if (!(MATE_ABLATE & 16)) assign_and_score(c, tick, g.scalars);
         ROLL_STAMP(4);
+        if constexpr (IMAGE) {
+            if (!(MATE_ABLATE & 32)) { image_targets(c, last_gw); image_blocks(c, roles, seen); }
+            ROLL_STAMP(5);
+            if (!(MATE_ABLATE & 64)) { image_store(c); store_masks(c); }
+        } else {
         if (!(MATE_ABLATE & 32)) fill_scratch(c, last_gw);
         ROLL_STAMP(5);
         if (!(MATE_ABLATE & 64)) pack_observations<true>(c, held);
+        }
         wave_sync();
         stepped = true;
         ROLL_STAMP(6);

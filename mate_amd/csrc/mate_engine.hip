@@ -44,8 +44,22 @@ using PolicyFn = void (*)(const Params *, const Ptrs, const PolicyPtrs);
 
 // step[flow]: the launch-flag specialisations (enum Flow) exist for f32 observations, the product path; f64
 // observations (the parity mirror) run the generic flow everywhere.
-static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, StepFn *step, StepFn *rollout, PolicyFn *policy, PolicyFn *rollout_greedy, int *specialised) {
-    *specialised = 0;
+// `image`: the row-image compilation of the fused random-policy rollout (engine_kernels.hpp: image_statics) where the shape has
+// one.  (The fused Greedy rollout keeps the descriptor packer: with the agents' memory next to a 6 KB row image only three
+// workgroups fit a CU -- 3072 of the 4096 environments of a MATE-4v8-9 batch resident -- and a second pass costs more than
+// the packer's instructions.  rollout_greedy_kernel compiles in row-image mode all the same, for the day the slices shrink.)
+template <int C, int T, int O>
+static void pick_image_kernels(StepFn *rollout, PolicyFn *rollout_greedy, int *image) {
+    (void)rollout_greedy;
+    if constexpr (image_fits(C, T, O)) {
+        rollout[1] = (StepFn)rollout_kernel<float, FixedShape<C, T, O, false, true>, FLOW_RANDOM>;
+        *image = 1;
+    }
+}
+
+static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no_image, StepFn *step, StepFn *rollout, PolicyFn *policy, PolicyFn *rollout_greedy,
+                         int *specialised, int *image) {
+    *specialised = 0; *image = 0;
     if (!generic) {
 #define X(C, T, O)                                                                                                  \
     if (Nc == C && Nt == T && No == O) {                                                                            \
@@ -57,6 +71,7 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, StepFn 
         rollout[1] = f64 ? rollout[0] : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                                   \
         *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, FixedShape<C, T, O, true>> : (PolicyFn)greedy_policy_kernel<float, FixedShape<C, T, O, false>>; \
         *rollout_greedy = f64 ? (PolicyFn)rollout_greedy_kernel<double, FixedShape<C, T, O, true>> : (PolicyFn)rollout_greedy_kernel<float, FixedShape<C, T, O, false>>; \
+        if (!f64 && !no_image) pick_image_kernels<C, T, O>(rollout, rollout_greedy, image);                         \
         return;                                                                                                     \
     }
         MATE_SHAPES(X)
@@ -79,6 +94,7 @@ struct Switches {
     int lut_small_cap = 0;         // MATE_LUT_SMALL_CAP=<rays>: sort-array size of the small-LDS table launch (0: half the full size)
     bool reset_monolithic = false; // MATE_RESET_MONOLITHIC=1: resets as one launch instead of placement / tables / view
     int rollout_rotate = 1;        // MATE_ROLLOUT_ROTATE=0: no wave-priority rotation in the fused rollouts
+    bool no_image = false;         // MATE_NO_IMAGE=1: the fused rollouts pack observations through the descriptor table even where the row-image compilation exists
     bool policy_split = false;     // MATE_POLICY_SPLIT=1: step_greedy / step_versus_greedy as two launches (agents' kernel, step kernel) even when the fused one-launch form applies
     bool zoom_iterate = false;     // MATE_ZOOM_ITERATE=1: the greedy camera agents iterate the zoom solve (greedy.py:139-145) instead of reading its table
 };
@@ -93,6 +109,7 @@ static Switches read_switches() {
     if (const char *v = getenv("MATE_ROLLOUT_ROTATE")) w.rollout_rotate = atoi(v);
     w.zoom_iterate = flag("MATE_ZOOM_ITERATE");
     w.policy_split = flag("MATE_POLICY_SPLIT");
+    w.no_image = flag("MATE_NO_IMAGE");
     return w;
 }
 
@@ -115,6 +132,8 @@ struct mate_engine {
     int dev_interval = 1;      // ... and the auto-reset interval every step() must then use
     int pending_interval = 0;  // auto_reset value of the batched-reset interval in progress (steps_since_reset > 0)
     size_t step_lds = 0, reset_lds = 0;
+    int image = 0;                         // the fused rollouts (random-policy flow, greedy) run their row-image compilation ...
+    size_t image_wave_bytes = 0;           // ... whose per-environment LDS slice is this
     PolicyFn policy_fn = nullptr, rollout_greedy_fn = nullptr;
     StepFn step_fn[3] = {nullptr, nullptr, nullptr}, rollout_fn[2] = {nullptr, nullptr};   // kernels chosen at create: shape-specialised when compiled for these counts; step_fn[flow]
     int last_flow = 0;
@@ -311,7 +330,8 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.first_env = (uint32_t)first_env_index;
     e->step_lds = 4 * (size_t)p.lds_wave_bytes;
     e->sw = read_switches();
-    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->sw.generic, e->step_fn, e->rollout_fn, &e->policy_fn, &e->rollout_greedy_fn, &e->specialised);
+    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->sw.generic, e->sw.no_image, e->step_fn, e->rollout_fn, &e->policy_fn, &e->rollout_greedy_fn, &e->specialised, &e->image);
+    { Params pi = p; fill_shape(pi, Nc, Nt, No, false, true); e->image_wave_bytes = e->image ? (size_t)pi.lds_wave_bytes : (size_t)p.lds_wave_bytes; }
     e->flow_generic = e->sw.flow_generic;
     if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }
     ResetLds &rl = e->rl;
@@ -394,7 +414,8 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         for (int f = 0; f < 3 && err == hipSuccess; ++f)
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->step_fn[f]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
         for (int f = 0; f < 2 && err == hipSuccess; ++f)
-            err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rollout_fn[f]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rollout_fn[f]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(f == 1 && e->image ? 4 * e->image_wave_bytes : e->step_lds));
         if (err != hipSuccess) {
         } else if (p.obs_f64) {
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
@@ -815,7 +836,8 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
     const int flow = (!e->flow_generic && !g.act_discrete && g.obs_mode == 0 && !g.xdesc && !g.xab && g.scratch_init &&
                       (g.cam_obs || e->p.Nc == 0) && g.tgt_obs && g.scalars) ? FLOW_RANDOM : FLOW_ANY;
     e->last_flow = flow;
-    hipExtLaunchKernelGGL(e->rollout_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
+    hipExtLaunchKernelGGL(e->rollout_fn[flow], dim3(blocks), dim3(256), (flow == FLOW_RANDOM && e->image) ? 4 * e->image_wave_bytes : e->step_lds, stream, ev0, ev1, 0,
+                          (const Params *)e->d_params, (const Ptrs)g);
     HIP_TRY(hipGetLastError());
     e->tick += (uint32_t)steps;
     if (auto_reset == 1) {

@@ -507,11 +507,15 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         if (in_batch) list_finished_at_entry(c);
         wave_sync();
     }
+    constexpr bool IMAGE = Shape::kImage;   // row-image mode (engine_kernels.hpp: image_statics)
     PackDescriptors held;
+    RangeRoles roles;
     {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
-        if constexpr (Shape::kGreedyHeld) load_pack_descriptors(c, held);
+        if constexpr (IMAGE) { range_roles(c, roles); image_statics(c); }
+        else if constexpr (Shape::kGreedyHeld) load_pack_descriptors(c, held);
     }
+    int last_gw = -1;                                              // image_targets: the goal word behind a target's goal / cargo slots
     uint32_t hw_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     const int wave_slot = (int)(hw_id & 15u);
@@ -574,15 +578,25 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         GREEDY_STAMP(1);
         if (!(MATE_ABLATE & 4)) simulate_targets(c, draws);
         GREEDY_STAMP(2);
-        if (!(MATE_ABLATE & 8)) { RangeRoles none; update_view<false, true>(c, tick, S_TRANSMIT, true, none); }
+        uint32_t seen = 0u;
+        if (!(MATE_ABLATE & 8)) {
+            if constexpr (IMAGE) update_view<true, true>(c, tick, S_TRANSMIT, true, roles, seen);
+            else { RangeRoles none; update_view<false, true>(c, tick, S_TRANSMIT, true, none); }
+        }
         GREEDY_STAMP(3);
         if (!(MATE_ABLATE & 16)) assign_and_score(c, tick, g.scalars);
         GREEDY_STAMP(4);
+        if constexpr (IMAGE) {
+            if (!(MATE_ABLATE & 32)) { image_targets(c, last_gw); image_blocks(c, roles, seen); }
+            GREEDY_STAMP(5);
+            if (!(MATE_ABLATE & 64)) { image_store(c); store_masks(c); }
+        } else {
         if (!(MATE_ABLATE & 32)) fill_scratch(c);
         GREEDY_STAMP(5);
         if (!(MATE_ABLATE & 64)) {
             if constexpr (Shape::kGreedyHeld) pack_observations<true>(c, held);
             else { PackDescriptors now; pack_observations<false>(c, now); }
+        }
         }
         wave_sync();
         stepped = true;

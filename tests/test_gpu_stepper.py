@@ -341,3 +341,35 @@ def test_idle_rows_of_a_fused_rollout_are_marked_and_never_written(policy):
     env.reset()
     _, _, done, info = env.rollout_greedy(K) if policy == 'greedy' else env.rollout_random(K)
     assert torch.equal(info['skipped'], idle) and torch.equal(done, sc[..., 2] == 1)
+
+
+@pytest.mark.parametrize('workload,n', [('MATE-4v8-9.yaml', 301), ('MATE-4v8-0.yaml', 130)])
+def test_row_image_rollout_equals_descriptor_rollout(workload, n):
+    """The fused random-policy rollout of the shapes with a row-image compilation (observation rows resident in LDS, every
+    visibility lane writes its own block) against the same kernel packing through the descriptor table (MATE_NO_IMAGE=1,
+    read at create): every output row, the masks and the state bit for bit, across launches, restarts and idle slots."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config(workload, max_episode_steps=11)
+    runs = []
+    for no_image in ('0', '1'):
+        os.environ['MATE_NO_IMAGE'] = no_image
+        try:
+            eng = Engine(cfg, n, seed=31, first_env_index=7)
+        finally:
+            os.environ.pop('MATE_NO_IMAGE', None)
+        eng.reset()
+        rec = []
+        for steps in (5, 9, 1, 16):
+            buf = eng.reserve_rollout(16, want_masks=True)
+            for key in ('camera_obs', 'target_obs'):
+                buf[key].fill_(-7.0)
+            cam, tgt, sc = eng.rollout_random(steps, auto_reset=True, want_masks=True)
+            torch.cuda.synchronize()
+            rec.append([cam.clone(), tgt.clone(), sc.clone(), buf['masks'][:steps].clone(), eng.export_state().clone()])
+        runs.append(rec)
+        assert eng.last_flow == 1
+    for a, b in zip(*runs):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+    assert (runs[0][-1][2][..., 2] == 2).any() and (runs[0][1][2][..., 2] == 1).any()      # episodes ended and slots idled inside the launches
