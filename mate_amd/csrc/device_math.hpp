@@ -75,6 +75,14 @@ __device__ __forceinline__ double norm2(double x, double y) { return sqrt_pos(fm
 // np.clip on finite operands with lo <= hi, neither bound a zero (action limits, viewing-angle limits, the terrain): two
 // v_max / v_min instead of two compares and four selects.
 __device__ __forceinline__ double clipd(double v, double lo, double hi) { return __builtin_fmin(__builtin_fmax(v, lo), hi); }
+// The same with WAVE-UNIFORM bounds (scenario constants, literals) as two instructions: fmax / fmin above cost five, because
+// the compiler first canonicalises every operand (v_max_f64 x, x) in case it is a signalling NaN.  The bounds travel in
+// scalar registers (one per instruction: the constant-bus limit), the value is finite by construction.
+__device__ __forceinline__ double clip_uniform(double v, double lo, double hi) {
+    double r;
+    asm("v_max_f64 %0, %1, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(r) : "v"(v), "s"(lo), "s"(hi));
+    return r;
+}
 
 // Python float `%` with a positive divisor (utils.py:158 uses it with 360.0).
 __device__ __forceinline__ double pymod_pos(double a, double b) {

@@ -512,10 +512,10 @@ __device__ __forceinline__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &
                 const float2 a = reinterpret_cast<const float2 *>(c.g.cam_act)[c.env * p.Nc + lane];
                 da = (double)a.x; dz = (double)a.y;
             }
-            da = clipd(da, -p.rot, p.rot);
-            dz = clipd(dz, -p.zoom, p.zoom);
+            da = clip_uniform(da, -p.rot, p.rot);
+            dz = clip_uniform(dz, -p.zoom, p.zoom);
             ph = normalize_angle(ph + da);
-            th = clipd(th + dz, p.theta_min, kMaxViewingAngle);
+            th = clip_uniform(th + dz, p.theta_min, kMaxViewingAngle);
             c.phi(lane) = ph; c.theta(lane) = th;
         }
         // sight_range = sqrt(area / viewing_angle) (entities.py:360).  The visibility phase compares SQUARED distances with
@@ -551,8 +551,12 @@ __device__ __forceinline__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &
 // screened in parallel with a sqrt-free conservative test; only flagged circles are walked, in index
 // order.  A hit never lengthens the step (|v'|^2 = |v|^2 - a s^2 (2|v| - a) <= |v|^2 for penetration a and
 // s = half_chord/r), so a circle out of reach of the original step stays out of reach.
+// `carried` (the fused rollouts with held lane roles): the screen was made by the PREVIOUS step's range tests -- the
+// (target, camera | obstacle) pairs of Sensor.perceive are the pairs of this screen, on the very positions this step starts
+// from -- and arrives as the ballots of their rounds (NearCarry, update_view); no screen pass, no LDS hand-off here.
+struct NearCarry { unsigned long long w[3]; };       // bit q = t * NJ + j of the range rounds: circle j may be touched by target t's next step
 template <typename ObsT>
-__device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws) {
+__device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws, const NearCarry *carried = nullptr) {
     const Params &p = c.p;
     const int lane = c.lane;
     const int t = lane - p.Nc;
@@ -587,9 +591,20 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
             vx = ax * k; vy = ay * k; n = step_size;
         }
         desx = ox + vx; desy = oy + vy;
-        c.snorm(t) = n;
-        c.near(t) = 0; c.near(p.Nt + t) = 0;
+        if (!carried) { c.snorm(t) = n; c.near(t) = 0; c.near(p.Nt + t) = 0; }
     }
+    uint64_t todo_carried = 0;
+    if (carried) {
+        if (is_target) {
+            // the target's NK bits out of the 192-bit string w2:w1:w0, then from entity order (cameras, obstacles) to the
+            // order the circles are walked in (obstacles, cameras: Target.add_obstacles, environment.py:743)
+            const int first = t * p.NJ, word = first >> 6, sh = first & 63;
+            const unsigned long long lo = word == 0 ? carried->w[0] : word == 1 ? carried->w[1] : carried->w[2];
+            const unsigned long long hi = word == 0 ? carried->w[1] : word == 1 ? carried->w[2] : 0ull;
+            const unsigned long long field = ((lo >> sh) | (sh ? hi << (64 - sh) : 0ull)) & ((1ull << p.NK) - 1ull);
+            todo_carried = (field >> p.Nc) | ((field & ((1ull << p.Nc) - 1ull)) << p.No);
+        }
+    } else {
     wave_sync();
     SUB_STAMP(c, 10);
     const int npairs = p.Nt * p.NK;
@@ -611,9 +626,10 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
         }
     }
     wave_sync();
+    }
     SUB_STAMP(c, 11);
     if (is_target) {
-        uint64_t todo = (uint64_t)(uint32_t)c.near(t) | ((uint64_t)(uint32_t)c.near(p.Nt + t) << 32);
+        uint64_t todo = carried ? todo_carried : ((uint64_t)(uint32_t)c.near(t) | ((uint64_t)(uint32_t)c.near(p.Nt + t) << 32));
         bool n_known = true;
         while (todo) {
             const int k = __ffsll((long long)todo) - 1;
@@ -627,8 +643,8 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
             if (n != 0.0 && fma(dy, dy, dx * dx) > reach * reach * (1.0 + 1e-12)) continue;
             obstruct_tangential(ox, oy, vx, vy, n, n_known, cx, cy, cr);
         }
-        const double nx = clipd(ox + vx, -kTerrain, kTerrain);   // entities.py:664-666
-        const double ny = clipd(oy + vy, -kTerrain, kTerrain);
+        const double nx = clip_uniform(ox + vx, -kTerrain, kTerrain);   // entities.py:664-666
+        const double ny = clip_uniform(oy + vy, -kTerrain, kTerrain);
         const bool colliding = (fabs(nx - desx) > 1e-6) || (fabs(ny - desy) > 1e-6);  // entities.py:668
         c.tx(t) = nx; c.ty(t) = ny;
         c.ex[c.tgt_slot(t)] = nx; c.ey[c.tgt_slot(t)] = ny;
@@ -728,6 +744,9 @@ struct RangeRoles {
     // slots 1.. the range rounds: LDS byte offset of the other's public state | of the block in the viewer's row << 16
     uint32_t block[1 + kRoleRounds];
     uint32_t block_bits;             // 2 bits per slot: 0 none, 1 = 4 floats (obstacle), 2 = 5 (target), 3 = 7 (camera)
+    // the collision screen of the NEXT step rides on the range tests (simulate_targets, NearCarry): (step size + the circle's
+    // radius + 1e-3)^2 for a camera or an obstacle, negative for a pair that is no (target, circle) pair
+    float reach2[kRoleRounds];
 };
 // LDS byte offsets (inside the wave's slice) of an entity's public state and of its block in a viewer's row; width code as above
 __device__ __forceinline__ void image_block_of(const Params &p, bool viewer_is_camera, int viewer, int j, uint32_t &word, uint32_t &code) {
@@ -743,6 +762,15 @@ __device__ __forceinline__ void image_block_of(const Params &p, bool viewer_is_c
         col = 27 + (j < p.Nc ? 7 * j : j < p.Nc + p.No ? 7 * p.Nc + 4 * (j - p.Nc) : 7 * p.Nc + 4 * p.No + 5 * (j - p.Nc - p.No));
         word = (uint32_t)src | ((uint32_t)(p.off_img + 4 * (p.cam_elems + viewer * p.Dt + col)) << 16);
     }
+}
+// The roles are pure functions of the lane id: left alone, the compiler re-derives them inside the step loop instead of
+// holding them (15 instructions per step for the sector role alone).  Passing each word through an empty asm makes it opaque.
+__device__ __forceinline__ void pin_roles(RangeRoles &r) {
+#pragma unroll
+    for (int i = 0; i < kRoleRounds; ++i) { asm volatile("" : "+v"(r.pair[i])); asm volatile("" : "+v"(r.lim2[i])); asm volatile("" : "+v"(r.rim[i])); asm volatile("" : "+v"(r.reach2[i])); }
+#pragma unroll
+    for (int i = 0; i < 1 + kRoleRounds; ++i) asm volatile("" : "+v"(r.block[i]));
+    asm volatile("" : "+v"(r.diag_bits)); asm volatile("" : "+v"(r.valid_bits)); asm volatile("" : "+v"(r.sector)); asm volatile("" : "+v"(r.block_bits));
 }
 template <typename ObsT>
 __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &roles) {
@@ -762,6 +790,12 @@ __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &role
         roles.rim[round] = range_rim(lim);
         roles.diag_bits |= (uint32_t)(j == tj) << round;
         roles.valid_bits |= (uint32_t)(q < p.n_range && round < p.range_rounds) << round;
+        {   // a SCREEN: conservative by the whole step size (the walk repeats the test on the actual step, exactly), f32 with
+            // an absolute margin eight times the worst rounding of the f32 shadow (see simulate_targets)
+            const float step = (float)(((c.capword() >> t) & 1ull) ? p.tgt_step * 0.5 : p.tgt_step);
+            const float reach = step + (float)c.er[j] + 1e-3f;
+            roles.reach2[round] = (q < p.n_range && round < p.range_rounds && j < p.Nc + p.No) ? reach * reach : -1.0f;
+        }
         roles.block[1 + round] = 0u;
         if (c.image() && q < p.n_range && round < p.range_rounds) {
             uint32_t code;
@@ -776,6 +810,20 @@ __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &role
         uint32_t code;
         image_block_of(p, true, cam, is_target ? c.tgt_slot(other) : other, roles.block[0], code);
         roles.block_bits |= code;
+    }
+}
+
+// The first step of a launch has no previous step: the same comparison on the positions the launch starts from.
+template <typename ObsT>
+__device__ __forceinline__ void near_seed(const Ctx<ObsT> &c, const RangeRoles &roles, NearCarry &near) {
+#pragma unroll
+    for (int round = 0; round < kRoleRounds; ++round) {
+        near.w[round] = 0ull;
+        if (round < c.p.range_rounds) {
+            const int tj = roles.pair[round] & 0xffff, j = roles.pair[round] >> 16;
+            const float dx = c.exf[tj] - c.exf[j], dy = c.eyf[tj] - c.eyf[j];
+            near.w[round] = __ballot(fmaf(dy, dy, dx * dx) <= roles.reach2[round]);
+        }
     }
 }
 
@@ -870,7 +918,8 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorE
 // `seen_out` (row-image mode, which writes no flag words): bit 0 = the lane's sector pair is seen, bit 1 + r = its pair of
 // range round r (image_blocks turns them into the pair's block of the observation rows).
 template <bool HELD, bool COMPACT = false, typename ObsT>
-__device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn, const RangeRoles &held, uint32_t &seen_out) {
+__device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn, const RangeRoles &held, uint32_t &seen_out,
+                                            NearCarry *near_next = nullptr) {
     const Params &p = c.p;
     const int lane = c.lane;
     seen_out = 0u;
@@ -923,6 +972,7 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
                 bool seen = d2 < lim2 - rim;
                 if (!seen && !(d2 > lim2 + rim)) seen = range_exact(c, tj, j);
                 seen_bits |= (uint32_t)((seen || diag) && ((held.valid_bits >> round) & 1u)) << round;
+                if (near_next) near_next->w[round] = __ballot(d2 <= held.reach2[round]);      // the next step's collision screen
             }
         }
     } else {
@@ -1688,7 +1738,13 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     if constexpr (Shape::kHoldRoles) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
         range_roles(c, roles);
+        pin_roles(roles);
         if constexpr (IMAGE) image_statics(c);
+    }
+    NearCarry near{{0ull, 0ull, 0ull}};     // the collision screen of the step to come, made by the range tests of the step before
+    if constexpr (Shape::kHoldRoles) {
+        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
+        near_seed(c, roles, near);
     }
     // Fair shares of the SIMD.  Its arbiter serves the oldest resident wave first, and in a launch that lasts for
     // tens of steps the age order never changes: of the four environment-waves of a SIMD the oldest ran a step in
@@ -1747,15 +1803,21 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
 #ifndef MATE_ABLATE            // experiment builds (tools/ablate_rollout.sh): a phase compiled out, to weigh it
 #define MATE_ABLATE 0
 #endif
+#ifndef MATE_DOUBLE            // experiment builds (tools/double_phase.sh): an idempotent phase executed TWICE -- the difference of the
+#define MATE_DOUBLE 0          // dynamic instruction counters against the plain build is that phase's exact share, on real data
+#endif
         StepDraws draws{0.0, 0.0};
         if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick, &carry);
+        if (MATE_DOUBLE & 1) { DrawCarry again = carry; again.block = 0xffffffffu; const StepDraws d2 = step_draws(c, tick, &again); draws.a0 += 0.0 * d2.a0; }
         ROLL_STAMP(0);
         if (!(MATE_ABLATE & 2)) simulate_cameras(c, draws, true);
+        if (MATE_DOUBLE & 2) { wave_sync(); simulate_cameras(c, StepDraws{0.0, 0.0}, true); }      // (a zero action: the same instructions, the same state)
         ROLL_STAMP(1);
-        if (!(MATE_ABLATE & 4)) simulate_targets(c, draws);
+        if (!(MATE_ABLATE & 4)) simulate_targets(c, draws, Shape::kHoldRoles ? &near : nullptr);
         ROLL_STAMP(2);
         uint32_t seen = 0u;
-        if (!(MATE_ABLATE & 8)) update_view<Shape::kHoldRoles, true>(c, tick, S_TRANSMIT, true, roles, seen);
+        if (!(MATE_ABLATE & 8)) update_view<Shape::kHoldRoles, true>(c, tick, S_TRANSMIT, true, roles, seen, Shape::kHoldRoles ? &near : nullptr);
+        if (MATE_DOUBLE & 8) { uint32_t again; update_view<Shape::kHoldRoles, true>(c, tick, S_TRANSMIT, true, roles, again, Shape::kHoldRoles ? &near : nullptr); seen |= again; }
         ROLL_STAMP(3);
         if (!(MATE_ABLATE & 16)) assign_and_score(c, tick, g.scalars);
         ROLL_STAMP(4);
@@ -1763,6 +1825,8 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
             if (!(MATE_ABLATE & 32)) { image_targets(c, last_gw); image_blocks(c, roles, seen); }
             ROLL_STAMP(5);
             if (!(MATE_ABLATE & 64)) { image_store(c); store_masks(c); }
+            if (MATE_DOUBLE & 32) { int gw2 = last_gw; image_targets(c, gw2); image_blocks(c, roles, seen); }
+            if (MATE_DOUBLE & 64) { wave_sync(); image_store(c); }
         } else {
         if (!(MATE_ABLATE & 32)) fill_scratch(c, last_gw);
         ROLL_STAMP(5);

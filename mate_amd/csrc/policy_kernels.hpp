@@ -320,8 +320,8 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         const int c = lane;
         double a0, a1;
         if (best >= 0) {
-            a0 = clipd(normalize_angle(best_orientation - orientation), -p.rot, p.rot);
-            a1 = clipd(best_va - theta, -p.zoom, p.zoom);
+            a0 = clip_uniform(normalize_angle(best_orientation - orientation), -p.rot, p.rot);
+            a1 = clip_uniform(best_va - theta, -p.zoom, p.zoom);
         } else {
             double u;
             if (q.tape.cam_binom_u) u = q.tape.cam_binom_u[env * Nc + c];
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
     RangeRoles roles;
     {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
-        if constexpr (IMAGE) { range_roles(c, roles); image_statics(c); }
+        if constexpr (IMAGE) { range_roles(c, roles); pin_roles(roles); image_statics(c); }
         else if constexpr (Shape::kGreedyHeld) load_pack_descriptors(c, held);
     }
     int last_gw = -1;                                              // image_targets: the goal word behind a target's goal / cargo slots
