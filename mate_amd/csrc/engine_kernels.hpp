@@ -917,9 +917,12 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorE
 // 96-SGPR budget where the list bookkeeping spills, and measured 3 % slower with it.
 // `seen_out` (row-image mode, which writes no flag words): bit 0 = the lane's sector pair is seen, bit 1 + r = its pair of
 // range round r (image_blocks turns them into the pair's block of the observation rows).
+// `sector_ballot` (the register-resident step of the fused rollout, HeldState): the packed camera->target / camera->camera
+// word as the ballot that made it, and NO tail here -- tracked bits and warehouse membership are derived from it and from the
+// positions in registers (view_tail_held), without the two LDS hand-offs of the tail below.
 template <bool HELD, bool COMPACT = false, typename ObsT>
 __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn, const RangeRoles &held, uint32_t &seen_out,
-                                            NearCarry *near_next = nullptr) {
+                                            NearCarry *near_next = nullptr, unsigned long long *sector_ballot = nullptr) {
     const Params &p = c.p;
     const int lane = c.lane;
     seen_out = 0u;
@@ -1037,6 +1040,7 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
             seen_out |= (uint32_t)seen;
             const unsigned long long b = __ballot(seen);
             if (lane == 0) { c.mask[2 * last] = (uint32_t)b; c.mask[2 * last + 1] = (uint32_t)(b >> 32); }
+            if (sector_ballot) *sector_ballot = b;
         }
     }
     SUB_STAMP(c, 14);
@@ -1055,6 +1059,7 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
             set_flag(c, p.fs_camobs + cam * p.No + o, (c.camobs(cam) >> o) & 1ull);
         }
     }
+    if (sector_ballot) return;
     wave_sync();
     // ---- tracked_bits = camera_target_view_mask.any(axis=0) (environment.py:1388); which warehouse holds the target
     if (lane < p.Nt) {
@@ -1084,6 +1089,60 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     update_view<false>(c, tick, stream, predrawn, none);
 }
 
+// The order-dependent part of _assign_goals (environment.py:1278-1318: the warehouses' remaining cargo is shared), on ONE lane,
+// for the targets standing in a warehouse (c.inside); dense and delayed rewards of the deliveries are added to `reward` / `delayed`.
+template <typename ObsT>
+__device__ __forceinline__ void goal_logistics(Ctx<ObsT> &c, uint32_t tick, double &reward, double &delayed) {
+    const Params &p = c.p;
+    for (int t = 0; t < p.Nt; ++t) {
+        const int w = c.inside(t);
+        if (w < 0) continue;
+        int gw = c.ti(t, TI_GW);
+        const int goal = (gw & 0xff) - 1;
+        const int weight0 = (gw >> 8) & 0xff;
+        bool proceed = true;
+        if (goal >= 0) {
+            if (goal == w) {                            // delivery, environment.py:1286-1293
+                const double total_bounty = (double)weight0 * p.bounty_scale;
+                const double r = (double)(c.ti(t, TI_FREIGHT) + c.ti(t, TI_BOUNTY));
+                reward += r;
+                delayed += r - (total_bounty - (double)c.ti(t, TI_BOUNTY));
+                c.ei(EI_DELIVERED) += weight0;
+                c.ei(EI_AWAITING + goal) -= weight0;
+            } else {
+                proceed = false;                        // environment.py:1294-1295
+            }
+        }
+        if (proceed) {
+            c.ti(t, TI_FREIGHT) = 0; c.ti(t, TI_BOUNTY) = 0;
+            c.ti(t, TI_TSTEPS) = 0; c.ti(t, TI_TRSTEPS) = 0;
+            gw &= ~0xffff;                              // goal := none, weight := 0
+            int *row = &c.ei(EI_REMAINING + 4 * w);
+            int k = 0;
+            for (int gq = 0; gq < 4; ++gq) k += row[gq] > 0;
+            if (k > 0) {                                // environment.py:1302-1315
+                const double u = c.tape_goal() ? c.tape_goal()[c.env * p.Nt + t] : c.draw(tick, S_GOAL, (uint32_t)t);
+                int j = (int)(u * (double)k);
+                if (j >= k) j = k - 1;
+                int new_goal = 0;
+                for (int gq = 0, seen = 0; gq < 4; ++gq) if (row[gq] > 0) { if (seen == j) new_goal = gq; ++seen; }
+                const int cap = 1 + (int)((c.capword() >> t) & 1ull);
+                const int rem = row[new_goal];
+                const int weight = cap < rem ? cap : rem;
+                row[new_goal] -= weight;
+                c.ti(t, TI_FREIGHT) = (int)((double)weight * p.freight_scale);
+                c.ti(t, TI_BOUNTY) = (int)((double)weight * p.bounty_scale);
+                gw |= (new_goal + 1) | (weight << 8);
+            }
+        }
+        // empty bits of the warehouse the target stands in (environment.py:1317-1318)
+        const int *row = &c.ei(EI_REMAINING + 4 * w);
+        const bool empty = !(row[0] || row[1] || row[2] || row[3]);
+        gw = (gw & ~(1 << (16 + w))) | ((int)empty << (16 + w));
+        c.ti(t, TI_GW) = gw;
+    }
+}
+
 // Phase C: _assign_goals + the bookkeeping of step() (environment.py:1271-1324, 613-632).
 template <typename ObsT>
 __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out) {
@@ -1103,53 +1162,7 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
     double reward = -(double)n_penal, delayed = 0.0;
     if (any_inside) {
         if (lane == 0) {
-            for (int t = 0; t < p.Nt; ++t) {
-                const int w = c.inside(t);
-                if (w < 0) continue;
-                int gw = c.ti(t, TI_GW);
-                const int goal = (gw & 0xff) - 1;
-                const int weight0 = (gw >> 8) & 0xff;
-                bool proceed = true;
-                if (goal >= 0) {
-                    if (goal == w) {                            // delivery, environment.py:1286-1293
-                        const double total_bounty = (double)weight0 * p.bounty_scale;
-                        const double r = (double)(c.ti(t, TI_FREIGHT) + c.ti(t, TI_BOUNTY));
-                        reward += r;
-                        delayed += r - (total_bounty - (double)c.ti(t, TI_BOUNTY));
-                        c.ei(EI_DELIVERED) += weight0;
-                        c.ei(EI_AWAITING + goal) -= weight0;
-                    } else {
-                        proceed = false;                        // environment.py:1294-1295
-                    }
-                }
-                if (proceed) {
-                    c.ti(t, TI_FREIGHT) = 0; c.ti(t, TI_BOUNTY) = 0;
-                    c.ti(t, TI_TSTEPS) = 0; c.ti(t, TI_TRSTEPS) = 0;
-                    gw &= ~0xffff;                              // goal := none, weight := 0
-                    int *row = &c.ei(EI_REMAINING + 4 * w);
-                    int k = 0;
-                    for (int gq = 0; gq < 4; ++gq) k += row[gq] > 0;
-                    if (k > 0) {                                // environment.py:1302-1315
-                        const double u = c.tape_goal() ? c.tape_goal()[c.env * p.Nt + t] : c.draw(tick, S_GOAL, (uint32_t)t);
-                        int j = (int)(u * (double)k);
-                        if (j >= k) j = k - 1;
-                        int new_goal = 0;
-                        for (int gq = 0, seen = 0; gq < 4; ++gq) if (row[gq] > 0) { if (seen == j) new_goal = gq; ++seen; }
-                        const int cap = 1 + (int)((c.capword() >> t) & 1ull);
-                        const int rem = row[new_goal];
-                        const int weight = cap < rem ? cap : rem;
-                        row[new_goal] -= weight;
-                        c.ti(t, TI_FREIGHT) = (int)((double)weight * p.freight_scale);
-                        c.ti(t, TI_BOUNTY) = (int)((double)weight * p.bounty_scale);
-                        gw |= (new_goal + 1) | (weight << 8);
-                    }
-                }
-                // empty bits of the warehouse the target stands in (environment.py:1317-1318)
-                const int *row = &c.ei(EI_REMAINING + 4 * w);
-                const bool empty = !(row[0] || row[1] || row[2] || row[3]);
-                gw = (gw & ~(1 << (16 + w))) | ((int)empty << (16 + w));
-                c.ti(t, TI_GW) = gw;
-            }
+            goal_logistics(c, tick, reward, delayed);
             c.xch(0) = __double2hiint(reward); c.xch(1) = __double2loint(reward);
             c.xch(2) = __double2hiint(delayed); c.xch(3) = __double2loint(delayed);
         }
@@ -1553,18 +1566,25 @@ __device__ __forceinline__ void image_targets(Ctx<ObsT> &c, int &last_gw) {
 template <typename ObsT>
 __device__ __forceinline__ void image_blocks(Ctx<ObsT> &c, const RangeRoles &roles, uint32_t seen) {
     const Params &p = c.p;
+    // all public states first, by every lane (a lane without a block in a slot reads offset 0 of the slice: harmless), so that
+    // the slots' LDS round trips overlap instead of following one another under four different execution masks
+    uint4 a[1 + kRoleRounds], b[1 + kRoleRounds];
+#pragma unroll
+    for (int slot = 0; slot < 1 + kRoleRounds; ++slot) {
+        if (slot > p.range_rounds) break;
+        const uint4 *src = reinterpret_cast<const uint4 *>(c.base + (roles.block[slot] & 0xffffu));
+        a[slot] = src[0]; b[slot] = src[1];
+    }
 #pragma unroll
     for (int slot = 0; slot < 1 + kRoleRounds; ++slot) {
         if (slot > p.range_rounds) break;
         const uint32_t code = (roles.block_bits >> (2 * slot)) & 3u;
         if (code != 0u) {
             const uint32_t m = ((seen >> slot) & 1u) ? ~0u : 0u;
-            const uint4 *src = reinterpret_cast<const uint4 *>(c.base + (roles.block[slot] & 0xffffu));
             uint32_t *dst = reinterpret_cast<uint32_t *>(c.base + (roles.block[slot] >> 16));
-            const uint4 a = src[0], b = src[1];
-            dst[0] = a.x & m; dst[1] = a.y & m; dst[2] = a.z & m; dst[3] = a.w & m;
-            if (code >= 2u) dst[4] = b.x & m;
-            if (code == 3u) { dst[5] = b.y & m; dst[6] = b.z & m; }
+            dst[0] = a[slot].x & m; dst[1] = a[slot].y & m; dst[2] = a[slot].z & m; dst[3] = a[slot].w & m;
+            if (code >= 2u) dst[4] = b[slot].x & m;
+            if (code == 3u) { dst[5] = b[slot].y & m; dst[6] = b[slot].z & m; }
         }
     }
     wave_sync();
@@ -1595,6 +1615,247 @@ __device__ __forceinline__ void image_store(const Ctx<ObsT> &c) {
     }
 }
 
+
+// =============================================================================================
+// Register-resident step state of the fused random-policy rollout (row-image shapes).
+//
+// A step of one environment is a chain of ~1200 dependent instructions that a lone wave walks in ~12 k cycles, and four
+// waves per SIMD add only a quarter to that: what a step costs is instructions AND LDS hand-offs (write, s_waitcnt, read: ~100
+// cycles each, ~40 of them per step).  Most of those hand-offs pass a value from a lane to ITSELF one phase later -- a
+// target's position from the kinematics to the warehouse test to the observation row, its bounty / goal word / step
+// counters from one step's bookkeeping to the next, the tracked bit from the ballot to the reward.  Here those values stay in
+// the registers of the lane that owns them for the whole launch (HeldState; target t on lane Nc + t, where its kinematics
+// run; the environment's reward sums and counters on lane 0), LDS keeps what OTHER lanes read (the entity table, the
+// cameras' angles, the masks), and the order-dependent goal logistics -- rare: a target stands in a warehouse -- runs on the
+// LDS record as before, between a spill and a reload.  held_store puts everything back before the record is stored.
+struct HeldState {
+    double x, y;                                      // target lanes: position
+    int32_t bounty, freight, gw, tsteps, trsteps;     // target lanes: the TI_* words of the record
+    double ph, th;                                    // camera lanes: orientation, viewing angle
+    double ep_reward, ep_delayed;                     // lane 0: the episode's reward sums ...
+    int32_t epstep, delivered, awaiting;              // ... its step counter, delivered cargoes, "cargo still awaited"
+};
+
+template <typename ObsT>
+__device__ __forceinline__ void held_load(Ctx<ObsT> &c, HeldState &h) {
+    const Params &p = c.p;
+    const int t = c.lane - p.Nc;
+    h = HeldState{};
+    if (t >= 0 && t < p.Nt) {
+        h.x = c.tx(t); h.y = c.ty(t);
+        h.bounty = c.ti(t, TI_BOUNTY); h.freight = c.ti(t, TI_FREIGHT); h.gw = c.ti(t, TI_GW);
+        h.tsteps = c.ti(t, TI_TSTEPS); h.trsteps = c.ti(t, TI_TRSTEPS);
+    }
+    if (c.lane < p.Nc) { h.ph = c.phi(c.lane); h.th = c.theta(c.lane); }
+    if (c.lane == 0) {
+        h.ep_reward = c.ep_reward(); h.ep_delayed = c.ep_delayed();
+        h.epstep = c.ei(EI_EPSTEP); h.delivered = c.ei(EI_DELIVERED);
+        h.awaiting = (c.ei(EI_AWAITING) | c.ei(EI_AWAITING + 1) | c.ei(EI_AWAITING + 2) | c.ei(EI_AWAITING + 3)) != 0;
+    }
+}
+
+template <typename ObsT>
+__device__ __forceinline__ void held_store(Ctx<ObsT> &c, const HeldState &h, uint32_t next_tick) {
+    const Params &p = c.p;
+    const int t = c.lane - p.Nc;
+    if (t >= 0 && t < p.Nt) {
+        c.tx(t) = h.x; c.ty(t) = h.y;
+        c.ti(t, TI_BOUNTY) = h.bounty; c.ti(t, TI_FREIGHT) = h.freight; c.ti(t, TI_GW) = h.gw;
+        c.ti(t, TI_TSTEPS) = h.tsteps; c.ti(t, TI_TRSTEPS) = h.trsteps;
+    }
+    if (c.lane == 0) {
+        c.ep_reward() = h.ep_reward; c.ep_delayed() = h.ep_delayed;
+        c.ei(EI_EPSTEP) = h.epstep; c.ei(EI_TICK) = (int)next_tick;
+    }
+    wave_sync();
+}
+
+// Camera.simulate with the angles in registers (simulate_cameras is the LDS form: same arithmetic, same stores for the others)
+template <typename ObsT>
+__device__ __forceinline__ void simulate_cameras_held(Ctx<ObsT> &c, const StepDraws &draws, HeldState &h) {
+    if constexpr (sizeof(ObsT) == 4) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    if (lane < p.Nc) {
+        const double da = clip_uniform(draws.a0, -p.rot, p.rot);
+        const double dz = clip_uniform(draws.a1, -p.zoom, p.zoom);
+        const double ph = normalize_angle(h.ph + da);
+        const double th = clip_uniform(h.th + dz, p.theta_min, kMaxViewingAngle);
+        h.ph = ph; h.th = th;
+        c.phi(lane) = ph; c.theta(lane) = th;                  // (the sector tests of the pair lanes read these)
+        const double sr2 = div_nz(p.area, th);
+        c.sight2(lane) = sr2;
+        float sn, cs;
+        sincos_deg_f32(ph, sn, cs);
+        const float srf = __builtin_sqrtf((float)sr2);
+        float *pc = c.pub_cam(lane), *row = c.img_cam_row(lane) + 13;
+        const float x = srf * cs, y = srf * sn, tf = (float)th;
+        pc[3] = x; pc[4] = y; pc[5] = tf; row[3] = x; row[4] = y; row[5] = tf;
+    }
+    }
+}
+
+// Target.simulate with the position in registers and the screen carried from the previous step (simulate_targets)
+template <typename ObsT>
+__device__ __forceinline__ void simulate_targets_held(Ctx<ObsT> &c, const StepDraws &draws, const NearCarry &carried, HeldState &h) {
+    const Params &p = c.p;
+    const int t = c.lane - p.Nc;
+    if (t >= 0 && t < p.Nt) {
+        const double ax = draws.a0, ay = draws.a1;
+        const double step_size = ((c.capword() >> t) & 1ull) ? p.tgt_step * 0.5 : p.tgt_step;   // entities.py:612-615
+        const double ox = h.x, oy = h.y;
+        double vx = ax, vy = ay;
+        double n = norm2(ax, ay);
+        if (n > step_size) { const double k = div_nz(step_size, n); vx = ax * k; vy = ay * k; n = step_size; }      // entities.py:649-650
+        const double desx = ox + vx, desy = oy + vy;
+        const int first = t * p.NJ, word = first >> 6, sh = first & 63;
+        const unsigned long long lo = word == 0 ? carried.w[0] : word == 1 ? carried.w[1] : carried.w[2];
+        const unsigned long long hi = word == 0 ? carried.w[1] : word == 1 ? carried.w[2] : 0ull;
+        const unsigned long long field = ((lo >> sh) | (sh ? hi << (64 - sh) : 0ull)) & ((1ull << p.NK) - 1ull);
+        uint64_t todo = (field >> p.Nc) | ((field & ((1ull << p.Nc) - 1ull)) << p.No);
+        bool n_known = true;
+        while (todo) {
+            const int k = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            double cx, cy, cr;
+            c.circle(k, cx, cy, cr);
+            if (!n_known) { n = norm2(vx, vy); n_known = true; }
+            const double dx = cx - ox, dy = cy - oy;
+            const double reach = n + cr;
+            if (n != 0.0 && fma(dy, dy, dx * dx) > reach * reach * (1.0 + 1e-12)) continue;
+            obstruct_tangential(ox, oy, vx, vy, n, n_known, cx, cy, cr);
+        }
+        const double nx = clip_uniform(ox + vx, -kTerrain, kTerrain);   // entities.py:664-666
+        const double ny = clip_uniform(oy + vy, -kTerrain, kTerrain);
+        const bool colliding = (fabs(nx - desx) > 1e-6) || (fabs(ny - desy) > 1e-6);  // entities.py:668
+        h.x = nx; h.y = ny;
+        const int slot = c.tgt_slot(t);
+        c.ex[slot] = nx; c.ey[slot] = ny; c.exf[slot] = (float)nx; c.eyf[slot] = (float)ny;
+        h.gw = (h.gw & ~(1 << 24)) | ((int)colliding << 24);
+    }
+    wave_sync();
+}
+
+// tracked bit and warehouse of the lane's target from the sector ballot and the position in registers (the tail of update_view)
+template <typename ObsT>
+__device__ __forceinline__ void view_tail_held(const Ctx<ObsT> &c, unsigned long long sector_ballot, const HeldState &h, bool &tracked, int &inside) {
+    const Params &p = c.p;
+    const int t = c.lane - p.Nc;
+    unsigned long long any = 0ull;                       // tracked_bits = camera_target_view_mask.any(axis=0), environment.py:1388
+    for (int cam = 0; cam < p.Nc; ++cam) any |= sector_ballot >> (cam * p.Nt);
+    tracked = t >= 0 && t < p.Nt && ((any >> (t & 63)) & 1ull);
+    const bool px = h.x > 0.0, py = h.y > 0.0;           // (see update_view: only the warehouse of the target's quadrant can hold it)
+    const double wx = px ? kWarehouseCenter : -kWarehouseCenter, wy = py ? kWarehouseCenter : -kWarehouseCenter;
+    const double sup = fmax(fabs(h.x - wx), fabs(h.y - wy));
+    inside = (t >= 0 && t < p.Nt && sup <= kWarehouseRadius) ? (px ? (py ? 0 : 3) : (py ? 1 : 2)) : -1;
+}
+
+// assign_and_score on the registers; returns 1 when the episode ended at this step (wave-uniform)
+template <typename ObsT>
+__device__ __forceinline__ int assign_and_score_held(Ctx<ObsT> &c, uint32_t tick, float *scalars_out, HeldState &h, bool tracked, int inside) {
+    const Params &p = c.p;
+    const int lane = c.lane, t = lane - p.Nc;
+    const bool is_target = t >= 0 && t < p.Nt;
+    const int tr = (int)tracked;
+    bool penal = false;
+    if (is_target) {
+        penal = tr && h.bounty > 0;                            // environment.py:1275
+        const int nb = h.bounty - tr;
+        h.bounty = nb > 0 ? nb : 0;                            // environment.py:1276
+    }
+    const int n_penal = __popcll(__ballot(penal));
+    double reward = -(double)n_penal, delayed = 0.0;
+    if (__ballot(inside >= 0) != 0ull) {                       // rare: through the LDS record, with the shared serial code
+        if (is_target) {
+            c.ti(t, TI_BOUNTY) = h.bounty; c.ti(t, TI_FREIGHT) = h.freight; c.ti(t, TI_GW) = h.gw;
+            c.ti(t, TI_TSTEPS) = h.tsteps; c.ti(t, TI_TRSTEPS) = h.trsteps;
+            c.inside(t) = inside;
+        }
+        wave_sync();
+        if (lane == 0) {
+            goal_logistics(c, tick, reward, delayed);
+            c.xch(0) = __double2hiint(reward); c.xch(1) = __double2loint(reward);
+            c.xch(2) = __double2hiint(delayed); c.xch(3) = __double2loint(delayed);
+        }
+        wave_sync();
+        reward = __hiloint2double(c.xch(0), c.xch(1));
+        delayed = __hiloint2double(c.xch(2), c.xch(3));
+        if (is_target) {
+            h.bounty = c.ti(t, TI_BOUNTY); h.freight = c.ti(t, TI_FREIGHT); h.gw = c.ti(t, TI_GW);
+            h.tsteps = c.ti(t, TI_TSTEPS); h.trsteps = c.ti(t, TI_TRSTEPS);
+        }
+        if (lane == 0) {
+            h.delivered = c.ei(EI_DELIVERED);
+            h.awaiting = (c.ei(EI_AWAITING) | c.ei(EI_AWAITING + 1) | c.ei(EI_AWAITING + 2) | c.ei(EI_AWAITING + 3)) != 0;
+        }
+    }
+    // metrics (environment.py:966-979), counters (environment.py:626-632)
+    const bool with_bounty = is_target && h.bounty > 0;
+    if (is_target) { h.tsteps += 1; h.trsteps += tr; }
+    const int n_tracked = __popcll(__ballot(tracked));
+    const int n_bounty = __popcll(__ballot(with_bounty));
+    const int n_both = __popcll(__ballot(tracked && with_bounty));
+    int done = 0;
+    if (lane == 0) {
+        const double epr = h.ep_reward + reward;
+        const double epd = h.ep_delayed + delayed;
+        h.ep_reward = epr; h.ep_delayed = epd;
+        const int delivered = h.delivered;
+        const double coverage = div_nz((double)n_tracked, (double)p.Nt);
+        const double real_cov = n_bounty > 0 ? div_nz((double)n_both, (double)n_bounty) : 0.0;
+        const double transport = delivered > 0 ? div_nz(epd, p.reward_scale * (double)delivered) : 0.0;
+        const double r = p.sparse_reward ? delayed : reward;
+        const int ep_step = h.epstep + 1;
+        h.epstep = ep_step;
+        done = !(ep_step <= p.max_episode_steps && h.awaiting);
+        if (scalars_out) {
+            float *o = scalars_out + c.out * 8;
+            o[0] = (float)(-r); o[1] = (float)r; o[2] = (float)done; o[3] = (float)coverage;
+            o[4] = (float)real_cov; o[5] = (float)transport; o[6] = (float)delivered; o[7] = (float)div_nz(r, p.max_team_reward);
+        }
+        if (done) {                                            // rare: the record's flag, the restart list, the statistics
+            c.ei(EI_DONE) = c.g.done_count ? 3 : 1;            // (3: on the list of the next reset launch, see assign_and_score)
+            if (c.g.done_count) {
+                const int parity = c.list_parity();
+                const int slot = atomicAdd(c.g.done_count + parity, 1);
+                c.g.done_list[(int64_t)parity * c.g.N + slot] = (int32_t)c.env;
+            }
+            if (c.g.ep_stats) {
+                double *es = c.g.ep_stats;
+                atomicAdd(es + 0, 1.0); atomicAdd(es + 1, epr); atomicAdd(es + 2, (double)ep_step);
+                atomicAdd(es + 3, coverage); atomicAdd(es + 4, (double)delivered);
+            }
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(done);
+}
+
+// image_targets from the registers (target t on lane Nc + t)
+template <typename ObsT>
+__device__ __forceinline__ void image_targets_held(Ctx<ObsT> &c, const HeldState &h, int &last_gw) {
+    if constexpr (sizeof(ObsT) == 4) {
+    const Params &p = c.p;
+    const int t = c.lane - p.Nc;
+    if (t >= 0 && t < p.Nt) {
+        float *pt = c.pub_tgt(t), *row = c.img_tgt_row(t) + 13;
+        const int gw = h.gw & 0xffffff;                       // bit 24 (colliding) is not part of the observation
+        const float x = (float)h.x, y = (float)h.y;
+        pt[0] = x; pt[1] = y; row[0] = x; row[1] = y;
+        if (gw != last_gw) {
+            last_gw = gw;
+            const int goal = (gw & 0xff) - 1, weight = (gw >> 8) & 0xff, empty = (gw >> 16) & 0xf;
+            const float loaded = goal >= 0 && weight > 0 ? 1.0f : 0.0f;
+            pt[3] = loaded; row[3] = loaded;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                row[6 + w] = (float)(goal == w ? weight : 0);
+                row[10 + w] = (float)((empty >> w) & 1);
+            }
+        }
+    }
+    wave_sync();
+    }
+}
 
 // =============================================================================================
 // The step kernel: one wave per environment, 4 environments per workgroup.
@@ -1764,8 +2025,20 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     bool stepped = false;            // a full step has written the static mask words, flags and scratch slots
     int last_gw = -1;                // fill_scratch: the goal word behind the target's goal / cargo slots
     DrawCarry carry{0u, 0u, 0xffffffffu};
+    // The register-resident step (HeldState): the row-image shapes under the random-policy flow
+    constexpr bool HELDSTATE = IMAGE && FLOW == FLOW_RANDOM;
+    HeldState h{};
+    int finished = 0;                // HELDSTATE: the episode is over (wave-uniform; the record's EI_DONE otherwise)
+    const uint32_t tick0 = g.tick;   // (launch arguments read once: inside the loop each read is a scalar load and a wait)
+    const int n_steps = g.rollout_steps;
+    uint32_t next_tick = tick0;
+    if constexpr (HELDSTATE) {
+        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
+        held_load(c, h);
+        finished = __builtin_amdgcn_readfirstlane((int)(c.ei(EI_DONE) != 0));
+    }
 #pragma clang loop unroll(disable)
-    for (int r = 0; r < g.rollout_steps; ++r) {
+    for (int r = 0; r < n_steps; ++r) {
         // an opaque copy of the lane id per iteration keeps the compiler from hoisting every lane-role
         // computation of the body out of the loop (which costs >100 VGPRs of spills)
         int lane_r = lane, wave_r = wave;
@@ -1776,15 +2049,18 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         const Shape shape_r(pr, true);
         const Params &p = shape_r.get();
         const int64_t env_r = (int64_t)blockIdx.x * 4 + wave_r;
+        // (... and the held roles: predicates derived from them would otherwise be hoisted out of the loop as SGPR masks, which
+        // the kernel has no scalar registers left for -- each came back as two v_readlane per step)
+        if constexpr (Shape::kHoldRoles) pin_roles(roles);
         Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW);
         c.out = (int64_t)r * g.N + env_r;
         c.statics_done = stepped;
-        if (c.ei(EI_DONE) != 0) {
+        if (HELDSTATE ? finished != 0 : c.ei(EI_DONE) != 0) {
             if (lane_r == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
             if (lane_r == 0 && g.idle_steps) g.idle_steps[env_r] += 1;      // a slot of the rollout, not an executed step
             continue;
         }
-        const uint32_t tick = g.tick + (uint32_t)r;
+        const uint32_t tick = tick0 + (uint32_t)r;
         if (g.rotate_prio) {
             const int turn = (r + wave_slot) & 3;
             if (turn == 0) __builtin_amdgcn_s_setprio(0);
@@ -1810,6 +2086,30 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick, &carry);
         if (MATE_DOUBLE & 1) { DrawCarry again = carry; again.block = 0xffffffffu; const StepDraws d2 = step_draws(c, tick, &again); draws.a0 += 0.0 * d2.a0; }
         ROLL_STAMP(0);
+        if constexpr (HELDSTATE) {
+            simulate_cameras_held(c, draws, h);
+            ROLL_STAMP(1);
+            simulate_targets_held(c, draws, near, h);
+            ROLL_STAMP(2);
+            uint32_t seen = 0u;
+            unsigned long long sector_ballot = 0ull;
+            update_view<true, true>(c, tick, S_TRANSMIT, true, roles, seen, &near, &sector_ballot);
+            if (MATE_DOUBLE & 8) { uint32_t again; update_view<true, true>(c, tick, S_TRANSMIT, true, roles, again, &near, &sector_ballot); seen |= again; }
+            bool tracked; int inside;
+            view_tail_held(c, sector_ballot, h, tracked, inside);
+            ROLL_STAMP(3);
+            finished = assign_and_score_held(c, tick, g.scalars, h, tracked, inside);
+            next_tick = tick + 1u;
+            ROLL_STAMP(4);
+            image_targets_held(c, h, last_gw);
+            image_blocks(c, roles, seen);
+            ROLL_STAMP(5);
+            image_store(c); store_masks(c);
+            wave_sync();
+            stepped = true;
+            ROLL_STAMP(6);
+            continue;
+        }
         if (!(MATE_ABLATE & 2)) simulate_cameras(c, draws, true);
         if (MATE_DOUBLE & 2) { wave_sync(); simulate_cameras(c, StepDraws{0.0, 0.0}, true); }      // (a zero action: the same instructions, the same state)
         ROLL_STAMP(1);
@@ -1850,6 +2150,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
 #endif
     {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env);
+        if constexpr (HELDSTATE) { if (stepped) held_store(c, h, next_tick); }
         store_dynamic(c);
     }
 }

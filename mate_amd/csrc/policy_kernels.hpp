@@ -474,8 +474,22 @@ __device__ __forceinline__ void load_caller_actions(Ctx<ObsT> &c, int team, doub
     }
 }
 
+// `q` as it lies in the kernel-argument segment (third argument: behind the 8-byte `pp` and `g`), read where it is used instead
+// of from the ~40 SGPRs the compiler preloads it into at entry and keeps for the whole kernel (see kernarg_ptrs): the fused
+// Greedy rollout spilled 77 scalar registers into vector lanes, and read them back ~100 times per step.
+__device__ __forceinline__ const PolicyPtrs &kernarg_policy_ptrs(const PolicyPtrs &q) {
+    static_assert(alignof(PolicyPtrs) == 8 && sizeof(Ptrs) % 8 == 0, "q follows pp and g in the kernel arguments");
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)q;
+    return *(const PolicyPtrs *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + 8 + sizeof(Ptrs));
+#else
+    return q;
+#endif
+}
+
 template <typename ObsT, typename Shape>
-__global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q) {
+__global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q_arg) {
+    const PolicyPtrs &q = kernarg_policy_ptrs(q_arg);
     const Shape shape(pp, true);
     const Params &p = shape.get();
     extern __shared__ __align__(16) unsigned char smem[];
@@ -542,6 +556,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         const Params &p = shape_r.get();
         const int64_t env_w = (int64_t)blockIdx.x * 4 + wave_r;
         const int64_t env_r = env_w < g.N ? env_w : g.N - 1;
+        if constexpr (IMAGE) pin_roles(roles);
         Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW_GREEDY);
         c.out = (int64_t)r * g.N + env_r;
         c.act_cam = act_cam; c.act_tgt = act_tgt;
