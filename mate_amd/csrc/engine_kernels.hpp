@@ -736,8 +736,8 @@ __device__ __forceinline__ bool range_exact(const Ctx<ObsT> &c, int tj, int j) {
 }
 struct RangeRoles {
     int32_t pair[kRoleRounds];       // entity slot of the target | entity slot of the other << 16
-    float lim2[kRoleRounds];         // (target sight range + other's radius)^2, f32
-    float rim[kRoleRounds];          // ... and the half-width of the band around it inside which the f64 test decides
+    float lim2[kRoleRounds];         // (target sight range + other's radius)^2 MINUS the band's half-width, f32: below, the pair is seen
+    float rim[kRoleRounds];          // ... PLUS the half-width: above, it is hidden; between the two the f64 test decides
     uint32_t diag_bits, valid_bits;  // bit `round`: the pair is (t, t) / the lane holds a pair in this round
     int32_t sector;                  // sector_role of the lane's pair in the last sector round
     // row-image mode: the (viewer, other) block each of the lane's pairs owns in the observation rows -- slot 0 the sector pair,
@@ -786,8 +786,8 @@ __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &role
         const int tj = c.tgt_slot(t);
         const float lim = (float)(p.tgt_sight + c.er[j]);
         roles.pair[round] = tj | (j << 16);
-        roles.lim2[round] = lim * lim;
-        roles.rim[round] = range_rim(lim);
+        roles.lim2[round] = lim * lim - range_rim(lim);      // below: seen; above rim[]: hidden; between: the f64 test decides
+        roles.rim[round] = lim * lim + range_rim(lim);
         roles.diag_bits |= (uint32_t)(j == tj) << round;
         roles.valid_bits |= (uint32_t)(q < p.n_range && round < p.range_rounds) << round;
         {   // a SCREEN: conservative by the whole step size (the walk repeats the test on the actual step, exactly), f32 with
@@ -878,7 +878,11 @@ __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t 
 template <typename ObsT>
 __device__ __forceinline__ void sector_fetch(const Ctx<ObsT> &c, const SectorEval &e, double2 (&w)[kDegSlots]) {
     if (e.need) {
+#ifdef MATE_LUT_FAKE      // experiment build: every lookup reads the same (cache-resident) record -- what the real fetch's latency costs
+        const double2 *rec = c.g.lut_deg + (0 * e.lc * 360 + degree_of(e.x)) * kDegSlots;
+#else
         const double2 *rec = c.g.lut_deg + (e.lc * 360 + degree_of(e.x)) * kDegSlots;
+#endif
 #pragma unroll
         for (int i = 0; i < kDegSlots; ++i) w[i] = rec[i];
     }
@@ -971,9 +975,9 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
                 const bool diag = (held.diag_bits >> round) & 1u;
                 const float dx = c.exf[tj] - c.exf[j], dy = c.eyf[tj] - c.eyf[j];
                 const float d2 = fmaf(dy, dy, dx * dx);
-                const float lim2 = held.lim2[round], rim = held.rim[round];
-                bool seen = d2 < lim2 - rim;
-                if (!seen && !(d2 > lim2 + rim)) seen = range_exact(c, tj, j);
+                // (held as the two ends of the band: lim2[] = limit^2 - rim, rim[] = limit^2 + rim)
+                bool seen = d2 < held.lim2[round];
+                if (!seen && !(d2 > held.rim[round])) seen = range_exact(c, tj, j);
                 seen_bits |= (uint32_t)((seen || diag) && ((held.valid_bits >> round) & 1u)) << round;
                 if (near_next) near_next->w[round] = __ballot(d2 <= held.reach2[round]);      // the next step's collision screen
             }
@@ -1029,6 +1033,8 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         const int last = p.sector_rounds - 1;
         SectorEval pending{false, false, 0.0, 0.0, 0};
         if (last >= 0) {
+            // (a branch-free form of this test -- every lane computing everything, verdicts combined at the end -- measured
+            // no faster: the early exits cost scalar instructions, which issue beside the other waves' vector work)
             pending = sector_eval(c, last * 64 + lane, tick, stream, predrawn, HELD ? held.sector : kNoRole);
             sector_fetch(c, pending, w);
         }
