@@ -1640,6 +1640,7 @@ struct HeldState {
     double ph, th;                                    // camera lanes: orientation, viewing angle
     double ep_reward, ep_delayed;                     // lane 0: the episode's reward sums ...
     int32_t epstep, delivered, awaiting;              // ... its step counter, delivered cargoes, "cargo still awaited"
+    int32_t tick;                                     // lane 0: EI_TICK (the tick after the last executed step)
 };
 
 template <typename ObsT>
@@ -1655,13 +1656,13 @@ __device__ __forceinline__ void held_load(Ctx<ObsT> &c, HeldState &h) {
     if (c.lane < p.Nc) { h.ph = c.phi(c.lane); h.th = c.theta(c.lane); }
     if (c.lane == 0) {
         h.ep_reward = c.ep_reward(); h.ep_delayed = c.ep_delayed();
-        h.epstep = c.ei(EI_EPSTEP); h.delivered = c.ei(EI_DELIVERED);
+        h.epstep = c.ei(EI_EPSTEP); h.delivered = c.ei(EI_DELIVERED); h.tick = c.ei(EI_TICK);
         h.awaiting = (c.ei(EI_AWAITING) | c.ei(EI_AWAITING + 1) | c.ei(EI_AWAITING + 2) | c.ei(EI_AWAITING + 3)) != 0;
     }
 }
 
 template <typename ObsT>
-__device__ __forceinline__ void held_store(Ctx<ObsT> &c, const HeldState &h, uint32_t next_tick) {
+__device__ __forceinline__ void held_store(Ctx<ObsT> &c, const HeldState &h) {
     const Params &p = c.p;
     const int t = c.lane - p.Nc;
     if (t >= 0 && t < p.Nt) {
@@ -1671,7 +1672,7 @@ __device__ __forceinline__ void held_store(Ctx<ObsT> &c, const HeldState &h, uin
     }
     if (c.lane == 0) {
         c.ep_reward() = h.ep_reward; c.ep_delayed() = h.ep_delayed;
-        c.ei(EI_EPSTEP) = h.epstep; c.ei(EI_TICK) = (int)next_tick;
+        c.ei(EI_EPSTEP) = h.epstep; c.ei(EI_TICK) = h.tick;
     }
     wave_sync();
 }
@@ -1812,7 +1813,7 @@ __device__ __forceinline__ int assign_and_score_held(Ctx<ObsT> &c, uint32_t tick
         const double transport = delivered > 0 ? div_nz(epd, p.reward_scale * (double)delivered) : 0.0;
         const double r = p.sparse_reward ? delayed : reward;
         const int ep_step = h.epstep + 1;
-        h.epstep = ep_step;
+        h.epstep = ep_step; h.tick = (int)(tick + 1u);
         done = !(ep_step <= p.max_episode_steps && h.awaiting);
         if (scalars_out) {
             float *o = scalars_out + c.out * 8;
@@ -2037,12 +2038,16 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     int finished = 0;                // HELDSTATE: the episode is over (wave-uniform; the record's EI_DONE otherwise)
     const uint32_t tick0 = g.tick;   // (launch arguments read once: inside the loop each read is a scalar load and a wait)
     const int n_steps = g.rollout_steps;
-    uint32_t next_tick = tick0;
     if constexpr (HELDSTATE) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
         held_load(c, h);
         finished = __builtin_amdgcn_readfirstlane((int)(c.ei(EI_DONE) != 0));
     }
+    // (Measured and dropped: the four waves of a workgroup -- one per SIMD of a CU, their environments' records all in this
+    // workgroup's LDS -- handing their environments on to each other after every quarter of the launch, so that every SIMD of
+    // the CU works on all sixteen environments.  It removed every dependence of a wave's pace on its environment (occlusion
+    // lookups, collisions: +-4 % before) and changed nothing: what separates the fastest wave of a launch from the slowest,
+    // ~15 %, goes with the SIMD / CU it runs on, not with the environment it steps.)
 #pragma clang loop unroll(disable)
     for (int r = 0; r < n_steps; ++r) {
         // an opaque copy of the lane id per iteration keeps the compiler from hoisting every lane-role
@@ -2105,7 +2110,6 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
             view_tail_held(c, sector_ballot, h, tracked, inside);
             ROLL_STAMP(3);
             finished = assign_and_score_held(c, tick, g.scalars, h, tracked, inside);
-            next_tick = tick + 1u;
             ROLL_STAMP(4);
             image_targets_held(c, h, last_gw);
             image_blocks(c, roles, seen);
@@ -2156,7 +2160,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
 #endif
     {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env);
-        if constexpr (HELDSTATE) { if (stepped) held_store(c, h, next_tick); }
+        if constexpr (HELDSTATE) held_store(c, h);
         store_dynamic(c);
     }
 }
