@@ -117,6 +117,7 @@ constexpr bool image_fits(int Nc, int Nt, int No) {
 // Kernel shape policies: AnyShape reads every constant from the device-resident Params on demand;
 // FixedShape<Nc, Nt, No> is compiled for one scenario shape (the host picks it when the counts match).
 struct AnyShape {
+    static constexpr int kHeldGC = 2, kHeldGT = 6;
     static constexpr bool kImage = false;
     static constexpr bool kHoldRoles = false;      // rollout kernel: lane roles in registers (needs compile-time round counts)
     static constexpr int kGreedyBlocks = 4;        // rollout_greedy_kernel: workgroups per CU the register budget is set for
@@ -139,7 +140,10 @@ template <int NC, int NT, int NO, bool F64, bool IMAGE = false>
 struct FixedShape {
     static constexpr bool kImage = IMAGE;
     static_assert(!IMAGE || (!F64 && image_fits(NC, NT, NO)), "row-image mode: f32 observations of a shape that fits");
-    static constexpr bool kHoldRoles = shape_range_rounds(NC, NT, NO) <= 3;      // 9 more VGPRs: fits beside the held descriptors
+    static constexpr bool kHoldRoles = shape_range_rounds(NC, NT, NO) <= 3;      // 4 words per round: fits beside the held descriptors
+    // observation descriptors the fused rollouts hold per lane: all chunks of the shape's rows (up to twelve uint4)
+    static constexpr int kRowsC = (NC * (13 + 9 + 5 * NT + 4 * NO + 7 * NC) / 4 + 63) / 64, kRowsT = (NT * (13 + 14 + 7 * NC + 4 * NO + 5 * NT) / 4 + 63) / 64;
+    static constexpr int kHeldGC = (kRowsC + kRowsT <= 12) ? kRowsC : 2, kHeldGT = (kRowsC + kRowsT <= 12) ? kRowsT : 6;
     static constexpr int kGreedyBlocks = 4;
     static constexpr bool kGreedyHeld = true;
     Params local;
@@ -396,6 +400,7 @@ __device__ __forceinline__ void load_records(Ctx<ObsT> &c) {
 // while they are in flight (all co-resident waves of a SIMD start together: without this they idle through the
 // HBM latency together and then contend for the VALU together), then the data is committed to LDS.
 struct StepDraws { double a0, a1; };
+constexpr int kNearWords = 3;                     // (= kRoleRounds, declared further down with the range-test roles)
 struct DrawCarry { uint32_t z, w, block; };      // second half of the lane's Philox block of the even tick, for the odd tick behind it
 template <typename ObsT> __device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry = nullptr);
 
@@ -554,7 +559,18 @@ __device__ __forceinline__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &
 // `carried` (the fused rollouts with held lane roles): the screen was made by the PREVIOUS step's range tests -- the
 // (target, camera | obstacle) pairs of Sensor.perceive are the pairs of this screen, on the very positions this step starts
 // from -- and arrives as the ballots of their rounds (NearCarry, update_view); no screen pass, no LDS hand-off here.
-struct NearCarry { unsigned long long w[3]; };       // bit q = t * NJ + j of the range rounds: circle j may be touched by target t's next step
+struct NearCarry { unsigned long long w[kNearWords]; };       // bit q = t * NJ + j of the range rounds: circle j may be touched by target t's next step
+// target t's NK bits out of the string w3:w2:w1:w0, moved from entity order (cameras, obstacles) to the order the circles are
+// walked in (obstacles, then cameras: Target.add_obstacles, environment.py:743)
+__device__ __forceinline__ uint64_t near_field(const Params &p, const NearCarry &carried, int t) {
+    const int first = t * p.NJ, word = first >> 6, sh = first & 63;
+    unsigned long long lo = carried.w[0], hi = carried.w[1];
+#pragma unroll
+    for (int k = 1; k < kNearWords; ++k)
+        if (word == k) { lo = carried.w[k]; hi = k + 1 < kNearWords ? carried.w[k + 1] : 0ull; }
+    const unsigned long long field = ((lo >> sh) | (sh ? hi << (64 - sh) : 0ull)) & ((1ull << p.NK) - 1ull);
+    return (field >> p.Nc) | ((field & ((1ull << p.Nc) - 1ull)) << p.No);
+}
 template <typename ObsT>
 __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws, const NearCarry *carried = nullptr) {
     const Params &p = c.p;
@@ -598,11 +614,7 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
         if (is_target) {
             // the target's NK bits out of the 192-bit string w2:w1:w0, then from entity order (cameras, obstacles) to the
             // order the circles are walked in (obstacles, cameras: Target.add_obstacles, environment.py:743)
-            const int first = t * p.NJ, word = first >> 6, sh = first & 63;
-            const unsigned long long lo = word == 0 ? carried->w[0] : word == 1 ? carried->w[1] : carried->w[2];
-            const unsigned long long hi = word == 0 ? carried->w[1] : word == 1 ? carried->w[2] : 0ull;
-            const unsigned long long field = ((lo >> sh) | (sh ? hi << (64 - sh) : 0ull)) & ((1ull << p.NK) - 1ull);
-            todo_carried = (field >> p.Nc) | ((field & ((1ull << p.Nc) - 1ull)) << p.No);
+            todo_carried = near_field(p, *carried, t);
         }
     } else {
     wave_sync();
@@ -719,7 +731,7 @@ struct SectorEval { bool seen, need; double rn, x; int64_t lc; };      // rn: th
 // whether that is the diagonal, and the squared limit (sight + the other's radius)^2 -- all static inside an episode.
 // The fused rollout, which is VALU-bound, computes them once per launch and keeps them in registers (`HELD`); the
 // single-step kernel derives them in place.
-constexpr int kRoleRounds = 3;
+constexpr int kRoleRounds = 3;       // (4 -- MATE-8v8-9's 200 range pairs -- was measured: no faster, and 126 of the 128 registers a wave may hold)
 // Sensor.perceive (entities.py:229-232), `distance <= sight_range + radius`, is first tried on the f32 shadow of the entity
 // table: with positions rounded to f32 the distance is off by at most 1.3e-4 and the squared distance by at most
 // 2 * lim * 1.3e-4 + 3e-7 * lim^2 near the limit; outside a band of 2e-3 * lim + 2e-5 * lim^2 (eight times that) the f32
@@ -1398,11 +1410,17 @@ __device__ __forceinline__ void pack_block_xf(const Ctx<ObsT> &c, ObsT *dst, con
 // lane (all of them for the shipped scenario shapes) are loaded BEFORE the first store: loads and stores share one
 // in-order counter on gfx9, so a descriptor load issued behind an observation store can only be waited for
 // together with that store's HBM acknowledgement -- seven such waits per step in a chunk-by-chunk loop.
+// (GC / GT per kernel: the fused rollouts of a compiled shape hold exactly the chunks its rows have -- MATE-8v8-9 has five
+// camera and five target chunks per lane; with the default two + six its other three camera chunks fetched their
+// descriptors INSIDE the step loop, behind the stores: the pack phase of the fused Greedy rollout was a fifth of its step.)
 constexpr int kPackGC = 2, kPackGT = 6;
-struct PackDescriptors { uint4 dc[kPackGC], dt[kPackGT]; };
+template <int GC_, int GT_> struct PackDescriptorsT { static constexpr int GC = GC_, GT = GT_; uint4 dc[GC_ > 0 ? GC_ : 1], dt[GT_]; };
+using PackDescriptors = PackDescriptorsT<kPackGC, kPackGT>;
+constexpr int pack_chunks_per_lane(int elems) { return (elems / 4 + 63) / 64; }
 
-template <typename ObsT>
-__device__ __forceinline__ void load_pack_descriptors(const Ctx<ObsT> &c, PackDescriptors &d) {
+template <typename ObsT, typename D>
+__device__ __forceinline__ void load_pack_descriptors(const Ctx<ObsT> &c, D &d) {
+    constexpr int kPackGC = D::GC, kPackGT = D::GT;
     const Params &p = c.p;
     const int nvc = p.cam_elems / 4, nvt = p.tgt_elems / 4;
     const uint4 *tabc = reinterpret_cast<const uint4 *>(c.table);
@@ -1417,12 +1435,12 @@ __device__ __forceinline__ void load_pack_descriptors(const Ctx<ObsT> &c, PackDe
     for (int k = 0; k < kPackGT; ++k) asm volatile("" : "+v"(d.dt[k].x), "+v"(d.dt[k].y), "+v"(d.dt[k].z), "+v"(d.dt[k].w));
 }
 
-template <typename ObsT>
-__device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT> &c, const PackDescriptors &d) {
+template <typename ObsT, typename D>
+__device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT> &c, const D &d) {
     if constexpr (sizeof(ObsT) == 4) {
         const Params &p = c.p;
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        constexpr int GC = kPackGC, GT = kPackGT;
+        constexpr int GC = D::GC, GT = D::GT;
         const int nvc = p.cam_elems / 4, nvt = p.tgt_elems / 4;
         const uint4 *tabc = reinterpret_cast<const uint4 *>(c.table);
         const uint4 *tabt = reinterpret_cast<const uint4 *>(c.table + p.tgt_table_off);
@@ -1459,8 +1477,8 @@ __device__ __forceinline__ void store_masks(const Ctx<ObsT> &c) {
 
 // HELD: the caller loaded this lane's descriptors before (the rollout kernel, once per launch); otherwise they are
 // loaded here.  A template switch, not a pointer: a nullable pointer to the register array would force it into memory.
-template <bool HELD, typename ObsT>
-__device__ __forceinline__ void pack_observations(Ctx<ObsT> &c, PackDescriptors &held) {
+template <bool HELD, typename ObsT, typename D>
+__device__ __forceinline__ void pack_observations(Ctx<ObsT> &c, D &held) {
     const Params &p = c.p;
     if (c.xdesc()) {
         const ObsT *xab = reinterpret_cast<const ObsT *>(c.g.xab);
@@ -1715,11 +1733,7 @@ __device__ __forceinline__ void simulate_targets_held(Ctx<ObsT> &c, const StepDr
         double n = norm2(ax, ay);
         if (n > step_size) { const double k = div_nz(step_size, n); vx = ax * k; vy = ay * k; n = step_size; }      // entities.py:649-650
         const double desx = ox + vx, desy = oy + vy;
-        const int first = t * p.NJ, word = first >> 6, sh = first & 63;
-        const unsigned long long lo = word == 0 ? carried.w[0] : word == 1 ? carried.w[1] : carried.w[2];
-        const unsigned long long hi = word == 0 ? carried.w[1] : word == 1 ? carried.w[2] : 0ull;
-        const unsigned long long field = ((lo >> sh) | (sh ? hi << (64 - sh) : 0ull)) & ((1ull << p.NK) - 1ull);
-        uint64_t todo = (field >> p.Nc) | ((field & ((1ull << p.Nc) - 1ull)) << p.No);
+        uint64_t todo = near_field(p, carried, t);
         bool n_known = true;
         while (todo) {
             const int k = __ffsll((long long)todo) - 1;
@@ -1996,8 +2010,9 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     // headline batch runs 4 waves per SIMD, the register file has room), which takes the table's two global-load
     // round trips out of every step's pack phase.
     constexpr bool IMAGE = Shape::kImage;   // row-image mode: the observation rows live in LDS (see image_statics)
+    static_assert(kNearWords == kRoleRounds, "one ballot per range round");
     static_assert(!IMAGE || (Shape::kHoldRoles && sizeof(ObsT) == 4 && FLOW != FLOW_ANY), "row-image mode: f32 rows, held lane roles, a folded flow");
-    PackDescriptors held;
+    PackDescriptorsT<Shape::kHeldGC, Shape::kHeldGT> held;
     if constexpr (!IMAGE) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
         load_pack_descriptors(c, held);      // (indices clamped: harmless when another pack path runs)
@@ -2009,7 +2024,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         pin_roles(roles);
         if constexpr (IMAGE) image_statics(c);
     }
-    NearCarry near{{0ull, 0ull, 0ull}};     // the collision screen of the step to come, made by the range tests of the step before
+    NearCarry near{};                       // the collision screen of the step to come, made by the range tests of the step before
     if constexpr (Shape::kHoldRoles) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
         near_seed(c, roles, near);

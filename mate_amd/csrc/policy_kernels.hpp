@@ -522,12 +522,20 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         wave_sync();
     }
     constexpr bool IMAGE = Shape::kImage;   // row-image mode (engine_kernels.hpp: image_statics)
-    PackDescriptors held;
+    PackDescriptorsT<Shape::kHeldGC, Shape::kHeldGT> held;
     RangeRoles roles;
     {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
         if constexpr (IMAGE) { range_roles(c, roles); pin_roles(roles); image_statics(c); }
         else if constexpr (Shape::kGreedyHeld) load_pack_descriptors(c, held);
+    }
+    // the lane's range-test roles held in registers, and with them the collision screen carried from step to step (NearCarry)
+    constexpr bool ROLES = Shape::kHoldRoles;
+    NearCarry near{};
+    if constexpr (ROLES) {
+        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
+        if constexpr (!IMAGE) { range_roles(c, roles); pin_roles(roles); }
+        near_seed(c, roles, near);
     }
     int last_gw = -1;                                              // image_targets: the goal word behind a target's goal / cargo slots
     uint32_t hw_id;
@@ -556,7 +564,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         const Params &p = shape_r.get();
         const int64_t env_w = (int64_t)blockIdx.x * 4 + wave_r;
         const int64_t env_r = env_w < g.N ? env_w : g.N - 1;
-        if constexpr (IMAGE) pin_roles(roles);
+        if constexpr (ROLES) pin_roles(roles);
         Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW_GREEDY);
         c.out = (int64_t)r * g.N + env_r;
         c.act_cam = act_cam; c.act_tgt = act_tgt;
@@ -591,11 +599,11 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         GREEDY_STAMP(0);
         if (!(MATE_ABLATE & 2)) simulate_cameras(c, draws, true);
         GREEDY_STAMP(1);
-        if (!(MATE_ABLATE & 4)) simulate_targets(c, draws);
+        if (!(MATE_ABLATE & 4)) simulate_targets(c, draws, ROLES ? &near : nullptr);
         GREEDY_STAMP(2);
         uint32_t seen = 0u;
         if (!(MATE_ABLATE & 8)) {
-            if constexpr (IMAGE) update_view<true, true>(c, tick, S_TRANSMIT, true, roles, seen);
+            if constexpr (ROLES) update_view<true, true>(c, tick, S_TRANSMIT, true, roles, seen, &near);
             else { RangeRoles none; update_view<false, true>(c, tick, S_TRANSMIT, true, none); }
         }
         GREEDY_STAMP(3);
