@@ -77,20 +77,20 @@ def algorithmic_bytes(Nc, Nt, No):
     return 4 * (Nc * Dc + Nt * Dt) + 8 * (Nc + Nt) + 2 * (16 * Nc + 35 * Nt + 72) + (24 * Nc + 24 * No + Nt) + 48
 
 
-def measured_traffic(kernel, env_steps_per_launch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc passes, counters in
-    KiB; see profiles/README.md).  gfx950 correction per the microarchitecture guide and this repo's own calibration
-    (tools/pmc_calibrate.py: a 256 MiB copy reports WRITE_SIZE 256.0 MiB and FETCH_SIZE 128.0 MiB): WRITE_SIZE is
-    exact, FETCH_SIZE counts half of the bytes read and is doubled.  The summary was collected on launches of
-    `env_steps_per_launch` env-steps (4096 environments x 128 steps for rollout_kernel when the field is absent); for
-    another launch length the per-env-step figure is scaled.  None when no profile is present."""
+def measured_traffic(kernel, steps_per_launch, envs):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/latest_pmc.json, written by
+    tools/pmc_collect.py: separate --pmc passes, one entry per (kernel, steps per launch) at the launch shapes the benches
+    run; counters in KiB).  gfx950 correction per the microarchitecture guide and this repo's own calibration
+    (tools/pmc_calibrate.py: a 256 MiB copy reports WRITE_SIZE 256.0 MiB and FETCH_SIZE 128.0 MiB): WRITE_SIZE is exact,
+    FETCH_SIZE counts half of the bytes read and is doubled.  Only an entry profiled at THIS launch length and batch is
+    used (no scaling between launch lengths: a launch's fixed part does not scale); None otherwise."""
     path = os.path.join(ROOT, 'profiles', 'latest_pmc.json')
     try:
         with open(path) as fh:
-            k = json.load(fh)[kernel]
-        per_launch = (2.0 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
-        profiled = float(k.get('env_steps_per_launch', BATCH_PER_GPU * (1 if kernel == 'step_kernel' else 128)))
-        return per_launch * env_steps_per_launch / profiled
+            k = json.load(fh)[f'{kernel}@{int(steps_per_launch)}']
+        if int(k['env_steps_per_launch']) != int(steps_per_launch) * int(envs):
+            return None
+        return (2.0 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
     except Exception:
         return None
 
@@ -422,16 +422,24 @@ def main():
                 gather.submit()
         elif R > 0:
             lengths = [R] * (steps // R) + ([steps % R] if steps % R else [])
-            # a gather every `stats_interval` launches -- and one behind the last launch of a region that holds fewer
+            # a gather every `stats_interval` launches: enqueued behind a launch, it runs on the side stream under the launches
+            # that follow.  A region that holds fewer launches than the interval gathers once, AHEAD of its first launch (the
+            # episodes finished so far: the previous repetitions'), so that it too runs under a launch instead of behind the
+            # last one, where its copy + collective would sit between the kernel's end and the region's closing synchronise
+            # (15 us of a 200 us region at the driver's `--steps 20`)
+            if timed and gather is not None and len(lengths) < args.stats_interval:
+                gather.submit()
             for i, n in enumerate(lengths):
                 rollout(n, auto_reset=True)
-                if timed and gather is not None and ((i + 1) % args.stats_interval == 0 or (i + 1 == len(lengths) < args.stats_interval)):
+                if timed and gather is not None and (i + 1) % args.stats_interval == 0:
                     gather.submit()
         else:
             every = args.stats_interval * 128
+            if timed and gather is not None and steps < every:
+                gather.submit()
             for i in range(steps):
                 step()
-                if timed and gather is not None and ((i + 1) % every == 0 or (i + 1 == steps < every)):
+                if timed and gather is not None and (i + 1) % every == 0:
                     gather.submit()
 
     eng.reset()
@@ -570,8 +578,8 @@ def main():
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': measured_traffic(kernel, args.batch * steps_per_launch) if headline_case else None,
-                'traffic_unit': 'bytes per launch (rocprofv3 2*FETCH_SIZE + WRITE_SIZE per env-step from profiles/latest_pmc.json x the env-steps of this launch)',
+                'traffic': measured_traffic(kernel, steps_per_launch, args.batch) if (headline_case and float(steps_per_launch).is_integer()) else None,
+                'traffic_unit': 'bytes per launch (rocprofv3 2*FETCH_SIZE + WRITE_SIZE of this kernel at this launch length, profiles/latest_pmc.json)',
                 'peak_measured': HBM_PEAK_MEASURED_GBS, 'frac_of_measured_peak': achieved / HBM_PEAK_MEASURED_GBS,
                 'kernel': '%s<float, %s, %s>' % (kernel, 'FixedShape' if eng.specialised else 'AnyShape', ('FLOW_ANY', 'FLOW_RANDOM', 'FLOW_ACT_F32', 'FLOW_GREEDY')[flow]),
                 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches, 'env_steps_per_launch': args.batch * steps_per_launch,

@@ -88,3 +88,11 @@ cg = tot[ck].reshape(-1, 16)
 print('  per-CU mean of the 16 resident waves: p50 %.0f p90 %.0f max %.0f min %.0f' % (np.percentile(cg.mean(axis=1), 50), np.percentile(cg.mean(axis=1), 90), cg.mean(axis=1).max(), cg.mean(axis=1).min()))
 xk = np.argsort(xcc, kind='stable')
 print('  per-XCD mean:', [round(tot[xcc == x].mean()) for x in sorted(set(xcc.tolist()))])
+# positional effects: the wave's SIMD inside its CU, the CU inside its shader array, the workgroup's generation
+print('  mean by SIMD id:', [round(tot[simd == i].mean()) for i in range(4)])
+print('  mean by CU id (0-15):', [round(tot[cu == i].mean()) for i in range(16) if (cu == i).any()])
+print('  mean by shader array / engine:', [round(tot[(se * 2 + sh) == i].mean()) for i in range(16) if ((se * 2 + sh) == i).any()])
+gen = np.arange(batch) // 1024
+print('  mean by dispatch generation (env // 1024):', [round(tot[gen == i].mean()) for i in range(int(gen.max()) + 1)])
+wv = (buf.cpu().numpy()[:, 13] & 0xf)
+print('  mean by hardware wave slot:', {int(i): round(tot[wv == i].mean()) for i in sorted(set(wv.tolist()))})

@@ -7,8 +7,8 @@ python3 bench.py > "$out/bench_default.log" 2>&1; grep '"metric"' "$out/bench_de
 python3 bench.py --steps 20 --warmup 5 > "$out/bench_steps20.log" 2>&1; grep '"metric"' "$out/bench_steps20.log" > "$out/bench_steps20.json"
 bash tools/profile_round.sh "$out/prof" > "$out/profile_round.log" 2>&1
 # config 3: Greedy vs Greedy on the device
-python3 bench.py --workload MATE-8v8-9.yaml --batch 8192 --policy greedy --steps 1024 --warmup 128 --reps 3 --no-cpu-baseline > "$out/c3.log" 2>&1; grep '"metric"' "$out/c3.log" > "$out/c3_bench.json"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/c3kt" -o c3 -- python3 bench.py --workload MATE-8v8-9.yaml --batch 8192 --policy greedy --steps 1024 --warmup 128 --reps 3 --no-cpu-baseline > "$out/c3kt.log" 2>&1
+python3 bench.py --workload MATE-8v8-9.yaml --batch 8192 --policy greedy --steps 1024 --warmup 128 --reps 3 --no-cpu-baseline --no-other-configs > "$out/c3.log" 2>&1; grep '"metric"' "$out/c3.log" > "$out/c3_bench.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/c3kt" -o c3 -- python3 bench.py --workload MATE-8v8-9.yaml --batch 8192 --policy greedy --steps 1024 --warmup 128 --reps 3 --no-cpu-baseline --no-other-configs > "$out/c3kt.log" 2>&1
 cp "$out"/c3kt/c3_kernel_stats.csv "$out/c3_kernel_stats.csv" 2>/dev/null || find "$out/c3kt" -name '*kernel_stats.csv' -exec cp {} "$out/c3_kernel_stats.csv" \;
 rm -rf "$out/c3kt"
 bash tools/sweep.sh "$out/sweep.jsonl" 2> "$out/sweep.err"
