@@ -240,10 +240,17 @@ class StatsGather:
         self.turn = self.last = 0
         self.count = 0
 
+    def mark(self):
+        """The point of the launch stream the next submit() gathers at (default: where submit() itself is called)."""
+        self.events[self.turn].record()
+        self.marked = True
+
     def submit(self):
         torch = self.torch
         ready = self.events[self.turn]
-        ready.record()
+        if not getattr(self, 'marked', False):
+            ready.record()
+        self.marked = False
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
             self.slots[self.turn].copy_(self.eng.episode_stats, non_blocking=True)
@@ -427,19 +434,21 @@ def main():
             # episodes finished so far: the previous repetitions'), so that it too runs under a launch instead of behind the
             # last one, where its copy + collective would sit between the kernel's end and the region's closing synchronise
             # (15 us of a 200 us region at the driver's `--steps 20`)
-            if timed and gather is not None and len(lengths) < args.stats_interval:
-                gather.submit()
-            for i, n in enumerate(lengths):
+            short = timed and gather is not None and len(lengths) < args.stats_interval
+            if short:
+                gather.mark()            # (an event record: the copy + collective are enqueued behind the first launch, below,
+            for i, n in enumerate(lengths):          # so that the host prepares them while the GPU already runs it)
                 rollout(n, auto_reset=True)
-                if timed and gather is not None and (i + 1) % args.stats_interval == 0:
+                if timed and gather is not None and ((i + 1) % args.stats_interval == 0 or (short and i == 0)):
                     gather.submit()
         else:
             every = args.stats_interval * 128
-            if timed and gather is not None and steps < every:
-                gather.submit()
+            short = timed and gather is not None and steps < every
+            if short:
+                gather.mark()
             for i in range(steps):
                 step()
-                if timed and gather is not None and (i + 1) % every == 0:
+                if timed and gather is not None and ((i + 1) % every == 0 or (short and i == 0)):
                     gather.submit()
 
     eng.reset()
