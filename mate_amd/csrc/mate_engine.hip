@@ -877,7 +877,10 @@ static int policy_enable(mate_engine *e) {
     {   // GreedyCameraAgent's zoom solve (greedy.py:139-145) as a function of K = area_product / distance^2 alone, tabulated with the
         // reference's own iteration (policy_kernels.hpp: zoom_lookup interpolates it to 1.5e-13)
         constexpr double kInvH = 40.0, kMaxK = 720.0;
-        const int n = (int)(kMaxK * kInvH) + 8;
+        // (the last node is K = 720 itself: beyond it the clamp of the half angle at 90 degrees kinks the function, and a stencil
+        // that reaches across the kink was off by 2e-8 degrees for K in (719.95, 720); zoom_lookup iterates where its four
+        // nodes are not all inside the table)
+        const int n = (int)(kMaxK * kInvH) + 1;
         std::vector<double> tab((size_t)n);
         for (int i = 0; i < n; ++i) {
             const double K = (double)i / kInvH;

@@ -1,6 +1,8 @@
 """GPU parity of the on-device rule-based policies (row f1): GreedyCameraAgent vs GreedyTargetAgent run
 closed-loop on the device with the reference agents' recorded draws must reproduce the reference's joint
 actions and the resulting environment trace (fixtures greedy_*.npz, recorded by tests/golden/make_golden.py agents)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -293,3 +295,45 @@ def test_policies_refuse_more_than_eight_cameras():
     eng.step_random()
     with pytest.raises(EngineError, match='at most 8 cameras'):
         eng.enable_policies()                  # ... but not with the on-device greedy agents
+
+
+@pytest.mark.parametrize('switch', ['MATE_ZOOM_ITERATE', 'MATE_POLICY_SPLIT'])
+def test_policy_implementation_switches_give_the_same_episodes(switch):
+    """Two implementation choices of the on-device Greedy agents, selected at create by an environment switch:
+    MATE_ZOOM_ITERATE=1 runs the reference's 20-iteration zoom solve (agents/greedy.py:139-145) instead of its tabulation --
+    joint actions within 1e-10 degrees, the episodes (masks, goals, rewards) identical; MATE_POLICY_SPLIT=1 runs
+    step_greedy / step_versus_greedy as two launches (agents' kernel, step kernel) instead of the fused one -- bit for bit."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-8v8-9.yaml', max_episode_steps=40)
+    n = 192
+    runs = []
+    for value in ('0', '1'):
+        os.environ[switch] = value
+        try:
+            eng = Engine(cfg, n, seed=17)
+        finally:
+            os.environ.pop(switch, None)
+        eng.enable_policies()
+        eng.reset()
+        rec = []
+        mine = torch.zeros((n, eng.num_targets, 2), device='cuda')
+        for s in range(60):
+            if s % 2:
+                eng.step_greedy(auto_reset=True)
+            else:
+                mine.fill_(float(3 * (s % 5) - 6))
+                eng.step_versus_greedy('target', mine, auto_reset=True)
+            cam, tgt = eng.policy_actions()
+            rec.append((cam.clone(), eng.scalars.clone(), eng.masks.clone(), eng.target_obs.clone()))
+        rec.append((eng.export_state().clone(),))
+        runs.append(rec)
+    exact = switch == 'MATE_POLICY_SPLIT'
+    for a, b in zip(*runs):
+        if exact:
+            assert all(torch.equal(x.view(torch.uint8), y.view(torch.uint8)) for x, y in zip(a, b))
+        else:
+            assert (a[0] - b[0]).abs().max() <= 1e-10            # the camera agents' joint action
+            for x, y in zip(a[1:], b[1:]):
+                assert torch.allclose(x.double(), y.double(), rtol=0, atol=1e-6) and (x.dtype.is_floating_point or torch.equal(x, y))
+    assert (runs[0][-1][0][:, -2] >= 2).all()                     # every environment went through an episode end

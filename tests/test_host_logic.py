@@ -237,3 +237,36 @@ def test_auxiliary_target_rewards_on_a_replayed_trace():
         AuxiliaryTargetRewards(eng, {'bogus': 1.0})
     with pytest.raises(AssertionError):
         AuxiliaryTargetRewards(eng, {'raw_reward': 1.0}, reduction='min')      # the reference's target wrapper has no 'min'
+
+
+def test_zoom_table_interpolation_matches_the_iteration_over_the_whole_range():
+    """The on-device GreedyCameraAgent reads the zoom solve of greedy.py:139-145 -- b <- K / (1 + sin(b / 2))^2, twenty times
+    from 180 -- from a table over K = area_product / distance^2 at steps of 1 / 40 with cubic (Lagrange) interpolation
+    (policy_enable in mate_engine.hip builds it, zoom_lookup in policy_kernels.hpp reads it; MATE_ZOOM_ITERATE=1 selects
+    the iteration itself).  The same construction in NumPy against the iteration, densely over (0.025, 720) and right
+    below the upper end of the solving branch: the interpolation error stays at the iteration's own rounding."""
+    import numpy as np
+
+    def iterate(K):
+        b = np.full_like(K, 180.0)
+        for _ in range(20):
+            half = np.minimum(b * 0.5, 90.0)
+            b = K / (1.0 + np.sin(np.deg2rad(half))) ** 2
+        return b
+
+    inv_h, n = 40.0, int(720.0 * 40.0) + 1            # nodes K = 0, 1/40, ..., 720: none beyond the kink of the 90-degree clamp
+    table = iterate(np.arange(n) / inv_h)
+    rng = np.random.default_rng(3)
+    K = np.concatenate([rng.uniform(0.025, 720.0, 400000), np.linspace(719.0, 720.0 - 1e-9, 4001), np.linspace(0.025, 0.2, 2001)])
+    x = K * inv_h
+    i = x.astype(np.int64)
+    inside = (i >= 1) & (i <= n - 3)                  # zoom_lookup iterates outside: K < 1/40, and the last cell below 720
+    assert inside.mean() > 0.999 and (~inside).sum() > 0
+    K, x, i = K[inside], x[inside], i[inside]
+    t = x - i
+    fm1, f0, f1, f2 = table[i - 1], table[i], table[i + 1], table[i + 2]
+    tp1, tm1, tm2 = t + 1.0, t - 1.0, t - 2.0
+    got = (t * tm1 * tm2 * (-1.0 / 6.0)) * fm1 + (tp1 * tm1 * tm2 * 0.5) * f0 + (tp1 * t * tm2 * (-0.5)) * f1 + (tp1 * t * tm1 * (1.0 / 6.0)) * f2
+    err = np.abs(got - iterate(K))
+    assert err.max() < 1e-11, err.max()               # (4e-12 for K < 10, where the function bends most; 1.5e-13 above K = 100)
+    assert np.median(err) < 2e-13 and err[K > 100.0].max() < 5e-13
