@@ -330,6 +330,18 @@ int mate_engine_kernel_time(mate_engine *engine, int32_t enable, double *avg_ms,
  * outputs present, immediate auto-reset); results are bit-identical.  MATE_FLOW_GENERIC=1 forces 0. */
 int mate_engine_last_flow(const mate_engine *engine);
 
+/* Device memory for the [steps][N][...] observation blocks of the fused rollouts (mate_step_io.camera_obs_dev /
+ * target_obs_dev of mate_engine_rollout_*), laid out for the way those kernels write: every environment-wave streams its
+ * own 2-4 KB rows, thousands of rows at a time, and how fast HBM takes that depends on where the pages lie -- blocks from
+ * hipMalloc measured 4.3-5.6 TB/s from one allocation to the next on the same GPU, physically contiguous ones
+ * (hipDeviceMallocContiguous) 2.9-3.2 TB/s, the same block built from 2 MiB physical chunks mapped in a SHUFFLED order
+ * 5.4-5.8 TB/s (tools/store_vmm.hip).  block_alloc builds such a block (hipMemCreate / hipMemMap, the virtual range is
+ * contiguous); any device pointer works in mate_step_io -- this one is only faster to write.  `bytes` is rounded up to
+ * 2 MiB.  block_free unmaps and releases it (the pointer must come from block_alloc; the CALLER has waited for every launch
+ * that reads or writes the block -- the library does not synchronise here). */
+int mate_engine_block_alloc(int32_t device, int64_t bytes, void **ptr_out);
+int mate_engine_block_free(void *ptr);
+
 #ifdef __cplusplus
 }
 #endif

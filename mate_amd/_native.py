@@ -16,6 +16,7 @@ EXPORTED_SYMBOLS = (
     'mate_engine_get_layout', 'mate_engine_set_obs_transform', 'mate_engine_set_obs_mode', 'mate_engine_set_action_grids', 'mate_engine_seed', 'mate_engine_reset', 'mate_engine_reset_tape', 'mate_engine_step', 'mate_engine_device_tick', 'mate_engine_set_episode_stats', 'mate_engine_step_random',
     'mate_engine_rollout_random', 'mate_engine_policy_enable', 'mate_engine_step_greedy', 'mate_engine_step_versus_greedy', 'mate_engine_rollout_greedy', 'mate_engine_rollout_versus_greedy', 'mate_engine_policy_actions',
     'mate_engine_observe', 'mate_engine_export_state', 'mate_engine_import_state', 'mate_engine_lut_read',
+    'mate_engine_block_alloc', 'mate_engine_block_free',
     'mate_engine_lut_write', 'mate_engine_enable_outer_boundary', 'mate_engine_lut_read_outer', 'mate_engine_lut_write_outer', 'mate_engine_soft_coverage', 'mate_engine_rebuild_luts', 'mate_engine_idle_steps', 'mate_engine_kernel_time', 'mate_engine_last_flow',
 )
 
@@ -122,12 +123,41 @@ def load():
     handle.mate_engine_idle_steps.argtypes = [P, ctypes.POINTER(I64)]
     handle.mate_engine_kernel_time.argtypes = [P, I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I64)]
     handle.mate_engine_last_flow.argtypes = [P]
+    handle.mate_engine_block_alloc.argtypes = [I32, I64, ctypes.POINTER(P)]
+    handle.mate_engine_block_free.argtypes = [P]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(handle, name)
         if name not in ('mate_engine_last_error',):
             fn.restype = ctypes.c_int
     lib = handle
     return lib
+
+
+class ScatteredBlock:
+    """Device memory from ``mate_engine_block_alloc`` (2 MiB physical chunks mapped in a shuffled order: what the fused
+    rollouts store fastest into, include/mate_engine.h) as a zero-copy torch tensor: ``tensor(dtype, shape)``.  The memory
+    lives as long as any tensor made from it."""
+
+    def __init__(self, device_index, nbytes):
+        ptr = ctypes.c_void_p()
+        check(load().mate_engine_block_alloc(int(device_index), int(nbytes), ctypes.byref(ptr)))
+        self.ptr, self.nbytes, self.device_index, self._lib = ptr.value, int(nbytes), int(device_index), lib
+        self.__cuda_array_interface__ = {'shape': (self.nbytes,), 'typestr': '|u1', 'data': (self.ptr, False), 'version': 2}
+
+    def tensor(self, dtype, shape):
+        import torch
+        flat = torch.as_tensor(self, device=torch.device('cuda', self.device_index))       # keeps a reference to this object
+        return flat.view(dtype).view(shape)
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, 'ptr', None), None
+        if ptr:
+            try:
+                import torch
+                torch.cuda.synchronize(self.device_index)      # block_free does not wait for launches in flight
+                self._lib.mate_engine_block_free(ctypes.c_void_p(ptr))
+            except Exception:       # interpreter shutdown: the process's memory goes with it
+                pass
 
 
 def check(status):

@@ -164,7 +164,7 @@ struct Ptrs {
     double *dyn;                  // [N][DW] (8-byte words: DF doubles then NI ints)
     double2 *lut_knots;           // [N][Nc][kmax]  (phi, rho)
     uint16_t *lut_bucket;         // [N][Nc][nbucket]
-    double2 *lut_deg;             // [N][Nc][360][kDegSlots] per-degree records (fast lookup path)
+    double2 *lut_deg;             // [N][Nc][360][kDegWords] per-degree segment records (fast lookup path)
     int32_t *lut_count;           // [N][Nc]
     double2 *lut_knots_outer;     // optional (mate_engine_enable_outer_boundary): [N][Nc][kmax_outer] knots of Camera.boundary_outer
     int32_t *lut_count_outer;     // [N][Nc]
@@ -692,14 +692,34 @@ __device__ __noinline__ double lut_lookup(const double2 *knots, const uint16_t *
     return res;
 }
 
-// Fast path: one 80-byte record per (camera, degree) holding the knots of that degree, the next
-// integer-degree knot and +inf padding (kDegSlots entries): one dependent memory round trip.  A degree
+// Fast path: one 96-byte record per (camera, degree): the up to four knots of that degree as SEGMENTS (angle, range, slope to the
+// next knot -- the last one's to the next integer-degree knot), +inf angles in the unused slots: one dependent memory round
+// trip, and np.interp (`slope * (x - xp[j]) + fp[j]`, slope = (fp[j+1] - fp[j]) / (xp[j+1] - xp[j])) without its division --
+// the builders make it once per table, with the same IEEE division, so the product and the sum see the same bits.  (Angles
+// of a table increase strictly, so the slopes are finite and np.interp's NaN repairs never apply; a query below the next
+// integer degree -- degree_of guarantees it -- never selects that knot, which is why it needs no slot.)  A degree
 // with more knots than fit (the arc of a small, distant obstacle) is marked by a NaN first angle and
 // carries (index of its first knot, number of knots incl. the next integer degree) instead: three pivot
 // angles pick the quarter of that degree's knots holding the query, and that quarter is fetched into the
-// same registers as a record (two more round trips, no extra registers; up to 4 (kDegSlots - 1) + 1 knots).
+// same registers as kDegSlots plain knots (two more round trips, no extra registers; up to 4 (kDegSlots - 1) + 1 knots).
 // Only beyond that the general path with its dependent binary search runs (8+ round trips: it used to set
 // the slowest wave of a launch).
+constexpr int kDegWords = 6;      // double2 per record: [x0 y0][s0 x1][y1 s1][x2 y2][s2 x3][y3 s3]
+__device__ __forceinline__ void degree_record_set(double2 *rec, int i, double x, double y, double slope) {
+    double *w = reinterpret_cast<double *>(rec) + 3 * i;
+    w[0] = x; w[1] = y; w[2] = slope;
+}
+__device__ __forceinline__ double segment_interp(const double2 (&w)[kDegWords], double x, bool &overflow) {
+    overflow = w[0].x != w[0].x;
+    // (every word read into a value first: selecting between the loads themselves keeps the record in memory)
+    const double xa = w[0].x, ya = w[0].y, sa = w[1].x, xb = w[1].y, yb = w[2].x, sb = w[2].y;
+    const double xc = w[3].x, yc = w[3].y, sc = w[4].x, xd = w[4].y, yd = w[5].x, sd = w[5].y;
+    double x0 = xa, y0 = ya, sl = sa;
+    if (xb <= x) { x0 = xb; y0 = yb; sl = sb; }
+    if (xc <= x) { x0 = xc; y0 = yc; sl = sc; }
+    if (xd <= x) { x0 = xd; y0 = yd; sl = sd; }
+    return sl * (x - x0) + y0;
+}
 constexpr int kDegSlots = 5;
 constexpr int kQuarterKnots = 4 * (kDegSlots - 1) + 1;
 __device__ __forceinline__ int degree_of(double x) {
@@ -708,7 +728,7 @@ __device__ __forceinline__ int degree_of(double x) {
     if (x < (double)(d - 180)) d -= 1;                // x + 180 rounded up across an integer
     return d < 0 ? 0 : d;
 }
-__device__ __forceinline__ double degree_interp(const double2 (&w)[kDegSlots], double x, bool &overflow) {
+__device__ __forceinline__ double degree_interp(const double2 (&w)[kDegWords], double x, bool &overflow) {      // (plain knots in w[0 .. kDegSlots))
     overflow = w[0].x != w[0].x;
     double2 k0 = w[0], k1 = w[1];
 #pragma unroll
@@ -746,12 +766,23 @@ __device__ __forceinline__ bool range_exact(const Ctx<ObsT> &c, int tj, int j) {
     if (d2 > lim2 * (1.0 + 1e-14)) return false;
     return sqrt_pos(d2) <= lim;
 }
+// A value in the wave's LDS slice through a 32-bit LDS address the lane HOLDS (roles below): the address goes into the ds_read
+// as it is, the byte offset into the instruction -- no shift / add per access.
+typedef __attribute__((address_space(3))) const double lds_cf64;
+typedef __attribute__((address_space(3))) const float lds_cf32;
+__device__ __forceinline__ uint32_t lds_addr(const void *q) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)q; }
+__device__ __forceinline__ double lds_f64(uint32_t a, int byte_off = 0) { return *(lds_cf64 *)(uintptr_t)(a + (uint32_t)byte_off); }
+__device__ __forceinline__ float lds_f32(uint32_t a, int byte_off = 0) { return *(lds_cf32 *)(uintptr_t)(a + (uint32_t)byte_off); }
+constexpr int kSectorDiag = -3;      // RangeRoles::sector of a camera and itself (always seen, environment.py:1383-1384)
 struct RangeRoles {
-    int32_t pair[kRoleRounds];       // entity slot of the target | entity slot of the other << 16
-    float lim2[kRoleRounds];         // (target sight range + other's radius)^2 MINUS the band's half-width, f32: below, the pair is seen
-    float rim[kRoleRounds];          // ... PLUS the half-width: above, it is hidden; between the two the f64 test decides
-    uint32_t diag_bits, valid_bits;  // bit `round`: the pair is (t, t) / the lane holds a pair in this round
-    int32_t sector;                  // sector_role of the lane's pair in the last sector round
+    uint32_t at[kRoleRounds], aj[kRoleRounds];   // LDS addresses of the f32 shadow x of the round's target / of the other (y: + 4 NJ)
+    // (target sight range + other's radius)^2 MINUS the band's half-width, f32: below, the pair is seen; ... PLUS the half-width:
+    // above, it is hidden; between the two the f64 test decides.  A target and itself: +inf, +inf (always seen); a lane without
+    // a pair in this round: -inf, -inf (never) -- no separate diagonal / validity tests.
+    float lim2[kRoleRounds];
+    float rim[kRoleRounds];
+    int32_t sector;                  // the lane's pair in the last sector round: sector_role, kSectorDiag, or -1
+    uint32_t sec_cam, sec_other, sec_draw;       // ... LDS addresses: slice + 8 cam, slice + 8 (the other's entity slot), slice + 8 pair
     // row-image mode: the (viewer, other) block each of the lane's pairs owns in the observation rows -- slot 0 the sector pair,
     // slots 1.. the range rounds: LDS byte offset of the other's public state | of the block in the viewer's row << 16
     uint32_t block[1 + kRoleRounds];
@@ -779,15 +810,16 @@ __device__ __forceinline__ void image_block_of(const Params &p, bool viewer_is_c
 // holding them (15 instructions per step for the sector role alone).  Passing each word through an empty asm makes it opaque.
 __device__ __forceinline__ void pin_roles(RangeRoles &r) {
 #pragma unroll
-    for (int i = 0; i < kRoleRounds; ++i) { asm volatile("" : "+v"(r.pair[i])); asm volatile("" : "+v"(r.lim2[i])); asm volatile("" : "+v"(r.rim[i])); asm volatile("" : "+v"(r.reach2[i])); }
+    for (int i = 0; i < kRoleRounds; ++i) { asm volatile("" : "+v"(r.at[i])); asm volatile("" : "+v"(r.aj[i])); asm volatile("" : "+v"(r.lim2[i])); asm volatile("" : "+v"(r.rim[i])); asm volatile("" : "+v"(r.reach2[i])); }
 #pragma unroll
     for (int i = 0; i < 1 + kRoleRounds; ++i) asm volatile("" : "+v"(r.block[i]));
-    asm volatile("" : "+v"(r.diag_bits)); asm volatile("" : "+v"(r.valid_bits)); asm volatile("" : "+v"(r.sector)); asm volatile("" : "+v"(r.block_bits));
+    asm volatile("" : "+v"(r.sector)); asm volatile("" : "+v"(r.block_bits));
+    asm volatile("" : "+v"(r.sec_cam)); asm volatile("" : "+v"(r.sec_other)); asm volatile("" : "+v"(r.sec_draw));
 }
 template <typename ObsT>
 __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &roles) {
     const Params &p = c.p;
-    roles.diag_bits = 0; roles.valid_bits = 0; roles.block_bits = 0;
+    roles.block_bits = 0;
     roles.sector = sector_role(p, (p.sector_rounds - 1) * 64 + c.lane);
 #pragma unroll
     for (int round = 0; round < kRoleRounds; ++round) {
@@ -797,11 +829,10 @@ __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &role
         const int j = qq - t * p.NJ;
         const int tj = c.tgt_slot(t);
         const float lim = (float)(p.tgt_sight + c.er[j]);
-        roles.pair[round] = tj | (j << 16);
-        roles.lim2[round] = lim * lim - range_rim(lim);      // below: seen; above rim[]: hidden; between: the f64 test decides
-        roles.rim[round] = lim * lim + range_rim(lim);
-        roles.diag_bits |= (uint32_t)(j == tj) << round;
-        roles.valid_bits |= (uint32_t)(q < p.n_range && round < p.range_rounds) << round;
+        const bool valid = q < p.n_range && round < p.range_rounds;
+        roles.at[round] = lds_addr(c.exf + tj); roles.aj[round] = lds_addr(c.exf + j);
+        roles.lim2[round] = !valid ? -INFINITY : j == tj ? INFINITY : lim * lim - range_rim(lim);
+        roles.rim[round] = !valid ? -INFINITY : j == tj ? INFINITY : lim * lim + range_rim(lim);
         {   // a SCREEN: conservative by the whole step size (the walk repeats the test on the actual step, exactly), f32 with
             // an absolute margin eight times the worst rounding of the f32 shadow (see simulate_targets)
             const float step = (float)(((c.capword() >> t) & 1ull) ? p.tgt_step * 0.5 : p.tgt_step);
@@ -816,12 +847,19 @@ __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &role
         }
     }
     roles.block[0] = 0u;
-    if (c.image() && roles.sector >= 0) {
+    roles.sec_cam = roles.sec_other = roles.sec_draw = lds_addr(c.base);
+    if (roles.sector >= 0) {
         const int cam = roles.sector & 0xff, other = (roles.sector >> 8) & 0xff;
         const bool is_target = (roles.sector >> 16) & 1;
-        uint32_t code;
-        image_block_of(p, true, cam, is_target ? c.tgt_slot(other) : other, roles.block[0], code);
-        roles.block_bits |= code;
+        const int oj = is_target ? c.tgt_slot(other) : other;
+        if (c.image()) {
+            uint32_t code;
+            image_block_of(p, true, cam, oj, roles.block[0], code);
+            roles.block_bits |= code;
+        }
+        roles.sec_cam += 8u * (uint32_t)cam; roles.sec_other += 8u * (uint32_t)oj;
+        if (is_target) roles.sec_draw += 8u * (uint32_t)(cam * p.Nt + other);
+        if (!is_target && cam == other) roles.sector = kSectorDiag;
     }
 }
 
@@ -832,8 +870,8 @@ __device__ __forceinline__ void near_seed(const Ctx<ObsT> &c, const RangeRoles &
     for (int round = 0; round < kRoleRounds; ++round) {
         near.w[round] = 0ull;
         if (round < c.p.range_rounds) {
-            const int tj = roles.pair[round] & 0xffff, j = roles.pair[round] >> 16;
-            const float dx = c.exf[tj] - c.exf[j], dy = c.eyf[tj] - c.eyf[j];
+            const float dx = lds_f32(roles.at[round]) - lds_f32(roles.aj[round]);
+            const float dy = lds_f32(roles.at[round], 4 * c.p.NJ) - lds_f32(roles.aj[round], 4 * c.p.NJ);
             near.w[round] = __ballot(fmaf(dy, dy, dx * dx) <= roles.reach2[round]);
         }
     }
@@ -857,7 +895,8 @@ __device__ __forceinline__ bool sector_out_of_range(double d2, double s2) {
 template <bool RANGED = false, typename ObsT>
 __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t tick, uint32_t stream, bool predrawn, int role = kNoRole) {
     const Params &p = c.p;
-    SectorEval e{false, false, 0.0, 0.0, 0};
+    SectorEval e;                    // rn, x, lc: meaningful under `need` only -- left undefined on the early exits (zeroing them on
+    e.seen = false; e.need = false;  // every exit path was 18 vector moves per step)
     if (role == kNoRole) role = sector_role(p, q);
     if (role < 0) return e;
     const int cam = role & 0xff, other = (role >> 8) & 0xff;
@@ -867,7 +906,7 @@ __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t 
     const double rx = c.ex[oj] - c.ex[cam], ry = c.ey[oj] - c.ey[cam];
     const double d2 = fma(ry, ry, rx * rx);
     if (!RANGED && sector_out_of_range(d2, c.sight2(cam))) return e;              // RANGED: the caller has made this test
-    const double ang = atan2_deg(ry, rx);
+    const double ang = atan2_sector(ry, rx) * kRad2Deg;
     double ra = fabs(c.phi(cam) - ang);
     const double alt = 360.0 - ra;
     if (alt < ra) ra = alt;
@@ -887,24 +926,57 @@ __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t 
     return e;
 }
 
+// The same test for the pair a lane of the fused rollouts HOLDS (RangeRoles: the last sector round): its operands through the
+// held LDS addresses, the pair's kind from the held role word.  Same arithmetic, same verdicts.
 template <typename ObsT>
-__device__ __forceinline__ void sector_fetch(const Ctx<ObsT> &c, const SectorEval &e, double2 (&w)[kDegSlots]) {
+__device__ __forceinline__ SectorEval sector_eval_held(Ctx<ObsT> &c, const RangeRoles &h, uint32_t tick, uint32_t stream, bool predrawn) {
+    const Params &p = c.p;
+    SectorEval e;
+    e.seen = false; e.need = false;
+    const int role = h.sector;
+    if (role < 0) { e.seen = role == kSectorDiag; return e; }
+    const int ent = p.off_ent, yoff = 8 * p.NJ;
+    const double rx = lds_f64(h.sec_other, ent) - lds_f64(h.sec_cam, ent), ry = lds_f64(h.sec_other, ent + yoff) - lds_f64(h.sec_cam, ent + yoff);
+    const double d2 = fma(ry, ry, rx * rx);
+    if (sector_out_of_range(d2, lds_f64(h.sec_cam, p.off_tmp))) return e;
+    const double ang = atan2_sector(ry, rx) * kRad2Deg;
+    double ra = fabs(lds_f64(h.sec_cam, p.off_dy) - ang);
+    const double alt = 360.0 - ra;
+    if (alt < ra) ra = alt;
+    if (ra * 2.0 > lds_f64(h.sec_cam, p.off_dy + 8 * p.Nc)) return e;
+    if (p.No == 0) { e.seen = true; return e; }
+    if ((role >> 16) & 1) {                                                        // np_random.binomial(1, tau), entities.py:503
+        double u;
+        if (predrawn && p.Nc * p.Nt <= 64 - p.Nc - p.Nt) u = lds_f64(h.sec_draw, p.off_tmp + 8 * (p.Nc + 3 * p.Nt));
+        else {
+            const int pair = (role & 0xff) * p.Nt + ((role >> 8) & 0xff);
+            if (predrawn && pair < 64 - p.Nc - p.Nt) u = c.udraw(pair);
+            else u = c.draw(tick, stream, (uint32_t)pair);
+        }
+        if ((p.tau <= 0.5) ? (u > 1.0 - p.tau) : (u <= p.tau)) { e.seen = true; return e; }
+    }
+    e.need = true; e.rn = d2; e.x = normalize_angle(ang); e.lc = c.env * p.Nc + (role & 0xff);
+    return e;
+}
+
+template <typename ObsT>
+__device__ __forceinline__ void sector_fetch(const Ctx<ObsT> &c, const SectorEval &e, double2 (&w)[kDegWords]) {
     if (e.need) {
 #ifdef MATE_LUT_FAKE      // experiment build: every lookup reads the same (cache-resident) record -- what the real fetch's latency costs
-        const double2 *rec = c.g.lut_deg + (0 * e.lc * 360 + degree_of(e.x)) * kDegSlots;
+        const double2 *rec = c.g.lut_deg + (0 * e.lc * 360 + degree_of(e.x)) * kDegWords;
 #else
-        const double2 *rec = c.g.lut_deg + (e.lc * 360 + degree_of(e.x)) * kDegSlots;
+        const double2 *rec = c.g.lut_deg + (e.lc * 360 + degree_of(e.x)) * kDegWords;
 #endif
 #pragma unroll
-        for (int i = 0; i < kDegSlots; ++i) w[i] = rec[i];
+        for (int i = 0; i < kDegWords; ++i) w[i] = rec[i];
     }
 }
 
 template <typename ObsT>
-__device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorEval &e, double2 (&w)[kDegSlots]) {
+__device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorEval &e, double2 (&w)[kDegWords]) {
     if (!e.need) return e.seen;
     bool overflow;
-    double limit = degree_interp(w, e.x, overflow);
+    double limit = segment_interp(w, e.x, overflow);
     if (overflow) {
         const int start = (int)w[0].y, count = (int)w[1].x;
         const double2 *knots = c.g.lut_knots + e.lc * c.p.kmax;
@@ -942,7 +1014,7 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     const Params &p = c.p;
     const int lane = c.lane;
     seen_out = 0u;
-    double2 w[kDegSlots];
+    double2 w[kDegWords];
     int n_cand = 0;
     uint8_t *cand = c.base + p.off_list;
     const bool compact = COMPACT && p.sector_rounds >= 2 && p.n_sector <= 256;
@@ -976,6 +1048,16 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     // ---- range tests: Sensor.perceive (entities.py:229-232) target -> camera / obstacle / target.
     // Two passes: (1) all rounds' LDS reads and arithmetic back to back (independent chains overlap their
     // latency), results collected in a per-lane bit set; (2) flags, ballots and mask words.
+    unsigned long long range_ballot[kRoleRounds] = {};       // HELD: the rounds' mask words, written by lane 0 in one go
+    auto write_range_ballots = [&]() {
+        if constexpr (HELD) {
+            const int rbase = p.bit_range >> 5;
+            if (lane == 0)
+#pragma unroll
+                for (int round = 0; round < kRoleRounds; ++round)
+                    if (round < p.range_rounds) { c.mask[rbase + 2 * round] = (uint32_t)range_ballot[round]; c.mask[rbase + 2 * round + 1] = (uint32_t)(range_ballot[round] >> 32); }
+        }
+    };
     auto range_tests = [&]() {
     const int rbase = p.bit_range >> 5;
     uint32_t seen_bits = 0;
@@ -983,14 +1065,17 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
 #pragma unroll
         for (int round = 0; round < kRoleRounds; ++round) {
             if (round < p.range_rounds) {
-                const int tj = held.pair[round] & 0xffff, j = held.pair[round] >> 16;
-                const bool diag = (held.diag_bits >> round) & 1u;
-                const float dx = c.exf[tj] - c.exf[j], dy = c.eyf[tj] - c.eyf[j];
+                const float dx = lds_f32(held.at[round]) - lds_f32(held.aj[round]);
+                const float dy = lds_f32(held.at[round], 4 * p.NJ) - lds_f32(held.aj[round], 4 * p.NJ);
                 const float d2 = fmaf(dy, dy, dx * dx);
-                // (held as the two ends of the band: lim2[] = limit^2 - rim, rim[] = limit^2 + rim)
+                // (held as the two ends of the band: lim2[] = limit^2 - rim, rim[] = limit^2 + rim; the diagonal and the lanes
+                // without a pair are decided by infinite ends)
                 bool seen = d2 < held.lim2[round];
-                if (!seen && !(d2 > held.rim[round])) seen = range_exact(c, tj, j);
-                seen_bits |= (uint32_t)((seen || diag) && ((held.valid_bits >> round) & 1u)) << round;
+                if (!seen && !(d2 > held.rim[round])) {
+                    const uint32_t first = lds_addr(c.exf);
+                    seen = range_exact(c, (int)((held.at[round] - first) >> 2), (int)((held.aj[round] - first) >> 2));
+                }
+                seen_bits |= (uint32_t)seen << round;
                 if (near_next) near_next->w[round] = __ballot(d2 <= held.reach2[round]);      // the next step's collision screen
             }
         }
@@ -1016,7 +1101,8 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         const bool seen = (seen_bits >> round) & 1u;
         if (!c.image() && q < p.n_range) set_flag(c, p.fs_range + q, seen);
         const unsigned long long b = __ballot(seen);
-        if (lane == 0) { c.mask[rbase + 2 * round] = (uint32_t)b; c.mask[rbase + 2 * round + 1] = (uint32_t)(b >> 32); }
+        if (HELD && round < kRoleRounds) range_ballot[round] = b;      // (written with the sector word, below)
+        else if (lane == 0) { c.mask[rbase + 2 * round] = (uint32_t)b; c.mask[rbase + 2 * round + 1] = (uint32_t)(b >> 32); }
     }
     seen_out |= seen_bits << 1;
     };
@@ -1031,6 +1117,7 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
             if (sector_resolve(c, e, w)) { set_flag(c, q, true); atomicOr(&c.mask[q >> 5], 1u << (q & 31)); }
         }
         range_tests();
+        write_range_ballots();
     } else {
         // ---- sector tests for camera->target and camera->camera; all rounds but the last resolve at once, the last round's
         // occlusion records travel while the range tests run
@@ -1043,11 +1130,13 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
             if (lane == 0) { c.mask[2 * round] = (uint32_t)b; c.mask[2 * round + 1] = (uint32_t)(b >> 32); }
         }
         const int last = p.sector_rounds - 1;
-        SectorEval pending{false, false, 0.0, 0.0, 0};
+        SectorEval pending;
+        pending.seen = false; pending.need = false;
         if (last >= 0) {
             // (a branch-free form of this test -- every lane computing everything, verdicts combined at the end -- measured
             // no faster: the early exits cost scalar instructions, which issue beside the other waves' vector work)
-            pending = sector_eval(c, last * 64 + lane, tick, stream, predrawn, HELD ? held.sector : kNoRole);
+            if constexpr (HELD) pending = sector_eval_held(c, held, tick, stream, predrawn);
+            else pending = sector_eval(c, last * 64 + lane, tick, stream, predrawn);
             sector_fetch(c, pending, w);
         }
         SUB_STAMP(c, 13);
@@ -1060,6 +1149,7 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
             if (lane == 0) { c.mask[2 * last] = (uint32_t)b; c.mask[2 * last + 1] = (uint32_t)(b >> 32); }
             if (sector_ballot) *sector_ballot = b;
         }
+        write_range_ballots();
     }
     SUB_STAMP(c, 14);
     // ---- static camera->obstacle bits (environment.py:752-755) and the always-true bit
@@ -1323,6 +1413,16 @@ __device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c) {
     fill_scratch(c, always);
 }
 
+// The observation rows leave through this store.  (MATE_STORE_PLAIN: experiment switch -- plain write-back stores instead of
+// non-temporal ones, tools/store_roof.hip)
+template <typename V>
+__device__ __forceinline__ void stream_store(V v, V *dst) {
+#ifdef MATE_STORE_PLAIN
+    *dst = v;
+#else
+    __builtin_nontemporal_store(v, dst);
+#endif
+}
 template <typename ObsT> struct Vec;
 template <> struct Vec<float> { using type = float4; static constexpr int W = 4; };
 template <> struct Vec<double> { using type = double2; static constexpr int W = 2; };
@@ -1354,14 +1454,14 @@ __device__ __forceinline__ void pack_block(const Ctx<ObsT> &c, ObsT *dst, const 
                 v.x = gather_one(c, d.x); v.y = gather_one(c, d.y); v.z = gather_one(c, d.z); v.w = gather_one(c, d.w);
                 typedef float f32x4 __attribute__((ext_vector_type(4)));
                 const f32x4 nv = {v.x, v.y, v.z, v.w};
-                __builtin_nontemporal_store(nv, reinterpret_cast<f32x4 *>(&out[i]));   // write-once stream: keep it out of the caches
+                stream_store(nv, reinterpret_cast<f32x4 *>(&out[i]));   // write-once stream: keep it out of the caches
             } else {
                 const uint2 d = reinterpret_cast<const uint2 *>(table)[i];
                 double2 v;
                 v.x = gather_one(c, d.x); v.y = gather_one(c, d.y);
                 typedef double f64x2 __attribute__((ext_vector_type(2)));
                 const f64x2 nv = {v.x, v.y};
-                __builtin_nontemporal_store(nv, reinterpret_cast<f64x2 *>(&out[i]));
+                stream_store(nv, reinterpret_cast<f64x2 *>(&out[i]));
             }
         }
     } else if (sizeof(ObsT) == 4 && (elems % 2) == 0) {      // blocks that are only 8-byte aligned (4v2: 202 floats per environment)
@@ -1378,7 +1478,7 @@ __device__ __forceinline__ void pack_block(const Ctx<ObsT> &c, ObsT *dst, const 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = base + 64 * k;
-                if (i < nvec) { const f32x2 v = {(float)gather_one(c, d[k].x), (float)gather_one(c, d[k].y)}; __builtin_nontemporal_store(v, &out[i]); }
+                if (i < nvec) { const f32x2 v = {(float)gather_one(c, d[k].x), (float)gather_one(c, d[k].y)}; stream_store(v, &out[i]); }
             }
         }
     } else {
@@ -1448,11 +1548,11 @@ __device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT> &c, const D &d) {
         f32x4 *tgt = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems);
         auto chunk = [&](const uint4 &d) { return f32x4{gather_one(c, d.x), gather_one(c, d.y), gather_one(c, d.z), gather_one(c, d.w)}; };
 #pragma unroll
-        for (int k = 0; k < GC; ++k) { const int s = c.lane + 64 * k; if (s < nvc) __builtin_nontemporal_store(chunk(d.dc[k]), &cam[s]); }
-        for (int s = c.lane + 64 * GC; s < nvc; s += 64) __builtin_nontemporal_store(chunk(tabc[s]), &cam[s]);   // larger scenarios
+        for (int k = 0; k < GC; ++k) { const int s = c.lane + 64 * k; if (s < nvc) stream_store(chunk(d.dc[k]), &cam[s]); }
+        for (int s = c.lane + 64 * GC; s < nvc; s += 64) stream_store(chunk(tabc[s]), &cam[s]);   // larger scenarios
 #pragma unroll
-        for (int k = 0; k < GT; ++k) { const int s = c.lane + 64 * k; if (s < nvt) __builtin_nontemporal_store(chunk(d.dt[k]), &tgt[s]); }
-        for (int s = c.lane + 64 * GT; s < nvt; s += 64) __builtin_nontemporal_store(chunk(tabt[s]), &tgt[s]);
+        for (int k = 0; k < GT; ++k) { const int s = c.lane + 64 * k; if (s < nvt) stream_store(chunk(d.dt[k]), &tgt[s]); }
+        for (int s = c.lane + 64 * GT; s < nvt; s += 64) stream_store(chunk(tabt[s]), &tgt[s]);
     }
 }
 
@@ -1624,18 +1724,34 @@ __device__ __forceinline__ void image_store(const Ctx<ObsT> &c) {
     const f32x4 *src_c = reinterpret_cast<const f32x4 *>(c.img), *src_t = reinterpret_cast<const f32x4 *>(c.img + p.cam_elems);
     f32x4 *cam = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.cam_obs) + c.out * p.cam_elems);
     f32x4 *tgt = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems);
-    // all LDS reads of a block before its first store (a store issued between them would be waited for with them)
-    constexpr int GC = 2, GT = 6;       // (image_fits shapes: at most 128 camera chunks and 384 target chunks; asserted by the host)
-    const int lane = c.lane & 63;       // (the range, for the compiler: whole chunks rounds fold their bounds checks)
+    // Every store instruction covers a 128-byte-ALIGNED kilobyte of the output: a row begins at a multiple of 16 bytes, not of a
+    // cache line, so the lanes' chunks are shifted by the row's offset inside its first line (wave-uniform: 0..7 chunks).
+    // Unshifted, every instruction straddles nine lines and the two partial ones are written again by its neighbour -- the
+    // access pattern alone stores 5 % slower (tools/store_roof.hip).
+    // All LDS reads of a block before its first store (a store issued between them would be waited for with them).
+    constexpr int GC = 3, GT = 7;       // (image_fits shapes: at most 128 camera chunks and 384 target chunks + 7 of shift; asserted by the host)
+    const int lane = c.lane & 63;       // (the range, for the compiler)
+    const int sc = (int)((reinterpret_cast<uintptr_t>(cam) >> 4) & 7u), st = (int)((reinterpret_cast<uintptr_t>(tgt) >> 4) & 7u);
+    // (the shift goes into the wave-uniform bases; the LDS reads are unconditional -- a lane outside its row reads a neighbouring
+    // part of the slice, or zeros past the workgroup's LDS, and stores nothing; only the first round needs the lower bound and
+    // only the rounds that can reach the row's end the upper one)
+    const f32x4 *from_c = src_c - sc, *from_t = src_t - st;
+    f32x4 *to_c = cam - sc, *to_t = tgt - st;
     f32x4 vc[GC], vt[GT];
 #pragma unroll
-    for (int k = 0; k < GC; ++k) { const int s = lane + 64 * k; if (s < nvc) vc[k] = src_c[s]; }
+    for (int k = 0; k < GC; ++k) if (64 * k - 7 < nvc) vc[k] = from_c[lane + 64 * k];
 #pragma unroll
-    for (int k = 0; k < GT; ++k) { const int s = lane + 64 * k; if (s < nvt) vt[k] = src_t[s]; }
+    for (int k = 0; k < GT; ++k) if (64 * k - 7 < nvt) vt[k] = from_t[lane + 64 * k];
 #pragma unroll
-    for (int k = 0; k < GC; ++k) { const int s = lane + 64 * k; if (s < nvc) __builtin_nontemporal_store(vc[k], &cam[s]); }
+    for (int k = 0; k < GC; ++k) if (64 * k - 7 < nvc) {
+        const bool inside = (k > 0 || lane >= sc) && (64 * (k + 1) <= nvc || lane + 64 * k - sc < nvc);
+        if (inside) stream_store(vc[k], &to_c[lane + 64 * k]);
+    }
 #pragma unroll
-    for (int k = 0; k < GT; ++k) { const int s = lane + 64 * k; if (s < nvt) __builtin_nontemporal_store(vt[k], &tgt[s]); }
+    for (int k = 0; k < GT; ++k) if (64 * k - 7 < nvt) {
+        const bool inside = (k > 0 || lane >= st) && (64 * (k + 1) <= nvt || lane + 64 * k - st < nvt);
+        if (inside) stream_store(vt[k], &to_t[lane + 64 * k]);
+    }
     }
 }
 
@@ -2129,7 +2245,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
             image_targets_held(c, h, last_gw);
             image_blocks(c, roles, seen);
             ROLL_STAMP(5);
-            image_store(c); store_masks(c);
+            if (!(MATE_ABLATE & 64)) { image_store(c); store_masks(c); }
             wave_sync();
             stepped = true;
             ROLL_STAMP(6);

@@ -9,6 +9,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -368,7 +371,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         if ((rc = dev_alloc(e, &g.lut_knots, N * std::max(Nc, 1) * (size_t)p.kmax, false))) break;
         if ((rc = dev_alloc(e, &g.lut_bucket, N * std::max(Nc, 1) * (size_t)p.nbucket))) break;
         if ((rc = dev_alloc(e, &g.lut_count, N * std::max(Nc, 1)))) break;
-        if ((rc = dev_alloc(e, &g.lut_deg, N * std::max(Nc, 1) * (size_t)360 * kDegSlots, false))) break;
+        if ((rc = dev_alloc(e, &g.lut_deg, N * std::max(Nc, 1) * (size_t)360 * kDegWords, false))) break;
         if ((rc = dev_alloc(e, &g.done_count, (size_t)2))) break;
         if ((rc = dev_alloc(e, &g.done_list, 2 * N))) break;
         if ((rc = dev_alloc(e, &g.flag_count, (size_t)4))) break;
@@ -1223,24 +1226,29 @@ extern "C" int mate_engine_lut_write(mate_engine *e, int64_t env, int32_t camera
     }
     const int64_t lc = env * e->p.Nc + camera;
     // per-degree records (same rule as the device builder in reset_kernels.hpp)
-    std::vector<double2> deg((size_t)360 * kDegSlots);
+    std::vector<double2> deg((size_t)360 * kDegWords);
     const double inf = INFINITY;
     for (int d = 0; d < 360; ++d) {
         const int start = bucket[d], endk = bucket[d + 1];
-        double2 *rec = deg.data() + (size_t)d * kDegSlots;
-        if (endk - start + 1 <= kDegSlots && phis[start] == (double)(d - 180)) {
-            for (int i = 0; i < kDegSlots; ++i) {
+        double2 *rec = deg.data() + (size_t)d * kDegWords;
+        double *words = reinterpret_cast<double *>(rec);
+        // a caller's table may repeat an angle (np.interp repairs the infinite slope): such a degree takes the general path
+        bool increasing = true;
+        for (int idx = start; idx < endk; ++idx) increasing = increasing && phis[idx + 1] > phis[idx];
+        if (endk - start + 1 <= kDegSlots && phis[start] == (double)(d - 180) && increasing) {
+            for (int i = 0; i < kDegSlots - 1; ++i) {
                 const int idx = start + i;
-                rec[i].x = idx <= endk ? phis[idx] : inf;
-                rec[i].y = idx <= endk ? rhos[idx] : 0.0;
+                words[3 * i] = idx < endk ? phis[idx] : inf;
+                words[3 * i + 1] = idx < endk ? rhos[idx] : 0.0;
+                words[3 * i + 2] = idx < endk ? (rhos[idx + 1] - rhos[idx]) / (phis[idx + 1] - phis[idx]) : 0.0;
             }
         } else {
-            for (int i = 0; i < kDegSlots; ++i) { rec[i].x = NAN; rec[i].y = 0.0; }
-            if (phis[start] == (double)(d - 180)) { rec[0].y = (double)start; rec[1].x = (double)(endk - start + 1); }   // burst path
+            for (int i = 0; i < kDegWords; ++i) { rec[i].x = NAN; rec[i].y = 0.0; }
+            if (phis[start] == (double)(d - 180) && increasing) { rec[0].y = (double)start; rec[1].x = (double)(endk - start + 1); }   // burst path
             else rec[1].x = 0.0;                                                                                   // general path
         }
     }
-    HIP_TRY(hipMemcpy(e->g.lut_deg + lc * 360 * kDegSlots, deg.data(), sizeof(double2) * deg.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->g.lut_deg + lc * 360 * kDegWords, deg.data(), sizeof(double2) * deg.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->g.lut_knots + lc * e->p.kmax, knots.data(), sizeof(double2) * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->g.lut_bucket + lc * e->p.nbucket, bucket.data(), sizeof(uint16_t) * bucket.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->g.lut_count + lc, &n, sizeof(n), hipMemcpyHostToDevice));
@@ -1274,6 +1282,80 @@ extern "C" int mate_engine_idle_steps(mate_engine *e, int64_t *total) {
 }
 
 extern "C" int mate_engine_last_flow(const mate_engine *e) { return e ? e->last_flow : MATE_EINVAL; }
+
+// ---- observation blocks from shuffled 2 MiB physical chunks (include/mate_engine.h: mate_engine_block_alloc)
+namespace {
+struct ScatteredBlock { int device; size_t bytes; std::vector<hipMemGenericAllocationHandle_t> chunks; };
+std::mutex g_blocks_mutex;
+std::map<void *, ScatteredBlock> g_blocks;
+constexpr size_t kBlockChunk = (size_t)2 << 20;      // smaller chunks cost TLB reach (1 MiB: 4.1-4.7 TB/s), larger ones scatter less
+}  // namespace
+
+extern "C" int mate_engine_block_alloc(int32_t device, int64_t bytes, void **ptr_out) {
+    if (!ptr_out || bytes <= 0) return fail(MATE_EINVAL, "block_alloc: null output or empty block");
+    *ptr_out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t granularity = 0;
+    HIP_TRY(hipMemGetAllocationGranularity(&granularity, &prop, hipMemAllocationGranularityMinimum));
+    if (granularity == 0 || kBlockChunk % granularity != 0) return fail(MATE_EHIP, "block_alloc: allocation granularity %zu does not divide 2 MiB", granularity);
+    const size_t n = ((size_t)bytes + kBlockChunk - 1) / kBlockChunk, total = n * kBlockChunk;
+    void *va = nullptr;
+    HIP_TRY(hipMemAddressReserve(&va, total, kBlockChunk, nullptr, 0));
+    ScatteredBlock blk{device, total, {}};
+    blk.chunks.reserve(n);
+    auto undo = [&](size_t mapped) {
+        for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap((char *)va + i * kBlockChunk, kBlockChunk);
+        for (auto h : blk.chunks) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(va, total);
+    };
+    for (size_t i = 0; i < n; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        const hipError_t err = hipMemCreate(&h, kBlockChunk, &prop, 0);
+        if (err != hipSuccess) { undo(0); return fail(MATE_EHIP, "block_alloc: hipMemCreate failed after %zu of %zu chunks: %s", i, n, hipGetErrorString(err)); }
+        blk.chunks.push_back(h);
+    }
+    // the chunks come out of the driver in address order, more or less: slot i of the virtual range takes chunk order[i]
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = i;
+    std::mt19937_64 rng(0x9e3779b97f4a7c15ull ^ (uint64_t)(uintptr_t)va);
+    std::shuffle(order.begin(), order.end(), rng);
+    for (size_t i = 0; i < n; ++i) {
+        const hipError_t err = hipMemMap((char *)va + i * kBlockChunk, kBlockChunk, 0, blk.chunks[order[i]], 0);
+        if (err != hipSuccess) { undo(i); return fail(MATE_EHIP, "block_alloc: hipMemMap failed: %s", hipGetErrorString(err)); }
+    }
+    hipMemAccessDesc access = {};
+    access.location = prop.location;
+    access.flags = hipMemAccessFlagsProtReadWrite;
+    {
+        const hipError_t err = hipMemSetAccess(va, total, &access, 1);
+        if (err != hipSuccess) { undo(n); return fail(MATE_EHIP, "block_alloc: hipMemSetAccess failed: %s", hipGetErrorString(err)); }
+    }
+    std::lock_guard<std::mutex> lock(g_blocks_mutex);
+    g_blocks.emplace(va, std::move(blk));
+    *ptr_out = va;
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_block_free(void *ptr) {
+    if (!ptr) return MATE_OK;
+    ScatteredBlock blk;
+    {
+        std::lock_guard<std::mutex> lock(g_blocks_mutex);
+        auto it = g_blocks.find(ptr);
+        if (it == g_blocks.end()) return fail(MATE_EINVAL, "block_free: %p was not returned by mate_engine_block_alloc", ptr);
+        blk = std::move(it->second);
+        g_blocks.erase(it);
+    }
+    HIP_TRY(hipSetDevice(blk.device));
+    HIP_TRY(hipMemUnmap(ptr, blk.bytes));
+    for (auto h : blk.chunks) HIP_TRY(hipMemRelease(h));
+    HIP_TRY(hipMemAddressFree(ptr, blk.bytes));
+    return MATE_OK;
+}
 
 extern "C" int mate_engine_kernel_time(mate_engine *e, int32_t enable, double *avg_ms, int64_t *launches) {
     if (!e) return fail(MATE_EINVAL, "null engine");

@@ -281,9 +281,9 @@ __device__ __forceinline__ bool build_lut(Ctx<ObsT> &c, int cam, double *keys, d
         if (outer) { __syncthreads(); return false; }
         for (int d = tid; d < p.nbucket; d += nthreads) bucket[d] = d >= 360 ? 1 : 0;
         for (int d = tid; d < 360; d += nthreads) {
-            double2 *rec = c.g.lut_deg + (lc * 360 + d) * kDegSlots;
-            rec[0] = make_double2(-180.0, 0.0); rec[1] = make_double2(180.0, 0.0);
-            for (int i = 2; i < kDegSlots; ++i) rec[i] = make_double2(__longlong_as_double(0x7ff0000000000000ll), 0.0);
+            double2 *rec = c.g.lut_deg + (lc * 360 + d) * kDegWords;
+            degree_record_set(rec, 0, -180.0, 0.0, 0.0);      // (one segment from -180 to 180, range 0)
+            for (int i = 1; i < kDegSlots - 1; ++i) degree_record_set(rec, i, __longlong_as_double(0x7ff0000000000000ll), 0.0, 0.0);
         }
         __syncthreads();
         return false;
@@ -442,11 +442,12 @@ __device__ __forceinline__ bool build_lut(Ctx<ObsT> &c, int cam, double *keys, d
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     for (int d = tid; d < 360; d += nthreads) {       // per-degree records of the fast lookup path
         const int start = lbucket[d], endk = lbucket[d + 1];
-        double2 *rec = c.g.lut_deg + (lc * 360 + d) * kDegSlots;
+        double2 *rec = c.g.lut_deg + (lc * 360 + d) * kDegWords;
         if (endk - start + 1 <= kDegSlots) {
-            for (int i = 0; i < kDegSlots; ++i) {
+            for (int i = 0; i < kDegSlots - 1; ++i) {          // the degree's knots as segments (np.interp's slope, its own division)
                 const int idx = start + i;
-                rec[i] = idx <= endk ? make_double2(okeys[idx], ovals[idx]) : make_double2(inf, 0.0);
+                if (idx < endk) degree_record_set(rec, i, okeys[idx], ovals[idx], (ovals[idx + 1] - ovals[idx]) / (okeys[idx + 1] - okeys[idx]));
+                else degree_record_set(rec, i, inf, 0.0, 0.0);
             }
         } else {                                   // overflow: (NaN, first knot) (knots of the degree incl. the next integer one, -)
             rec[0] = make_double2(__longlong_as_double(0x7ff8000000000000ll), (double)start);
