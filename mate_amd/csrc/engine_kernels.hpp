@@ -1423,6 +1423,14 @@ __device__ __forceinline__ void stream_store(V v, V *dst) {
     __builtin_nontemporal_store(v, dst);
 #endif
 }
+template <typename V>
+__device__ __forceinline__ void stream_store(V v, __attribute__((address_space(1))) V *dst) {
+#ifdef MATE_STORE_PLAIN
+    *dst = v;
+#else
+    __builtin_nontemporal_store(v, dst);
+#endif
+}
 template <typename ObsT> struct Vec;
 template <> struct Vec<float> { using type = float4; static constexpr int W = 4; };
 template <> struct Vec<double> { using type = double2; static constexpr int W = 2; };
@@ -1715,15 +1723,15 @@ __device__ __forceinline__ void image_blocks(Ctx<ObsT> &c, const RangeRoles &rol
 }
 
 // The rows as they lie in LDS, 16 bytes per lane and chunk, to the output buffers (write-once stream: non-temporal).
+// `cam_low` / `tgt_low`: 16-byte chunk index of the two output BLOCKS' bases inside their cache lines ((address >> 4) & 7), read once
+// per launch -- the shift of a row follows from it and the row's index without waiting for the pointer itself.
 template <typename ObsT>
-__device__ __forceinline__ void image_store(const Ctx<ObsT> &c) {
+__device__ __forceinline__ void image_store(const Ctx<ObsT> &c, uint32_t cam_low, uint32_t tgt_low) {
     if constexpr (sizeof(ObsT) == 4) {
     const Params &p = c.p;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int nvc = p.cam_elems / 4, nvt = p.tgt_elems / 4;
     const f32x4 *src_c = reinterpret_cast<const f32x4 *>(c.img), *src_t = reinterpret_cast<const f32x4 *>(c.img + p.cam_elems);
-    f32x4 *cam = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.cam_obs) + c.out * p.cam_elems);
-    f32x4 *tgt = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems);
     // Every store instruction covers a 128-byte-ALIGNED kilobyte of the output: a row begins at a multiple of 16 bytes, not of a
     // cache line, so the lanes' chunks are shifted by the row's offset inside its first line (wave-uniform: 0..7 chunks).
     // Unshifted, every instruction straddles nine lines and the two partial ones are written again by its neighbour -- the
@@ -1731,17 +1739,31 @@ __device__ __forceinline__ void image_store(const Ctx<ObsT> &c) {
     // All LDS reads of a block before its first store (a store issued between them would be waited for with them).
     constexpr int GC = 3, GT = 7;       // (image_fits shapes: at most 128 camera chunks and 384 target chunks + 7 of shift; asserted by the host)
     const int lane = c.lane & 63;       // (the range, for the compiler)
-    const int sc = (int)((reinterpret_cast<uintptr_t>(cam) >> 4) & 7u), st = (int)((reinterpret_cast<uintptr_t>(tgt) >> 4) & 7u);
+#ifdef MATE_STORE_UNSHIFTED      // experiment switch: the rows' chunks as they lie, every instruction straddling nine lines
+    const int sc = 0, st = 0; (void)cam_low; (void)tgt_low;
+#else
+    const int sc = (int)((cam_low + (uint32_t)c.out * (uint32_t)nvc) & 7u), st = (int)((tgt_low + (uint32_t)c.out * (uint32_t)nvt) & 7u);
+#endif
     // (the shift goes into the wave-uniform bases; the LDS reads are unconditional -- a lane outside its row reads a neighbouring
     // part of the slice, or zeros past the workgroup's LDS, and stores nothing; only the first round needs the lower bound and
     // only the rounds that can reach the row's end the upper one)
     const f32x4 *from_c = src_c - sc, *from_t = src_t - st;
-    f32x4 *to_c = cam - sc, *to_t = tgt - st;
     f32x4 vc[GC], vt[GT];
 #pragma unroll
     for (int k = 0; k < GC; ++k) if (64 * k - 7 < nvc) vc[k] = from_c[lane + 64 * k];
 #pragma unroll
     for (int k = 0; k < GT; ++k) if (64 * k - 7 < nvt) vt[k] = from_t[lane + 64 * k];
+    // The blocks' base pointers come from the kernel-argument segment (a scalar load): first USED here, behind the LDS reads, so
+    // that one wait covers both -- used earlier, the reads would queue up behind the pointers' round trip (+350 cycles per step).
+    // (as integers through the barrier, and back as GLOBAL pointers: a generic pointer out of an asm stores through flat_store)
+    typedef __attribute__((address_space(1))) f32x4 global_f32x4;
+    uint64_t cam_base = reinterpret_cast<uint64_t>(c.g.cam_obs), tgt_base = reinterpret_cast<uint64_t>(c.g.tgt_obs);
+    asm volatile("" : "+s"(cam_base), "+s"(tgt_base), "+v"(vt[0]));
+    // (what comes out of an asm counts as divergent: say again that it is not, or the row arithmetic runs on the vector unit)
+    cam_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(cam_base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)cam_base);
+    tgt_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(tgt_base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)tgt_base);
+    global_f32x4 *to_c = (global_f32x4 *)(cam_base + (uint64_t)c.out * (uint64_t)(p.cam_elems * 4)) - sc;
+    global_f32x4 *to_t = (global_f32x4 *)(tgt_base + (uint64_t)c.out * (uint64_t)(p.tgt_elems * 4)) - st;
 #pragma unroll
     for (int k = 0; k < GC; ++k) if (64 * k - 7 < nvc) {
         const bool inside = (k > 0 || lane >= sc) && (64 * (k + 1) <= nvc || lane + 64 * k - sc < nvc);
@@ -1755,6 +1777,11 @@ __device__ __forceinline__ void image_store(const Ctx<ObsT> &c) {
     }
 }
 
+
+template <typename ObsT>
+__device__ __forceinline__ void image_store(const Ctx<ObsT> &c) {
+    image_store(c, (uint32_t)(reinterpret_cast<uintptr_t>(c.g.cam_obs) >> 4) & 7u, (uint32_t)(reinterpret_cast<uintptr_t>(c.g.tgt_obs) >> 4) & 7u);
+}
 
 // =============================================================================================
 // Register-resident step state of the fused random-policy rollout (row-image shapes).
@@ -2168,6 +2195,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     HeldState h{};
     int finished = 0;                // HELDSTATE: the episode is over (wave-uniform; the record's EI_DONE otherwise)
     const uint32_t tick0 = g.tick;   // (launch arguments read once: inside the loop each read is a scalar load and a wait)
+    const uint32_t cam_low = (uint32_t)(reinterpret_cast<uintptr_t>(g.cam_obs) >> 4) & 7u, tgt_low = (uint32_t)(reinterpret_cast<uintptr_t>(g.tgt_obs) >> 4) & 7u;
     const int n_steps = g.rollout_steps;
     if constexpr (HELDSTATE) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
@@ -2204,11 +2232,12 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         }
         const uint32_t tick = tick0 + (uint32_t)r;
         if (g.rotate_prio) {
-            const int turn = (r + wave_slot) & 3;
-            if (turn == 0) __builtin_amdgcn_s_setprio(0);
-            else if (turn == 1) __builtin_amdgcn_s_setprio(1);
-            else if (turn == 2) __builtin_amdgcn_s_setprio(2);
-            else __builtin_amdgcn_s_setprio(3);
+            // (s_setprio takes an immediate: a two-level tree of scalar branches, not a chain of four)
+            // rotate_prio >= 8 (experiment): the turn follows the shader clock >> rotate_prio instead of the wave's own step count --
+            // the four waves of a SIMD read the same clock, so their turns never coincide however far their steps drift apart
+            const int turn = g.rotate_prio >= 8 ? ((int)(__builtin_amdgcn_s_memtime() >> g.rotate_prio) + wave_slot) & 3 : (r + wave_slot) & 3;
+            if (turn & 2) { if (turn & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+            else { if (turn & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         }
 #ifdef MATE_PHASE_CLOCKS
 #define ROLL_STAMP(i) do { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
@@ -2245,7 +2274,9 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
             image_targets_held(c, h, last_gw);
             image_blocks(c, roles, seen);
             ROLL_STAMP(5);
-            if (!(MATE_ABLATE & 64)) { image_store(c); store_masks(c); }
+            // (measured and dropped: the rows of step r leaving in the MIDDLE of step r + 1, behind its occlusion wait, so that their
+            // acknowledgements have a whole step before the next wait instead of 40 % of one -- no faster)
+            if (!(MATE_ABLATE & 64)) { image_store(c, cam_low, tgt_low); store_masks(c); }
             wave_sync();
             stepped = true;
             ROLL_STAMP(6);
@@ -2265,9 +2296,9 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         if constexpr (IMAGE) {
             if (!(MATE_ABLATE & 32)) { image_targets(c, last_gw); image_blocks(c, roles, seen); }
             ROLL_STAMP(5);
-            if (!(MATE_ABLATE & 64)) { image_store(c); store_masks(c); }
+            if (!(MATE_ABLATE & 64)) { image_store(c, cam_low, tgt_low); store_masks(c); }
             if (MATE_DOUBLE & 32) { int gw2 = last_gw; image_targets(c, gw2); image_blocks(c, roles, seen); }
-            if (MATE_DOUBLE & 64) { wave_sync(); image_store(c); }
+            if (MATE_DOUBLE & 64) { wave_sync(); image_store(c, cam_low, tgt_low); }
         } else {
         if (!(MATE_ABLATE & 32)) fill_scratch(c, last_gw);
         ROLL_STAMP(5);

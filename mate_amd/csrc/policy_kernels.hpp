@@ -572,10 +572,8 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         const bool active = in_batch && c.ei(EI_DONE) == 0;
         if (g.rotate_prio) {
             const int turn = (r + wave_slot) & 3;
-            if (turn == 0) __builtin_amdgcn_s_setprio(0);
-            else if (turn == 1) __builtin_amdgcn_s_setprio(1);
-            else if (turn == 2) __builtin_amdgcn_s_setprio(2);
-            else __builtin_amdgcn_s_setprio(3);
+            if (turn & 2) { if (turn & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+            else { if (turn & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         }
         GREEDY_STAMP(7);
         if (!active) {                                             // past the end of the batch, or the episode has ended: no agents, no step

@@ -1,0 +1,106 @@
+"""Observation blocks of the fused rollouts: the scattered allocator behind ``mate_engine_block_alloc`` and the line-aligned
+row stores of the row-image kernels (a block may begin at any multiple of 16 bytes)."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_scattered_block_is_ordinary_device_memory():
+    """block_alloc hands out a contiguous virtual range (2 MiB chunks mapped in a shuffled order): a torch view over it reads
+    back what was written, a second block does not alias the first, block_free refuses a foreign pointer."""
+    from mate_amd import _native
+    nbytes = 5 * (1 << 20) + 4096                   # not a multiple of the chunk size
+    a = _native.ScatteredBlock(0, nbytes)
+    b = _native.ScatteredBlock(0, nbytes)
+    assert a.ptr % (2 << 20) == 0 and a.ptr != b.ptr
+    ta, tb = a.tensor(torch.int32, (nbytes // 4,)), b.tensor(torch.int32, (nbytes // 4,))
+    ref = torch.arange(nbytes // 4, dtype=torch.int32, device='cuda')
+    ta.copy_(ref); tb.copy_(-ref)
+    torch.cuda.synchronize()
+    assert torch.equal(ta, ref) and torch.equal(tb, -ref)
+    assert ta.data_ptr() == a.ptr
+    lib = _native.load()
+    assert lib.mate_engine_block_free(ctypes.c_void_p(ta.data_ptr() + 4096)) != 0
+    assert b'block_alloc' in lib.mate_engine_last_error()
+    del ta, a                                        # the tensor keeps the block alive; freeing happens with the last reference
+    torch.cuda.synchronize()
+    assert torch.equal(tb, -ref)
+
+
+@pytest.mark.parametrize('workload,n', [('MATE-4v8-9.yaml', 203), ('MATE-4v8-0.yaml', 66)])
+def test_rollout_rows_do_not_depend_on_the_blocks(workload, n):
+    """The same rollout into scattered blocks (the default of Engine.reserve_rollout for blocks of 64 MiB and more), into
+    torch's own memory (MATE_PLAIN_BLOCKS=1) and into blocks that begin 16 .. 112 bytes into a cache line -- the row-image
+    kernels shift every row's chunks so that a store instruction covers an aligned kilobyte, by the offset of the ROW inside
+    its line, which depends on the block's base: every row bit for bit, and nothing written outside the rows."""
+    from mate_amd._native import MateStepIO, check
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config(workload, max_episode_steps=13)
+    steps = 24
+
+    def run(mode):
+        os.environ['MATE_PLAIN_BLOCKS'] = '1' if mode == 'plain' else '0'
+        try:
+            eng = Engine(cfg, n, seed=5)
+            eng.reset()
+            L = eng.layout
+            big = (steps * n * eng.num_cameras * L.camera_obs_dim * 4) >= (64 << 20)
+            if isinstance(mode, int):            # a caller's own blocks, `mode` 16-byte chunks into a cache line, guard words around them
+                cam_elems, tgt_elems = n * eng.num_cameras * L.camera_obs_dim, n * eng.num_targets * L.target_obs_dim
+                pad = 64
+                cam_raw = torch.full((steps * cam_elems + 2 * pad,), -3.0, dtype=torch.float32, device='cuda')
+                tgt_raw = torch.full((steps * tgt_elems + 2 * pad,), -3.0, dtype=torch.float32, device='cuda')
+                cam = cam_raw[pad + 4 * mode: pad + 4 * mode + steps * cam_elems]
+                tgt = tgt_raw[pad + 4 * ((mode + 3) % 8): pad + 4 * ((mode + 3) % 8) + steps * tgt_elems]
+                sc = torch.zeros((steps, n, 8), dtype=torch.float32, device='cuda')
+                io = MateStepIO()
+                io.camera_obs_dev, io.target_obs_dev, io.scalars_dev, io.masks_dev = cam.data_ptr(), tgt.data_ptr(), sc.data_ptr(), None
+                out = []
+                for _ in range(2):
+                    cam.fill_(-3.0); tgt.fill_(-3.0)      # (rows of idle slots are not written: the same fill everywhere)
+                    check(eng.lib.mate_engine_rollout_random(eng._h, ctypes.byref(io), steps, 1, eng._stream()))
+                    torch.cuda.synchronize()
+                    out.append((cam.clone(), tgt.clone(), sc.clone()))
+                for raw, view in ((cam_raw, cam), (tgt_raw, tgt)):
+                    first = (view.data_ptr() - raw.data_ptr()) // 4
+                    assert (raw[:first] == -3.0).all() and (raw[first + view.numel():] == -3.0).all()
+                return out, eng.export_state().clone(), big
+            out = []
+            for _ in range(2):
+                buf = eng.reserve_rollout(steps)
+                buf['camera_obs'].fill_(-3.0); buf['target_obs'].fill_(-3.0)
+                c, t, s = eng.rollout_random(steps, auto_reset=True)
+                torch.cuda.synchronize()
+                out.append((c.reshape(-1).clone(), t.reshape(-1).clone(), s.clone()))
+            return out, eng.export_state().clone(), big
+        finally:
+            os.environ.pop('MATE_PLAIN_BLOCKS', None)
+
+    ref, ref_state, _ = run('plain')
+    for mode in ('scattered', 1, 2, 5, 7):
+        got, state, _ = run(mode)
+        for (c0, t0, s0), (c1, t1, s1) in zip(ref, got):
+            assert torch.equal(c0.view(torch.int32), c1.view(torch.int32)), mode
+            assert torch.equal(t0.view(torch.int32), t1.view(torch.int32)), mode
+            assert torch.equal(s0, s1), mode
+        assert torch.equal(ref_state, state), mode
+
+
+def test_reserve_rollout_uses_scattered_blocks_for_large_rollouts():
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    eng = Engine(read_config('MATE-4v8-9.yaml'), 2048, seed=0)
+    buf = eng.reserve_rollout(32)                   # 2048 x 32 x 4192 B = 262 MiB of target rows
+    assert buf['target_obs'].data_ptr() % (2 << 20) == 0
+    eng.reset()
+    cam, tgt, sc = eng.rollout_random(32, auto_reset=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(cam).all() and torch.isfinite(tgt).all() and (sc[..., 2] != 2).all()
+    eng._rollout = None                              # frees the blocks (after a device synchronise)
+    del buf, cam, tgt
+    torch.cuda.synchronize()
