@@ -16,7 +16,7 @@ EXPORTED_SYMBOLS = (
     'mate_engine_get_layout', 'mate_engine_set_obs_transform', 'mate_engine_set_obs_mode', 'mate_engine_set_action_grids', 'mate_engine_seed', 'mate_engine_reset', 'mate_engine_reset_tape', 'mate_engine_step', 'mate_engine_device_tick', 'mate_engine_set_episode_stats', 'mate_engine_step_random',
     'mate_engine_rollout_random', 'mate_engine_policy_enable', 'mate_engine_step_greedy', 'mate_engine_step_versus_greedy', 'mate_engine_rollout_greedy', 'mate_engine_rollout_versus_greedy', 'mate_engine_policy_actions',
     'mate_engine_observe', 'mate_engine_export_state', 'mate_engine_import_state', 'mate_engine_lut_read',
-    'mate_engine_block_alloc', 'mate_engine_block_free',
+    'mate_engine_block_alloc', 'mate_engine_block_free', 'mate_engine_block_probe',
     'mate_engine_lut_write', 'mate_engine_enable_outer_boundary', 'mate_engine_lut_read_outer', 'mate_engine_lut_write_outer', 'mate_engine_soft_coverage', 'mate_engine_rebuild_luts', 'mate_engine_idle_steps', 'mate_engine_kernel_time', 'mate_engine_last_flow',
 )
 
@@ -125,6 +125,7 @@ def load():
     handle.mate_engine_last_flow.argtypes = [P]
     handle.mate_engine_block_alloc.argtypes = [I32, I64, ctypes.POINTER(P)]
     handle.mate_engine_block_free.argtypes = [P]
+    handle.mate_engine_block_probe.argtypes = [I32, P, I64, I32, I32, P, ctypes.POINTER(ctypes.c_double)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(handle, name)
         if name not in ('mate_engine_last_error',):
@@ -143,6 +144,13 @@ class ScatteredBlock:
         check(load().mate_engine_block_alloc(int(device_index), int(nbytes), ctypes.byref(ptr)))
         self.ptr, self.nbytes, self.device_index, self._lib = ptr.value, int(nbytes), int(device_index), lib
         self.__cuda_array_interface__ = {'shape': (self.nbytes,), 'typestr': '|u1', 'data': (self.ptr, False), 'version': 2}
+
+    def store_rate(self, rows_per_step, row_bytes, stream=None):
+        """GB/s this block takes in the fused rollouts' store pattern (mate_engine_block_probe); leaves it zeroed."""
+        rate = ctypes.c_double()
+        check(self._lib.mate_engine_block_probe(self.device_index, ctypes.c_void_p(self.ptr), self.nbytes, int(rows_per_step), int(row_bytes),
+                                                stream, ctypes.byref(rate)))
+        return rate.value
 
     def tensor(self, dtype, shape):
         import torch

@@ -1340,6 +1340,51 @@ extern "C" int mate_engine_block_alloc(int32_t device, int64_t bytes, void **ptr
     return MATE_OK;
 }
 
+namespace {
+// the store pattern of image_store / pack_rows_f32 on one block: row r * rows_per_step + env, by the wave that owns env
+__global__ __launch_bounds__(256, 4) void block_probe_kernel(char *block, int64_t steps, int32_t rows_per_step, int32_t row_chunks) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t env = (int64_t)blockIdx.x * 4 + wave;
+    if (env >= rows_per_step) return;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = 0; r < steps; ++r) {
+        f32x4 *row = reinterpret_cast<f32x4 *>(block) + (r * rows_per_step + env) * row_chunks;
+        const int shift = (int)((reinterpret_cast<uintptr_t>(row) >> 4) & 7u);
+        for (int s = lane - shift; s < row_chunks; s += 64)
+            if (s >= 0) __builtin_nontemporal_store(zero, row + s);
+    }
+}
+}  // namespace
+
+extern "C" int mate_engine_block_probe(int32_t device, void *block, int64_t bytes, int32_t rows_per_step, int32_t row_bytes, void *stream,
+                                       double *gbytes_per_s) {
+    if (!block || !gbytes_per_s || rows_per_step <= 0 || row_bytes <= 0 || row_bytes % 16 != 0) return fail(MATE_EINVAL, "block_probe: null block / rate or a row that is no multiple of 16 bytes");
+    const int64_t steps = bytes / ((int64_t)rows_per_step * row_bytes);
+    if (steps <= 0) return fail(MATE_EINVAL, "block_probe: the block holds less than one step of rows");
+    HIP_TRY(hipSetDevice(device));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float best = 0.f;
+    for (int rep = 0; rep < 4; ++rep) {      // (the first launch also pages the kernel in)
+        HIP_TRY(hipEventRecord(e0, (hipStream_t)stream));
+        hipLaunchKernelGGL(block_probe_kernel, dim3((unsigned)((rows_per_step + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (char *)block, steps, rows_per_step, row_bytes / 16);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(e1, (hipStream_t)stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && (best == 0.f || ms < best)) best = ms;
+    }
+    HIP_TRY(hipEventDestroy(e0));
+    HIP_TRY(hipEventDestroy(e1));
+    const int64_t tail = bytes - steps * rows_per_step * row_bytes;
+    if (tail > 0) HIP_TRY(hipMemsetAsync((char *)block + (bytes - tail), 0, (size_t)tail, (hipStream_t)stream));
+    *gbytes_per_s = (double)(steps * rows_per_step) * row_bytes / ((double)best * 1e6);
+    return MATE_OK;
+}
+
 extern "C" int mate_engine_block_free(void *ptr) {
     if (!ptr) return MATE_OK;
     ScatteredBlock blk;

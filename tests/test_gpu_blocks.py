@@ -104,3 +104,31 @@ def test_reserve_rollout_uses_scattered_blocks_for_large_rollouts():
     eng._rollout = None                              # frees the blocks (after a device synchronise)
     del buf, cam, tgt
     torch.cuda.synchronize()
+
+
+def test_block_probe_and_candidate_search():
+    """block_probe reports a plausible store rate, leaves zeros behind and refuses rows that are no multiple of 16 bytes;
+    reserve_rollout's search over candidates (blocks of a GiB and more) records the rates it saw."""
+    from mate_amd import _native
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    rows, row_bytes, steps = 1024, 4192, 64
+    blk = _native.ScatteredBlock(0, rows * row_bytes * steps + 4096)
+    t = blk.tensor(torch.uint8, (blk.nbytes,))
+    t.fill_(7)
+    rate = blk.store_rate(rows, row_bytes)
+    torch.cuda.synchronize()
+    assert 200.0 < rate < 9000.0 and int(t.max()) == 0
+    with pytest.raises(_native.EngineError):
+        blk.store_rate(rows, row_bytes + 4)
+    os.environ['MATE_BLOCK_CANDIDATES'] = '2'
+    try:
+        eng = Engine(read_config('MATE-4v8-9.yaml'), 4096, seed=0)
+        eng.reserve_rollout(64)                      # 4096 x 64 x 4192 B = 1.02 GiB of target rows: searched; the camera block is not
+    finally:
+        os.environ.pop('MATE_BLOCK_CANDIDATES', None)
+    assert [len(r) for r in eng.block_rates] == [0, 2] and all(200.0 < x < 9000.0 for x in eng.block_rates[1])
+    eng.reset()
+    cam, tgt, sc = eng.rollout_random(64, auto_reset=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tgt).all() and float(tgt.abs().sum()) > 0.0

@@ -35,4 +35,5 @@ for _ in range(8):
         times[i].append(e0.elapsed_time(e1) * 1e3)
 for i, eng in enumerate(engines):
     r = eng._rollout
-    print('engine #%d: rollout median %.1f us | fill GB/s: camera block %.0f target block %.0f' % (i, statistics.median(times[i]), fill_rate(r['camera_obs']), fill_rate(r['target_obs'])))
+    print('engine #%d: rollout median %.1f us | fill GB/s: camera block %.0f target block %.0f' % (i, statistics.median(times[i]), fill_rate(r['camera_obs']), fill_rate(r['target_obs'])),
+          '| candidates probed [GB/s]:', [[round(x) for x in rr] for rr in getattr(eng, 'block_rates', [])])

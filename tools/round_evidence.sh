@@ -13,4 +13,11 @@ cp "$out"/c3kt/c3_kernel_stats.csv "$out/c3_kernel_stats.csv" 2>/dev/null || fin
 rm -rf "$out/c3kt"
 bash tools/sweep.sh "$out/sweep.jsonl" 2> "$out/sweep.err"
 cp mate_amd/lib/kernel_resources.json "$out/kernel_resources.json"
+# what the observation stores cost by themselves, and what the placement of the blocks does to them (binaries built by mate_amd.build --tools)
+[ -x tools/store_roof ] && tools/store_roof 4096 256 6 > "$out/store_roof.txt" 2>&1
+[ -x tools/store_vmm ] && tools/store_vmm 8 2 > "$out/store_vmm.txt" 2>&1
+[ -x tools/store_contig ] && tools/store_contig 4 > "$out/store_contig.txt" 2>&1
+[ -x tools/store_bits ] && tools/store_bits > "$out/store_bits.txt" 2>&1
+python3 tools/alloc_probe2.py 5 > "$out/blocks_scattered.txt" 2>&1
+MATE_PLAIN_BLOCKS=1 python3 tools/alloc_probe2.py 5 > "$out/blocks_plain.txt" 2>&1
 ls -la "$out"
