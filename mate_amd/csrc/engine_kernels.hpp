@@ -534,7 +534,7 @@ __device__ __forceinline__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &
         if constexpr (sizeof(ObsT) == 4) {         // f32 observations: f64 argument reduction, f32 polynomials (+8 % on the fused rollout:
             float sn, cs;                          // the camera lanes' f64 sincos was the longest dependent chain of the phase)
             sincos_deg_f32(ph, sn, cs);
-            const float srf = __builtin_sqrtf((float)sr2);
+            const float srf = sqrt_f32_1ulp((float)sr2);
             if (c.image()) {                       // the camera's public state (read by every block that shows it) and its own row
                 float *pc = c.pub_cam(lane), *row = c.img_cam_row(lane) + 13;
                 const float x = srf * cs, y = srf * sn, t = (float)th;
@@ -1855,7 +1855,7 @@ __device__ __forceinline__ void simulate_cameras_held(Ctx<ObsT> &c, const StepDr
         c.sight2(lane) = sr2;
         float sn, cs;
         sincos_deg_f32(ph, sn, cs);
-        const float srf = __builtin_sqrtf((float)sr2);
+        const float srf = sqrt_f32_1ulp((float)sr2);
         float *pc = c.pub_cam(lane), *row = c.img_cam_row(lane) + 13;
         const float x = srf * cs, y = srf * sn, tf = (float)th;
         pc[3] = x; pc[4] = y; pc[5] = tf; row[3] = x; row[4] = y; row[5] = tf;
