@@ -74,6 +74,11 @@ __device__ __forceinline__ double div_nz(double a, double b) {
 // The hardware's f32 root as it is (one unit in the last place; the argument is a normal number -- a squared sight range): the
 // correctly rounded sqrtf expands to fourteen instructions, for a value that is multiplied by a sine good to 3e-7 next.
 __device__ __forceinline__ float sqrt_f32_1ulp(float x) { return __builtin_amdgcn_sqrtf(x); }
+// a / n for a count n that a shape-specialised kernel knows at compile time: a power of two (eight targets) is an exact multiply
+__device__ __forceinline__ double div_by_count(double a, int n) {
+    if (__builtin_constant_p(n) && n > 0 && (n & (n - 1)) == 0) return a * (1.0 / (double)n);
+    return div_nz(a, (double)n);
+}
 __device__ __forceinline__ double norm2(double x, double y) { return sqrt_pos(fma(y, y, x * x)); }
 // np.clip on finite operands with lo <= hi, neither bound a zero (action limits, viewing-angle limits, the terrain): two
 // v_max / v_min instead of two compares and four selects.

@@ -402,7 +402,10 @@ __device__ __forceinline__ void load_records(Ctx<ObsT> &c) {
 struct StepDraws { double a0, a1; };
 constexpr int kNearWords = 3;                     // (= kRoleRounds, declared further down with the range-test roles)
 struct DrawCarry { uint32_t z, w, block; };      // second half of the lane's Philox block of the even tick, for the odd tick behind it
-template <typename ObsT> __device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry = nullptr);
+// What a lane draws is the same at every step of a launch: its stream and index, whether it draws at all, and -- an agent -- the
+// bounds of its two action components.  The fused rollout derives it once and holds it (22 vector instructions per step).
+struct DrawRole { uint32_t stream, sub; int32_t kind; double m0, m1; };      // kind: 0 none, 1 agent (action sample), 2 pair (transmittance draw)
+template <typename ObsT> __device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry = nullptr, const DrawRole *held = nullptr);
 
 template <typename ObsT>
 __device__ __forceinline__ StepDraws load_records_with_draws(Ctx<ObsT> &c, uint32_t tick, bool draw) {
@@ -463,18 +466,29 @@ __device__ __forceinline__ void store_dynamic(Ctx<ObsT> &c) {
 // actions, [Nc, Nc+Nt) target actions, the remaining lanes pre-draw the see-through uniforms of the
 // first camera->target pairs (cheaper than a second divergent Philox in the visibility phase).
 template <typename ObsT>
-__device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry) {
+__device__ __forceinline__ DrawRole draw_role(const Ctx<ObsT> &c) {
+    const Params &p = c.p;
+    const int lane = c.lane, nact = p.Nc + p.Nt;
+    const bool random_policy = c.mode() == MODE_STEP_RANDOM;
+    const bool need_draws = !c.tape_ct() && p.Nc > 0 && p.No > 0;      // (without obstacles nothing is ever seen THROUGH one)
+    DrawRole r{0u, 0u, 0, 0.0, 0.0};
+    if (lane < p.Nc) { r.stream = S_ACT_CAM; r.sub = (uint32_t)lane; r.kind = random_policy ? 1 : 0; r.m0 = p.rot; r.m1 = p.zoom; }
+    else if (lane < nact) { r.stream = S_ACT_TGT; r.sub = (uint32_t)(lane - p.Nc); r.kind = random_policy ? 1 : 0; r.m0 = p.tgt_step; r.m1 = p.tgt_step; }
+    else if (lane - nact < p.Nc * p.Nt) { r.stream = S_TRANSMIT; r.sub = (uint32_t)(lane - nact); r.kind = need_draws ? 2 : 0; }
+    return r;
+}
+__device__ __forceinline__ void pin_draw_role(DrawRole &r) {
+    asm volatile("" : "+v"(r.stream)); asm volatile("" : "+v"(r.sub)); asm volatile("" : "+v"(r.kind)); asm volatile("" : "+v"(r.m0)); asm volatile("" : "+v"(r.m1));
+}
+template <typename ObsT>
+__device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry, const DrawRole *held) {
     const Params &p = c.p;
     const int lane = c.lane;
     StepDraws d{0.0, 0.0};
     const int nact = p.Nc + p.Nt;
-    const bool random_policy = c.mode() == MODE_STEP_RANDOM;
-    const bool need_draws = !c.tape_ct() && p.Nc > 0 && p.No > 0;      // (without obstacles nothing is ever seen THROUGH one)
-    uint32_t stream = 0, sub = 0;
-    bool active = false;
-    if (lane < p.Nc) { stream = S_ACT_CAM; sub = (uint32_t)lane; active = random_policy; }
-    else if (lane < nact) { stream = S_ACT_TGT; sub = (uint32_t)(lane - p.Nc); active = random_policy; }
-    else if (lane - nact < p.Nc * p.Nt) { stream = S_TRANSMIT; sub = (uint32_t)(lane - nact); active = need_draws; }
+    const DrawRole role = held ? *held : draw_role(c);
+    const uint32_t stream = role.stream, sub = role.sub;
+    const bool active = role.kind != 0;
     // (a lane's role -- stream, sub -- is the same at every step of a launch, so the words it carries are its own)
     const uint32_t block = tick >> 1;
     uint32_t w0 = 0, w1 = 0;
@@ -486,10 +500,8 @@ __device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, Dra
     }
     if (carry && !(tick & 1u)) carry->block = block;
     if (active) {
-        if (lane < nact) {                        // one instruction stream for both kinds of agent
-            const double m0 = lane < p.Nc ? p.rot : p.tgt_step, m1 = lane < p.Nc ? p.zoom : p.tgt_step;
-            d.a0 = action_component(w0, m0); d.a1 = action_component(w1, m1);
-        } else c.udraw(lane - nact) = u53(w0, w1);
+        if (role.kind == 1) { d.a0 = action_component(w0, role.m0); d.a1 = action_component(w1, role.m1); }      // one instruction stream for both kinds of agent
+        else c.udraw(lane - nact) = u53(w0, w1);
     }
     return d;
 }
@@ -1294,7 +1306,7 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
         const double epd = c.ep_delayed() + delayed;
         c.ep_reward() = epr; c.ep_delayed() = epd;
         const int delivered = c.ei(EI_DELIVERED);
-        const double coverage = div_nz((double)n_tracked, (double)p.Nt);
+        const double coverage = div_by_count((double)n_tracked, p.Nt);
         const double real_cov = n_bounty > 0 ? div_nz((double)n_both, (double)n_bounty) : 0.0;
         const double transport = delivered > 0 ? div_nz(epd, p.reward_scale * (double)delivered) : 0.0;
         const double r = p.sparse_reward ? delayed : reward;
@@ -1573,13 +1585,17 @@ __device__ __forceinline__ bool packs_rows_f32(const Ctx<ObsT> &c) {
 template <typename ObsT>
 __device__ __forceinline__ void store_masks(const Ctx<ObsT> &c) {
     const Params &p = c.p;
+    // (one round when the words fit a wave -- every shipped scenario: the general loop's trip-count arithmetic is a dozen
+    // vector instructions per step)
     if (c.g.masks) {
         uint32_t *m = c.g.masks + c.out * p.MW;
-        for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
+        if (p.MW <= 64) { if (c.lane < p.MW) m[c.lane] = c.mask[c.lane]; }
+        else for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
     }
     if (c.g.own_masks) {
         uint32_t *m = c.g.own_masks + c.env * p.MW;
-        for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
+        if (p.MW <= 64) { if (c.lane < p.MW) m[c.lane] = c.mask[c.lane]; }
+        else for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
     }
 }
 
@@ -1965,7 +1981,7 @@ __device__ __forceinline__ int assign_and_score_held(Ctx<ObsT> &c, uint32_t tick
         const double epd = h.ep_delayed + delayed;
         h.ep_reward = epr; h.ep_delayed = epd;
         const int delivered = h.delivered;
-        const double coverage = div_nz((double)n_tracked, (double)p.Nt);
+        const double coverage = div_by_count((double)n_tracked, p.Nt);
         const double real_cov = n_bounty > 0 ? div_nz((double)n_both, (double)n_bounty) : 0.0;
         const double transport = delivered > 0 ? div_nz(epd, p.reward_scale * (double)delivered) : 0.0;
         const double r = p.sparse_reward ? delayed : reward;
@@ -2190,6 +2206,11 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     bool stepped = false;            // a full step has written the static mask words, flags and scratch slots
     int last_gw = -1;                // fill_scratch: the goal word behind the target's goal / cargo slots
     DrawCarry carry{0u, 0u, 0xffffffffu};
+    DrawRole draws_of_lane;
+    {
+        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
+        draws_of_lane = draw_role(c);
+    }
     // The register-resident step (HeldState): the row-image shapes under the random-policy flow
     constexpr bool HELDSTATE = IMAGE && FLOW == FLOW_RANDOM;
     HeldState h{};
@@ -2254,7 +2275,8 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
 #define MATE_DOUBLE 0          // dynamic instruction counters against the plain build is that phase's exact share, on real data
 #endif
         StepDraws draws{0.0, 0.0};
-        if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick, &carry);
+        pin_draw_role(draws_of_lane);
+        if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick, &carry, &draws_of_lane);
         if (MATE_DOUBLE & 1) { DrawCarry again = carry; again.block = 0xffffffffu; const StepDraws d2 = step_draws(c, tick, &again); draws.a0 += 0.0 * d2.a0; }
         ROLL_STAMP(0);
         if constexpr (HELDSTATE) {
