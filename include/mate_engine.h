@@ -24,7 +24,8 @@
  *                            for the common flows (mate_engine_last_flow)
  *   MATE_STAGGER=<digits>    wave priorities of the single-step kernel at its five phase boundaries, one decimal digit
  *                            (0-3) each; 0 = off; default 33210 while the batch is one resident generation, else off
- *   MATE_ROLLOUT_ROTATE=0    no per-step rotation of the wave priorities in the fused rollout kernels (default 1)
+ *   MATE_ROLLOUT_ROTATE=0    no per-step rotation of the wave priorities in the fused rollout kernels (default 1; 8..20: the
+ *                            turn follows the shader clock >> n instead of the wave's step count -- measured, no gain)
  *   MATE_RESET_MONOLITHIC=1  whole-batch / masked / batched resets as ONE launch instead of placement, per-camera
  *                            occlusion tables and first view as separate launches
  *   MATE_LUT_SMALL_CAP=<n>   ray capacity of the small-LDS occlusion-table launch (default: half of the worst case);

@@ -18,6 +18,14 @@ cp mate_amd/lib/kernel_resources.json "$out/kernel_resources.json"
 [ -x tools/store_vmm ] && tools/store_vmm 8 2 > "$out/store_vmm.txt" 2>&1
 [ -x tools/store_contig ] && tools/store_contig 4 > "$out/store_contig.txt" 2>&1
 [ -x tools/store_bits ] && tools/store_bits > "$out/store_bits.txt" 2>&1
+# per-wave phase clocks (profiling build), the single-step and learner-versus-greedy probes
+if [ -f mate_amd/lib/libmate_engine_prof.so ]; then
+  MATE_ENGINE_LIB=$PWD/mate_amd/lib/libmate_engine_prof.so python3 tools/rollout_phases.py MATE-4v8-9.yaml 4096 256 > "$out/rollout_phases_4096.txt" 2>&1
+  MATE_ENGINE_LIB=$PWD/mate_amd/lib/libmate_engine_prof.so python3 tools/rollout_phases.py MATE-4v8-9.yaml 1024 256 > "$out/rollout_phases_1024.txt" 2>&1
+  MATE_ENGINE_LIB=$PWD/mate_amd/lib/libmate_engine_prof.so python3 tools/greedy_phases.py MATE-8v8-9.yaml 8192 32 > "$out/greedy_phases.txt" 2>&1
+fi
+python3 tools/k1_probe.py > "$out/k1_probe.txt" 2>&1
+python3 tools/versus_probe.py > "$out/versus_probe.txt" 2>&1
 python3 tools/alloc_probe2.py 5 > "$out/blocks_scattered.txt" 2>&1
 MATE_PLAIN_BLOCKS=1 python3 tools/alloc_probe2.py 5 > "$out/blocks_plain.txt" 2>&1
 ls -la "$out"
