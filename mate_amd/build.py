@@ -66,5 +66,25 @@ def build_engine(force=False, verbose=False):
     return OUT
 
 
+def build_tools(verbose=False):
+    """The stand-alone measurement programs under tools/ (store rooflines, issue rates): one hipcc call each, binaries next to
+    the sources (git-ignored; they travel to the GPU box with the tree)."""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    built = []
+    for name in ('store_roof', 'store_bits', 'store_contig', 'store_vmm', 'region_bw', 'valu_rates'):
+        src, out = os.path.join(tools, name + '.hip'), os.path.join(tools, name)
+        if not os.path.exists(src) or (os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src)):
+            continue
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.dirname(SRC), '-o', out, src]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        built.append(out)
+    return built
+
+
 if __name__ == '__main__':
     build_engine(force='--force' in sys.argv, verbose=True)
+    if '--tools' in sys.argv:
+        build_tools(verbose=True)
