@@ -120,6 +120,7 @@ struct AnyShape {
     static constexpr int kHeldGC = 2, kHeldGT = 6;
     static constexpr bool kImage = false;
     static constexpr bool kHoldRoles = false;      // rollout kernel: lane roles in registers (needs compile-time round counts)
+    static constexpr bool kGreedyRoles = false;
     static constexpr int kGreedyBlocks = 4;        // rollout_greedy_kernel: workgroups per CU the register budget is set for
     static constexpr bool kGreedyHeld = false;     // ... and whether it keeps the observation descriptors in registers across steps
     const Params *pp;
@@ -140,7 +141,8 @@ template <int NC, int NT, int NO, bool F64, bool IMAGE = false>
 struct FixedShape {
     static constexpr bool kImage = IMAGE;
     static_assert(!IMAGE || (!F64 && image_fits(NC, NT, NO)), "row-image mode: f32 observations of a shape that fits");
-    static constexpr bool kHoldRoles = shape_range_rounds(NC, NT, NO) <= 3;      // 4 words per round: fits beside the held descriptors
+    static constexpr bool kHoldRoles = shape_range_rounds(NC, NT, NO) <= 3;      // 5 words per round: fits beside the held descriptors
+    static constexpr bool kGreedyRoles = shape_range_rounds(NC, NT, NO) <= 4;    // rollout_greedy_kernel: MATE-8v8-9's four rounds too
     // observation descriptors the fused rollouts hold per lane: all chunks of the shape's rows (up to twelve uint4)
     static constexpr int kRowsC = (NC * (13 + 9 + 5 * NT + 4 * NO + 7 * NC) / 4 + 63) / 64, kRowsT = (NT * (13 + 14 + 7 * NC + 4 * NO + 5 * NT) / 4 + 63) / 64;
     static constexpr int kHeldGC = (kRowsC + kRowsT <= 12) ? kRowsC : 2, kHeldGT = (kRowsC + kRowsT <= 12) ? kRowsT : 6;
@@ -400,7 +402,7 @@ __device__ __forceinline__ void load_records(Ctx<ObsT> &c) {
 // while they are in flight (all co-resident waves of a SIMD start together: without this they idle through the
 // HBM latency together and then contend for the VALU together), then the data is committed to LDS.
 struct StepDraws { double a0, a1; };
-constexpr int kNearWords = 3;                     // (= kRoleRounds, declared further down with the range-test roles)
+constexpr int kNearWords = 4;                     // (= kRoleRounds, declared further down with the range-test roles)
 struct DrawCarry { uint32_t z, w, block; };      // second half of the lane's Philox block of the even tick, for the odd tick behind it
 // What a lane draws is the same at every step of a launch: its stream and index, whether it draws at all, and -- an agent -- the
 // bounds of its two action components.  The fused rollout derives it once and holds it (22 vector instructions per step).
@@ -769,7 +771,8 @@ struct SectorEval { bool seen, need; double rn, x; int64_t lc; };      // rn: th
 // whether that is the diagonal, and the squared limit (sight + the other's radius)^2 -- all static inside an episode.
 // The fused rollout, which is VALU-bound, computes them once per launch and keeps them in registers (`HELD`); the
 // single-step kernel derives them in place.
-constexpr int kRoleRounds = 3;       // (4 -- MATE-8v8-9's 200 range pairs -- was measured: no faster, and 126 of the 128 registers a wave may hold)
+constexpr int kRoleRounds = 4;       // (the fused random-policy rollout holds up to three -- Shape::kHoldRoles: a fourth, MATE-8v8-9's 200 range pairs,
+                                     // measured no faster there at 126 of the 128 registers a wave may hold -- the fused Greedy rollout all four)
 // Sensor.perceive (entities.py:229-232), `distance <= sight_range + radius`, is first tried on the f32 shadow of the entity
 // table: with positions rounded to f32 the distance is off by at most 1.3e-4 and the squared distance by at most
 // 2 * lim * 1.3e-4 + 3e-7 * lim^2 near the limit; outside a band of 2e-3 * lim + 2e-5 * lim^2 (eight times that) the f32
@@ -826,13 +829,19 @@ __device__ __forceinline__ void image_block_of(const Params &p, bool viewer_is_c
 }
 // The roles are pure functions of the lane id: left alone, the compiler re-derives them inside the step loop instead of
 // holding them (15 instructions per step for the sector role alone).  Passing each word through an empty asm makes it opaque.
-__device__ __forceinline__ void pin_roles(RangeRoles &r) {
+// (only what the kernel at hand reads is pinned -- a pinned word is a live register: `rounds` range rounds, the block words of the
+// row-image mode, the sector pair of the shapes with one sector round)
+__device__ __forceinline__ void pin_roles(RangeRoles &r, int rounds = kRoleRounds, bool image = true, bool sector = true) {
 #pragma unroll
-    for (int i = 0; i < kRoleRounds; ++i) { asm volatile("" : "+v"(r.at[i])); asm volatile("" : "+v"(r.aj[i])); asm volatile("" : "+v"(r.lim2[i])); asm volatile("" : "+v"(r.rim[i])); asm volatile("" : "+v"(r.reach2[i])); }
+    for (int i = 0; i < kRoleRounds; ++i)
+        if (i < rounds) { asm volatile("" : "+v"(r.at[i])); asm volatile("" : "+v"(r.aj[i])); asm volatile("" : "+v"(r.lim2[i])); asm volatile("" : "+v"(r.rim[i])); asm volatile("" : "+v"(r.reach2[i])); }
+    if (image) {
 #pragma unroll
-    for (int i = 0; i < 1 + kRoleRounds; ++i) asm volatile("" : "+v"(r.block[i]));
-    asm volatile("" : "+v"(r.sector)); asm volatile("" : "+v"(r.block_bits));
-    asm volatile("" : "+v"(r.sec_cam)); asm volatile("" : "+v"(r.sec_other)); asm volatile("" : "+v"(r.sec_draw));
+        for (int i = 0; i < 1 + kRoleRounds; ++i)
+            if (i <= rounds) asm volatile("" : "+v"(r.block[i]));
+        asm volatile("" : "+v"(r.block_bits));
+    }
+    if (sector) { asm volatile("" : "+v"(r.sector)); asm volatile("" : "+v"(r.sec_cam)); asm volatile("" : "+v"(r.sec_other)); asm volatile("" : "+v"(r.sec_draw)); }
 }
 template <typename ObsT>
 __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &roles) {
@@ -2248,7 +2257,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         const int64_t env_r = (int64_t)blockIdx.x * 4 + wave_r;
         // (... and the held roles: predicates derived from them would otherwise be hoisted out of the loop as SGPR masks, which
         // the kernel has no scalar registers left for -- each came back as two v_readlane per step)
-        if constexpr (Shape::kHoldRoles) pin_roles(roles);
+        if constexpr (Shape::kHoldRoles) pin_roles(roles, p.range_rounds, IMAGE, p.sector_rounds == 1);
         Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW);
         c.out = (int64_t)r * g.N + env_r;
         c.statics_done = stepped;

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         else if constexpr (Shape::kGreedyHeld) load_pack_descriptors(c, held);
     }
     // the lane's range-test roles held in registers, and with them the collision screen carried from step to step (NearCarry)
-    constexpr bool ROLES = Shape::kHoldRoles;
+    constexpr bool ROLES = Shape::kGreedyRoles;
     NearCarry near{};
     if constexpr (ROLES) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         const Params &p = shape_r.get();
         const int64_t env_w = (int64_t)blockIdx.x * 4 + wave_r;
         const int64_t env_r = env_w < g.N ? env_w : g.N - 1;
-        if constexpr (ROLES) pin_roles(roles);
+        if constexpr (ROLES) pin_roles(roles, p.range_rounds, IMAGE, p.sector_rounds == 1);
         Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW_GREEDY);
         c.out = (int64_t)r * g.N + env_r;
         c.act_cam = act_cam; c.act_tgt = act_tgt;
