@@ -1134,17 +1134,38 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     seen_out |= seen_bits << 1;
     };
     if (compact) {
-        // pass 2: the long part on the compacted list, 64 candidates at a time (usually one chunk).  (Not overlapped with the
-        // range tests as the one-round path below is: the occlusion records held across them cost 20 VGPRs the fused
-        // rollouts of these shapes do not have.)
-        for (int k = lane; k < n_cand; k += 64) {
+        // pass 2: the long part on the compacted list, 64 candidates at a time (usually one chunk).  The occlusion records of the
+        // FIRST chunk travel while the range tests run -- not into registers, as in the one-round path below (24 VGPRs the
+        // fused rollouts of these shapes do not have), but into the caches: one dword of each of the record's two possible
+        // lines is touched before the range tests, the record itself is fetched behind them (a hit instead of a round trip
+        // to HBM: the lookup's latency was a fifth of this phase).
+        SectorEval first;
+        first.seen = false; first.need = false;
+        int q_first = 0;
+        uint32_t touch0 = 0u, touch1 = 0u;
+        if (lane < n_cand) {
+            q_first = cand[lane];
+            first = sector_eval<true>(c, q_first, tick, stream, predrawn);
+            if (first.need) {
+                const double2 *rec = c.g.lut_deg + (first.lc * 360 + degree_of(first.x)) * kDegWords;
+                asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:92" : "+v"(touch0), "+v"(touch1) : "v"(rec) : "memory");
+            }
+        }
+        range_tests();
+        write_range_ballots();
+        if (lane < n_cand) {
+            sector_fetch(c, first, w);
+            if (sector_resolve(c, first, w)) { set_flag(c, q_first, true); atomicOr(&c.mask[q_first >> 5], 1u << (q_first & 31)); }
+        }
+        // (the two touched words land whenever they land -- in order, so before the record behind them: their registers stay
+        // reserved until here, or a late arrival would overwrite whatever the compiler had put there)
+        asm volatile("" :: "v"(touch0), "v"(touch1));
+        for (int k = lane + 64; k < n_cand; k += 64) {
             const int q = cand[k];
             const SectorEval e = sector_eval<true>(c, q, tick, stream, predrawn);
             sector_fetch(c, e, w);
             if (sector_resolve(c, e, w)) { set_flag(c, q, true); atomicOr(&c.mask[q >> 5], 1u << (q & 31)); }
         }
-        range_tests();
-        write_range_ballots();
     } else {
         // ---- sector tests for camera->target and camera->camera; all rounds but the last resolve at once, the last round's
         // occlusion records travel while the range tests run
