@@ -321,6 +321,9 @@ struct Ctx {
     // launch switches (constants in the specialised flows)
     __device__ __forceinline__ int mode() const { return flow == FLOW_RANDOM ? (int)MODE_STEP_RANDOM : (flow == FLOW_ACT_F32 || flow == FLOW_GREEDY) ? (int)MODE_STEP : g.mode; }
     __device__ __forceinline__ bool act_from_lds() const { return flow == FLOW_GREEDY; }
+    // camera->target pairs whose transmittance draw step_draws makes ahead of the visibility phase: one lane each -- the lanes
+    // behind the agents', and the agents' own wherever those draw no actions (every flow but the on-device random policy)
+    __device__ __forceinline__ int predrawn_pairs() const { return mode() == MODE_STEP_RANDOM ? 64 - p.Nc - p.Nt : 64; }
     __device__ __forceinline__ int act_f64() const { return g.act_f64; }     // (a launch argument in every flow: f32 and f64 joint actions, per team, run the specialised kernel)
     __device__ __forceinline__ int act_discrete() const { return flow != FLOW_ANY ? 0 : g.act_discrete; }
     __device__ __forceinline__ const double *tape_ct() const { return flow != FLOW_ANY ? nullptr : g.tape_ct; }
@@ -474,8 +477,12 @@ __device__ __forceinline__ DrawRole draw_role(const Ctx<ObsT> &c) {
     const bool random_policy = c.mode() == MODE_STEP_RANDOM;
     const bool need_draws = !c.tape_ct() && p.Nc > 0 && p.No > 0;      // (without obstacles nothing is ever seen THROUGH one)
     DrawRole r{0u, 0u, 0, 0.0, 0.0};
-    if (lane < p.Nc) { r.stream = S_ACT_CAM; r.sub = (uint32_t)lane; r.kind = random_policy ? 1 : 0; r.m0 = p.rot; r.m1 = p.zoom; }
-    else if (lane < nact) { r.stream = S_ACT_TGT; r.sub = (uint32_t)(lane - p.Nc); r.kind = random_policy ? 1 : 0; r.m0 = p.tgt_step; r.m1 = p.tgt_step; }
+    if (lane < nact && !random_policy) {       // an agent's lane with no action to draw: the pair behind the last pair lane's (predrawn_pairs)
+        const int pair = 64 - nact + lane;
+        if (pair < p.Nc * p.Nt) { r.stream = S_TRANSMIT; r.sub = (uint32_t)pair; r.kind = need_draws ? 2 : 0; }
+    }
+    else if (lane < p.Nc) { r.stream = S_ACT_CAM; r.sub = (uint32_t)lane; r.kind = 1; r.m0 = p.rot; r.m1 = p.zoom; }
+    else if (lane < nact) { r.stream = S_ACT_TGT; r.sub = (uint32_t)(lane - p.Nc); r.kind = 1; r.m0 = p.tgt_step; r.m1 = p.tgt_step; }
     else if (lane - nact < p.Nc * p.Nt) { r.stream = S_TRANSMIT; r.sub = (uint32_t)(lane - nact); r.kind = need_draws ? 2 : 0; }
     return r;
 }
@@ -503,7 +510,7 @@ __device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, Dra
     if (carry && !(tick & 1u)) carry->block = block;
     if (active) {
         if (role.kind == 1) { d.a0 = action_component(w0, role.m0); d.a1 = action_component(w1, role.m1); }      // one instruction stream for both kinds of agent
-        else c.udraw(lane - nact) = u53(w0, w1);
+        else c.udraw((int)sub) = u53(w0, w1);
     }
     return d;
 }
@@ -945,7 +952,7 @@ __device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t 
         const int pair = cam * p.Nt + other;
         double u;
         if (c.tape_ct()) u = c.tape_ct()[c.env * p.Nc * p.Nt + pair];
-        else if (predrawn && pair < 64 - p.Nc - p.Nt) u = c.udraw(pair);
+        else if (predrawn && pair < c.predrawn_pairs()) u = c.udraw(pair);
         else u = c.draw(tick, stream, (uint32_t)pair);
         if ((p.tau <= 0.5) ? (u > 1.0 - p.tau) : (u <= p.tau)) { e.seen = true; return e; }
     }
@@ -974,10 +981,10 @@ __device__ __forceinline__ SectorEval sector_eval_held(Ctx<ObsT> &c, const Range
     if (p.No == 0) { e.seen = true; return e; }
     if ((role >> 16) & 1) {                                                        // np_random.binomial(1, tau), entities.py:503
         double u;
-        if (predrawn && p.Nc * p.Nt <= 64 - p.Nc - p.Nt) u = lds_f64(h.sec_draw, p.off_tmp + 8 * (p.Nc + 3 * p.Nt));
+        if (predrawn && p.Nc * p.Nt <= c.predrawn_pairs()) u = lds_f64(h.sec_draw, p.off_tmp + 8 * (p.Nc + 3 * p.Nt));
         else {
             const int pair = (role & 0xff) * p.Nt + ((role >> 8) & 0xff);
-            if (predrawn && pair < 64 - p.Nc - p.Nt) u = c.udraw(pair);
+            if (predrawn && pair < c.predrawn_pairs()) u = c.udraw(pair);
             else u = c.draw(tick, stream, (uint32_t)pair);
         }
         if ((p.tau <= 0.5) ? (u > 1.0 - p.tau) : (u <= p.tau)) { e.seen = true; return e; }
