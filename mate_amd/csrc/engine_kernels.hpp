@@ -801,6 +801,7 @@ typedef __attribute__((address_space(3))) const float lds_cf32;
 __device__ __forceinline__ uint32_t lds_addr(const void *q) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)q; }
 __device__ __forceinline__ double lds_f64(uint32_t a, int byte_off = 0) { return *(lds_cf64 *)(uintptr_t)(a + (uint32_t)byte_off); }
 __device__ __forceinline__ float lds_f32(uint32_t a, int byte_off = 0) { return *(lds_cf32 *)(uintptr_t)(a + (uint32_t)byte_off); }
+constexpr uint32_t kPass1Diag = 0xfffffffeu, kPass1None = 0xffffffffu;
 constexpr int kSectorDiag = -3;      // RangeRoles::sector of a camera and itself (always seen, environment.py:1383-1384)
 struct RangeRoles {
     uint32_t at[kRoleRounds], aj[kRoleRounds];   // LDS addresses of the f32 shadow x of the round's target / of the other (y: + 4 NJ)
@@ -811,6 +812,9 @@ struct RangeRoles {
     float rim[kRoleRounds];
     int32_t sector;                  // the lane's pair in the last sector round: sector_role, kSectorDiag, or -1
     uint32_t sec_cam, sec_other, sec_draw;       // ... LDS addresses: slice + 8 cam, slice + 8 (the other's entity slot), slice + 8 pair
+    // shapes with two sector rounds (the compacted list): the lane's pair of each round for the range test that fills the list --
+    // 8 cam | 8 (the other's entity slot) << 16, kPass1Diag for a camera and itself, kPass1None without a pair
+    uint32_t pass1[2];
     // row-image mode: the (viewer, other) block each of the lane's pairs owns in the observation rows -- slot 0 the sector pair,
     // slots 1.. the range rounds: LDS byte offset of the other's public state | of the block in the viewer's row << 16
     uint32_t block[1 + kRoleRounds];
@@ -849,6 +853,7 @@ __device__ __forceinline__ void pin_roles(RangeRoles &r, int rounds = kRoleRound
         asm volatile("" : "+v"(r.block_bits));
     }
     if (sector) { asm volatile("" : "+v"(r.sector)); asm volatile("" : "+v"(r.sec_cam)); asm volatile("" : "+v"(r.sec_other)); asm volatile("" : "+v"(r.sec_draw)); }
+    else { asm volatile("" : "+v"(r.pass1[0])); asm volatile("" : "+v"(r.pass1[1])); }
 }
 template <typename ObsT>
 __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &roles) {
@@ -878,6 +883,16 @@ __device__ __forceinline__ void range_roles(const Ctx<ObsT> &c, RangeRoles &role
             uint32_t code;
             image_block_of(p, false, t, j, roles.block[1 + round], code);
             roles.block_bits |= code << (2 * (1 + round));
+        }
+    }
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const int role = sector_role(p, round * 64 + c.lane);
+        roles.pass1[round] = kPass1None;
+        if (role >= 0) {
+            const int cam = role & 0xff, other = (role >> 8) & 0xff;
+            const bool is_target = (role >> 16) & 1;
+            roles.pass1[round] = !is_target && cam == other ? kPass1Diag : (uint32_t)(8 * cam) | ((uint32_t)(8 * (is_target ? c.tgt_slot(other) : other)) << 16);
         }
     }
     roles.block[0] = 0u;
@@ -1059,8 +1074,20 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         // rest into a list; pass 2 runs the long part on the list, 64 candidates at a time (usually once).
         for (int round = 0; round < p.sector_rounds; ++round) {
             const int q = round * 64 + lane;
-            const int role = sector_role(p, q);
             bool diag = false, in_range = false;
+            if (HELD && p.sector_rounds == 2) {       // the pair's LDS offsets held since the launch began (RangeRoles::pass1)
+                const uint32_t held_pair = held.pass1[round & 1];
+                if (held_pair != kPass1None) {
+                    diag = held_pair == kPass1Diag;
+                    if (!diag) {
+                        const uint32_t a_cam = lds_addr(c.base) + (held_pair & 0xffffu), a_oj = lds_addr(c.base) + (held_pair >> 16);
+                        const double rx = lds_f64(a_oj, p.off_ent) - lds_f64(a_cam, p.off_ent), ry = lds_f64(a_oj, p.off_ent + 8 * p.NJ) - lds_f64(a_cam, p.off_ent + 8 * p.NJ);
+                        in_range = !sector_out_of_range(fma(ry, ry, rx * rx), lds_f64(a_cam, p.off_tmp));
+                    }
+                    set_flag(c, q, diag);
+                }
+            } else {
+            const int role = sector_role(p, q);
             if (role >= 0) {
                 const int cam = role & 0xff, other = (role >> 8) & 0xff;
                 const bool is_target = (role >> 16) & 1;
@@ -1071,6 +1098,7 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
                     in_range = !sector_out_of_range(fma(ry, ry, rx * rx), c.sight2(cam));
                 }
                 set_flag(c, q, diag);
+            }
             }
             const unsigned long long b = __ballot(diag), m = __ballot(in_range);
             if (lane == 0) { c.mask[2 * round] = (uint32_t)b; c.mask[2 * round + 1] = (uint32_t)(b >> 32); }
