@@ -26,7 +26,14 @@ def test_scattered_block_is_ordinary_device_memory():
     lib = _native.load()
     assert lib.mate_engine_block_free(ctypes.c_void_p(ta.data_ptr() + 4096)) != 0
     assert b'block_alloc' in lib.mate_engine_last_error()
-    del ta, a                                        # the tensor keeps the block alive; freeing happens with the last reference
+    del a                                            # the tensor keeps the block alive; freeing happens with the last reference
+    import gc
+    gc.collect()
+    ta.add_(1)
+    torch.cuda.synchronize()
+    assert torch.equal(ta, ref + 1)
+    del ta
+    gc.collect()
     torch.cuda.synchronize()
     assert torch.equal(tb, -ref)
 
