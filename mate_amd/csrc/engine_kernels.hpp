@@ -1819,17 +1819,21 @@ __device__ __forceinline__ void image_store(const Ctx<ObsT> &c, uint32_t cam_low
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int nvc = p.cam_elems / 4, nvt = p.tgt_elems / 4;
     const f32x4 *src_c = reinterpret_cast<const f32x4 *>(c.img), *src_t = reinterpret_cast<const f32x4 *>(c.img + p.cam_elems);
-    // Every store instruction covers a 128-byte-ALIGNED kilobyte of the output: a row begins at a multiple of 16 bytes, not of a
-    // cache line, so the lanes' chunks are shifted by the row's offset inside its first line (wave-uniform: 0..7 chunks).
-    // Unshifted, every instruction straddles nine lines and the two partial ones are written again by its neighbour -- the
-    // access pattern alone stores 5 % slower (tools/store_roof.hip).
+    // -DMATE_STORE_SHIFTED (measured, not shipped): every store instruction covers a 128-byte-ALIGNED kilobyte of the output -- a row
+    // begins at a multiple of 32 bytes, not of a cache line, so the lanes' chunks are shifted by the row's offset inside its first
+    // line (wave-uniform: 0..7 chunks).  Unshifted, every instruction straddles nine lines and the two partial ones are written
+    // again by its neighbour: the store pattern BY ITSELF is 5 % slower (tools/store_roof.hip) -- and the kernel 1.3 % faster, on
+    // every box it was tried on and in either order (30 interleaved launches each): the shifted form is one store instruction and
+    // two execution masks more.
     // All LDS reads of a block before its first store (a store issued between them would be waited for with them).
     constexpr int GC = 3, GT = 7;       // (image_fits shapes: at most 128 camera chunks and 384 target chunks + 7 of shift; asserted by the host)
     const int lane = c.lane & 63;       // (the range, for the compiler)
-#ifdef MATE_STORE_UNSHIFTED      // experiment switch: the rows' chunks as they lie, every instruction straddling nine lines
-    const int sc = 0, st = 0; (void)cam_low; (void)tgt_low;
-#else
+#ifdef MATE_STORE_SHIFTED
+    constexpr int slack = 7;
     const int sc = (int)((cam_low + (uint32_t)c.out * (uint32_t)nvc) & 7u), st = (int)((tgt_low + (uint32_t)c.out * (uint32_t)nvt) & 7u);
+#else
+    constexpr int slack = 0;
+    constexpr int sc = 0, st = 0; (void)cam_low; (void)tgt_low;
 #endif
     // (the shift goes into the wave-uniform bases; the LDS reads are unconditional -- a lane outside its row reads a neighbouring
     // part of the slice, or zeros past the workgroup's LDS, and stores nothing; only the first round needs the lower bound and
@@ -1837,9 +1841,9 @@ __device__ __forceinline__ void image_store(const Ctx<ObsT> &c, uint32_t cam_low
     const f32x4 *from_c = src_c - sc, *from_t = src_t - st;
     f32x4 vc[GC], vt[GT];
 #pragma unroll
-    for (int k = 0; k < GC; ++k) if (64 * k - 7 < nvc) vc[k] = from_c[lane + 64 * k];
+    for (int k = 0; k < GC; ++k) if (64 * k - slack < nvc) vc[k] = from_c[lane + 64 * k];
 #pragma unroll
-    for (int k = 0; k < GT; ++k) if (64 * k - 7 < nvt) vt[k] = from_t[lane + 64 * k];
+    for (int k = 0; k < GT; ++k) if (64 * k - slack < nvt) vt[k] = from_t[lane + 64 * k];
     // The blocks' base pointers come from the kernel-argument segment (a scalar load): first USED here, behind the LDS reads, so
     // that one wait covers both -- used earlier, the reads would queue up behind the pointers' round trip (+350 cycles per step).
     // (as integers through the barrier, and back as GLOBAL pointers: a generic pointer out of an asm stores through flat_store)
@@ -1852,12 +1856,12 @@ __device__ __forceinline__ void image_store(const Ctx<ObsT> &c, uint32_t cam_low
     global_f32x4 *to_c = (global_f32x4 *)(cam_base + (uint64_t)c.out * (uint64_t)(p.cam_elems * 4)) - sc;
     global_f32x4 *to_t = (global_f32x4 *)(tgt_base + (uint64_t)c.out * (uint64_t)(p.tgt_elems * 4)) - st;
 #pragma unroll
-    for (int k = 0; k < GC; ++k) if (64 * k - 7 < nvc) {
+    for (int k = 0; k < GC; ++k) if (64 * k - slack < nvc) {
         const bool inside = (k > 0 || lane >= sc) && (64 * (k + 1) <= nvc || lane + 64 * k - sc < nvc);
         if (inside) stream_store(vc[k], &to_c[lane + 64 * k]);
     }
 #pragma unroll
-    for (int k = 0; k < GT; ++k) if (64 * k - 7 < nvt) {
+    for (int k = 0; k < GT; ++k) if (64 * k - slack < nvt) {
         const bool inside = (k > 0 || lane >= st) && (64 * (k + 1) <= nvt || lane + 64 * k - st < nvt);
         if (inside) stream_store(vt[k], &to_t[lane + 64 * k]);
     }

@@ -41,9 +41,9 @@ def test_scattered_block_is_ordinary_device_memory():
 @pytest.mark.parametrize('workload,n', [('MATE-4v8-9.yaml', 203), ('MATE-4v8-0.yaml', 66)])
 def test_rollout_rows_do_not_depend_on_the_blocks(workload, n):
     """The same rollout into scattered blocks (the default of Engine.reserve_rollout for blocks of 64 MiB and more), into
-    torch's own memory (MATE_PLAIN_BLOCKS=1) and into blocks that begin 16 .. 112 bytes into a cache line -- the row-image
-    kernels shift every row's chunks so that a store instruction covers an aligned kilobyte, by the offset of the ROW inside
-    its line, which depends on the block's base: every row bit for bit, and nothing written outside the rows."""
+    torch's own memory (MATE_PLAIN_BLOCKS=1) and into a caller's blocks that begin 16 .. 112 bytes into a cache line (any
+    16-byte-aligned device pointer is a valid block; the -DMATE_STORE_SHIFTED form of the row stores derives its lane shifts
+    from the base): every row bit for bit, and nothing written outside the rows."""
     from mate_amd._native import MateStepIO, check
     from mate_amd.config import read_config
     from mate_amd.engine import Engine
