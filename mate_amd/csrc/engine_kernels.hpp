@@ -2355,21 +2355,20 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         if (MATE_DOUBLE & 1) { DrawCarry again = carry; again.block = 0xffffffffu; const StepDraws d2 = step_draws(c, tick, &again); draws.a0 += 0.0 * d2.a0; }
         ROLL_STAMP(0);
         if constexpr (HELDSTATE) {
-            simulate_cameras_held(c, draws, h);
+            if (!(MATE_ABLATE & 2)) simulate_cameras_held(c, draws, h);
             ROLL_STAMP(1);
-            simulate_targets_held(c, draws, near, h);
+            if (!(MATE_ABLATE & 4)) simulate_targets_held(c, draws, near, h);
             ROLL_STAMP(2);
             uint32_t seen = 0u;
             unsigned long long sector_ballot = 0ull;
-            update_view<true, true>(c, tick, S_TRANSMIT, true, roles, seen, &near, &sector_ballot);
+            if (!(MATE_ABLATE & 8)) update_view<true, true>(c, tick, S_TRANSMIT, true, roles, seen, &near, &sector_ballot);
             if (MATE_DOUBLE & 8) { uint32_t again; update_view<true, true>(c, tick, S_TRANSMIT, true, roles, again, &near, &sector_ballot); seen |= again; }
             bool tracked; int inside;
             view_tail_held(c, sector_ballot, h, tracked, inside);
             ROLL_STAMP(3);
-            finished = assign_and_score_held(c, tick, g.scalars, h, tracked, inside);
+            if (!(MATE_ABLATE & 16)) finished = assign_and_score_held(c, tick, g.scalars, h, tracked, inside);
             ROLL_STAMP(4);
-            image_targets_held(c, h, last_gw);
-            image_blocks(c, roles, seen);
+            if (!(MATE_ABLATE & 32)) { image_targets_held(c, h, last_gw); image_blocks(c, roles, seen); }
             ROLL_STAMP(5);
             // (measured and dropped: the rows of step r leaving in the MIDDLE of step r + 1, behind its occlusion wait, so that their
             // acknowledgements have a whole step before the next wait instead of 40 % of one -- no faster)
