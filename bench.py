@@ -597,6 +597,9 @@ def main():
                 'achieved_resident': resident / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
                 'frac_resident': resident / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else 0.0,
                 'end_to_end_frac': b_alg * value / world / 1e9 / HBM_PEAK_GBS,
+                # where the observation blocks lie decides up to a fifth of a fused launch (the stores): the store
+                # rates [GB/s] of the candidates Engine.reserve_rollout probed for the camera and the target block (it kept the fastest)
+                'observation_block_candidates_gbs': [[round(x) for x in r] for r in getattr(eng, 'block_rates', [])],
             },
             'episode_stats': {'mean_target_reward': float(stats[0]), 'mean_coverage_rate': float(stats[1]),
                               'mean_delivered': float(stats[2]), 'gathered_in_loop': gathered_stats},

@@ -284,11 +284,12 @@ class Engine:
         if nbytes < (64 << 20) or os.environ.get('MATE_PLAIN_BLOCKS') == '1':
             return torch.zeros(shape, dtype=self.obs_dtype, device=self.device)
         # Shuffled chunks make a slow block unlikely, not impossible (tools/store_vmm.hip): blocks of a GiB and more -- the ones
-        # a launch is bounded by -- are the fastest of up to MATE_BLOCK_CANDIDATES (default 4) candidates in the kernels' own
+        # a launch is bounded by -- are the fastest of up to MATE_BLOCK_CANDIDATES (default 6) candidates in the kernels' own
         # store pattern, where the device has the memory to hold them side by side; the search ends at the first candidate
-        # that is clearly (12 %) faster than another.
+        # that is a class (25 %) faster than another -- blocks come in three: ~4.5, ~5.2 and ~5.9 TB/s on MATE-4v8-9's rows, about
+        # one in three of the last.
         row_bytes = nbytes // (shape[0] * shape[1])
-        tries = int(os.environ.get('MATE_BLOCK_CANDIDATES', '4')) if nbytes >= (1 << 30) and row_bytes % 16 == 0 else 1
+        tries = int(os.environ.get('MATE_BLOCK_CANDIDATES', '6')) if nbytes >= (1 << 30) and row_bytes % 16 == 0 else 1
         free = torch.cuda.mem_get_info(self.device)[0]
         tries = max(1, min(tries, int(free // (2 * nbytes))))
         best, rates, held = None, [], []
@@ -302,7 +303,7 @@ class Engine:
             held.append(block)          # (kept until the search ends: a freed candidate would be handed out again)
             if best is None or rate > best[0]:
                 best = (rate, block)
-            if len(rates) > 1 and best[0] >= 1.12 * min(rates):
+            if len(rates) > 1 and best[0] >= 1.25 * min(rates):
                 break
         self.block_rates = getattr(self, 'block_rates', []) + [rates]
         block = best[1]
