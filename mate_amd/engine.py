@@ -294,7 +294,15 @@ class Engine:
         tries = max(1, min(tries, int(free // (2 * nbytes))))
         best, rates, held = None, [], []
         for _ in range(tries):
-            block = _native.ScatteredBlock(self.device_index, nbytes)
+            try:
+                block = _native.ScatteredBlock(self.device_index, nbytes)
+            except _native.EngineError as err:      # no virtual-memory management on this driver, or out of memory: plain memory works as well
+                if best is None:
+                    import warnings
+                    warnings.warn(f'mate_engine_block_alloc failed ({err}); the rollout block comes from torch.zeros')
+                    self.block_rates = getattr(self, 'block_rates', []) + [rates]
+                    return torch.zeros(shape, dtype=self.obs_dtype, device=self.device)
+                break
             if tries == 1:
                 best = (0.0, block)
                 break
