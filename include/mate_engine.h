@@ -343,8 +343,8 @@ int mate_engine_last_flow(const mate_engine *engine);
 int mate_engine_block_alloc(int32_t device, int64_t bytes, void **ptr_out);
 int mate_engine_block_free(void *ptr);
 /* How fast THIS block takes the fused rollouts' stores: a store-only launch with their shape (one wave per environment, four
- * per workgroup, `rows_per_step` environments, `row_bytes` per environment and step -- a multiple of 16 --, every store
- * instruction an aligned kilobyte of non-temporal 16-byte stores) over the whole block, best of three, in GB/s.  Shuffled chunks
+ * per workgroup, `rows_per_step` environments, `row_bytes` per environment and step -- a multiple of 16 --, a kilobyte of
+ * non-temporal 16-byte stores per instruction) over the whole block, best of three, in GB/s.  Shuffled chunks
  * make a slow block unlikely, not impossible (one in four on some GPUs of the pool): a caller that has memory to spare allocates
  * a few candidates, keeps the fastest and frees the rest -- Engine.reserve_rollout does.  The block is left filled with zeros. */
 int mate_engine_block_probe(int32_t device, void *block, int64_t bytes, int32_t rows_per_step, int32_t row_bytes, void *stream,

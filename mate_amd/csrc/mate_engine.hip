@@ -1350,9 +1350,7 @@ __global__ __launch_bounds__(256, 4) void block_probe_kernel(char *block, int64_
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int64_t r = 0; r < steps; ++r) {
         f32x4 *row = reinterpret_cast<f32x4 *>(block) + (r * rows_per_step + env) * row_chunks;
-        const int shift = (int)((reinterpret_cast<uintptr_t>(row) >> 4) & 7u);
-        for (int s = lane - shift; s < row_chunks; s += 64)
-            if (s >= 0) __builtin_nontemporal_store(zero, row + s);
+        for (int s = lane; s < row_chunks; s += 64) __builtin_nontemporal_store(zero, row + s);
     }
 }
 }  // namespace
