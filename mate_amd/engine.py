@@ -283,13 +283,13 @@ class Engine:
         nbytes = int(np.prod(shape)) * torch.empty((), dtype=self.obs_dtype).element_size()
         if nbytes < (64 << 20) or os.environ.get('MATE_PLAIN_BLOCKS') == '1':
             return torch.zeros(shape, dtype=self.obs_dtype, device=self.device)
-        # Shuffled chunks make a slow block unlikely, not impossible (tools/store_vmm.hip): blocks of a GiB and more -- the ones
+        # Shuffled chunks make a slow block unlikely, not impossible (tools/store_vmm.hip): blocks of 128 MiB and more -- the ones
         # a launch is bounded by -- are the fastest of up to MATE_BLOCK_CANDIDATES (default 6) candidates in the kernels' own
         # store pattern, where the device has the memory to hold them side by side; the search ends at the first candidate
         # that is a class (25 %) faster than another -- blocks come in three: ~4.5, ~5.2 and ~5.9 TB/s on MATE-4v8-9's rows, about
         # one in three of the last.
         row_bytes = nbytes // (shape[0] * shape[1])
-        tries = int(os.environ.get('MATE_BLOCK_CANDIDATES', '6')) if nbytes >= (1 << 30) and row_bytes % 16 == 0 else 1
+        tries = int(os.environ.get('MATE_BLOCK_CANDIDATES', '6')) if nbytes >= (128 << 20) and row_bytes % 16 == 0 else 1
         free = torch.cuda.mem_get_info(self.device)[0]
         tries = max(1, min(tries, int(free // (2 * nbytes))))
         best, rates, held = None, [], []

@@ -131,10 +131,13 @@ def test_block_probe_and_candidate_search():
     os.environ['MATE_BLOCK_CANDIDATES'] = '2'
     try:
         eng = Engine(read_config('MATE-4v8-9.yaml'), 4096, seed=0)
-        eng.reserve_rollout(64)                      # 4096 x 64 x 4192 B = 1.02 GiB of target rows: searched; the camera block is not
+        eng.reserve_rollout(5)                       # 4096 x 5 x 4192 B = 82 MiB of target rows: not searched
+        assert [len(r) for r in eng.block_rates] == [0] and eng._rollout['target_obs'].data_ptr() % (2 << 20) == 0
+        eng.block_rates = []
+        eng.reserve_rollout(64)                      # 1.02 GiB of target rows and 0.5 GiB of camera rows: both searched
     finally:
         os.environ.pop('MATE_BLOCK_CANDIDATES', None)
-    assert [len(r) for r in eng.block_rates] == [0, 2] and all(200.0 < x < 9000.0 for x in eng.block_rates[1])
+    assert [len(r) for r in eng.block_rates] == [2, 2] and all(200.0 < x < 9000.0 for r in eng.block_rates for x in r)
     eng.reset()
     cam, tgt, sc = eng.rollout_random(64, auto_reset=True)
     torch.cuda.synchronize()
