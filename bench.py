@@ -259,7 +259,7 @@ class StatsGather:
             elif self.distributed:
                 self.dist.all_gather(self.gathered[self.turn], self.slots[self.turn])
             else:
-                self.gathered[self.turn][0].copy_(self.slots[self.turn], non_blocking=True)
+                self.gathered[self.turn][0] = self.slots[self.turn]      # one rank: the all-gather is the identity (no second copy)
         self.last = self.turn
         self.turn ^= 1
         self.count += 1
