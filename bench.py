@@ -239,6 +239,7 @@ class StatsGather:
         self.events = [torch.cuda.Event() for _ in range(2)]
         self.turn = self.last = 0
         self.count = 0
+        self.marked = False
 
     def mark(self):
         """The point of the launch stream the next submit() gathers at (default: where submit() itself is called)."""
@@ -248,7 +249,7 @@ class StatsGather:
     def submit(self):
         torch = self.torch
         ready = self.events[self.turn]
-        if not getattr(self, 'marked', False):
+        if not self.marked:
             ready.record()
         self.marked = False
         with torch.cuda.stream(self.side):
@@ -435,7 +436,7 @@ def main():
             # last one, where its copy + collective would sit between the kernel's end and the region's closing synchronise
             # (15 us of a 200 us region at the driver's `--steps 20`)
             short = timed and gather is not None and len(lengths) < args.stats_interval
-            if short:
+            if short and not gather.marked:
                 gather.mark()            # (an event record: the copy + collective are enqueued behind the first launch, below,
             for i, n in enumerate(lengths):          # so that the host prepares them while the GPU already runs it)
                 rollout(n, auto_reset=True)
@@ -444,7 +445,7 @@ def main():
         else:
             every = args.stats_interval * 128
             short = timed and gather is not None and steps < every
-            if short:
+            if short and not gather.marked:
                 gather.mark()
             for i in range(steps):
                 step()
@@ -486,6 +487,11 @@ def main():
     rep_ms, rep_executed, kernel_times = [], [], []
     for rep in range(max(0, args.rep_warmup) + max(1, args.reps)):
         eng.kernel_time(enable=1 if R > 0 else 16)   # HIP-event pair around (every 16th) launch of the dominant kernel
+        # a region shorter than the gather interval gathers the episodes finished BEFORE it (see run): the marker of what that
+        # gather may read is recorded here, behind the previous repetition's last launch -- an event record in front of the
+        # region's only launch delays it by 4 us (tools/region_probe.py); the gather itself is enqueued inside the region
+        if gather is not None and ((R > 0 and -(-args.steps // R) < args.stats_interval) or (R == 0 and external is None and args.steps < args.stats_interval * 128)):
+            gather.mark()
         barrier()
         idle0 = eng.idle_steps()
         allocated0 = torch.cuda.memory_allocated()

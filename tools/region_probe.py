@@ -19,12 +19,14 @@ slot = torch.zeros(5, dtype=torch.float64, device='cuda')
 
 
 def region(kind):
+    if kind == 'premark':
+        ev.record()              # (the marker of what the gather may read: recorded behind the previous region's last launch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if kind == 'gather':
         ev.record()
     eng.rollout_random(20, auto_reset=6)
-    if kind == 'gather':
+    if kind in ('gather', 'premark'):
         with torch.cuda.stream(side):
             side.wait_event(ev)
             slot.copy_(eng.episode_stats, non_blocking=True)
@@ -32,7 +34,7 @@ def region(kind):
     return (time.perf_counter() - t0) * 1e6
 
 
-for kind, timing in (('plain', 0), ('plain', 1), ('gather', 1), ('plain', 0)):
+for kind, timing in (('plain', 0), ('plain', 1), ('gather', 1), ('premark', 1), ('gather', 1), ('premark', 1), ('plain', 0)):
     eng.kernel_time(enable=timing)
     ts = sorted(region(kind) for _ in range(300))
     avg, n = eng.kernel_time(enable=0)
