@@ -11,11 +11,12 @@ from mate_amd.config import read_config  # noqa: E402
 import mate_amd._native as native  # noqa: E402
 import mate_amd.engine as engine_mod  # noqa: E402
 
-libs = [os.path.abspath(p) for p in sys.argv[1:3]]
-workload = sys.argv[3] if len(sys.argv) > 3 else 'MATE-4v8-9.yaml'
-batch = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
-R = int(sys.argv[5]) if len(sys.argv) > 5 else 256
-rounds = int(sys.argv[6]) if len(sys.argv) > 6 else 12
+libs = [os.path.abspath(p) for p in sys.argv[1:] if p.endswith('.so')]      # two or more builds
+rest = [p for p in sys.argv[1:] if not p.endswith('.so')]
+workload = rest[0] if len(rest) > 0 else 'MATE-4v8-9.yaml'
+batch = int(rest[1]) if len(rest) > 1 else 4096
+R = int(rest[2]) if len(rest) > 2 else 256
+rounds = int(rest[3]) if len(rest) > 3 else 12
 # where the observation blocks lie decides 5-25 % of a launch (tools/store_roof.hip): BOTH builds write the SAME blocks here, and
 # BALLAST_GB (default 64) of device memory is taken first -- the blocks then lie in the part of the memory where every
 # allocation measured fast
