@@ -340,6 +340,11 @@ int mate_engine_last_flow(const mate_engine *engine);
  * contiguous); any device pointer works in mate_step_io -- this one is only faster to write.  `bytes` is rounded up to
  * 2 MiB.  block_free unmaps and releases it (the pointer must come from block_alloc; the CALLER has waited for every launch
  * that reads or writes the block -- the library does not synchronise here). */
+/* The form of the row stores of the row-image rollouts (MATE-4v8-9, MATE-4v8-0 under mate_engine_rollout_random): 0 (default) the
+ * rows' 16-byte chunks as they lie -- 1.3-2 % faster where the blocks take the rows fast, i.e. where the arithmetic bounds a launch
+ * --, 1 every store instruction an aligned kilobyte -- 3 % faster where they do not (mate_engine_block_probe of the target block
+ * below ~4.8 TB/s: the stores bound the launch).  Same rows either way.  Engine.reserve_rollout sets it from what it probed. */
+int mate_engine_set_store_form(mate_engine *engine, int32_t shifted);
 int mate_engine_block_alloc(int32_t device, int64_t bytes, void **ptr_out);
 int mate_engine_block_free(void *ptr);
 /* How fast THIS block takes the fused rollouts' stores: a store-only launch with their shape (one wave per environment, four

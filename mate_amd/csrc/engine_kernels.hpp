@@ -212,6 +212,7 @@ struct Ptrs {
     int32_t act_discrete;         // bit 0 camera actions, bit 1 target actions are int32 grid indices
     int32_t obs_mode;             // bits 0-1 camera team, bits 2-3 target team: 0 plain, 1 EnhancedObservation, 2 SharedFieldOfView
     int32_t rotate_prio;          // rollout kernel: rotate the wave priorities (fair SIMD shares, see rollout_kernel)
+    int32_t store_shifted;        // row-image rollouts: the line-aligned form of the row stores (image_store_form; mate_engine_set_store_form)
 };
 
 #ifdef MATE_PHASE_CLOCKS
@@ -1812,29 +1813,24 @@ __device__ __forceinline__ void image_blocks(Ctx<ObsT> &c, const RangeRoles &rol
 // The rows as they lie in LDS, 16 bytes per lane and chunk, to the output buffers (write-once stream: non-temporal).
 // `cam_low` / `tgt_low`: 16-byte chunk index of the two output BLOCKS' bases inside their cache lines ((address >> 4) & 7), read once
 // per launch -- the shift of a row follows from it and the row's index without waiting for the pointer itself.
-template <typename ObsT>
-__device__ __forceinline__ void image_store(const Ctx<ObsT> &c, uint32_t cam_low, uint32_t tgt_low) {
+template <bool SHIFTED, typename ObsT>
+__device__ __forceinline__ void image_store_form(const Ctx<ObsT> &c, uint32_t cam_low, uint32_t tgt_low) {
     if constexpr (sizeof(ObsT) == 4) {
     const Params &p = c.p;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int nvc = p.cam_elems / 4, nvt = p.tgt_elems / 4;
     const f32x4 *src_c = reinterpret_cast<const f32x4 *>(c.img), *src_t = reinterpret_cast<const f32x4 *>(c.img + p.cam_elems);
-    // -DMATE_STORE_SHIFTED (measured, not shipped): every store instruction covers a 128-byte-ALIGNED kilobyte of the output -- a row
-    // begins at a multiple of 32 bytes, not of a cache line, so the lanes' chunks are shifted by the row's offset inside its first
-    // line (wave-uniform: 0..7 chunks).  Unshifted, every instruction straddles nine lines and the two partial ones are written
-    // again by its neighbour: the store pattern BY ITSELF is 5 % slower (tools/store_roof.hip) -- and the kernel 1.3 % faster, on
-    // every box it was tried on and in either order (30 interleaved launches each): the shifted form is one store instruction and
-    // two execution masks more.
+    // SHIFTED: every store instruction covers a 128-byte-ALIGNED kilobyte of the output -- a row begins at a multiple of 32 bytes, not
+    // of a cache line, so the lanes' chunks are shifted by the row's offset inside its first line (wave-uniform: 0..7 chunks).
+    // Unshifted, every instruction straddles nine lines and the two partial ones are written again by its neighbour: the store
+    // pattern BY ITSELF is 5 % slower (tools/store_roof.hip).  In the kernel the shifted form -- one store instruction and two
+    // execution masks more -- is 1.3-2 % slower where the blocks take the rows fast (the arithmetic bounds the launch) and 3 %
+    // faster where they do not (the stores do): Ptrs::store_shifted picks the form per launch (mate_engine_set_store_form).
     // All LDS reads of a block before its first store (a store issued between them would be waited for with them).
     constexpr int GC = 3, GT = 7;       // (image_fits shapes: at most 128 camera chunks and 384 target chunks + 7 of shift; asserted by the host)
     const int lane = c.lane & 63;       // (the range, for the compiler)
-#ifdef MATE_STORE_SHIFTED
-    constexpr int slack = 7;
-    const int sc = (int)((cam_low + (uint32_t)c.out * (uint32_t)nvc) & 7u), st = (int)((tgt_low + (uint32_t)c.out * (uint32_t)nvt) & 7u);
-#else
-    constexpr int slack = 0;
-    constexpr int sc = 0, st = 0; (void)cam_low; (void)tgt_low;
-#endif
+    constexpr int slack = SHIFTED ? 7 : 0;
+    const int sc = SHIFTED ? (int)((cam_low + (uint32_t)c.out * (uint32_t)nvc) & 7u) : 0, st = SHIFTED ? (int)((tgt_low + (uint32_t)c.out * (uint32_t)nvt) & 7u) : 0;
     // (the shift goes into the wave-uniform bases; the LDS reads are unconditional -- a lane outside its row reads a neighbouring
     // part of the slice, or zeros past the workgroup's LDS, and stores nothing; only the first round needs the lower bound and
     // only the rounds that can reach the row's end the upper one)
@@ -1869,6 +1865,11 @@ __device__ __forceinline__ void image_store(const Ctx<ObsT> &c, uint32_t cam_low
 }
 
 
+template <typename ObsT>
+__device__ __forceinline__ void image_store(const Ctx<ObsT> &c, uint32_t cam_low, uint32_t tgt_low) {
+    if (c.g.store_shifted) image_store_form<true>(c, cam_low, tgt_low);      // (wave-uniform: a launch argument)
+    else image_store_form<false>(c, cam_low, tgt_low);
+}
 template <typename ObsT>
 __device__ __forceinline__ void image_store(const Ctx<ObsT> &c) {
     image_store(c, (uint32_t)(reinterpret_cast<uintptr_t>(c.g.cam_obs) >> 4) & 7u, (uint32_t)(reinterpret_cast<uintptr_t>(c.g.tgt_obs) >> 4) & 7u);

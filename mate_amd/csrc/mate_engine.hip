@@ -1283,6 +1283,12 @@ extern "C" int mate_engine_idle_steps(mate_engine *e, int64_t *total) {
 
 extern "C" int mate_engine_last_flow(const mate_engine *e) { return e ? e->last_flow : MATE_EINVAL; }
 
+extern "C" int mate_engine_set_store_form(mate_engine *e, int32_t shifted) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    e->g.store_shifted = shifted ? 1 : 0;
+    return MATE_OK;
+}
+
 // ---- observation blocks from shuffled 2 MiB physical chunks (include/mate_engine.h: mate_engine_block_alloc)
 namespace {
 struct ScatteredBlock { int device; size_t bytes; std::vector<hipMemGenericAllocationHandle_t> chunks; };

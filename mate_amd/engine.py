@@ -337,6 +337,13 @@ class Engine:
                     'masks': torch.zeros((steps, N, L.mask_words), dtype=torch.int32, device=self.device) if want_masks else None,
                 }
             self._rollout = buf
+            # where even the best candidate takes the rows slowly the stores bound a launch, and the line-aligned form of the row
+            # stores wins 3 %; elsewhere it costs 1.3-2 % (include/mate_engine.h).  MATE_STORE_FORM=0 / 1 forces a form.
+            form = os.environ.get('MATE_STORE_FORM', 'auto')
+            probed = [max(r) for r in getattr(self, 'block_rates', [])[-2:] if r]
+            shifted = form == '1' or (form == 'auto' and bool(probed) and probed[-1] < 4800.0)
+            self.store_form = int(shifted)
+            check(self.lib.mate_engine_set_store_form(self._h, int(shifted)))
         return buf
 
     def _run_rollout(self, entry_point, steps, auto_reset, want_masks):

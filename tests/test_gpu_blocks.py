@@ -42,8 +42,8 @@ def test_scattered_block_is_ordinary_device_memory():
 def test_rollout_rows_do_not_depend_on_the_blocks(workload, n):
     """The same rollout into scattered blocks (the default of Engine.reserve_rollout for blocks of 64 MiB and more), into
     torch's own memory (MATE_PLAIN_BLOCKS=1) and into a caller's blocks that begin 16 .. 112 bytes into a cache line (any
-    16-byte-aligned device pointer is a valid block; the -DMATE_STORE_SHIFTED form of the row stores derives its lane shifts
-    from the base): every row bit for bit, and nothing written outside the rows."""
+    16-byte-aligned device pointer is a valid block; the line-aligned form of the row stores, mate_engine_set_store_form,
+    derives its lane shifts from the base and the row index): every row bit for bit, and nothing written outside the rows."""
     from mate_amd._native import MateStepIO, check
     from mate_amd.config import read_config
     from mate_amd.engine import Engine
@@ -58,6 +58,7 @@ def test_rollout_rows_do_not_depend_on_the_blocks(workload, n):
             L = eng.layout
             big = (steps * n * eng.num_cameras * L.camera_obs_dim * 4) >= (64 << 20)
             if isinstance(mode, int):            # a caller's own blocks, `mode` 16-byte chunks into a cache line, guard words around them
+                check(eng.lib.mate_engine_set_store_form(eng._h, mode & 1))      # (odd offsets: the line-aligned form of the row stores)
                 cam_elems, tgt_elems = n * eng.num_cameras * L.camera_obs_dim, n * eng.num_targets * L.target_obs_dim
                 pad = 64
                 cam_raw = torch.full((steps * cam_elems + 2 * pad,), -3.0, dtype=torch.float32, device='cuda')
