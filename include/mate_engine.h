@@ -338,8 +338,10 @@ int mate_engine_last_flow(const mate_engine *engine);
  * (hipDeviceMallocContiguous) 2.9-3.2 TB/s, the same block built from 2 MiB physical chunks mapped in a SHUFFLED order
  * 5.4-5.8 TB/s (tools/store_vmm.hip).  block_alloc builds such a block (hipMemCreate / hipMemMap, the virtual range is
  * contiguous); any device pointer works in mate_step_io -- this one is only faster to write.  `bytes` is rounded up to
- * 2 MiB.  block_free unmaps and releases it (the pointer must come from block_alloc; the CALLER has waited for every launch
- * that reads or writes the block -- the library does not synchronise here). */
+ * 2 MiB.  block_free unmaps the block and releases its memory (the pointer must come from block_alloc; the CALLER has waited for
+ * every launch that reads or writes the block -- the library does not synchronise here).  The block's virtual range stays
+ * reserved for the life of the process: a range handed out again after a free was seen to lose stores of the next kernel that
+ * wrote through it (address space only: 2^47 bytes of it, a block is a few GB). */
 /* The form of the row stores of the row-image rollouts (MATE-4v8-9, MATE-4v8-0 under mate_engine_rollout_random): 0 (default) the
  * rows' 16-byte chunks as they lie -- 1.3-2 % faster where the blocks take the rows fast, i.e. where the arithmetic bounds a launch
  * --, 1 every store instruction an aligned kilobyte -- 3 % faster where they do not (mate_engine_block_probe of the target block

@@ -143,3 +143,31 @@ def test_block_probe_and_candidate_search():
     cam, tgt, sc = eng.rollout_random(64, auto_reset=True)
     torch.cuda.synchronize()
     assert torch.isfinite(tgt).all() and float(tgt.abs().sum()) > 0.0
+
+
+def test_rows_survive_block_churn():
+    """Blocks allocated and freed over and over, then a fused rollout into fresh ones: every row arrives (a virtual range handed
+    out again after a free once lost rows of the last step -- block_free keeps the range reserved since)."""
+    from mate_amd import _native
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    for i in range(24):
+        blk = _native.ScatteredBlock(0, (96 + 16 * (i % 7)) << 20)
+        blk.store_rate(4096, 4192)
+        del blk
+    cfg = read_config('MATE-8v8-9.yaml', max_episode_steps=50)
+    outs = []
+    for plain in ('1', '0'):
+        os.environ['MATE_PLAIN_BLOCKS'] = plain
+        try:
+            eng = Engine(cfg, 8192, seed=13)
+            eng.reset()
+            cam, tgt, sc = eng.rollout_random(5, auto_reset=False)      # 8192 x 5 x 5088 B = 199 MiB of target rows: searched
+            torch.cuda.synchronize()
+            outs.append((cam.clone(), tgt.clone(), sc.clone()))
+        finally:
+            os.environ.pop('MATE_PLAIN_BLOCKS', None)
+        del eng
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert float(outs[0][1][-1, -1].abs().sum()) > 0.0
