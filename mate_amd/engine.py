@@ -276,7 +276,7 @@ class Engine:
         steps skipped because the episode had already ended inside this rollout."""
         return self._run_rollout(self.lib.mate_engine_rollout_random, steps, auto_reset, want_masks)
 
-    def _observation_block(self, shape):
+    def _observation_block(self, shape, deep=False):
         """A zeroed [steps][N][...] observation block.  Blocks of 64 MiB and more come from ``mate_engine_block_alloc``
         (2 MiB physical chunks in a shuffled order): the fused rollouts store 10-25 % faster into them than into what
         hipMalloc / the caching allocator hands out (include/mate_engine.h).  MATE_PLAIN_BLOCKS=1: torch.zeros."""
@@ -286,13 +286,22 @@ class Engine:
         # Shuffled chunks make a slow block unlikely, not impossible (tools/store_vmm.hip): blocks of 128 MiB and more -- the ones
         # a launch is bounded by -- are the fastest of up to MATE_BLOCK_CANDIDATES (default 6) candidates in the kernels' own
         # store pattern, where the device has the memory to hold them side by side; the search ends at the first candidate
-        # that is a class (25 %) faster than another -- blocks come in three: ~4.5, ~5.2 and ~5.9 TB/s on MATE-4v8-9's rows, about
-        # one in three of the last.
+        # that is a class (28 %) faster than another.
+        # `deep` (the target block, which decides a launch's store rate): the fast blocks of a device lie in ZONES of its memory, 20-35 GB
+        # wide and at a different depth on every GPU (tools/depth_probe.py: forty 4.4 GB blocks allocated in a row and held -- five to
+        # twelve consecutive ones fast, the rest slow).  The deep search walks through the memory in allocation order -- a
+        # candidate, a 12 GB spacer that is not probed, a candidate ... -- until one is fast (5.35 TB/s, or 28 % above the
+        # slowest seen: the classes lie at ~4.2, ~5.0 and 5.4-6.1), within 70 % of what is free; everything but the winner is freed
+        # at the end.
         row_bytes = nbytes // (shape[0] * shape[1])
         tries = int(os.environ.get('MATE_BLOCK_CANDIDATES', '6')) if nbytes >= (128 << 20) and row_bytes % 16 == 0 else 1
         free = torch.cuda.mem_get_info(self.device)[0]
+        deep = deep and tries > 1 and os.environ.get('MATE_BLOCK_DEEP', '1') != '0'
+        spacer_bytes = 12 << 30
+        if deep and 'MATE_BLOCK_CANDIDATES' not in os.environ:      # (an explicit count bounds the deep search too)
+            tries = max(tries, int(0.7 * free // (nbytes + spacer_bytes)))
         tries = max(1, min(tries, int(free // (2 * nbytes))))
-        best, rates, held = None, [], []
+        best, rates, held, spacers = None, [], [], []
         for _ in range(tries):
             try:
                 block = _native.ScatteredBlock(self.device_index, nbytes)
@@ -311,11 +320,21 @@ class Engine:
             held.append(block)          # (kept until the search ends: a freed candidate would be handed out again)
             if best is None or rate > best[0]:
                 best = (rate, block)
-            if len(rates) > 1 and best[0] >= 1.25 * min(rates):
+            if len(rates) > 1 and best[0] >= 1.28 * min(rates):
                 break
+            if deep:
+                if rate >= 5350.0:
+                    break
+                try:
+                    spacers.append(torch.empty(spacer_bytes, dtype=torch.uint8, device=self.device))      # (moves the allocation on; never touched)
+                except torch.cuda.OutOfMemoryError:
+                    break
         self.block_rates = getattr(self, 'block_rates', []) + [rates]
         block = best[1]
         del held, best
+        if spacers:
+            del spacers
+            torch.cuda.empty_cache()        # the spacers go back to the driver, not into the caching allocator's pool
         return block.tensor(self.obs_dtype, shape).zero_()
 
     def reserve_rollout(self, steps, want_masks=False):
@@ -328,11 +347,13 @@ class Engine:
         if buf is None or buf['steps'] < steps or (want_masks and buf['masks'] is None):     # a shorter rollout fills a prefix
             N, Nc, Nt, L = self.num_envs, self.num_cameras, self.num_targets, self.layout
             self._rollout = None
+            searched = len(getattr(self, 'block_rates', []))
             with torch.cuda.device(self.device):
+                target_block = self._observation_block((steps, N, Nt, L.target_obs_dim), deep=True)      # (first: its search holds the most memory)
                 buf = {
                     'steps': steps,
                     'camera_obs': self._observation_block((steps, N, Nc, L.camera_obs_dim)),
-                    'target_obs': self._observation_block((steps, N, Nt, L.target_obs_dim)),
+                    'target_obs': target_block,
                     'scalars': torch.zeros((steps, N, 8), dtype=torch.float32, device=self.device),
                     'masks': torch.zeros((steps, N, L.mask_words), dtype=torch.int32, device=self.device) if want_masks else None,
                 }
@@ -340,8 +361,8 @@ class Engine:
             # where even the best candidate takes the rows slowly the stores bound a launch, and the line-aligned form of the row
             # stores wins 3 %; elsewhere it costs 1.3-2 % (include/mate_engine.h).  MATE_STORE_FORM=0 / 1 forces a form.
             form = os.environ.get('MATE_STORE_FORM', 'auto')
-            probed = [max(r) for r in getattr(self, 'block_rates', [])[-2:] if r]
-            shifted = form == '1' or (form == 'auto' and bool(probed) and probed[-1] < 4800.0)
+            probed = [max(r) for r in getattr(self, 'block_rates', [])[searched:searched + 1] if r]       # (the target block's candidates come first)
+            shifted = form == '1' or (form == 'auto' and bool(probed) and probed[0] < 4800.0)
             self.store_form = int(shifted)
             check(self.lib.mate_engine_set_store_form(self._h, int(shifted)))
         return buf

@@ -138,7 +138,9 @@ def test_block_probe_and_candidate_search():
         eng.reserve_rollout(64)                      # 1.02 GiB of target rows and 0.5 GiB of camera rows: both searched
     finally:
         os.environ.pop('MATE_BLOCK_CANDIDATES', None)
-    assert [len(r) for r in eng.block_rates] == [2, 2] and all(200.0 < x < 9000.0 for r in eng.block_rates for x in r)
+    # (the target block first: its search may end at the first candidate if that one is fast)
+    assert len(eng.block_rates) == 2 and len(eng.block_rates[0]) in (1, 2) and len(eng.block_rates[1]) == 2
+    assert all(200.0 < x < 9000.0 for r in eng.block_rates for x in r)
     eng.reset()
     cam, tgt, sc = eng.rollout_random(64, auto_reset=True)
     torch.cuda.synchronize()
