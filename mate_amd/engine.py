@@ -291,15 +291,15 @@ class Engine:
         # wide and at a different depth on every GPU (tools/depth_probe.py: forty 4.4 GB blocks allocated in a row and held -- five to
         # twelve consecutive ones fast, the rest slow).  The deep search walks through the memory in allocation order -- a
         # candidate, a 12 GB spacer that is not probed, a candidate ... -- until one is fast (5.35 TB/s, or 28 % above the
-        # slowest seen: the classes lie at ~4.2, ~5.0 and 5.4-6.1), within 70 % of what is free; everything but the winner is freed
-        # at the end.
+        # slowest seen: the classes lie at ~4.2, ~5.0 and 5.4-6.1), within 45 % of what is free (two ranks that share a GPU in a
+        # test must both fit); everything but the winner is freed at the end.
         row_bytes = nbytes // (shape[0] * shape[1])
         tries = int(os.environ.get('MATE_BLOCK_CANDIDATES', '6')) if nbytes >= (128 << 20) and row_bytes % 16 == 0 else 1
         free = torch.cuda.mem_get_info(self.device)[0]
         deep = deep and tries > 1 and os.environ.get('MATE_BLOCK_DEEP', '1') != '0'
         spacer_bytes = 12 << 30
         if deep and 'MATE_BLOCK_CANDIDATES' not in os.environ:      # (an explicit count bounds the deep search too)
-            tries = max(tries, int(0.7 * free // (nbytes + spacer_bytes)))
+            tries = max(tries, int(0.45 * free // (nbytes + spacer_bytes)))
         tries = max(1, min(tries, int(free // (2 * nbytes))))
         best, rates, held, spacers = None, [], [], []
         for _ in range(tries):
