@@ -356,6 +356,11 @@ int mate_engine_block_free(void *ptr);
  * a few candidates, keeps the fastest and frees the rest -- Engine.reserve_rollout does.  The block is left filled with zeros. */
 int mate_engine_block_probe(int32_t device, void *block, int64_t bytes, int32_t rows_per_step, int32_t row_bytes, void *stream,
                             double *gbytes_per_s);
+/* Physical device memory taken and held without being mapped (hipMemCreate in 256 MiB pieces), and given back: what a search
+ * for a fast block puts between two candidates so that the next one comes from further into the device's memory -- the blocks'
+ * chunks come out of the same pool, in order; memory from hipMalloc does not move that pool's cursor. */
+int mate_engine_memory_hold(int32_t device, int64_t bytes, void **token_out);
+int mate_engine_memory_release(void *token);
 
 #ifdef __cplusplus
 }

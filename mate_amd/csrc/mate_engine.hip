@@ -1389,6 +1389,39 @@ extern "C" int mate_engine_block_probe(int32_t device, void *block, int64_t byte
     return MATE_OK;
 }
 
+extern "C" int mate_engine_memory_hold(int32_t device, int64_t bytes, void **token_out) {
+    if (!token_out || bytes <= 0) return fail(MATE_EINVAL, "memory_hold: null output or nothing to hold");
+    *token_out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    constexpr size_t piece = (size_t)256 << 20;
+    auto *held = new std::vector<hipMemGenericAllocationHandle_t>();
+    for (size_t done = 0; done < (size_t)bytes; done += piece) {
+        hipMemGenericAllocationHandle_t h;
+        const hipError_t err = hipMemCreate(&h, piece, &prop, 0);
+        if (err != hipSuccess) {
+            for (auto x : *held) (void)hipMemRelease(x);
+            delete held;
+            (void)hipGetLastError();
+            return fail(MATE_ENOMEM, "memory_hold: hipMemCreate failed after %zu bytes: %s", done, hipGetErrorString(err));
+        }
+        held->push_back(h);
+    }
+    *token_out = held;
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_memory_release(void *token) {
+    if (!token) return MATE_OK;
+    auto *held = static_cast<std::vector<hipMemGenericAllocationHandle_t> *>(token);
+    for (auto h : *held) (void)hipMemRelease(h);
+    delete held;
+    return MATE_OK;
+}
+
 extern "C" int mate_engine_block_free(void *ptr) {
     if (!ptr) return MATE_OK;
     ScatteredBlock blk;

@@ -323,18 +323,16 @@ class Engine:
             if len(rates) > 1 and best[0] >= 1.28 * min(rates):
                 break
             if deep:
-                if rate >= 5350.0:
+                if rate >= (5350.0 if nbytes >= (1 << 30) else 5100.0):      # (a short block's probe is a short launch: its ramp weighs more)
                     break
                 try:
-                    spacers.append(torch.empty(spacer_bytes, dtype=torch.uint8, device=self.device))      # (moves the allocation on; never touched)
-                except torch.cuda.OutOfMemoryError:
+                    spacers.append(_native.HeldMemory(self.device_index, spacer_bytes))      # (moves the allocation on; never mapped, never touched)
+                except _native.EngineError:
                     break
         self.block_rates = getattr(self, 'block_rates', []) + [rates]
         block = best[1]
         del held, best
-        if spacers:
-            del spacers
-            torch.cuda.empty_cache()        # the spacers go back to the driver, not into the caching allocator's pool
+        del spacers
         return block.tensor(self.obs_dtype, shape).zero_()
 
     def reserve_rollout(self, steps, want_masks=False):
