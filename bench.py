@@ -9,8 +9,8 @@ One "step" = one `step()` of every environment of the batch (BASELINE.json confi
 MATE-4v8-9.yaml, 4096 environments per GPU, uniform random policy generated on-device by the
 engine's Philox streams, auto-reset of finished episodes inside the timed loop).  State,
 actions and observations are resident in HBM for the whole timed region.  With the random
-policy the K timed steps run as fused `--rollout R`-step launches (default 128, the usual horizon of an on-policy
-update, or 64 / 32 when K holds fewer than eight such launches, or K itself when K is smaller: rollout_kernel
+policy the K timed steps run as fused `--rollout R`-step launches (default 256, or 128 / 64 / 32 when K holds fewer than
+eight such launches, or K itself when K is smaller -- the driver's `--steps 20` is ONE 20-step launch: rollout_kernel
 keeps an environment's records in LDS across the R steps and writes every step's observations,
 rewards and masks to [R][N][...] buffers; an environment whose episode ends inside a rollout
 idles until the reset launch that follows it, and those idle slots are NOT counted in `value`);
@@ -44,6 +44,18 @@ Rank 0 prints ONE JSON line (see the driver contract).  Extra objects:
                 headline in the default N = 1 run: config 3 (MATE-8v8-9 x 8192, on-device Greedy vs Greedy, fused
                 48-step launches), the per-GPU shard of config 4 (MATE-4v8-0 x 8192) and of config 5
                 (MATE-Navigation x 4096), each with its dominant kernel's dispatch-event average and roofline fraction.
+
+  reset_amortised  what the driver's region never contains: all environments of the random-policy batch hit the time limit together
+                every max_episode_steps + 1 steps and restart in one whole-batch reset; `value_with_resets` = the headline with
+                that reset's measured time spread over an episode.
+  n1_api        BASELINE config 1: the N = 1 NumPy API (mate_amd.MultiAgentTracking, a PCIe copy + sync per step) under the
+                evaluate-style harness, random actions, steps/s beside the reference's own 1101.
+  startup       seconds per rank: process group, engine creation, first reset, reserve_rollout (candidate search included),
+                everything up to the first timed repetition.
+
+`--force-collectives` runs every collective of the N-rank path on ONE rank: the `nccl` (= RCCL) process group with
+`device_id`, `dist.barrier()`, the side-stream `all_gather` of StatsGather and the job-level reduction on device tensors -- the
+single-GPU rehearsal of what `--gpus 8` executes (tests/test_gpu_multirank.py runs it as a child process).
 
 `--dry-run` exercises the launcher and the job-level reduction without a GPU (gloo, fabricated timings; the line says
 `"data": "dry-run"`): it exists for the CPU test of the N-rank launch path and measures nothing.
@@ -196,6 +208,10 @@ def parse_args(argv=None):
     ap.add_argument('--max-episode-steps', type=int, default=0, help='override the scenario\'s time limit (tests: episodes that end inside a short run)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the BASELINE config 3 / 4-shard / 5-shard side measurements')
     ap.add_argument('--other-seconds', type=float, default=1.0, help='timed seconds per entry of other_configs')
+    ap.add_argument('--force-collectives', action='store_true',
+                    help='one rank: initialise the process group anyway (nccl = RCCL with device_id, or --backend gloo) and run every collective of the '
+                         'N-rank path -- barrier, the side-stream all_gather of the episode statistics, the job-level reduction')
+    ap.add_argument('--no-side-measurements', action='store_true', help='skip reset_amortised / n1_api')
     return ap.parse_args(argv)
 
 
@@ -334,6 +350,46 @@ def measure_other_config(torch, device_index, spec, seconds, buffer_gib):
     return out
 
 
+def measure_reset_amortised(torch, eng, cfg, value, seconds_per_step):
+    """The cost the timed region never contains.  Under the random policy cargo never runs out, so every environment of the
+    batch hits the time limit on the same step, every max_episode_steps + 1 steps, and the batch restarts in ONE whole-batch
+    reset (placement, Nc occlusion tables per environment, first view).  Its time, measured here (median of 7, each
+    bracketed by synchronisations), spread over an episode: value_with_resets = N / (t_step + t_reset / (max_episode_steps + 1))."""
+    times = []
+    for _ in range(8):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.reset()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    t_reset = sorted(times[1:])[len(times[1:]) // 2]
+    episode = int(cfg['max_episode_steps']) + 1
+    with_resets = eng.num_envs / (seconds_per_step + t_reset / episode)
+    return {'whole_batch_reset_ms': t_reset * 1e3, 'episode_steps': episode, 'value_with_resets': with_resets, 'unit': 'env-steps/s',
+            'cost_frac': 1.0 - with_resets / value if value > 0 else None,
+            'note': 'value = N / t_step as timed; value_with_resets = N / (t_step + t_reset / episode_steps): one whole-batch reset per episode of the random-policy batch'}
+
+
+def measure_n1_api(torch, steps=1500):
+    """BASELINE config 1 (MATE-4v2-9.yaml, one environment, random actions, the reference's evaluate loop, mate/evaluate.py:85-167
+    -> mate_amd/evaluate.py) on the N = 1 NumPy API: every step is a launch, a synchronisation and a PCIe copy of the observations
+    and the state -- the compatibility path the reference's own wrappers use, not a throughput path."""
+    import mate_amd
+    from mate_amd.evaluate import evaluate, random_policy
+    env = mate_amd.MultiAgentTracking('MATE-4v2-9.yaml', max_episode_steps=steps)
+    env.seed(0)
+    evaluate(env, random_policy(0))                  # untimed: code objects, allocations
+    history = []
+    t0 = time.perf_counter()
+    evaluate(env, random_policy(1), history=history)
+    elapsed = time.perf_counter() - t0
+    out = {'workload': 'MATE-4v2-9.yaml, 1 environment, uniform random actions from NumPy, mate_amd.evaluate (reset + one episode)',
+           'value': len(history) / elapsed, 'unit': 'env-steps/s', 'steps': len(history), 'seconds': elapsed,
+           'reference_numpy': 1101.0, 'reference_note': 'mate/evaluate.py FPS of the reference on one core of the build container (BASELINE.md section 2)'}
+    env.close()
+    return out
+
+
 OTHER_CONFIGS = (
     ('MATE-8v8-9.yaml', 8192, 'greedy', 'BASELINE config 3'),
     ('MATE-4v8-0.yaml', 8192, 'random', 'BASELINE config 4, the shard of one of its 8 GPUs'),
@@ -361,9 +417,13 @@ def dry_run(args, world, rank):
 
 
 def main():
+    t_main = time.perf_counter()
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(launch_ranks(args))
+    if args.force_collectives and 'WORLD_SIZE' not in os.environ:      # a one-rank rendezvous of our own
+        os.environ.update({'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(free_port())})
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -377,21 +437,34 @@ def main():
     from mate_amd.config import read_config
     from mate_amd.engine import Engine
 
-    distributed = world > 1
+    distributed = world > 1 or args.force_collectives
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
     host_staged = args.backend == 'gloo'
     if host_staged:
         local_rank = local_rank % torch.cuda.device_count()      # ranks may share a GPU
     torch.cuda.set_device(local_rank)
+    startup = {}
+    t_phase = time.perf_counter()
     if distributed:
         if host_staged:
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            # the communicator and RCCL's own device buffers exist BEFORE anything here takes a large share of the HBM (the
+            # candidate search of reserve_rollout holds up to 45 % of the free memory for seconds): one barrier and one all_gather
+            # of the statistics record's shape, on the side of the first launch
+            warm = torch.zeros(5, dtype=torch.float64, device='cuda')
+            dist.barrier()
+            dist.all_gather([torch.zeros_like(warm) for _ in range(world)], warm)
+            torch.cuda.synchronize()
+    startup['process_group_s'] = time.perf_counter() - t_phase
 
+    t_phase = time.perf_counter()
     cfg = read_config(args.workload, **({'max_episode_steps': args.max_episode_steps} if args.max_episode_steps > 0 else {}))
     eng = Engine(cfg, args.batch, device=local_rank, seed=0, first_env_index=rank * args.batch)
+    torch.cuda.synchronize()
+    startup['engine_create_s'] = time.perf_counter() - t_phase
     b_obs = 4 * (eng.num_cameras * eng.camera_obs_dim + eng.num_targets * eng.target_obs_dim) + 48   # written per env-step
     R = args.rollout
     if args.policy == 'external':
@@ -452,9 +525,13 @@ def main():
                 if timed and gather is not None and ((i + 1) % every == 0 or (short and i == 0)):
                     gather.submit()
 
+    t_phase = time.perf_counter()
     eng.reset()
+    torch.cuda.synchronize()
+    startup['first_reset_s'] = time.perf_counter() - t_phase
     if R > 0:
         eng.reserve_rollout(R)       # [R][N][...] output buffers: allocated here, never inside the timed region
+        startup['reserve_rollout_s'] = eng.reserve_seconds
     run(args.warmup)
     # one untimed pass over every launch shape of the timed region (kernel code objects loaded, graphs instantiated)
     if R > 0:
@@ -484,6 +561,7 @@ def main():
         torch.cuda.synchronize()
 
     from mate_amd.distributed import reduce_job
+    startup['startup_s'] = time.perf_counter() - t_main      # everything of this rank's main() before the first pass through the measuring loop
     rep_ms, rep_executed, kernel_times = [], [], []
     for rep in range(max(0, args.rep_warmup) + max(1, args.reps)):
         eng.kernel_time(enable=1 if R > 0 else 16)   # HIP-event pair around (every 16th) launch of the dominant kernel
@@ -505,7 +583,7 @@ def main():
         stats = eng.scalars[:, [1, 3, 6]].mean(dim=0)    # reward, coverage, delivered: logging only
         if host_staged:
             stats = stats.cpu()
-        elapsed, executed, stats = reduce_job(elapsed, executed, stats, device='cpu' if host_staged else 'cuda')   # MAX time, SUM env-steps, gathered stats
+        elapsed, executed, stats = reduce_job(elapsed, executed, stats, device='cpu' if host_staged else 'cuda', force=args.force_collectives)   # MAX time, SUM env-steps, gathered stats
         if rep < max(0, args.rep_warmup):
             kernel_times.pop()
             if gather is not None:
@@ -519,6 +597,14 @@ def main():
     kernel_ms, launches = kernel_times[mid]
     flow = eng.last_flow
     gathered_stats = gather.result() if gather is not None else None
+    keys = ('process_group_s', 'engine_create_s', 'first_reset_s', 'reserve_rollout_s', 'startup_s')
+    mine = torch.tensor([startup.get(k, 0.0) for k in keys], dtype=torch.float64, device='cpu' if host_staged or not distributed else 'cuda')
+    per_rank = [torch.zeros_like(mine) for _ in range(world)] if distributed else [mine]
+    if distributed:
+        dist.all_gather(per_rank, mine)
+    startup_line = {k: [round(float(t[i]), 3) for t in per_rank] for i, k in enumerate(keys)}
+    startup_line['note'] = ('seconds per rank; startup_s = main() entry to the first pass through the measuring loop (imports, process group, engine, reset, '
+                            'reserve_rollout with its candidate search, warm-up); reserve_rollout_s is bounded by MATE_BLOCK_SECONDS / MATE_BLOCK_GIB')
 
     if args.dump:      # every rank: the final state and the last outputs of its shard (compared across shardings by the tests)
         torch.cuda.synchronize()
@@ -611,14 +697,28 @@ def main():
                               'mean_delivered': float(stats[2]), 'gathered_in_loop': gathered_stats},
         }
         line.update(extras)
+        line['startup'] = startup_line
+        short_region = (R > 0 and -(-args.steps // R) < args.stats_interval) or (R == 0 and external is None and args.steps < args.stats_interval * 128)
+        line['episode_stats']['stats_gather'] = (
+            'none' if gather is None else
+            'region shorter than the gather interval: ONE gather per repetition, copy + collective enqueued on the side stream inside the region behind its '
+            'first launch; the marker of what it may read is recorded BEFORE the region (behind the previous repetition), so it carries the episodes '
+            'finished before this region, not its own' if short_region else
+            f'every {args.stats_interval} launches inside the region, each behind the launch whose episodes it carries')
         line['config']['backend'] = ('gloo (ranks may share a GPU; statistics staged through the host)' if host_staged else 'nccl (RCCL)') if distributed else 'single process'
+        line['config']['collectives'] = ('forced on one rank: barrier, side-stream all_gather, job reduction' if args.force_collectives and world == 1
+                                         else 'barrier, side-stream all_gather, job reduction' if distributed else 'none (one rank)')
         default_case = world == 1 and args.policy == 'random' and args.workload == WORKLOAD and args.batch == BATCH_PER_GPU
+        if default_case and not args.no_side_measurements and not args.dump:
+            line['reset_amortised'] = measure_reset_amortised(torch, eng, cfg, value, elapsed / args.steps)
         if default_case and not args.no_other_configs and not args.dump:
             # the other BASELINE configurations that fit one GPU, about a second each (the headline engine's buffers are released first)
             eng.close()
             eng._rollout = None
             torch.cuda.empty_cache()
             line['other_configs'] = [measure_other_config(torch, local_rank, spec, args.other_seconds, args.buffer_gib) for spec in OTHER_CONFIGS]
+        if default_case and not args.no_side_measurements and not args.dump:
+            line['n1_api'] = measure_n1_api(torch)
         if not args.no_cpu_baseline and world == 1 and args.policy == 'random' and args.workload == WORKLOAD:
             line['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -13,7 +13,9 @@
  * Synchronisation.  Launching entry points only enqueue on `stream`.  The host-side accessors without a stream
  * argument (seed, lut_read / lut_write(_outer), set_obs_transform, set_obs_mode, set_action_grids,
  * enable_outer_boundary, idle_steps, kernel_time) wait for the stream of the handle's MOST RECENT launch
- * (hipStreamSynchronize), never for the whole device: other streams of the caller keep running.
+ * (hipStreamSynchronize), never for the whole device: other streams of the caller keep running.  Exception: a caller that
+ * launched through this handle on MORE than one stream since the last such wait, or that has destroyed that stream, gets
+ * hipDeviceSynchronize instead -- an accessor never touches engine memory under a launch in flight.
  *
  * Environment switches.  All are read ONCE, in mate_engine_create(), and fixed for the life of the handle; none
  * changes results (each selects between implementations the tests hold bit-identical, except MATE_ZOOM_ITERATE,
@@ -37,6 +39,17 @@
  *   MATE_ZOOM_ITERATE=1      the on-device GreedyCameraAgent runs the reference's 20-iteration zoom solve
  *                            (mate/agents/greedy.py:139-145) instead of reading its tabulation; the two differ by
  *                            <= 1.5e-13 degrees in the viewing angle (parity runs that want the iteration itself)
+ *   MATE_BLOCK_KEEP_RANGE=1  mate_engine_block_free keeps the block's virtual address range reserved (rounds 1-3 behaviour)
+ *                            instead of giving it back with hipMemAddressFree (read once, at the first block_free)
+ * Read by the Python host (mate_amd/engine.py), once, when an Engine object is built -- they steer where
+ * Engine.reserve_rollout puts the [steps][N][...] observation blocks of the fused rollouts, never what is written there:
+ *   MATE_PLAIN_BLOCKS=1      blocks from torch.zeros instead of mate_engine_block_alloc
+ *   MATE_BLOCK_CANDIDATES=n  at most n candidates probed per block (default 6; the deep search of the target block: as
+ *                            many as its memory and time bounds allow)
+ *   MATE_BLOCK_DEEP=0        no deep search (candidates separated by unmapped 12 GB spacers) for the target block
+ *   MATE_BLOCK_SECONDS=s     wall-time bound of the deep search (default 3)
+ *   MATE_BLOCK_GIB=g         bound of its transient footprint in GiB (default 96; always at most 45 % of the free memory)
+ *   MATE_STORE_FORM=0|1      force the form of the row stores (mate_engine_set_store_form) instead of choosing by the probed rate
  */
 #ifndef MATE_ENGINE_H
 #define MATE_ENGINE_H
@@ -338,10 +351,10 @@ int mate_engine_last_flow(const mate_engine *engine);
  * (hipDeviceMallocContiguous) 2.9-3.2 TB/s, the same block built from 2 MiB physical chunks mapped in a SHUFFLED order
  * 5.4-5.8 TB/s (tools/store_vmm.hip).  block_alloc builds such a block (hipMemCreate / hipMemMap, the virtual range is
  * contiguous); any device pointer works in mate_step_io -- this one is only faster to write.  `bytes` is rounded up to
- * 2 MiB.  block_free unmaps the block and releases its memory (the pointer must come from block_alloc; the CALLER has waited for
- * every launch that reads or writes the block -- the library does not synchronise here).  The block's virtual range stays
- * reserved for the life of the process: a range handed out again after a free was seen to lose stores of the next kernel that
- * wrote through it (address space only: 2^47 bytes of it, a block is a few GB). */
+ * 2 MiB.  block_free unmaps the block chunk by chunk (one hipMemUnmap per hipMemMap), releases its memory and gives the virtual
+ * range back (the pointer must come from block_alloc; the CALLER has waited for every launch that reads or writes the block --
+ * the library does not synchronise here).  A failed block_alloc / block_probe / block_free reports through its return code
+ * only: HIP's sticky last-error is cleared, so the caller's next launch check does not see it. */
 /* The form of the row stores of the row-image rollouts (MATE-4v8-9, MATE-4v8-0 under mate_engine_rollout_random): 0 (default) the
  * rows' 16-byte chunks as they lie -- 1.3-2 % faster where the blocks take the rows fast, i.e. where the arithmetic bounds a launch
  * --, 1 every store instruction an aligned kilobyte -- 3 % faster where they do not (mate_engine_block_probe of the target block

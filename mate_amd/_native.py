@@ -184,9 +184,12 @@ class ScatteredBlock:
             try:
                 import torch
                 torch.cuda.synchronize(self.device_index)      # block_free does not wait for launches in flight
-                self._lib.mate_engine_block_free(ctypes.c_void_p(ptr))
+                status = self._lib.mate_engine_block_free(ctypes.c_void_p(ptr))
             except Exception:       # interpreter shutdown: the process's memory goes with it
-                pass
+                return
+            if status != 0:         # (a finaliser cannot raise: say that device memory may not have come back)
+                import warnings
+                warnings.warn(f'mate_engine_block_free failed ({status}): {self._lib.mate_engine_last_error().decode()}', RuntimeWarning)
 
 
 def check(status):

@@ -2161,7 +2161,8 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     if (c.freeze_done() && mode != MODE_OBSERVE) {
         wave_sync();
         if (c.ei(EI_DONE) != 0) {     // waiting for the next batched reset: no step, no new observation
-            if (lane == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; }
+            // (the whole row, like the idle rows of the fused kernels: the one-launch and the two-launch form of a step write the same bytes)
+            if (lane == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
             if (lane == 0 && g.idle_steps) g.idle_steps[env] += 1;
             if (lane == 0 && g.done_count && c.ei(EI_DONE) == 1) {      // finished under auto_reset = 0 earlier: not on the list yet
                 const int parity = c.list_parity();

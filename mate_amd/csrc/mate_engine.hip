@@ -32,10 +32,12 @@ static int fail(int code, const char *fmt, ...) {
     g_error = buf;
     return code;
 }
+// (a failed runtime call leaves HIP's sticky "last error" set: it is read here, so that the next launch check -- ours or the
+// caller's, e.g. torch's -- does not report it a second time)
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess) return fail(MATE_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
+        if (e_ != hipSuccess) { (void)hipGetLastError(); return fail(MATE_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); }    \
     } while (0)
 
 using StepFn = void (*)(const Params *, const Ptrs);
@@ -118,7 +120,8 @@ static Switches read_switches() {
 
 struct mate_engine {
     Switches sw{};
-    hipStream_t last_stream = nullptr;   // stream of the most recent launch: what the host-side accessors wait for
+    hipStream_t last_stream = nullptr;   // stream of the most recent launch: what the host-side accessors wait for ...
+    bool launched = false, multi_stream = false;   // ... unless launches went to more than one stream since the last wait (then: the device)
     Params p{};
     Params *d_params = nullptr;   // device copy read by the kernels
     Ptrs g{};
@@ -159,6 +162,20 @@ struct mate_engine {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
 };
+
+// The host-side accessors wait for the stream of the handle's most recent launch, not for the device.  Work the caller enqueued
+// through this handle on ANOTHER stream since the last wait, or a stream handle that has been destroyed since, falls back to
+// hipDeviceSynchronize: an accessor never reads or writes engine memory under a launch in flight.
+static void note_stream(mate_engine *e, hipStream_t stream) {
+    if (e->launched && stream != e->last_stream) e->multi_stream = true;
+    e->last_stream = stream; e->launched = true;
+}
+static hipError_t wait_for_launches(mate_engine *e) {
+    hipError_t err = e->multi_stream ? hipErrorInvalidHandle : hipStreamSynchronize(e->last_stream);
+    if (err != hipSuccess) { (void)hipGetLastError(); e->last_stream = nullptr; err = hipDeviceSynchronize(); }
+    if (err == hipSuccess) e->multi_stream = false;
+    return err;
+}
 
 extern "C" const char *mate_engine_last_error(void) { return g_error.c_str(); }
 extern "C" int mate_engine_abi_version(void) { return MATE_ABI_VERSION; }
@@ -513,7 +530,7 @@ extern "C" int mate_engine_set_obs_transform(mate_engine *e, int32_t relative, c
     if (!e) return fail(MATE_EINVAL, "null engine");
     if ((cam_scale && !cam_bias) || (tgt_scale && !tgt_bias)) return fail(MATE_EINVAL, "scale without bias");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->last_stream));
+    HIP_TRY(wait_for_launches(e));
     const Params &p = e->p;
     e->xf_relative = relative != 0;
     e->xf_cam = cam_scale != nullptr; e->xf_tgt = tgt_scale != nullptr;
@@ -528,7 +545,7 @@ extern "C" int mate_engine_set_obs_mode(mate_engine *e, int32_t camera_mode, int
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (camera_mode < 0 || camera_mode > 2 || target_mode < 0 || target_mode > 2) return fail(MATE_EINVAL, "observation mode must be 0 (plain), 1 (enhanced) or 2 (shared field of view)");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->last_stream));
+    HIP_TRY(wait_for_launches(e));
     e->cam_mode = camera_mode; e->tgt_mode = target_mode;
     return apply_obs_tables(e);
 }
@@ -537,7 +554,7 @@ extern "C" int mate_engine_set_action_grids(mate_engine *e, const double *camera
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (n_cam < 0 || n_tgt < 0 || (n_cam > 0 && !camera_grid) || (n_tgt > 0 && !target_grid)) return fail(MATE_EINVAL, "invalid action grid");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->last_stream));
+    HIP_TRY(wait_for_launches(e));
     auto upload = [&](const double *src, int n, const double2 **dst, int32_t *count) -> int {
         *dst = nullptr; *count = 0;
         if (n == 0) return MATE_OK;
@@ -571,13 +588,13 @@ extern "C" int mate_engine_seed(mate_engine *e, uint64_t seed) {
     if (e->dev_tick) return fail(MATE_ESTATE, "seed() while the step counter is device-resident (mate_engine_device_tick)");
     e->p.seed_lo = (uint32_t)seed; e->p.seed_hi = (uint32_t)(seed >> 32);
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->last_stream));
+    HIP_TRY(wait_for_launches(e));
     HIP_TRY(hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice));
     // the reference re-creates its generators (environment.py:1219-1225): the same seed gives the same episodes again,
     // whatever ran before.  Here: the key, and every counter that enters a Philox counter word (episode, tick) rewound.
     hipLaunchKernelGGL(rewind_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, e->last_stream, (const Params *)e->d_params, (const Ptrs)e->g);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(e->last_stream));
+    HIP_TRY(wait_for_launches(e));
     e->tick = 0;
     return MATE_OK;
 }
@@ -594,7 +611,7 @@ static void apply_io(Ptrs &g, const mate_step_io *io) {
 
 static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_t stream, bool split_done = false) {
     g.mode = MODE_OBSERVE; g.reset_kind = kind; g.parity = e->parity; g.freeze_done = 0;
-    e->last_stream = stream;
+    note_stream(e, stream);
     const Params &p = e->p;
     auto launch = [&](int ph, int fan, unsigned threads, size_t lds, const ResetLds *layout = nullptr, int64_t grid = 0) {
         int64_t items = ((g.reset_kind == RESET_DONE || g.reset_kind == RESET_LIST) ? std::min<int64_t>(e->N, 256) : e->N) * fan;
@@ -715,7 +732,7 @@ extern "C" int mate_engine_device_tick(mate_engine *e, int32_t enable, void *str
     if (!e) return fail(MATE_EINVAL, "null engine");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
-    e->last_stream = stream;
+    note_stream(e, stream);
     if ((enable != 0) == e->dev_tick && (!enable || enable == e->dev_interval)) return MATE_OK;
     if (enable && e->dev_tick) return fail(MATE_ESTATE, "device_tick: already enabled with interval %d", e->dev_interval);
     if (enable) { int rc = flush_pending(e, 0, stream); if (rc != MATE_OK) return rc; }
@@ -744,7 +761,7 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     if (e->dev_tick && mode != MODE_OBSERVE && auto_reset != e->dev_interval)
         return fail(MATE_ESTATE, "with a device-resident step counter (mate_engine_device_tick) step() needs auto_reset = %d: the auto-reset launch advances it", e->dev_interval);
     HIP_TRY(hipSetDevice(e->device));
-    e->last_stream = stream;
+    note_stream(e, stream);
     if (mode != MODE_OBSERVE) { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | kStepFlow) : auto_reset, stream); if (rc != MATE_OK) return rc; }
     Ptrs g = e->g;
     apply_io(g, io);
@@ -818,7 +835,7 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
     if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
-    e->last_stream = stream;
+    note_stream(e, stream);
     { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | kRolloutFlow) : auto_reset, stream); if (rc != MATE_OK) return rc; }
     Ptrs g = e->g;
     apply_io(g, io);
@@ -938,7 +955,7 @@ static int step_with_policies(mate_engine *e, int team_caller, const mate_step_i
     if (team_caller >= 0 && (!io || !(team_caller == 0 ? io->camera_actions_dev : io->target_actions_dev)))
         return fail(MATE_EINVAL, "step_versus_greedy needs the %s team's joint action", team_caller == 0 ? "camera" : "target");
     HIP_TRY(hipSetDevice(e->device));
-    e->last_stream = stream;
+    note_stream(e, stream);
     PolicyPtrs q = e->q;
     std::memset(&q.tape, 0, sizeof(q.tape));
     if (tape) {
@@ -988,7 +1005,7 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
-    e->last_stream = stream;
+    note_stream(e, stream);
     { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | (per_step ? kStepFlow : kRolloutFlow)) : auto_reset, stream); if (rc != MATE_OK) return rc; }
     Ptrs g = e->g;
     apply_io(g, io);
@@ -1072,7 +1089,7 @@ extern "C" int mate_engine_rollout_versus_greedy(mate_engine *e, int32_t team, c
 extern "C" int mate_engine_policy_actions(mate_engine *e, double *camera_actions_dev, double *target_actions_dev, void *stream) {
     if (!e || !e->policy_ready) return fail(MATE_ESTATE, "policies are not enabled");
     HIP_TRY(hipSetDevice(e->device));
-    e->last_stream = (hipStream_t)stream;
+    note_stream(e, (hipStream_t)stream);
     if (camera_actions_dev && e->p.Nc > 0)
         HIP_TRY(hipMemcpyAsync(camera_actions_dev, e->q.cam_act, sizeof(double) * 2 * e->p.Nc * (size_t)e->N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (target_actions_dev)
@@ -1087,7 +1104,7 @@ extern "C" int mate_engine_observe(mate_engine *e, const mate_step_io *io, void 
 extern "C" int mate_engine_export_state(mate_engine *e, double *dst_dev, void *stream) {
     if (!e || !dst_dev) return fail(MATE_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(e->device));
-    e->last_stream = (hipStream_t)stream;
+    note_stream(e, (hipStream_t)stream);
     hipLaunchKernelGGL(export_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->d_params, e->g, dst_dev);
     HIP_TRY(hipGetLastError());
     return MATE_OK;
@@ -1097,7 +1114,7 @@ extern "C" int mate_engine_import_state(mate_engine *e, const double *src_dev, v
     if (!e || !src_dev) return fail(MATE_EINVAL, "null argument");
     if (e->dev_tick) return fail(MATE_ESTATE, "import_state while the step counter is device-resident (mate_engine_device_tick)");
     HIP_TRY(hipSetDevice(e->device));
-    e->last_stream = (hipStream_t)stream;
+    note_stream(e, (hipStream_t)stream);
     hipLaunchKernelGGL(import_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->d_params, e->g, src_dev);
     HIP_TRY(hipGetLastError());
     // all environments step together, so they share one tick: adopt the imported one
@@ -1113,7 +1130,7 @@ extern "C" int mate_engine_lut_read(mate_engine *e, int64_t env, int32_t camera,
     if (!e || !phis || !rhos || !count) return fail(MATE_EINVAL, "null argument");
     if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_read: index out of range");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->last_stream));
+    HIP_TRY(wait_for_launches(e));
     const int64_t lc = env * e->p.Nc + camera;
     int32_t n = 0;
     HIP_TRY(hipMemcpy(&n, e->g.lut_count + lc, sizeof(n), hipMemcpyDeviceToHost));
@@ -1130,7 +1147,7 @@ extern "C" int mate_engine_lut_read_outer(mate_engine *e, int64_t env, int32_t c
     if (!e->g.lut_knots_outer) return fail(MATE_ESTATE, "outer boundary not enabled (mate_engine_enable_outer_boundary)");
     if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_read_outer: index out of range");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->last_stream));
+    HIP_TRY(wait_for_launches(e));
     const int64_t lc = env * e->p.Nc + camera;
     int32_t n = 0;
     HIP_TRY(hipMemcpy(&n, e->g.lut_count_outer + lc, sizeof(n), hipMemcpyDeviceToHost));
@@ -1150,7 +1167,7 @@ extern "C" int mate_engine_enable_outer_boundary(mate_engine *e, int32_t *capaci
     if (p.Nc == 0) return fail(MATE_EINVAL, "no cameras in this scenario");
     if (e->g.lut_knots_outer) { if (capacity) *capacity = e->g.kmax_outer; return MATE_OK; }
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->last_stream));
+    HIP_TRY(wait_for_launches(e));
     // 360 + per obstacle (arc <= 181 rays + two 21-point flanks) rays are sorted in LDS
     const int rays = 360 + p.No * (181 + 42) + 1;
     ResetLds rl = e->rl;
@@ -1183,7 +1200,7 @@ extern "C" int mate_engine_lut_write_outer(mate_engine *e, int64_t env, int32_t 
     if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_write_outer: index out of range");
     if (n < 2 || n > e->g.kmax_outer) return fail(MATE_EINVAL, "lut_write_outer: %d knots do not fit (capacity %d)", n, e->g.kmax_outer);
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->last_stream));
+    HIP_TRY(wait_for_launches(e));
     std::vector<double2> knots((size_t)n);
     for (int i = 0; i < n; ++i) { knots[i].x = phis[i]; knots[i].y = rhos[i]; }
     const int64_t lc = env * e->p.Nc + camera;
@@ -1201,7 +1218,7 @@ extern "C" int mate_engine_soft_coverage(mate_engine *e, const uint32_t *masks_d
     if (!e->was_reset) return fail(MATE_ESTATE, "soft_coverage called before reset() (or import_state)");
     HIP_TRY(hipSetDevice(e->device));
     const int64_t items = e->N * e->p.Nc;
-    e->last_stream = (hipStream_t)stream;
+    note_stream(e, (hipStream_t)stream);
     hipLaunchKernelGGL(soft_coverage_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const Params *)e->d_params, (const Ptrs)e->g, masks_dev, matrix_dev, scores_dev);
     HIP_TRY(hipGetLastError());
@@ -1213,7 +1230,7 @@ extern "C" int mate_engine_lut_write(mate_engine *e, int64_t env, int32_t camera
     if (env < 0 || env >= e->N || camera < 0 || camera >= e->p.Nc) return fail(MATE_EINVAL, "lut_write: index out of range");
     if (n < 2 || n > e->p.kmax) return fail(MATE_EINVAL, "lut_write: %d knots do not fit (capacity %d)", n, e->p.kmax);
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->last_stream));
+    HIP_TRY(wait_for_launches(e));
     std::vector<double2> knots((size_t)n);
     std::vector<uint16_t> bucket((size_t)e->p.nbucket, 0);
     for (int i = 0; i < n; ++i) { knots[i].x = phis[i]; knots[i].y = rhos[i]; }
@@ -1272,7 +1289,7 @@ extern "C" int mate_engine_debug_skip(mate_engine *e, int32_t mask) {
 extern "C" int mate_engine_idle_steps(mate_engine *e, int64_t *total) {
     if (!e || !total) return fail(MATE_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->last_stream));
+    HIP_TRY(wait_for_launches(e));
     std::vector<int32_t> host((size_t)e->N);
     HIP_TRY(hipMemcpy(host.data(), e->g.idle_steps, sizeof(int32_t) * host.size(), hipMemcpyDeviceToHost));
     int64_t sum = 0;
@@ -1317,6 +1334,7 @@ extern "C" int mate_engine_block_alloc(int32_t device, int64_t bytes, void **ptr
         for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap((char *)va + i * kBlockChunk, kBlockChunk);
         for (auto h : blk.chunks) (void)hipMemRelease(h);
         (void)hipMemAddressFree(va, total);
+        (void)hipGetLastError();      // (the sticky error of the call that failed: reported through the return code, not through the next launch check)
     };
     for (size_t i = 0; i < n; ++i) {
         hipMemGenericAllocationHandle_t h;
@@ -1367,22 +1385,28 @@ extern "C" int mate_engine_block_probe(int32_t device, void *block, int64_t byte
     const int64_t steps = bytes / ((int64_t)rows_per_step * row_bytes);
     if (steps <= 0) return fail(MATE_EINVAL, "block_probe: the block holds less than one step of rows");
     HIP_TRY(hipSetDevice(device));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     float best = 0.f;
-    for (int rep = 0; rep < 4; ++rep) {      // (the first launch also pages the kernel in)
-        HIP_TRY(hipEventRecord(e0, (hipStream_t)stream));
-        hipLaunchKernelGGL(block_probe_kernel, dim3((unsigned)((rows_per_step + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (char *)block, steps, rows_per_step, row_bytes / 16);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(e1, (hipStream_t)stream));
-        HIP_TRY(hipEventSynchronize(e1));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        if (rep > 0 && (best == 0.f || ms < best)) best = ms;
-    }
-    HIP_TRY(hipEventDestroy(e0));
-    HIP_TRY(hipEventDestroy(e1));
+    auto measure = [&]() -> hipError_t {
+        hipError_t err;
+        if ((err = hipEventCreate(&e0)) != hipSuccess) return err;
+        if ((err = hipEventCreate(&e1)) != hipSuccess) return err;
+        for (int rep = 0; rep < 4; ++rep) {      // (the first launch also pages the kernel in)
+            if ((err = hipEventRecord(e0, (hipStream_t)stream)) != hipSuccess) return err;
+            hipLaunchKernelGGL(block_probe_kernel, dim3((unsigned)((rows_per_step + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (char *)block, steps, rows_per_step, row_bytes / 16);
+            if ((err = hipGetLastError()) != hipSuccess) return err;
+            if ((err = hipEventRecord(e1, (hipStream_t)stream)) != hipSuccess) return err;
+            if ((err = hipEventSynchronize(e1)) != hipSuccess) return err;
+            float ms = 0.f;
+            if ((err = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) return err;
+            if (rep > 0 && (best == 0.f || ms < best)) best = ms;
+        }
+        return hipSuccess;
+    };
+    const hipError_t probe_err = measure();
+    if (e0) (void)hipEventDestroy(e0);       // (on the error paths too)
+    if (e1) (void)hipEventDestroy(e1);
+    if (probe_err != hipSuccess) { (void)hipGetLastError(); return fail(MATE_EHIP, "block_probe: %s", hipGetErrorString(probe_err)); }
     const int64_t tail = bytes - steps * rows_per_step * row_bytes;
     if (tail > 0) HIP_TRY(hipMemsetAsync((char *)block + (bytes - tail), 0, (size_t)tail, (hipStream_t)stream));
     *gbytes_per_s = (double)(steps * rows_per_step) * row_bytes / ((double)best * 1e6);
@@ -1432,12 +1456,30 @@ extern "C" int mate_engine_block_free(void *ptr) {
         blk = std::move(it->second);
         g_blocks.erase(it);
     }
-    HIP_TRY(hipSetDevice(blk.device));
-    HIP_TRY(hipMemUnmap(ptr, blk.bytes));
-    for (auto h : blk.chunks) HIP_TRY(hipMemRelease(h));
-    // The virtual range is NOT given back: a later reservation that received the range of a freed block lost rows of a fused
-    // rollout's last step (the full GPU test suite, reproducibly) -- translations of the old mapping outliving the unmap.  A
-    // range is address space only (2^47 bytes of it; a block is a few GB), the physical chunks are released above.
+    hipError_t first = hipSetDevice(blk.device);
+    // One hipMemUnmap per hipMemMap: the runtime keeps a record per mapping, and a single unmap of the whole range (rounds 1-3)
+    // retired only the first chunk's -- the other chunks stayed mapped behind a range the next reservation could receive,
+    // which is how "a reused range lost rows of the next rollout" came about.  Every step runs even after a failure (the
+    // remaining chunks are still worth releasing); the first error is reported.
+    const size_t n = blk.chunks.size();
+    for (size_t i = 0; i < n; ++i) {
+        const hipError_t err = hipMemUnmap((char *)ptr + i * kBlockChunk, kBlockChunk);
+        if (err != hipSuccess && first == hipSuccess) first = err;
+    }
+    for (auto h : blk.chunks) {
+        const hipError_t err = hipMemRelease(h);
+        if (err != hipSuccess && first == hipSuccess) first = err;
+    }
+    // MATE_BLOCK_KEEP_RANGE=1: the former workaround -- the virtual range stays reserved for the life of the process
+    static const bool keep_range = [] { const char *v = getenv("MATE_BLOCK_KEEP_RANGE"); return v && atoi(v) != 0; }();
+    if (!keep_range) {
+        const hipError_t err = hipMemAddressFree(ptr, blk.bytes);
+        if (err != hipSuccess && first == hipSuccess) first = err;
+    }
+    if (first != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(MATE_EHIP, "block_free: %s", hipGetErrorString(first));
+    }
     return MATE_OK;
 }
 
@@ -1447,7 +1489,7 @@ extern "C" int mate_engine_kernel_time(mate_engine *e, int32_t enable, double *a
     double total = 0.0;
     int64_t n = 0;
     if (e->events_used) {
-        HIP_TRY(hipStreamSynchronize(e->last_stream));
+        HIP_TRY(wait_for_launches(e));
         for (size_t i = 0; i < e->events_used; ++i) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, e->events[i].first, e->events[i].second));

@@ -47,10 +47,11 @@ def gather_episode_stats(stats):
     return stats.as_dict(total), parts
 
 
-def reduce_job(elapsed, executed, stats, device='cpu'):
+def reduce_job(elapsed, executed, stats, device='cpu', force=False):
     """Whole-job numbers of a sharded benchmark run: (MAX over ranks of the timed region, SUM of the env-steps every
-    rank executed, per-rank statistics averaged).  Three tiny collectives after the timed region; identity on one rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    rank executed, per-rank statistics averaged).  Three tiny collectives after the timed region; identity on one rank
+    (`force`: run them on one rank too -- the single-GPU rehearsal of the N-rank path)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return float(elapsed), float(executed), stats
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -43,6 +43,7 @@ class Engine:
     def __init__(self, config, num_envs, device=0, seed=0, first_env_index=0, obs_dtype=torch.float32):
         """`config` is a validated scenario mapping (mate_amd.config.read_config)."""
         self.lib = _native.load()
+        self._block_switches = self._read_block_switches()
         self.config = config
         self.num_envs = int(num_envs)
         self.device_index = int(device)
@@ -276,13 +277,28 @@ class Engine:
         steps skipped because the episode had already ended inside this rollout."""
         return self._run_rollout(self.lib.mate_engine_rollout_random, steps, auto_reset, want_masks)
 
+    # Host-side switches of the observation-block search (read ONCE, when the Engine is built; include/mate_engine.h lists them)
+    @staticmethod
+    def _read_block_switches():
+        env = os.environ
+        return {
+            'plain': env.get('MATE_PLAIN_BLOCKS') == '1',
+            'candidates': int(env['MATE_BLOCK_CANDIDATES']) if 'MATE_BLOCK_CANDIDATES' in env else None,
+            'deep': env.get('MATE_BLOCK_DEEP', '1') != '0',
+            'deep_seconds': float(env.get('MATE_BLOCK_SECONDS', '3.0')),
+            'deep_gib': float(env.get('MATE_BLOCK_GIB', '96')),
+            'store_form': env.get('MATE_STORE_FORM', 'auto'),
+        }
+
     def _observation_block(self, shape, deep=False):
-        """A zeroed [steps][N][...] observation block.  Blocks of 64 MiB and more come from ``mate_engine_block_alloc``
-        (2 MiB physical chunks in a shuffled order): the fused rollouts store 10-25 % faster into them than into what
-        hipMalloc / the caching allocator hands out (include/mate_engine.h).  MATE_PLAIN_BLOCKS=1: torch.zeros."""
+        """A zeroed [steps][N][...] observation block and the store rates [GB/s] of the candidates probed for it.  Blocks of
+        64 MiB and more come from ``mate_engine_block_alloc`` (2 MiB physical chunks in a shuffled order): the fused rollouts
+        store 10-25 % faster into them than into what hipMalloc / the caching allocator hands out (include/mate_engine.h).
+        MATE_PLAIN_BLOCKS=1: torch.zeros."""
+        sw = self._block_switches
         nbytes = int(np.prod(shape)) * torch.empty((), dtype=self.obs_dtype).element_size()
-        if nbytes < (64 << 20) or os.environ.get('MATE_PLAIN_BLOCKS') == '1':
-            return torch.zeros(shape, dtype=self.obs_dtype, device=self.device)
+        if nbytes < (64 << 20) or sw['plain']:
+            return torch.zeros(shape, dtype=self.obs_dtype, device=self.device), []
         # Shuffled chunks make a slow block unlikely, not impossible (tools/store_vmm.hip): blocks of 128 MiB and more -- the ones
         # a launch is bounded by -- are the fastest of up to MATE_BLOCK_CANDIDATES (default 6) candidates in the kernels' own
         # store pattern, where the device has the memory to hold them side by side; the search ends at the first candidate
@@ -291,16 +307,22 @@ class Engine:
         # wide and at a different depth on every GPU (tools/depth_probe.py: forty 4.4 GB blocks allocated in a row and held -- five to
         # twelve consecutive ones fast, the rest slow).  The deep search walks through the memory in allocation order -- a
         # candidate, a 12 GB spacer that is not probed, a candidate ... -- until one is fast (5.35 TB/s, or 28 % above the
-        # slowest seen: the classes lie at ~4.2, ~5.0 and 5.4-6.1), within 45 % of what is free (two ranks that share a GPU in a
-        # test must both fit); everything but the winner is freed at the end.
+        # slowest seen: the classes lie at ~4.2, ~5.0 and 5.4-6.1).  Its transient footprint is bounded three ways: 45 % of what is
+        # free (two ranks that share a GPU in a test must both fit), MATE_BLOCK_GIB (default 96) GiB in absolute terms, and
+        # MATE_BLOCK_SECONDS (default 3) of wall time -- a learner whose model already holds most of the HBM gets a short search,
+        # not an out-of-memory error.  Everything but the winner is freed at the end (mate_engine_block_free gives the memory AND the
+        # address range back).
         row_bytes = nbytes // (shape[0] * shape[1])
-        tries = int(os.environ.get('MATE_BLOCK_CANDIDATES', '6')) if nbytes >= (128 << 20) and row_bytes % 16 == 0 else 1
+        tries = (sw['candidates'] or 6) if nbytes >= (128 << 20) and row_bytes % 16 == 0 else 1
         free = torch.cuda.mem_get_info(self.device)[0]
-        deep = deep and tries > 1 and os.environ.get('MATE_BLOCK_DEEP', '1') != '0'
+        deep = deep and tries > 1 and sw['deep']
         spacer_bytes = 12 << 30
-        if deep and 'MATE_BLOCK_CANDIDATES' not in os.environ:      # (an explicit count bounds the deep search too)
-            tries = max(tries, int(0.45 * free // (nbytes + spacer_bytes)))
+        budget = min(0.45 * free, sw['deep_gib'] * (1 << 30))
+        if deep and sw['candidates'] is None:      # (an explicit count bounds the deep search too)
+            tries = max(tries, int(budget // (nbytes + spacer_bytes)))
         tries = max(1, min(tries, int(free // (2 * nbytes))))
+        import time
+        t0 = time.perf_counter()
         best, rates, held, spacers = None, [], [], []
         for _ in range(tries):
             try:
@@ -309,8 +331,7 @@ class Engine:
                 if best is None:
                     import warnings
                     warnings.warn(f'mate_engine_block_alloc failed ({err}); the rollout block comes from torch.zeros')
-                    self.block_rates = getattr(self, 'block_rates', []) + [rates]
-                    return torch.zeros(shape, dtype=self.obs_dtype, device=self.device)
+                    return torch.zeros(shape, dtype=self.obs_dtype, device=self.device), rates
                 break
             if tries == 1:
                 best = (0.0, block)
@@ -325,44 +346,50 @@ class Engine:
             if deep:
                 if rate >= (5350.0 if nbytes >= (1 << 30) else 5100.0):      # (a short block's probe is a short launch: its ramp weighs more)
                     break
+                if time.perf_counter() - t0 > sw['deep_seconds']:
+                    break
                 try:
                     spacers.append(_native.HeldMemory(self.device_index, spacer_bytes))      # (moves the allocation on; never mapped, never touched)
                 except _native.EngineError:
                     break
-        self.block_rates = getattr(self, 'block_rates', []) + [rates]
         block = best[1]
         del held, best
         del spacers
-        return block.tensor(self.obs_dtype, shape).zero_()
+        return block.tensor(self.obs_dtype, shape).zero_(), rates
 
     def reserve_rollout(self, steps, want_masks=False):
         """Allocate the rollout-shaped output buffers ([steps][N][...]) now, so that a later rollout of up to `steps`
         steps allocates nothing (a training loop or a timed region calls this once up front).  Rows a launch does not
         write -- the observation rows of an environment that had finished earlier in the launch -- keep whatever they
-        held; its scalar rows say done = 2."""
+        held; its scalar rows say done = 2.  `Engine.reserve_seconds` says how long the last (re)allocation took, candidate
+        search included; `Engine.block_rates` = [target block's candidates, camera block's candidates] in GB/s."""
         steps = int(steps)
         buf = getattr(self, '_rollout', None)
         if buf is None or buf['steps'] < steps or (want_masks and buf['masks'] is None):     # a shorter rollout fills a prefix
+            import time
+            t0 = time.perf_counter()
             N, Nc, Nt, L = self.num_envs, self.num_cameras, self.num_targets, self.layout
             self._rollout = None
-            searched = len(getattr(self, 'block_rates', []))
             with torch.cuda.device(self.device):
-                target_block = self._observation_block((steps, N, Nt, L.target_obs_dim), deep=True)      # (first: its search holds the most memory)
+                target_block, target_rates = self._observation_block((steps, N, Nt, L.target_obs_dim), deep=True)      # (first: its search holds the most memory)
+                camera_block, camera_rates = self._observation_block((steps, N, Nc, L.camera_obs_dim))
                 buf = {
                     'steps': steps,
-                    'camera_obs': self._observation_block((steps, N, Nc, L.camera_obs_dim)),
+                    'camera_obs': camera_block,
                     'target_obs': target_block,
                     'scalars': torch.zeros((steps, N, 8), dtype=torch.float32, device=self.device),
                     'masks': torch.zeros((steps, N, L.mask_words), dtype=torch.int32, device=self.device) if want_masks else None,
                 }
             self._rollout = buf
+            self.block_rates = [target_rates, camera_rates]
             # where even the best candidate takes the rows slowly the stores bound a launch, and the line-aligned form of the row
             # stores wins 3 %; elsewhere it costs 1.3-2 % (include/mate_engine.h).  MATE_STORE_FORM=0 / 1 forces a form.
-            form = os.environ.get('MATE_STORE_FORM', 'auto')
-            probed = [max(r) for r in getattr(self, 'block_rates', [])[searched:searched + 1] if r]       # (the target block's candidates come first)
-            shifted = form == '1' or (form == 'auto' and bool(probed) and probed[0] < 4800.0)
+            form = self._block_switches['store_form']
+            shifted = form == '1' or (form == 'auto' and bool(target_rates) and max(target_rates) < 4800.0)
             self.store_form = int(shifted)
             check(self.lib.mate_engine_set_store_form(self._h, int(shifted)))
+            torch.cuda.synchronize(self.device)
+            self.reserve_seconds = time.perf_counter() - t0
         return buf
 
     def _run_rollout(self, entry_point, steps, auto_reset, want_masks):

@@ -78,3 +78,28 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=env_bad,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=120)
     assert bad.returncode != 0 and 'WORLD_SIZE=1' in bad.stderr
+
+
+def test_reduce_job_runs_its_collectives_on_one_rank_when_forced():
+    """`bench.py --force-collectives` (the one-GPU rehearsal of the N-rank path) needs the job-level reduction to really call
+    all_reduce / all_gather on a world of one: gloo here, RCCL in tests/test_gpu_multirank.py."""
+    import torch
+    import torch.distributed as dist
+    from mate_amd.distributed import reduce_job
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    try:
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda *a, **k: (calls.append('all_reduce'), real(*a, **k))[1]
+        try:
+            stats = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
+            assert reduce_job(0.5, 100.0, stats) == (0.5, 100.0, stats) and not calls          # identity on one rank ...
+            elapsed, executed, out = reduce_job(0.5, 100.0, stats, force=True)                  # ... unless forced
+            assert calls == ['all_reduce', 'all_reduce'] and (elapsed, executed) == (0.5, 100.0) and torch.equal(out, stats)
+        finally:
+            dist.all_reduce = real
+    finally:
+        dist.destroy_process_group()

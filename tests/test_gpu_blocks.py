@@ -133,12 +133,12 @@ def test_block_probe_and_candidate_search():
     try:
         eng = Engine(read_config('MATE-4v8-9.yaml'), 4096, seed=0)
         eng.reserve_rollout(5)                       # 4096 x 5 x 4192 B = 82 MiB of target rows: not searched
-        assert [len(r) for r in eng.block_rates] == [0] and eng._rollout['target_obs'].data_ptr() % (2 << 20) == 0
-        eng.block_rates = []
+        assert [len(r) for r in eng.block_rates] == [0, 0] and eng._rollout['target_obs'].data_ptr() % (2 << 20) == 0
         eng.reserve_rollout(64)                      # 1.02 GiB of target rows and 0.5 GiB of camera rows: both searched
     finally:
         os.environ.pop('MATE_BLOCK_CANDIDATES', None)
-    # (the target block first: its search may end at the first candidate if that one is fast)
+    # (block_rates = [target block's candidates, camera block's]; the target block's search may end at the first candidate if that one is fast)
+    assert eng.reserve_seconds > 0.0
     assert len(eng.block_rates) == 2 and len(eng.block_rates[0]) in (1, 2) and len(eng.block_rates[1]) == 2
     assert all(200.0 < x < 9000.0 for r in eng.block_rates for x in r)
     eng.reset()
@@ -149,7 +149,9 @@ def test_block_probe_and_candidate_search():
 
 def test_rows_survive_block_churn():
     """Blocks allocated and freed over and over, then a fused rollout into fresh ones: every row arrives (a virtual range handed
-    out again after a free once lost rows of the last step -- block_free keeps the range reserved since)."""
+    out again after a free once lost rows of the last step: block_free had unmapped the whole block with ONE hipMemUnmap although it
+    had been mapped chunk by chunk, which retired the first chunk's mapping only -- it now unmaps per chunk and gives the range
+    back, so reuse of a range is exactly what this test provokes)."""
     from mate_amd import _native
     from mate_amd.config import read_config
     from mate_amd.engine import Engine
@@ -173,3 +175,88 @@ def test_rows_survive_block_churn():
     for x, y in zip(*outs):
         assert torch.equal(x, y)
     assert float(outs[0][1][-1, -1].abs().sum()) > 0.0
+
+
+def test_block_free_returns_the_memory():
+    """Blocks allocated and freed: the device's free memory comes back (every chunk unmapped and released, the address range
+    given back), also after the candidate search of reserve_rollout, which frees everything but the winners."""
+    import gc
+    from mate_amd import _native
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    torch.cuda.synchronize()
+    gc.collect()
+    torch.cuda.empty_cache()
+    base = torch.cuda.mem_get_info(0)[0]
+    lib = _native.load()
+    for i in range(6):
+        blk = _native.ScatteredBlock(0, (256 + 64 * i) << 20)
+        blk.tensor(torch.uint8, (blk.nbytes,)).fill_(3)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] <= base - (200 << 20)
+        ptr, blk.ptr = blk.ptr, None                 # free it here, with the status checked (__del__ only warns)
+        assert lib.mate_engine_block_free(ctypes.c_void_p(ptr)) == 0, lib.mate_engine_last_error()
+        del blk
+    assert abs(torch.cuda.mem_get_info(0)[0] - base) <= (64 << 20)
+    os.environ['MATE_BLOCK_CANDIDATES'] = '3'
+    try:
+        eng = Engine(read_config('MATE-4v8-9.yaml'), 4096, seed=0)
+    finally:
+        os.environ.pop('MATE_BLOCK_CANDIDATES', None)
+    torch.cuda.synchronize()
+    before = torch.cuda.mem_get_info(0)[0]
+    buf = eng.reserve_rollout(64)                    # 1.02 GiB + 0.5 GiB, up to three candidates each
+    kept = sum(buf[k].numel() * buf[k].element_size() for k in ('camera_obs', 'target_obs', 'scalars'))
+    gc.collect()
+    torch.cuda.synchronize()
+    assert before - torch.cuda.mem_get_info(0)[0] <= kept + (96 << 20)      # the losers of the search are gone
+    eng._rollout = None
+    del buf, eng
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    assert abs(torch.cuda.mem_get_info(0)[0] - base) <= (128 << 20)
+
+
+def test_a_failed_block_alloc_leaves_no_sticky_error_and_the_fallback_runs():
+    """mate_engine_block_alloc fails (a block larger than the device): the error comes back through the return code ONLY -- the
+    next kernel launch check, the engine's own and torch's, must not see it -- and Engine.reserve_rollout falls back to
+    torch.zeros with a warning; the rollout into the fallback buffers equals the one into scattered blocks."""
+    from mate_amd import _native
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    lib = _native.load()
+    ptr = ctypes.c_void_p()
+    assert lib.mate_engine_block_alloc(0, 1 << 42, ctypes.byref(ptr)) != 0 and not ptr.value      # 4 TiB
+    torch.zeros(16, device='cuda').add_(1)           # torch's launch check
+    torch.cuda.synchronize()
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=30)
+    outs = []
+    for broken in (False, True):
+        eng = Engine(cfg, 1024, seed=3)
+        eng.reset()
+        if broken:
+            real = _native.ScatteredBlock
+
+            def failing(device_index, nbytes):
+                return real(device_index, 1 << 42)
+            _native.ScatteredBlock = failing
+        try:
+            with (pytest.warns(UserWarning, match='block_alloc failed') if broken else _nullcontext()):
+                cam, tgt, sc = eng.rollout_random(40, auto_reset=True)      # 1024 x 40 x 4192 B = 164 MiB of target rows
+        finally:
+            if broken:
+                _native.ScatteredBlock = real
+        torch.cuda.synchronize()
+        assert (eng._rollout['target_obs'].data_ptr() % (2 << 20) == 0) or broken
+        outs.append((cam.clone(), tgt.clone(), sc.clone(), eng.export_state().clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False

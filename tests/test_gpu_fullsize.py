@@ -161,23 +161,31 @@ def test_greedy_workload_sharding_and_progress():
     assert 0 < idle < 0.12 * n * steps                                 # finished environments waited for the next batched reset
 
 
-def test_benchmark_flow_equals_single_steps_at_the_headline_size():
-    """bench.py's default flow -- 32-step fused rollout launches of MATE-4v8-9 x 4096 with auto-reset after each launch --
-    against 32 single-step launches: every row of both observation blocks, the scalar records and the masks, then the
-    state, bit for bit, over two launches."""
+@pytest.mark.parametrize('K,launches,resets,store_form', [(32, 2, 1, 'auto'), (20, 7, 6, '0'), (20, 7, 6, '1')])
+def test_benchmark_flow_equals_single_steps_at_the_headline_size(K, launches, resets, store_form):
+    """bench.py's flows at MATE-4v8-9 x 4096 -- fused 32-step launches with a restart launch behind each, and the DRIVER's own
+    launch shape: `--steps 20` = one 20-step launch per region, finished environments restarted after every 6th launch, in either
+    form of the row stores (Engine.reserve_rollout picks one per box from the probed store rate; MATE_STORE_FORM forces it) --
+    against single-step launches: every row of both observation blocks, the scalar records and the masks, then the state, bit
+    for bit."""
+    import os
     cfg = read_config('MATE-4v8-9.yaml')
-    n, K = 4096, 32
-    a = Engine(cfg, n, seed=21)
+    n = 4096
+    os.environ['MATE_STORE_FORM'] = store_form
+    try:
+        a = Engine(cfg, n, seed=21)
+    finally:
+        os.environ.pop('MATE_STORE_FORM', None)
     b = Engine(cfg, n, seed=21)
     a.reset(); b.reset()
-    for launch in range(2):
-        cam, tgt, sc = a.rollout_random(K, auto_reset=True, want_masks=True)
-        assert a.last_flow == 1
+    for launch in range(launches):
+        cam, tgt, sc = a.rollout_random(K, auto_reset=resets, want_masks=True)
+        assert a.last_flow == 1 and (store_form == 'auto' or a.store_form == int(store_form))
         for r in range(K):
             b.step_random(auto_reset=False, want_masks=True)
             assert torch.equal(cam[r], b.camera_obs) and torch.equal(tgt[r], b.target_obs), (launch, r)
             assert torch.equal(sc[r], b.scalars) and torch.equal(a._rollout['masks'][r], b.masks), (launch, r)
-        assert not bool((sc[:, :, 2] != 0).any())           # nothing ends this early: no idle slot, no reset
+        assert not bool((sc[:, :, 2] != 0).any())           # nothing ends this early: no idle slot, the restart launches find nothing
         assert torch.equal(a.export_state(), b.export_state())
 
 

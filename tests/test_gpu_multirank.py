@@ -111,6 +111,30 @@ def test_two_ranks_on_one_gpu_run_the_real_engine_and_shard_bit_for_bit(tmp_path
     assert parts[0]['idle_steps'] + parts[1]['idle_steps'] == one['idle_steps']
 
 
+def test_one_rank_runs_every_collective_of_the_sharded_path_on_rccl():
+    """`bench.py --force-collectives`: ONE rank initialises the `nccl` (= RCCL) process group with `device_id`, and every
+    collective `--gpus 8` executes runs on the GPU -- `dist.barrier()` around the timed regions, the side-stream `all_gather` of
+    the episode statistics inside them (StatsGather.submit), the job-level reduction on device tensors (reduce_job) and the
+    per-rank start-up record.  A child process (this one has initialised the GPU); the plain run beside it bounds what the
+    collectives may cost: a barrier is a ~15 us kernel on a 2.5 ms region."""
+    common = ['--steps', '512', '--warmup', '64', '--reps', '3', '--rep-warmup', '2', '--no-cpu-baseline', '--no-extras', '--no-other-configs',
+              '--no-side-measurements']
+    forced = _bench(common + ['--force-collectives'])
+    plain = _bench(common)
+    assert forced['config']['backend'] == 'nccl (RCCL)' and forced['n_gpus'] == 1 and 'forced' in forced['config']['collectives']
+    assert plain['config']['backend'] == 'single process'
+    gathered = forced['episode_stats']['gathered_in_loop']
+    assert gathered is not None and gathered['gathers_in_timed_loops'] >= 1
+    assert forced['roofline']['kernel_avg_us'] > 0 and forced['data'] == 'synthetic'
+    for line in (forced, plain):
+        st = line['startup']
+        assert len(st['startup_s']) == 1 and st['startup_s'][0] > 0 and 0 < st['reserve_rollout_s'][0] < 30.0
+    assert forced['startup']['process_group_s'][0] > 0.0
+    ratio = forced['value'] / plain['value']
+    print(f"forced collectives {forced['value']:.4g} vs plain {plain['value']:.4g} env-steps/s: {ratio:.3f}; start-up {forced['startup']}")
+    assert 0.97 <= ratio <= 1.06, (forced['value'], plain['value'])
+
+
 def test_time_limited_episodes_reach_the_gathered_statistics(tmp_path):
     """With episodes that end inside the run the gathered record is not empty: max_episode_steps is a config override the
     bench does not expose, so this drives StatsGather itself on a short-episode engine (one rank)."""

@@ -190,7 +190,7 @@ def test_greedy_rollout_on_philox_streams():
     assert float(eng.scalars[:, 3].mean()) > 0.2   # greedy cameras keep a sizeable coverage
 
 
-@pytest.mark.parametrize('config,n,steps', [('MATE-8v8-9.yaml', 48, 120), ('MATE-4v8-9.yaml', 64, 120), ('MATE-Navigation.yaml', 32, 80)])
+@pytest.mark.parametrize('config,n,steps', [('MATE-8v8-9.yaml', 256, 200), ('MATE-4v8-9.yaml', 64, 120), ('MATE-Navigation.yaml', 32, 80)])
 def test_greedy_policies_batch_vs_oracle(config, n, steps, oracle_lib):
     """The on-device policies against the oracle's restatement of the reference agents, closed loop, on a batch of
     independently reset environments with random draw tapes (every agent branch fires somewhere in the batch):
@@ -297,12 +297,13 @@ def test_policies_refuse_more_than_eight_cameras():
         eng.enable_policies()                  # ... but not with the on-device greedy agents
 
 
-@pytest.mark.parametrize('switch', ['MATE_ZOOM_ITERATE', 'MATE_POLICY_SPLIT'])
-def test_policy_implementation_switches_give_the_same_episodes(switch):
+@pytest.mark.parametrize('switch,auto_reset', [('MATE_ZOOM_ITERATE', 1), ('MATE_POLICY_SPLIT', 1), ('MATE_POLICY_SPLIT', 4)])
+def test_policy_implementation_switches_give_the_same_episodes(switch, auto_reset):
     """Two implementation choices of the on-device Greedy agents, selected at create by an environment switch:
     MATE_ZOOM_ITERATE=1 runs the reference's 20-iteration zoom solve (agents/greedy.py:139-145) instead of its tabulation --
     joint actions within 1e-10 degrees, the episodes (masks, goals, rewards) identical; MATE_POLICY_SPLIT=1 runs
-    step_greedy / step_versus_greedy as two launches (agents' kernel, step kernel) instead of the fused one -- bit for bit."""
+    step_greedy / step_versus_greedy as two launches (agents' kernel, step kernel) instead of the fused one -- bit for bit,
+    also with batched resets (auto_reset = 4: the idle rows of finished environments included)."""
     from mate_amd.config import read_config
     from mate_amd.engine import Engine
     cfg = read_config('MATE-8v8-9.yaml', max_episode_steps=40)
@@ -318,16 +319,19 @@ def test_policy_implementation_switches_give_the_same_episodes(switch):
         eng.reset()
         rec = []
         mine = torch.zeros((n, eng.num_targets, 2), device='cuda')
+        idle_rows = 0
         for s in range(60):
             if s % 2:
-                eng.step_greedy(auto_reset=True)
+                eng.step_greedy(auto_reset=auto_reset)
             else:
                 mine.fill_(float(3 * (s % 5) - 6))
-                eng.step_versus_greedy('target', mine, auto_reset=True)
+                eng.step_versus_greedy('target', mine, auto_reset=auto_reset)
             cam, tgt = eng.policy_actions()
+            idle_rows += int((eng.scalars[:, 2] == 2).sum())
             rec.append((cam.clone(), eng.scalars.clone(), eng.masks.clone(), eng.target_obs.clone()))
         rec.append((eng.export_state().clone(),))
         runs.append(rec)
+        assert (idle_rows > 0) == (auto_reset > 1)
     exact = switch == 'MATE_POLICY_SPLIT'
     for a, b in zip(*runs):
         if exact:
@@ -337,3 +341,38 @@ def test_policy_implementation_switches_give_the_same_episodes(switch):
             for x, y in zip(a[1:], b[1:]):
                 assert torch.allclose(x.double(), y.double(), rtol=0, atol=1e-6) and (x.dtype.is_floating_point or torch.equal(x, y))
     assert (runs[0][-1][0][:, -2] >= 2).all()                     # every environment went through an episode end
+
+
+def test_policy_split_switch_under_the_graph_stepper_versus_greedy():
+    """The learner-versus-greedy loop replayed from a HIP graph (Engine.make_stepper(versus=...)) with the one-launch and with
+    the two-launch form of a step (MATE_POLICY_SPLIT), batched resets inside the graph: the same bytes."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=25)
+    n, runs = 96, []
+    for value in ('0', '1'):
+        os.environ['MATE_POLICY_SPLIT'] = value
+        try:
+            eng = Engine(cfg, n, seed=5)
+        finally:
+            os.environ.pop('MATE_POLICY_SPLIT', None)
+        eng.enable_policies()
+        eng.reset()
+        mine = torch.zeros((n, eng.num_cameras, 2), device='cuda')
+        counter = torch.zeros((), device='cuda')
+
+        def policy():
+            counter.add_(1.0)
+            mine.copy_((torch.sin(counter) * 4.0).expand_as(mine))
+
+        stepper = eng.make_stepper(mine, None, auto_reset=4, graph_steps=8, between=policy, versus='camera')
+        rec = []
+        for _ in range(9):
+            stepper.run(8)
+            rec.append((eng.scalars.clone(), eng.masks.clone(), eng.camera_obs.clone(), eng.target_obs.clone()))
+        stepper.close()
+        rec.append((eng.export_state().clone(),))
+        runs.append(rec)
+    for a, b in zip(*runs):
+        assert all(torch.equal(x.view(torch.uint8), y.view(torch.uint8)) for x, y in zip(a, b))
+    assert (runs[0][-1][0][:, -2] >= 2).all()
