@@ -36,6 +36,10 @@
  *                            row-image compilation (same rows; tests compare the two)
  *   MATE_POLICY_SPLIT=1      mate_engine_step_greedy / _step_versus_greedy as two launches (the agents' kernel, then the step
  *                            kernel) even where the fused one-launch form applies (same results; tests compare the two)
+ *   MATE_STEP_SPLIT=0|1      the per-step kernel of the folded flows (step_random / step with real-valued actions, f32 observations)
+ *                            as one wave per environment (0) or two (1: cameras, sector tests and goals on one wave, targets
+ *                            and range tests on the other; engine_kernels.hpp: step_split_kernel); default: by what measured
+ *                            faster at the batch size; the same bytes either way (tests compare the two)
  *   MATE_ZOOM_ITERATE=1      the on-device GreedyCameraAgent runs the reference's 20-iteration zoom solve
  *                            (mate/agents/greedy.py:139-145) instead of reading its tabulation; the two differ by
  *                            <= 1.5e-13 degrees in the viewing angle (parity runs that want the iteration itself)

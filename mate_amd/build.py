@@ -66,6 +66,18 @@ def build_engine(force=False, verbose=False):
     return OUT
 
 
+def build_profiling(verbose=False):
+    """The profiling build (per-wave s_memtime stamps at the phase boundaries, -DMATE_PHASE_CLOCKS): lib/libmate_engine_prof.so,
+    selected with MATE_ENGINE_LIB by tools/*_phases.py.  Never loaded by the package itself."""
+    out = os.path.join(HERE, 'lib', 'libmate_engine_prof.so')
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc] + FLAGS + ['-DMATE_PHASE_CLOCKS', '-o', out, SRC]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return out
+
+
 def build_tools(verbose=False):
     """The stand-alone measurement programs under tools/ (store rooflines, issue rates): one hipcc call each, binaries next to
     the sources (git-ignored; they travel to the GPU box with the tree)."""
@@ -88,3 +100,5 @@ if __name__ == '__main__':
     build_engine(force='--force' in sys.argv, verbose=True)
     if '--tools' in sys.argv:
         build_tools(verbose=True)
+    if '--prof' in sys.argv:
+        build_profiling(verbose=True)

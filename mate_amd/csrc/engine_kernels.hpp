@@ -218,6 +218,9 @@ struct Ptrs {
 #ifdef MATE_PHASE_CLOCKS
 #define PHASE_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #define SUB_STAMP(c, i) do { if ((c).lane == 0 && (c).g.phase_clocks) (c).g.phase_clocks[(c).env * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#elif defined(MATE_ISA_MARKS)      // tools/isa_phases.py: phase boundaries of step_kernel as comments in the -S output (no instruction is emitted)
+#define PHASE_STAMP(i) asm volatile("; ==== MATE_STEP_PHASE " #i)
+#define SUB_STAMP(c, i) asm volatile("; ==== MATE_STEP_SUB " #i)
 #else
 #define PHASE_STAMP(i) do { } while (0)
 #define SUB_STAMP(c, i) do { } while (0)
@@ -599,8 +602,10 @@ __device__ __forceinline__ uint64_t near_field(const Params &p, const NearCarry 
     const unsigned long long field = ((lo >> sh) | (sh ? hi << (64 - sh) : 0ull)) & ((1ull << p.NK) - 1ull);
     return (field >> p.Nc) | ((field & ((1ull << p.Nc) - 1ull)) << p.No);
 }
+// `collide_word` (the two-wave step, whose target wave does not own the targets' integer words): the colliding bits of all
+// targets as one word, bit t, instead of bit 24 of each TI_GW.
 template <typename ObsT>
-__device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws, const NearCarry *carried = nullptr) {
+__device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws, const NearCarry *carried = nullptr, int32_t *collide_word = nullptr) {
     const Params &p = c.p;
     const int lane = c.lane;
     const int t = lane - p.Nc;
@@ -689,8 +694,13 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
         c.tx(t) = nx; c.ty(t) = ny;
         c.ex[c.tgt_slot(t)] = nx; c.ey[c.tgt_slot(t)] = ny;
         c.exf[c.tgt_slot(t)] = (float)nx; c.eyf[c.tgt_slot(t)] = (float)ny;
+        if (collide_word) {
+            const unsigned long long b = __ballot(colliding);
+            if (t == 0) *collide_word = (int32_t)(b >> p.Nc);
+        } else {
         int gw = c.ti(t, TI_GW) & ~(1 << 24);
         c.ti(t, TI_GW) = gw | ((int)colliding << 24);
+        }
     }
     wave_sync();
 }
@@ -2201,6 +2211,293 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
 #ifdef MATE_PHASE_CLOCKS
     if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
 #endif
+}
+
+// =============================================================================================
+// The step kernel with an environment split over TWO waves (one 128-thread workgroup per environment).
+//
+// At the headline batch step_kernel holds one generation of waves, four per SIMD, each walking ONE chain of ~1500 dependent
+// instructions: its vector unit is busy 60 % of the time (0.15 of a wave's life, times four) and the launch lasts as long as
+// that chain.  The chain has two halves that meet only twice:
+//   wave A (cameras)  records -> Camera.simulate            | sector tests + occlusion lookups -> tracked bits ->   | camera rows,
+//                                                            | _assign_goals, rewards, counters, targets' slots      | masks, state
+//   wave B (targets)  records -> Target.simulate (screen,    | range tests, obstacle slots                           | target rows
+//                     walk), entity table                    |                                                       |
+//                                              barrier 1 ----^                                        barrier 2 -----^
+// Everything in the environment's LDS slice has ONE writer per interval: A owns the camera angles, the integer words, the sector
+// / camera->obstacle mask words and flags, the constant, camera and target slots of the gather scratch; B owns the targets'
+// positions, the entity table, its collision screen, the range mask words and flags and the obstacle slots.  (Both write the
+// static record: identical values.)  B reports the colliding bits as one word, which A folds into the goal words it owns.
+// Same phase functions, same arithmetic, same bytes as step_kernel (tested); compiled for the two folded flows (f32 observations).
+template <typename ObsT>
+__device__ __forceinline__ void split_commit_records(Ctx<ObsT> &c, int role, double s0, double s1, double d0, double d1, const ObsT (&q)[4]) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    const double *s = c.g.stat + c.env * p.SW;
+    const double *d = c.g.dyn + c.env * p.DW;
+    const int t_lo = 2 * p.Nc, t_hi = 2 * p.Nc + 2 * p.Nt;          // words of the dynamic record that hold the targets' positions: B's
+    auto mine = [&](int i) { const bool pos = i >= t_lo && i < t_hi; return role == 0 ? !pos : pos; };
+    if (lane < p.SW) c.st[lane] = s0;
+    if (lane + 64 < p.SW) c.st[lane + 64] = s1;
+    for (int i = lane + 128; i < p.SW; i += 64) c.st[i] = s[i];
+    if (lane < p.DW && mine(lane)) c.dy[lane] = d0;
+    if (lane + 64 < p.DW && mine(lane + 64)) c.dy[lane + 64] = d1;
+    for (int i = lane + 128; i < p.DW; i += 64) if (mine(i)) c.dy[i] = d[i];
+    // gather scratch: [0, sc_obs) constants, cameras, targets: A; [sc_obs, nscratch) obstacles: B
+    const ObsT *si = reinterpret_cast<const ObsT *>(c.g.scratch_init);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k;
+        if (i < p.nscratch && (role == 0 ? i < p.sc_obs : i >= p.sc_obs)) c.scratch[i] = q[k];
+    }
+    for (int i = lane + 256; i < p.nscratch; i += 64) if (role == 0 ? i < p.sc_obs : i >= p.sc_obs) c.scratch[i] = si[i];
+    // mask words: the range rounds' are B's, all others A's
+    const int r_lo = p.bit_range >> 5, r_hi = r_lo + 2 * p.range_rounds;
+    for (int i = lane; i < p.MW; i += 64) { const bool rng = i >= r_lo && i < r_hi; if (role == 0 ? !rng : rng) c.mask[i] = 0u; }
+}
+
+// Camera.perceive for all (camera, target) and (camera, camera) pairs: update_view's sector rounds, on wave A
+template <typename ObsT>
+__device__ __forceinline__ void split_view_sector(Ctx<ObsT> &c, uint32_t tick) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    double2 w[kDegWords];
+    for (int round = 0; round + 1 < p.sector_rounds; ++round) {
+        const SectorEval e = sector_eval(c, round * 64 + lane, tick, S_TRANSMIT, true);
+        sector_fetch(c, e, w);
+        const bool seen = sector_resolve(c, e, w);
+        if (round * 64 + lane < p.n_sector) set_flag(c, round * 64 + lane, seen);
+        const unsigned long long b = __ballot(seen);
+        if (lane == 0) { c.mask[2 * round] = (uint32_t)b; c.mask[2 * round + 1] = (uint32_t)(b >> 32); }
+    }
+    const int last = p.sector_rounds - 1;
+    SectorEval pending;
+    pending.seen = false; pending.need = false;
+    if (last >= 0) {
+        pending = sector_eval(c, last * 64 + lane, tick, S_TRANSMIT, true);
+        sector_fetch(c, pending, w);
+    }
+    // under the occlusion records' round trip: the static camera->obstacle bits (environment.py:752-755), the always-true bit ...
+    if (lane < p.Nc) {
+        const uint64_t m = c.camobs(lane);
+        c.mask[(p.bit_camobs >> 5) + 2 * lane] = (uint32_t)m;
+        c.mask[(p.bit_camobs >> 5) + 2 * lane + 1] = (uint32_t)(m >> 32);
+    }
+    if (lane == 0) { c.mask[p.bit_always >> 5] = 1u; set_flag(c, p.fs_always, true); }
+    for (int q = lane; q < p.Nc * p.No; q += 64) {
+        const int cam = (int)(((float)q + 0.5f) * p.inv_No);
+        const int o = q - cam * p.No;
+        set_flag(c, p.fs_camobs + cam * p.No + o, (c.camobs(cam) >> o) & 1ull);
+    }
+    // ... and which warehouse holds a target (the second half of update_view's tail)
+    if (lane < p.Nt) {
+        const double x = c.tx(lane), y = c.ty(lane);
+        const bool px = x > 0.0, py = y > 0.0;
+        const double wx = px ? kWarehouseCenter : -kWarehouseCenter, wy = py ? kWarehouseCenter : -kWarehouseCenter;
+        const double sup = fmax(fabs(x - wx), fabs(y - wy));
+        c.inside(lane) = sup <= kWarehouseRadius ? (px ? (py ? 0 : 3) : (py ? 1 : 2)) : -1;
+    }
+    unsigned long long b = 0ull;
+    if (last >= 0) {
+        const bool seen = sector_resolve(c, pending, w);
+        if (last * 64 + lane < p.n_sector) set_flag(c, last * 64 + lane, seen);
+        b = __ballot(seen);
+        if (lane == 0) { c.mask[2 * last] = (uint32_t)b; c.mask[2 * last + 1] = (uint32_t)(b >> 32); }
+    }
+    wave_sync();
+    // tracked_bits = camera_target_view_mask.any(axis=0) (environment.py:1388)
+    if (lane < p.Nt) {
+        int any = 0;
+        for (int cam = 0; cam < p.Nc; ++cam) any |= (int)c.mask_bit(cam * p.Nt + lane);
+        c.tracked(lane) = any;
+    }
+    wave_sync();
+}
+
+// Sensor.perceive for all (target, camera | obstacle | target) pairs: update_view's range rounds, on wave B
+template <typename ObsT>
+__device__ __forceinline__ void split_view_range(Ctx<ObsT> &c) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    const int rbase = p.bit_range >> 5;
+    uint32_t seen_bits = 0;
+#pragma unroll 4
+    for (int round = 0; round < p.range_rounds; ++round) {
+        const int q = round * 64 + lane;
+        const int qq = q < p.n_range ? q : 0;
+        const int t = (int)(((float)qq + 0.5f) * p.inv_NJ);
+        const int j = qq - t * p.NJ;
+        const int tj = c.tgt_slot(t);
+        const bool diag = (j == tj);
+        const float dx = c.exf[tj] - c.exf[j], dy = c.eyf[tj] - c.eyf[j];
+        const float d2 = fmaf(dy, dy, dx * dx);
+        const float lim = (float)p.tgt_sight + c.erf[j], lim2 = lim * lim, rim = range_rim(lim);
+        bool seen = d2 < lim2 - rim;
+        if (!seen && !(d2 > lim2 + rim)) seen = range_exact(c, tj, j);
+        seen_bits |= (uint32_t)((seen || diag) && q < p.n_range) << round;
+    }
+    for (int round = 0; round < p.range_rounds; ++round) {
+        const int q = round * 64 + lane;
+        const bool seen = (seen_bits >> round) & 1u;
+        if (q < p.n_range) set_flag(c, p.fs_range + q, seen);
+        const unsigned long long b = __ballot(seen);
+        if (lane == 0) { c.mask[rbase + 2 * round] = (uint32_t)b; c.mask[rbase + 2 * round + 1] = (uint32_t)(b >> 32); }
+    }
+}
+
+// one team's rows through the descriptor table (pack_rows_f32, one block): descriptors before the first store
+template <int G, typename ObsT>
+__device__ __forceinline__ void split_pack_rows(const Ctx<ObsT> &c, const uint32_t *table, float *dst, int elems) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int nv = elems / 4;
+    const uint4 *tab = reinterpret_cast<const uint4 *>(table);
+    f32x4 *out = reinterpret_cast<f32x4 *>(dst);
+    uint4 d[G > 0 ? G : 1];
+#pragma unroll
+    for (int k = 0; k < G; ++k) { const int i = c.lane + 64 * k; d[k] = tab[i < nv ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < G; ++k) asm volatile("" : "+v"(d[k].x), "+v"(d[k].y), "+v"(d[k].z), "+v"(d[k].w));
+    auto chunk = [&](const uint4 &x) { return f32x4{gather_one(c, x.x), gather_one(c, x.y), gather_one(c, x.z), gather_one(c, x.w)}; };
+#pragma unroll
+    for (int k = 0; k < G; ++k) { const int i = c.lane + 64 * k; if (i < nv) stream_store(chunk(d[k]), &out[i]); }
+    for (int i = c.lane + 64 * G; i < nv; i += 64) stream_store(chunk(tab[i]), &out[i]);
+}
+
+template <typename ObsT, typename Shape, int FLOW>
+__global__ __launch_bounds__(128, 4) __attribute__((amdgpu_num_sgpr(96)))
+void step_split_kernel(const Params *__restrict__ pp, const Ptrs g) {
+    static_assert(sizeof(ObsT) == 4 && (FLOW == FLOW_RANDOM || FLOW == FLOW_ACT_F32), "the two-wave step: f32 observations, a folded flow");
+    const Shape shape(pp);
+    const Params &p = shape.get();
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) {
+        const int32_t parity = (int32_t)((p.dev_group + (uint32_t)g.parity) & 1u);
+        g.done_count[parity ^ 1] = 0;  // next step's counter
+        g.ctrl[0] = parity;            // read by the auto-reset launch behind a device-counted interval
+    }
+    const uint32_t tick = p.dev_tick + g.tick;
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // 0: wave A (cameras), 1: wave B (targets)
+    const int64_t env = (int64_t)blockIdx.x;
+    phase_prio(g.stagger, 0);
+    const Ptrs &gk = kernarg_ptrs(g);
+    Ctx<ObsT> c(p, gk, smem, lane, env, FLOW);
+#ifdef MATE_PHASE_CLOCKS      // per-wave stamps: slots 0-7 wave A, 8-15 wave B (tools/split_phases.py)
+#define SPLIT_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + role * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SPLIT_STAMP(i) do { } while (0)
+#endif
+    SPLIT_STAMP(0);
+    // ---- records into registers (both waves: all of both records), the step's draws under their latency
+    const double *s = c.g.stat + env * p.SW;
+    const double *d = c.g.dyn + env * p.DW;
+    const ObsT *si = reinterpret_cast<const ObsT *>(c.g.scratch_init);
+    double s0 = s[lane < p.SW ? lane : 0], d0 = d[lane < p.DW ? lane : 0], s1 = 0.0, d1 = 0.0;
+    if (p.SW > 64) s1 = s[lane + 64 < p.SW ? lane + 64 : 0];
+    if (p.DW > 64) d1 = d[lane + 64 < p.DW ? lane + 64 : 0];
+    ObsT q[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (p.nscratch > 64 * k) q[k] = si[lane + 64 * k < p.nscratch ? lane + 64 * k : 0];
+    asm volatile("" : "+v"(s0), "+v"(s1), "+v"(d0), "+v"(d1));
+    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+    StepDraws draws{0.0, 0.0};
+    {
+        // A: its cameras' actions (random policy) and the transmittance draws of the camera->target pairs; B: its targets' actions
+        DrawRole r = draw_role(c);
+        const bool target_lane = lane >= p.Nc && lane < p.Nc + p.Nt;
+        if (role == 0 ? (r.kind == 1 && target_lane) : (r.kind == 2 || (r.kind == 1 && !target_lane))) r.kind = 0;
+        if (role == 0 || c.mode() == MODE_STEP_RANDOM) draws = step_draws(c, tick, nullptr, &r);
+    }
+    // the batched auto-reset's idle environments: decided from the record in registers, by both waves alike
+    int done_word;
+    {
+        const int idx = p.Nt * TI_STRIDE + EI_DONE, word = p.DF + (idx >> 1);      // (wave-uniform)
+        const double dw = word < 64 ? d0 : d1;
+        const int half = (idx & 1) ? __double2hiint(dw) : __double2loint(dw);
+        done_word = __builtin_amdgcn_readlane(half, word & 63);
+        if (p.DW > 128 && word >= 128) done_word = reinterpret_cast<const int32_t *>(d + p.DF)[idx];
+    }
+    if (c.freeze_done() && done_word != 0) {
+        if (role == 0 && lane == 0) {
+            if (g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
+            if (g.idle_steps) g.idle_steps[env] += 1;
+            if (g.done_count && done_word == 1) {      // finished under auto_reset = 0 earlier: not on the list yet
+                const int parity = c.list_parity();
+                const int slot = atomicAdd(g.done_count + parity, 1);
+                g.done_list[(int64_t)parity * g.N + slot] = (int32_t)env;
+                reinterpret_cast<int32_t *>(g.dyn + env * p.DW + p.DF)[p.Nt * TI_STRIDE + EI_DONE] = 3;
+            }
+        }
+        return;
+    }
+    split_commit_records(c, role, s0, s1, d0, d1, q);
+    wave_sync();
+    SPLIT_STAMP(1);
+    phase_prio(g.stagger, 1);
+    if (role == 0) {
+        simulate_cameras(c, draws, true);
+        wave_sync();
+    } else {
+        build_entities(c);
+        wave_sync();
+        simulate_targets(c, draws, nullptr, &c.xch(4));
+        // Obstacle.state slots of the gather scratch (fill_scratch's static part)
+        for (int o = lane; o < p.No; o += 64) {
+            ObsT *sc = c.scratch + p.sc_obs + o * 3;
+            sc[0] = (ObsT)c.obs_x(o); sc[1] = (ObsT)c.obs_y(o); sc[2] = (ObsT)c.obs_r(o);
+        }
+    }
+    SPLIT_STAMP(2);
+    __syncthreads();          // barrier 1: camera angles and sight ranges, target positions, the entity table
+    SPLIT_STAMP(3);
+    phase_prio(g.stagger, 2);
+    constexpr int GC = Shape::kHeldGC, GT = Shape::kHeldGT;
+    if (role == 0) {
+        split_view_sector(c, tick);
+        SPLIT_STAMP(4);
+        phase_prio(g.stagger, 3);
+        if (lane < p.Nt) {          // the colliding bits B reported, into the goal words (Target.simulate, entities.py:668)
+            const int gw = c.ti(lane, TI_GW) & ~(1 << 24);
+            c.ti(lane, TI_GW) = gw | (((c.xch(4) >> lane) & 1) << 24);
+        }
+        wave_sync();
+        assign_and_score(c, tick, g.scalars);
+        // Target.state slots (fill_scratch's per-target part; obs_mode 0 in the folded flows)
+        if (lane < p.Nt) {
+            ObsT *sc = c.scratch + p.sc_tgt + lane * 14;
+            const int gw = c.ti(lane, TI_GW) & 0xffffff;
+            const int cap = 1 + (int)((c.capword() >> lane) & 1ull);
+            sc[0] = (ObsT)c.tx(lane); sc[1] = (ObsT)c.ty(lane);
+            sc[4] = (ObsT)(cap == 2 ? p.tgt_step * 0.5 : p.tgt_step); sc[5] = (ObsT)cap;
+            const int goal = (gw & 0xff) - 1, weight = (gw >> 8) & 0xff, empty = (gw >> 16) & 0xf;
+            sc[3] = (ObsT)(goal >= 0 && weight > 0 ? 1.0 : 0.0);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                sc[6 + w] = (ObsT)(goal == w ? weight : 0);
+                sc[10 + w] = (ObsT)((empty >> w) & 1);
+            }
+        }
+    } else {
+        split_view_range(c);
+    }
+    SPLIT_STAMP(5);
+    __syncthreads();          // barrier 2: flags, gather scratch, integer words
+    SPLIT_STAMP(6);
+    phase_prio(g.stagger, 4);
+    if (role == 0) {
+        if (p.cam_elems > 0) {
+            float *dst = reinterpret_cast<float *>(c.g.cam_obs) + c.out * p.cam_elems;
+            if ((p.cam_elems % 4) == 0) split_pack_rows<GC>(c, c.table, dst, p.cam_elems);
+            else pack_block<ObsT>(c, dst, c.table, p.cam_elems);
+        }
+        store_masks(c);
+        store_dynamic(c);
+    } else {
+        float *dst = reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems;
+        if ((p.tgt_elems % 4) == 0) split_pack_rows<GT>(c, c.table + p.tgt_table_off, dst, p.tgt_elems);
+        else pack_block<ObsT>(c, dst, c.table + p.tgt_table_off, p.tgt_elems);
+    }
+    SPLIT_STAMP(7);
 }
 
 // An environment whose episode had ended BEFORE a fused rollout began (a step or rollout with auto_reset = 0, or an

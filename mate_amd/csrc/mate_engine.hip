@@ -63,8 +63,9 @@ static void pick_image_kernels(StepFn *rollout, PolicyFn *rollout_greedy, int *i
 }
 
 static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no_image, StepFn *step, StepFn *rollout, PolicyFn *policy, PolicyFn *rollout_greedy,
-                         int *specialised, int *image) {
+                         int *specialised, int *image, StepFn *split) {
     *specialised = 0; *image = 0;
+    split[FLOW_ANY] = split[FLOW_RANDOM] = split[FLOW_ACT_F32] = nullptr;      // the two-wave step (step_split_kernel): f32 observations, the folded flows
     if (!generic) {
 #define X(C, T, O)                                                                                                  \
     if (Nc == C && Nt == T && No == O) {                                                                            \
@@ -72,6 +73,8 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no
         step[FLOW_ANY] = f64 ? (StepFn)step_kernel<double, FixedShape<C, T, O, true>> : (StepFn)step_kernel<float, FixedShape<C, T, O, false>>;   \
         step[FLOW_RANDOM] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                            \
         step[FLOW_ACT_F32] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, FixedShape<C, T, O, false>, FLOW_ACT_F32>;                          \
+        if (!f64) { split[FLOW_RANDOM] = (StepFn)step_split_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                                \
+                    split[FLOW_ACT_F32] = (StepFn)step_split_kernel<float, FixedShape<C, T, O, false>, FLOW_ACT_F32>; }                            \
         rollout[0] = f64 ? (StepFn)rollout_kernel<double, FixedShape<C, T, O, true>> : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>>; \
         rollout[1] = f64 ? rollout[0] : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                                   \
         *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, FixedShape<C, T, O, true>> : (PolicyFn)greedy_policy_kernel<float, FixedShape<C, T, O, false>>; \
@@ -85,6 +88,7 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no
     step[FLOW_ANY] = f64 ? (StepFn)step_kernel<double, AnyShape> : (StepFn)step_kernel<float, AnyShape>;
     step[FLOW_RANDOM] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, AnyShape, FLOW_RANDOM>;
     step[FLOW_ACT_F32] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, AnyShape, FLOW_ACT_F32>;
+    if (!f64) { split[FLOW_RANDOM] = (StepFn)step_split_kernel<float, AnyShape, FLOW_RANDOM>; split[FLOW_ACT_F32] = (StepFn)step_split_kernel<float, AnyShape, FLOW_ACT_F32>; }
     rollout[0] = f64 ? (StepFn)rollout_kernel<double, AnyShape> : (StepFn)rollout_kernel<float, AnyShape>;
     rollout[1] = f64 ? rollout[0] : (StepFn)rollout_kernel<float, AnyShape, FLOW_RANDOM>;
     *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, AnyShape> : (PolicyFn)greedy_policy_kernel<float, AnyShape>;
@@ -101,6 +105,7 @@ struct Switches {
     int rollout_rotate = 1;        // MATE_ROLLOUT_ROTATE=0: no wave-priority rotation in the fused rollouts
     bool no_image = false;         // MATE_NO_IMAGE=1: the fused rollouts pack observations through the descriptor table even where the row-image compilation exists
     bool policy_split = false;     // MATE_POLICY_SPLIT=1: step_greedy / step_versus_greedy as two launches (agents' kernel, step kernel) even when the fused one-launch form applies
+    int step_split = -1;           // MATE_STEP_SPLIT=0 / 1: the one-wave / two-wave form of the per-step kernel in the folded flows (-1: by batch size)
     bool zoom_iterate = false;     // MATE_ZOOM_ITERATE=1: the greedy camera agents iterate the zoom solve (greedy.py:139-145) instead of reading its table
 };
 static Switches read_switches() {
@@ -115,6 +120,7 @@ static Switches read_switches() {
     w.zoom_iterate = flag("MATE_ZOOM_ITERATE");
     w.policy_split = flag("MATE_POLICY_SPLIT");
     w.no_image = flag("MATE_NO_IMAGE");
+    if (const char *v = getenv("MATE_STEP_SPLIT")) w.step_split = atoi(v) != 0;
     return w;
 }
 
@@ -141,6 +147,8 @@ struct mate_engine {
     int image = 0;                         // the fused rollouts (random-policy flow, greedy) run their row-image compilation ...
     size_t image_wave_bytes = 0;           // ... whose per-environment LDS slice is this
     PolicyFn policy_fn = nullptr, rollout_greedy_fn = nullptr;
+    StepFn split_fn[3] = {nullptr, nullptr, nullptr};      // step_split_kernel per flow (two waves per environment), or null
+    bool split_on = false;                                 // ... and whether launch_step uses it (MATE_STEP_SPLIT, or the batch is one resident generation)
     StepFn step_fn[3] = {nullptr, nullptr, nullptr}, rollout_fn[2] = {nullptr, nullptr};   // kernels chosen at create: shape-specialised when compiled for these counts; step_fn[flow]
     int last_flow = 0;
     bool flow_generic = false;                        // MATE_FLOW_GENERIC=1: every launch runs the FLOW_ANY kernel (tests)
@@ -350,7 +358,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.first_env = (uint32_t)first_env_index;
     e->step_lds = 4 * (size_t)p.lds_wave_bytes;
     e->sw = read_switches();
-    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->sw.generic, e->sw.no_image, e->step_fn, e->rollout_fn, &e->policy_fn, &e->rollout_greedy_fn, &e->specialised, &e->image);
+    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->sw.generic, e->sw.no_image, e->step_fn, e->rollout_fn, &e->policy_fn, &e->rollout_greedy_fn, &e->specialised, &e->image, e->split_fn);
     { Params pi = p; fill_shape(pi, Nc, Nt, No, false, true); e->image_wave_bytes = e->image ? (size_t)pi.lds_wave_bytes : (size_t)p.lds_wave_bytes; }
     e->flow_generic = e->sw.flow_generic;
     if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }
@@ -381,6 +389,8 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
             for (int phase = 4; phase >= 0; --phase, d /= 10) g.stagger |= ((d % 10) & 3) << (2 * phase);
             g.stagger |= (int32_t)0x40000000;
         }
+        // the two-wave step: until measured otherwise only on request (MATE_STEP_SPLIT=1)
+        e->split_on = e->sw.step_split > 0 && Nc > 0;
     }
     do {
         if ((rc = dev_alloc(e, &g.stat, N * p.SW))) break;
@@ -794,7 +804,11 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
         else if (mode == MODE_STEP) flow = FLOW_ACT_F32;      // caller-supplied real-valued actions, f32 or f64 per team
     }
     e->last_flow = flow;
-    if (ev0) hipExtLaunchKernelGGL(e->step_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
+    if (e->split_on && e->split_fn[flow]) {      // two waves per environment: one 128-thread workgroup each
+        if (ev0) hipExtLaunchKernelGGL(e->split_fn[flow], dim3((unsigned)e->N), dim3(128), e->step_lds / 4, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
+        else hipLaunchKernelGGL(e->split_fn[flow], dim3((unsigned)e->N), dim3(128), e->step_lds / 4, stream, (const Params *)e->d_params, (const Ptrs)g);
+    }
+    else if (ev0) hipExtLaunchKernelGGL(e->step_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
     else hipLaunchKernelGGL(e->step_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, (const Params *)e->d_params, (const Ptrs)g);   // (capturable)
     HIP_TRY(hipGetLastError());
     if (mode != MODE_OBSERVE && !e->dev_tick) e->tick += 1;

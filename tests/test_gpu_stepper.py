@@ -373,3 +373,70 @@ def test_row_image_rollout_equals_descriptor_rollout(workload, n):
         for x, y in zip(a, b):
             assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
     assert (runs[0][-1][2][..., 2] == 2).any() and (runs[0][1][2][..., 2] == 1).any()      # episodes ended and slots idled inside the launches
+
+
+@pytest.mark.parametrize('workload,n', [('MATE-4v8-9.yaml', 517), ('MATE-8v8-9.yaml', 130), ('MATE-4v2-9.yaml', 66), ('MATE-4v8-0.yaml', 129),
+                                        ('MATE-2v4-any', 33)])
+def test_two_wave_step_equals_one_wave_step(workload, n):
+    """step_split_kernel (an environment split over two waves: cameras / sector tests / goals on one, targets / range tests on the
+    other, two workgroup barriers; MATE_STEP_SPLIT=1) against step_kernel (MATE_STEP_SPLIT=0) in the folded flows it is compiled
+    for -- the on-device random policy with immediate and with batched resets, caller-supplied f32 and f64 joint actions, the
+    graph-replayed stepper -- every output and the whole state bit for bit, across episode ends (time limit 9).  The last case is
+    a shape without a compiled specialisation (2 cameras, 4 targets, 3 obstacles: the generic kernels)."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    if workload == 'MATE-2v4-any':
+        cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=9)
+        cfg['camera']['location_random_range'] = list(cfg['camera']['location_random_range'])[:2]
+        cfg['target']['location_random_range'] = list(cfg['target']['location_random_range'])[:4]
+        cfg['obstacle']['location_random_range'] = list(cfg['obstacle']['location_random_range'])[:3]
+    else:
+        cfg = read_config(workload, max_episode_steps=9)
+    outs = []
+    for split in ('0', '1'):
+        os.environ['MATE_STEP_SPLIT'] = split
+        try:
+            eng = Engine(cfg, n, seed=31, first_env_index=7)
+        finally:
+            os.environ.pop('MATE_STEP_SPLIT', None)
+        eng.reset()
+        rec = []
+
+        def snap():
+            rec.append([t.clone() for t in (eng.camera_obs, eng.target_obs, eng.scalars, eng.masks)])
+
+        for s in range(14):
+            eng.step_random(auto_reset=True, want_masks=True)
+            assert eng.last_flow == 1
+            snap()
+        for s in range(17):
+            eng.step_random(auto_reset=5, want_masks=True)
+            snap()
+        gen = torch.Generator(device='cuda').manual_seed(11)
+        for dtype in (torch.float32, torch.float64):
+            cam = ((torch.rand((n, eng.num_cameras, 2), device='cuda', generator=gen) * 2 - 1) * 7).to(dtype)
+            tgt = ((torch.rand((n, eng.num_targets, 2), device='cuda', generator=gen) * 2 - 1) * 30).to(dtype)
+            for s in range(12):
+                eng.step(cam, tgt, auto_reset=True)
+                assert eng.last_flow == 2
+                snap()
+                cam.mul_(-1.0).add_(0.25); tgt.mul_(-1.0).add_(0.5)
+        cam = (torch.rand((n, eng.num_cameras, 2), device='cuda', generator=gen) * 2 - 1) * 7
+        tgt = (torch.rand((n, eng.num_targets, 2), device='cuda', generator=gen) * 2 - 1) * 30
+
+        def policy():
+            cam.mul_(-1.0).add_(0.125)
+            tgt.mul_(-1.0).add_(0.25)
+
+        stepper = eng.make_stepper(cam, tgt, auto_reset=4, graph_steps=8, between=policy)
+        for _ in range(3):
+            stepper.run(8)
+            snap()
+        stepper.close()
+        rec.append([eng.export_state().clone()])
+        outs.append(rec)
+        assert (eng.state_dict()['episode'] >= 3).all()
+        del stepper, eng
+    for i, (a, b) in enumerate(zip(*outs)):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), i
