@@ -25,7 +25,7 @@
  *   MATE_FLOW_GENERIC=1      run the kernel that reads every launch switch at run time instead of the ones compiled
  *                            for the common flows (mate_engine_last_flow)
  *   MATE_STAGGER=<digits>    wave priorities of the single-step kernel at its five phase boundaries, one decimal digit
- *                            (0-3) each; 0 = off; default 33210 while the batch is one resident generation, else off
+ *                            (0-3) each, e.g. 33210; default 0 = off (round 4: they cost 3 % once the rows leave early)
  *   MATE_ROLLOUT_ROTATE=0    no per-step rotation of the wave priorities in the fused rollout kernels (default 1; 8..20: the
  *                            turn follows the shader clock >> n instead of the wave's step count -- measured, no gain)
  *   MATE_RESET_MONOLITHIC=1  whole-batch / masked / batched resets as ONE launch instead of placement, per-camera
@@ -43,8 +43,9 @@
  *   MATE_ZOOM_ITERATE=1      the on-device GreedyCameraAgent runs the reference's 20-iteration zoom solve
  *                            (mate/agents/greedy.py:139-145) instead of reading its tabulation; the two differ by
  *                            <= 1.5e-13 degrees in the viewing angle (parity runs that want the iteration itself)
- *   MATE_BLOCK_KEEP_RANGE=1  mate_engine_block_free keeps the block's virtual address range reserved (rounds 1-3 behaviour)
- *                            instead of giving it back with hipMemAddressFree (read once, at the first block_free)
+ *   MATE_BLOCK_FREE_RANGE=1  mate_engine_block_free also gives the block's virtual address range back (hipMemAddressFree) instead
+ *                            of keeping it reserved for the life of the process (read once, at the first block_free).  Unsafe on
+ *                            this driver: a range handed out again lost stores of the next kernel (tools/va_reuse.hip)
  * Read by the Python host (mate_amd/engine.py), once, when an Engine object is built -- they steer where
  * Engine.reserve_rollout puts the [steps][N][...] observation blocks of the fused rollouts, never what is written there:
  *   MATE_PLAIN_BLOCKS=1      blocks from torch.zeros instead of mate_engine_block_alloc
@@ -355,9 +356,9 @@ int mate_engine_last_flow(const mate_engine *engine);
  * (hipDeviceMallocContiguous) 2.9-3.2 TB/s, the same block built from 2 MiB physical chunks mapped in a SHUFFLED order
  * 5.4-5.8 TB/s (tools/store_vmm.hip).  block_alloc builds such a block (hipMemCreate / hipMemMap, the virtual range is
  * contiguous); any device pointer works in mate_step_io -- this one is only faster to write.  `bytes` is rounded up to
- * 2 MiB.  block_free unmaps the block chunk by chunk (one hipMemUnmap per hipMemMap), releases its memory and gives the virtual
- * range back (the pointer must come from block_alloc; the CALLER has waited for every launch that reads or writes the block --
- * the library does not synchronise here).  A failed block_alloc / block_probe / block_free reports through its return code
+ * 2 MiB.  block_free unmaps the block chunk by chunk (one hipMemUnmap per hipMemMap) and releases its memory; the virtual
+ * range stays reserved (address space only; MATE_BLOCK_FREE_RANGE above).  The pointer must come from block_alloc; the CALLER
+ * has waited for every launch that reads or writes the block -- the library does not synchronise here.  A failed block_alloc / block_probe / block_free reports through its return code
  * only: HIP's sticky last-error is cleared, so the caller's next launch check does not see it. */
 /* The form of the row stores of the row-image rollouts (MATE-4v8-9, MATE-4v8-0 under mate_engine_rollout_random): 0 (default) the
  * rows' 16-byte chunks as they lie -- 1.3-2 % faster where the blocks take the rows fast, i.e. where the arithmetic bounds a launch

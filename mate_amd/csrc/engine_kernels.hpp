@@ -295,7 +295,7 @@ struct Ctx {
     bool statics_done = false;    // fused rollouts, steps after the first: what never changes inside an episode (static
                                   // mask words and flags, obstacle / capacity slots of the scratch) is in LDS already
 
-    __device__ Ctx(const Params &p_, const Ptrs &g_, unsigned char *wave_base, int lane_, int64_t env_, int flow_ = FLOW_ANY)
+    __device__ __forceinline__ Ctx(const Params &p_, const Ptrs &g_, unsigned char *wave_base, int lane_, int64_t env_, int flow_ = FLOW_ANY)
         : p(p_), g(g_), flow(flow_), lane(lane_), env(env_), out(env_) {
         st = reinterpret_cast<double *>(wave_base + p.off_st);
         dy = reinterpret_cast<double *>(wave_base + p.off_dy);
@@ -325,6 +325,10 @@ struct Ctx {
     // launch switches (constants in the specialised flows)
     __device__ __forceinline__ int mode() const { return flow == FLOW_RANDOM ? (int)MODE_STEP_RANDOM : (flow == FLOW_ACT_F32 || flow == FLOW_GREEDY) ? (int)MODE_STEP : g.mode; }
     __device__ __forceinline__ bool act_from_lds() const { return flow == FLOW_GREEDY; }
+    // FLOW_ACT_F32 (the single-step kernels): an agent's lane fetches its own action together with the records, into the StepDraws
+    // the kinematics read anyway (prefetch_action) -- read where it is used, behind the LDS commit, the load's round trip to
+    // L2 / HBM lay bare on every wave's critical path (1.4 us of a 14 us step)
+    __device__ __forceinline__ bool act_prefetched() const { return flow == FLOW_ACT_F32; }
     // camera->target pairs whose transmittance draw step_draws makes ahead of the visibility phase: one lane each -- the lanes
     // behind the agents', and the agents' own wherever those draw no actions (every flow but the on-device random policy)
     __device__ __forceinline__ int predrawn_pairs() const { return mode() == MODE_STEP_RANDOM ? 64 - p.Nc - p.Nt : 64; }
@@ -340,42 +344,42 @@ struct Ctx {
     __device__ __forceinline__ bool has_tgt_obs() const { return flow != FLOW_ANY ? true : g.tgt_obs != nullptr; }
     __device__ __forceinline__ bool has_scalars() const { return flow != FLOW_ANY ? true : g.scalars != nullptr; }
     // static record
-    __device__ double cam_x(int c) const { return st[c]; }
-    __device__ double cam_y(int c) const { return st[p.Nc + c]; }
-    __device__ double obs_x(int o) const { return st[2 * p.Nc + o]; }
-    __device__ double obs_y(int o) const { return st[2 * p.Nc + p.No + o]; }
-    __device__ double obs_r(int o) const { return st[2 * p.Nc + 2 * p.No + o]; }
-    __device__ uint64_t camobs(int c) const { return reinterpret_cast<const uint64_t *>(st)[2 * p.Nc + 3 * p.No + c]; }
-    __device__ uint64_t capword() const { return reinterpret_cast<const uint64_t *>(st)[3 * p.Nc + 3 * p.No]; }
-    __device__ void circle(int k, double &x, double &y, double &r) const {  // obstacles, then cameras (Target.add_obstacles, environment.py:743)
+    __device__ __forceinline__ double cam_x(int c) const { return st[c]; }
+    __device__ __forceinline__ double cam_y(int c) const { return st[p.Nc + c]; }
+    __device__ __forceinline__ double obs_x(int o) const { return st[2 * p.Nc + o]; }
+    __device__ __forceinline__ double obs_y(int o) const { return st[2 * p.Nc + p.No + o]; }
+    __device__ __forceinline__ double obs_r(int o) const { return st[2 * p.Nc + 2 * p.No + o]; }
+    __device__ __forceinline__ uint64_t camobs(int c) const { return reinterpret_cast<const uint64_t *>(st)[2 * p.Nc + 3 * p.No + c]; }
+    __device__ __forceinline__ uint64_t capword() const { return reinterpret_cast<const uint64_t *>(st)[3 * p.Nc + 3 * p.No]; }
+    __device__ __forceinline__ void circle(int k, double &x, double &y, double &r) const {  // obstacles, then cameras (Target.add_obstacles, environment.py:743)
         const int j = k < p.No ? p.Nc + k : k - p.No;
         x = ex[j]; y = ey[j]; r = er[j];
     }
-    __device__ int tgt_slot(int t) const { return p.Nc + p.No + t; }
+    __device__ __forceinline__ int tgt_slot(int t) const { return p.Nc + p.No + t; }
     // dynamic record
-    __device__ double &phi(int c) { return dy[c]; }
-    __device__ double &theta(int c) { return dy[p.Nc + c]; }
-    __device__ double &tx(int t) { return dy[2 * p.Nc + t]; }
-    __device__ double &ty(int t) { return dy[2 * p.Nc + p.Nt + t]; }
-    __device__ double &ep_reward() { return dy[2 * p.Nc + 2 * p.Nt]; }
-    __device__ double &ep_delayed() { return dy[2 * p.Nc + 2 * p.Nt + 1]; }
-    __device__ int32_t &ti(int t, int f) { return di[t * TI_STRIDE + f]; }
-    __device__ int32_t &ei(int f) { return di[p.Nt * TI_STRIDE + f]; }
+    __device__ __forceinline__ double &phi(int c) { return dy[c]; }
+    __device__ __forceinline__ double &theta(int c) { return dy[p.Nc + c]; }
+    __device__ __forceinline__ double &tx(int t) { return dy[2 * p.Nc + t]; }
+    __device__ __forceinline__ double &ty(int t) { return dy[2 * p.Nc + p.Nt + t]; }
+    __device__ __forceinline__ double &ep_reward() { return dy[2 * p.Nc + 2 * p.Nt]; }
+    __device__ __forceinline__ double &ep_delayed() { return dy[2 * p.Nc + 2 * p.Nt + 1]; }
+    __device__ __forceinline__ int32_t &ti(int t, int f) { return di[t * TI_STRIDE + f]; }
+    __device__ __forceinline__ int32_t &ei(int f) { return di[p.Nt * TI_STRIDE + f]; }
     // temporaries
-    __device__ double &sight2(int c) { return tmp[c]; }          // a camera's SQUARED sight range: area / viewing angle
-    __device__ double &svx(int t) { return tmp[p.Nc + t]; }
-    __device__ double &svy(int t) { return tmp[p.Nc + p.Nt + t]; }
-    __device__ double &snorm(int t) { return tmp[p.Nc + 2 * p.Nt + t]; }
-    __device__ double &udraw(int pair) { return tmp[p.Nc + 3 * p.Nt + pair]; }
-    __device__ int32_t &near(int t) { return misc[t]; }
-    __device__ int32_t &inside(int t) { return misc[2 * p.Nt + t]; }
-    __device__ int32_t &tracked(int t) { return misc[3 * p.Nt + t]; }
-    __device__ int32_t &xch(int i) { return misc[4 * p.Nt + i]; }
-    __device__ bool mask_bit(int b) const { return (mask[b >> 5] >> (b & 31)) & 1u; }
-    __device__ uint32_t env_global() const { return p.first_env + (uint32_t)env; }
+    __device__ __forceinline__ double &sight2(int c) { return tmp[c]; }          // a camera's SQUARED sight range: area / viewing angle
+    __device__ __forceinline__ double &svx(int t) { return tmp[p.Nc + t]; }
+    __device__ __forceinline__ double &svy(int t) { return tmp[p.Nc + p.Nt + t]; }
+    __device__ __forceinline__ double &snorm(int t) { return tmp[p.Nc + 2 * p.Nt + t]; }
+    __device__ __forceinline__ double &udraw(int pair) { return tmp[p.Nc + 3 * p.Nt + pair]; }
+    __device__ __forceinline__ int32_t &near(int t) { return misc[t]; }
+    __device__ __forceinline__ int32_t &inside(int t) { return misc[2 * p.Nt + t]; }
+    __device__ __forceinline__ int32_t &tracked(int t) { return misc[3 * p.Nt + t]; }
+    __device__ __forceinline__ int32_t &xch(int i) { return misc[4 * p.Nt + i]; }
+    __device__ __forceinline__ bool mask_bit(int b) const { return (mask[b >> 5] >> (b & 31)) & 1u; }
+    __device__ __forceinline__ uint32_t env_global() const { return p.first_env + (uint32_t)env; }
     // A tick-keyed draw.  One Philox-4x32 block holds two 64-bit draws: ticks 2k and 2k + 1 share the block with counter k and
     // take its first / second half -- the fused rollouts compute a block once per TWO steps (DrawCarry).
-    __device__ double draw(uint32_t tick, uint32_t stream, uint32_t sub) const {
+    __device__ __forceinline__ double draw(uint32_t tick, uint32_t stream, uint32_t sub) const {
         const U4 r = philox(p.seed_lo, p.seed_hi, env_global(), tick >> 1, stream, sub);
         return (tick & 1u) ? u53(r.z, r.w) : u53(r.x, r.y);
     }
@@ -416,6 +420,22 @@ struct DrawCarry { uint32_t z, w, block; };      // second half of the lane's Ph
 struct DrawRole { uint32_t stream, sub; int32_t kind; double m0, m1; };      // kind: 0 none, 1 agent (action sample), 2 pair (transmittance draw)
 template <typename ObsT> __device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry = nullptr, const DrawRole *held = nullptr);
 
+// The caller's joint action of this lane's agent (lanes [0, Nc): cameras, [Nc, Nc + Nt): targets), f32 or f64 per team, as issued loads
+template <typename ObsT>
+__device__ __forceinline__ StepDraws prefetch_action(const Ctx<ObsT> &c) {
+    const Params &p = c.p;
+    const int lane = c.lane, t = lane - p.Nc;
+    StepDraws a{0.0, 0.0};
+    if (lane < p.Nc) {
+        if (c.act_f64() & 1) { const double *q = reinterpret_cast<const double *>(c.g.cam_act) + (c.env * p.Nc + lane) * 2; a.a0 = q[0]; a.a1 = q[1]; }
+        else { const float2 q = reinterpret_cast<const float2 *>(c.g.cam_act)[c.env * p.Nc + lane]; a.a0 = (double)q.x; a.a1 = (double)q.y; }
+    } else if (t < p.Nt) {
+        if (c.act_f64() & 2) { const double *q = reinterpret_cast<const double *>(c.g.tgt_act) + (c.env * p.Nt + t) * 2; a.a0 = q[0]; a.a1 = q[1]; }
+        else { const float2 q = reinterpret_cast<const float2 *>(c.g.tgt_act)[c.env * p.Nt + t]; a.a0 = (double)q.x; a.a1 = (double)q.y; }
+    }
+    return a;
+}
+
 template <typename ObsT>
 __device__ __forceinline__ StepDraws load_records_with_draws(Ctx<ObsT> &c, uint32_t tick, bool draw) {
     const Params &p = c.p;
@@ -433,6 +453,12 @@ __device__ __forceinline__ StepDraws load_records_with_draws(Ctx<ObsT> &c, uint3
     asm volatile("" : "+v"(s0), "+v"(s1), "+v"(d0), "+v"(d1));     // keep the loads up here: the optimiser would sink each into its use
     asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
     StepDraws draws{0.0, 0.0};
+    if (c.act_prefetched()) {       // (the agents' lanes draw nothing of their own in this flow: their draws carry the caller's action)
+        StepDraws act = prefetch_action(c);
+        asm volatile("" : "+v"(act.a0), "+v"(act.a1));
+        if (draw) (void)step_draws(c, tick);
+        draws = act;
+    } else
     if (draw) draws = step_draws(c, tick);
     if (lane < p.SW) c.st[lane] = s0;
     if (lane < p.DW) c.dy[lane] = d0;
@@ -528,7 +554,7 @@ __device__ __forceinline__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &
         double ph = c.phi(lane), th = c.theta(lane);
         if (advance) {
             double da, dz;
-            if (c.mode() == MODE_STEP_RANDOM) { da = draws.a0; dz = draws.a1; }
+            if (c.mode() == MODE_STEP_RANDOM || c.act_prefetched()) { da = draws.a0; dz = draws.a1; }
             else if (c.act_from_lds()) { da = c.act_cam[2 * lane]; dz = c.act_cam[2 * lane + 1]; }
             else if (c.act_discrete() & 1) {                 // DiscreteCamera.action, discrete_action_spaces.py:71-73
                 int idx = reinterpret_cast<const int32_t *>(c.g.cam_act)[c.env * p.Nc + lane];
@@ -610,10 +636,11 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
     const int lane = c.lane;
     const int t = lane - p.Nc;
     const bool is_target = t >= 0 && t < p.Nt;
+    const bool ballot_screen = !carried && p.Nt * p.NK <= 64 * kNearWords && p.NK <= 64;
     double ox = 0.0, oy = 0.0, vx = 0.0, vy = 0.0, n = 0.0, desx = 0.0, desy = 0.0;
     if (is_target) {
         double ax, ay;
-        if (c.mode() == MODE_STEP_RANDOM) { ax = draws.a0; ay = draws.a1; }
+        if (c.mode() == MODE_STEP_RANDOM || c.act_prefetched()) { ax = draws.a0; ay = draws.a1; }
         else if (c.act_from_lds()) { ax = c.act_tgt[2 * t]; ay = c.act_tgt[2 * t + 1]; }
         else if (c.act_discrete() & 2) {                     // DiscreteTarget.action, discrete_action_spaces.py:177-179
             int idx = reinterpret_cast<const int32_t *>(c.g.tgt_act)[c.env * p.Nt + t];
@@ -640,7 +667,7 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
             vx = ax * k; vy = ay * k; n = step_size;
         }
         desx = ox + vx; desy = oy + vy;
-        if (!carried) { c.snorm(t) = n; c.near(t) = 0; c.near(p.Nt + t) = 0; }
+        if (!carried) { c.snorm(t) = n; if (!ballot_screen) { c.near(t) = 0; c.near(p.Nt + t) = 0; } }
     }
     uint64_t todo_carried = 0;
     if (carried) {
@@ -648,6 +675,36 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
             // the target's NK bits out of the 192-bit string w2:w1:w0, then from entity order (cameras, obstacles) to the
             // order the circles are walked in (obstacles, cameras: Target.add_obstacles, environment.py:743)
             todo_carried = near_field(p, *carried, t);
+        }
+    } else if (p.Nt * p.NK <= 64 * kNearWords && p.NK <= 64) {
+        // every shipped scenario: the screen's verdicts as ballots (one 64-bit word per round of pairs, in scalar registers), a
+        // target's lane cuts its NK bits out of them -- no LDS atomics, no second hand-off
+        wave_sync();
+        SUB_STAMP(c, 10);
+        const int npairs = p.Nt * p.NK;
+        unsigned long long hit[kNearWords];
+#pragma unroll
+        for (int round = 0; round < kNearWords; ++round) {
+            hit[round] = 0ull;
+            if (round * 64 < npairs) {
+                const int q = round * 64 + lane, qq = q < npairs ? q : 0;
+                const int tt = (int)(((float)qq + 0.5f) * p.inv_NK);
+                const int k = qq - tt * p.NK;
+                const int j = k < p.No ? p.Nc + k : k - p.No, tj = c.tgt_slot(tt);
+                const float dx = c.exf[j] - c.exf[tj], dy = c.eyf[j] - c.eyf[tj];
+                const float d2 = fmaf(dy, dy, dx * dx);
+                const float nn = (float)c.snorm(tt);
+                const float reach = nn + c.erf[j] + 1e-3f;         // (the same conservative f32 test as the LDS form below)
+                hit[round] = __ballot(q < npairs && nn != 0.0f && !(d2 > reach * reach));
+            }
+        }
+        if (is_target) {
+            const int first = t * p.NK, word = first >> 6, sh = first & 63;
+            unsigned long long lo = hit[0], hi = kNearWords > 1 ? hit[1] : 0ull;
+#pragma unroll
+            for (int k = 1; k < kNearWords; ++k)
+                if (word == k) { lo = hit[k]; hi = k + 1 < kNearWords ? hit[k + 1] : 0ull; }
+            todo_carried = ((lo >> sh) | (sh ? hi << (64 - sh) : 0ull)) & (p.NK >= 64 ? ~0ull : ((1ull << p.NK) - 1ull));
         }
     } else {
     wave_sync();
@@ -674,7 +731,7 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
     }
     SUB_STAMP(c, 11);
     if (is_target) {
-        uint64_t todo = carried ? todo_carried : ((uint64_t)(uint32_t)c.near(t) | ((uint64_t)(uint32_t)c.near(p.Nt + t) << 32));
+        uint64_t todo = (carried || ballot_screen) ? todo_carried : ((uint64_t)(uint32_t)c.near(t) | ((uint64_t)(uint32_t)c.near(p.Nt + t) << 32));
         bool n_known = true;
         while (todo) {
             const int k = __ffsll((long long)todo) - 1;
@@ -1291,6 +1348,21 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     update_view<false>(c, tick, stream, predrawn, none);
 }
 
+// real_coverage_rate = (tracked and with bounty) / (with bounty), mean_transport_rate = delayed episode reward / (reward scale x
+// delivered), normalised reward = reward / max team episode reward (environment.py:966-979, 661): lane 0, 1, 2 each make one
+struct MetricQuotients { double q; };
+__device__ __forceinline__ MetricQuotients metric_quotients(int lane, int n_both, int n_bounty, double epd, double reward_scale, int delivered, double r, double max_team_reward) {
+    double num = r, den = max_team_reward;
+    bool valid = lane == 2;
+    if (lane == 0) { num = (double)n_both; den = (double)n_bounty; valid = n_bounty > 0; }
+    else if (lane == 1) { num = epd; den = reward_scale * (double)delivered; valid = delivered > 0; }
+    if (!valid) { num = 0.0; den = 1.0; }
+    MetricQuotients m;
+    m.q = lane <= 2 ? div_nz(num, den) : 0.0;
+    if (!valid) m.q = 0.0;
+    return m;
+}
+
 // The order-dependent part of _assign_goals (environment.py:1278-1318: the warehouses' remaining cargo is shared), on ONE lane,
 // for the targets standing in a warehouse (c.inside); dense and delayed rewards of the deliveries are added to `reward` / `delayed`.
 template <typename ObsT>
@@ -1345,21 +1417,45 @@ __device__ __forceinline__ void goal_logistics(Ctx<ObsT> &c, uint32_t tick, doub
     }
 }
 
-// Phase C: _assign_goals + the bookkeeping of step() (environment.py:1271-1324, 613-632).
+// update_view's tail for lanes [0, Nt) from the ballot of the (only) sector round: tracked_bits = camera_target_view_mask.any(axis=0)
+// (environment.py:1388), and which warehouse holds the target (see update_view)
 template <typename ObsT>
-__device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out) {
+__device__ __forceinline__ void view_tail_regs(Ctx<ObsT> &c, unsigned long long sector_ballot, int &tracked, int &inside) {
+    const Params &p = c.p;
+    const int lane = c.lane;
+    unsigned long long any = 0ull;
+    for (int cam = 0; cam < p.Nc; ++cam) any |= sector_ballot >> (cam * p.Nt);
+    tracked = lane < p.Nt ? (int)((any >> (lane & 63)) & 1ull) : 0;
+    inside = -1;
+    if (lane < p.Nt) {
+        const double x = c.tx(lane), y = c.ty(lane);
+        const bool px = x > 0.0, py = y > 0.0;
+        const double wx = px ? kWarehouseCenter : -kWarehouseCenter, wy = py ? kWarehouseCenter : -kWarehouseCenter;
+        const double sup = fmax(fabs(x - wx), fabs(y - wy));
+        inside = sup <= kWarehouseRadius ? (px ? (py ? 0 : 3) : (py ? 1 : 2)) : -1;
+    }
+}
+
+// Phase C: _assign_goals + the bookkeeping of step() (environment.py:1271-1324, 613-632).
+// `tracked_reg` / `inside_reg` (the single-step kernel, shapes with one sector round): the lane's tracked bit and warehouse straight
+// from the sector ballot and the position (view_tail_regs) instead of through update_view's tail and its two LDS hand-offs.
+template <typename ObsT>
+__device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out, const int *tracked_reg = nullptr, const int *inside_reg = nullptr) {
     const Params &p = c.p;
     const int lane = c.lane;
     bool penal = false;
+    if (tracked_reg && lane < p.Nt) { c.tracked(lane) = *tracked_reg; c.inside(lane) = *inside_reg; }      // (for goal_logistics and the team-wide flags)
+    const int tracked_lane = lane < p.Nt ? (tracked_reg ? *tracked_reg : c.tracked(lane)) : 0;
+    const int inside_lane = lane < p.Nt ? (inside_reg ? *inside_reg : c.inside(lane)) : -1;
     if (lane < p.Nt) {
         const int b = c.ti(lane, TI_BOUNTY);
-        const int tr = c.tracked(lane);
+        const int tr = tracked_lane;
         penal = tr && b > 0;                                  // environment.py:1275
         const int nb = b - tr;
         c.ti(lane, TI_BOUNTY) = nb > 0 ? nb : 0;               // environment.py:1276
     }
     const int n_penal = __popcll(__ballot(penal));
-    const bool any_inside = __ballot(lane < p.Nt && c.inside(lane) >= 0) != 0ull;
+    const bool any_inside = __ballot(lane < p.Nt && inside_lane >= 0) != 0ull;
     wave_sync();
     double reward = -(double)n_penal, delayed = 0.0;
     if (any_inside) {
@@ -1376,22 +1472,29 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
     bool with_bounty = false, tr = false;
     if (lane < p.Nt) {
         with_bounty = c.ti(lane, TI_BOUNTY) > 0;
-        tr = c.tracked(lane) != 0;
+        tr = tracked_lane != 0;
         c.ti(lane, TI_TSTEPS) += 1;
         c.ti(lane, TI_TRSTEPS) += (int)tr;
     }
     const int n_tracked = __popcll(__ballot(tr));
     const int n_bounty = __popcll(__ballot(with_bounty));
     const int n_both = __popcll(__ballot(tr && with_bounty));
+    // The three quotients of the metric record (real coverage rate, mean transport rate, normalised reward) on lanes 0, 1, 2 -- ONE
+    // division's dependent chain instead of three in a row on lane 0, for numbers nothing later in the step reads (same operands,
+    // same IEEE division: same bits).  Every lane reads the record words BEFORE lane 0 rewrites them below (program order).
+    const double epd_all = c.ep_delayed() + delayed;
+    const int delivered_all = c.ei(EI_DELIVERED);
+    const double r_all = p.sparse_reward ? delayed : reward;
+    const MetricQuotients mq = metric_quotients(lane, n_both, n_bounty, epd_all, p.reward_scale, delivered_all, r_all, p.max_team_reward);
+    if (c.has_scalars() && scalars_out && (lane == 1 || lane == 2)) scalars_out[c.out * 8 + (lane == 1 ? 5 : 7)] = (float)mq.q;
     if (lane == 0) {
         const double epr = c.ep_reward() + reward;
-        const double epd = c.ep_delayed() + delayed;
+        const double epd = epd_all;
         c.ep_reward() = epr; c.ep_delayed() = epd;
-        const int delivered = c.ei(EI_DELIVERED);
+        const int delivered = delivered_all;
         const double coverage = div_by_count((double)n_tracked, p.Nt);
-        const double real_cov = n_bounty > 0 ? div_nz((double)n_both, (double)n_bounty) : 0.0;
-        const double transport = delivered > 0 ? div_nz(epd, p.reward_scale * (double)delivered) : 0.0;
-        const double r = p.sparse_reward ? delayed : reward;
+        const double real_cov = mq.q;
+        const double r = r_all;
         const int ep_step = c.ei(EI_EPSTEP) + 1;
         c.ei(EI_EPSTEP) = ep_step;
         const bool awaiting = c.ei(EI_AWAITING) || c.ei(EI_AWAITING + 1) || c.ei(EI_AWAITING + 2) || c.ei(EI_AWAITING + 3);
@@ -1402,7 +1505,7 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
         if (c.has_scalars() && scalars_out) {
             float *o = scalars_out + c.out * 8;
             o[0] = (float)(-r); o[1] = (float)r; o[2] = (float)done; o[3] = (float)coverage;
-            o[4] = (float)real_cov; o[5] = (float)transport; o[6] = (float)delivered; o[7] = (float)div_nz(r, p.max_team_reward);
+            o[4] = (float)real_cov; o[6] = (float)delivered;      // ([5], [7]: lanes 1 and 2, above)
         }
         if (done && c.g.done_count) {
             const int parity = c.list_parity();
@@ -1637,7 +1740,8 @@ __device__ __forceinline__ void load_pack_descriptors(const Ctx<ObsT> &c, D &d) 
     for (int k = 0; k < kPackGT; ++k) asm volatile("" : "+v"(d.dt[k].x), "+v"(d.dt[k].y), "+v"(d.dt[k].z), "+v"(d.dt[k].w));
 }
 
-template <typename ObsT, typename D>
+// `PART`: 3 both teams' rows (default), 1 the camera rows only, 2 the target rows only
+template <int PART = 3, typename ObsT, typename D>
 __device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT> &c, const D &d) {
     if constexpr (sizeof(ObsT) == 4) {
         const Params &p = c.p;
@@ -1649,12 +1753,16 @@ __device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT> &c, const D &d) {
         f32x4 *cam = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.cam_obs) + c.out * p.cam_elems);
         f32x4 *tgt = reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems);
         auto chunk = [&](const uint4 &d) { return f32x4{gather_one(c, d.x), gather_one(c, d.y), gather_one(c, d.z), gather_one(c, d.w)}; };
+        if constexpr ((PART & 1) != 0) {
 #pragma unroll
         for (int k = 0; k < GC; ++k) { const int s = c.lane + 64 * k; if (s < nvc) stream_store(chunk(d.dc[k]), &cam[s]); }
         for (int s = c.lane + 64 * GC; s < nvc; s += 64) stream_store(chunk(tabc[s]), &cam[s]);   // larger scenarios
+        }
+        if constexpr ((PART & 2) != 0) {
 #pragma unroll
         for (int k = 0; k < GT; ++k) { const int s = c.lane + 64 * k; if (s < nvt) stream_store(chunk(d.dt[k]), &tgt[s]); }
         for (int s = c.lane + 64 * GT; s < nvt; s += 64) stream_store(chunk(tabt[s]), &tgt[s]);
+        }
     }
 }
 
@@ -2062,22 +2170,28 @@ __device__ __forceinline__ int assign_and_score_held(Ctx<ObsT> &c, uint32_t tick
     const int n_bounty = __popcll(__ballot(with_bounty));
     const int n_both = __popcll(__ballot(tracked && with_bounty));
     int done = 0;
+    // (the metric record's three quotients on lanes 0, 1, 2: metric_quotients; lane 0's sums and counters broadcast as scalars)
+    const double epd0 = h.ep_delayed + delayed;
+    const double epd_all = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(epd0)), __builtin_amdgcn_readfirstlane(__double2loint(epd0)));
+    const int delivered_all = __builtin_amdgcn_readfirstlane(h.delivered);
+    const double r_all = p.sparse_reward ? delayed : reward;
+    const MetricQuotients mq = metric_quotients(lane, n_both, n_bounty, epd_all, p.reward_scale, delivered_all, r_all, p.max_team_reward);
+    if (scalars_out && (lane == 1 || lane == 2)) scalars_out[c.out * 8 + (lane == 1 ? 5 : 7)] = (float)mq.q;
     if (lane == 0) {
         const double epr = h.ep_reward + reward;
-        const double epd = h.ep_delayed + delayed;
+        const double epd = epd_all;
         h.ep_reward = epr; h.ep_delayed = epd;
         const int delivered = h.delivered;
         const double coverage = div_by_count((double)n_tracked, p.Nt);
-        const double real_cov = n_bounty > 0 ? div_nz((double)n_both, (double)n_bounty) : 0.0;
-        const double transport = delivered > 0 ? div_nz(epd, p.reward_scale * (double)delivered) : 0.0;
-        const double r = p.sparse_reward ? delayed : reward;
+        const double real_cov = mq.q;
+        const double r = r_all;
         const int ep_step = h.epstep + 1;
         h.epstep = ep_step; h.tick = (int)(tick + 1u);
         done = !(ep_step <= p.max_episode_steps && h.awaiting);
         if (scalars_out) {
             float *o = scalars_out + c.out * 8;
             o[0] = (float)(-r); o[1] = (float)r; o[2] = (float)done; o[3] = (float)coverage;
-            o[4] = (float)real_cov; o[5] = (float)transport; o[6] = (float)delivered; o[7] = (float)div_nz(r, p.max_team_reward);
+            o[4] = (float)real_cov; o[6] = (float)delivered;      // ([5], [7]: lanes 1 and 2, above)
         }
         if (done) {                                            // rare: the record's flag, the restart list, the statistics
             c.ei(EI_DONE) = c.g.done_count ? 3 : 1;            // (3: on the list of the next reset launch, see assign_and_score)
@@ -2195,16 +2309,65 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     else wave_sync();
     PHASE_STAMP(3);
     phase_prio(g.stagger, 2);
+    // shapes with one round of sector pairs: the tracked bits and the warehouses from the round's ballot, in registers
+    const bool reg_tail = p.sector_rounds <= 1 && mode != MODE_OBSERVE && !SKIP(8) && !SKIP(32);
+    int tracked_reg = 0, inside_reg = -1;
+    // The folded flows of the compiled shapes: THE TARGET ROWS LEAVE RIGHT BEHIND THE VISIBILITY PHASE, ahead of the goals and the
+    // rewards.  A launch of the headline batch writes 30 MB, and a kernel ends when its last store is acknowledged: with every row
+    // stored at the very end of every wave's chain the whole batch's stores arrived within a few microseconds of each other and
+    // the launch lasted as long as they took to drain, whatever the chain in front of them cost (four trims of that chain -- 3 % of
+    // its instructions and five LDS hand-offs -- changed the launch by 0.0 us).  The target rows are two thirds of the bytes and
+    // need only the range tests' verdicts and the kinematics; what _assign_goals may still change in them -- a target's cargo
+    // flag, goal and empty-warehouse bits when it picks up, delivers or learns of an empty warehouse: rare -- is repaired by
+    // packing them once more behind the goals (same values as the late packer: the rows are a pure function of scratch and flags).
+    PackDescriptors pack_desc;
+    constexpr int GCE = Shape::kHeldGC, GTE = Shape::kHeldGT;
+    uint4 cam_desc[GCE > 0 ? GCE : 1];
+    const bool early_desc = FLOW != FLOW_ANY && Shape::kGreedyHeld && GCE + GTE <= 8 && packs_rows_f32(c);      // (wave-uniform; elsewhere the held registers cost the eighth wave per SIMD)
+    const bool early_rows = early_desc && reg_tail && !SKIP(64) && !SKIP(128);
+    int gw_packed = 0;
+    if (reg_tail) {
+        RangeRoles none;
+        uint32_t seen_unused;
+        unsigned long long sector_ballot = 0ull;
+        update_view<false, false>(c, tick, S_TRANSMIT, true, none, seen_unused, nullptr, &sector_ballot);
+        if (early_rows) {
+            // the camera rows' descriptors before the first store (loads and stores share one in-order counter), held across the goals
+            load_row_descriptors<GCE>(c, c.table, p.cam_elems, cam_desc);
+            wave_sync();                               // (the range flags and mask words of update_view, which skipped its tail)
+            if (lane < p.Nt) gw_packed = c.ti(lane, TI_GW) & 0xffffff;
+            fill_scratch(c);
+            split_pack_rows<GTE>(c, c.table + p.tgt_table_off, reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems, p.tgt_elems);
+        }
+        view_tail_regs(c, sector_ballot, tracked_reg, inside_reg);
+    } else
     if (!SKIP(8)) update_view(c, tick, S_TRANSMIT, true);
     PHASE_STAMP(4);
     phase_prio(g.stagger, 3);
+    // (otherwise: the packer's descriptors on their way -- L2 / L1: every wave reads the same table -- while the goals, the rewards
+    // and the gather scratch are made)
+    if (early_desc && !early_rows) load_pack_descriptors(c, pack_desc);
     if (mode == MODE_OBSERVE) score_only(c, g.scalars);
+    else if (reg_tail) assign_and_score(c, tick, g.scalars, &tracked_reg, &inside_reg);
     else if (!SKIP(32)) assign_and_score(c, tick, g.scalars);
     PHASE_STAMP(5);
+    if (early_rows) {
+        const bool changed = __ballot(lane < p.Nt && (c.ti(lane, TI_GW) & 0xffffff) != gw_packed) != 0ull;
+        if (changed) {                                 // rare: a pick-up, a delivery, a newly known empty warehouse
+            fill_scratch(c);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the rows' first version has arrived before the second leaves)
+            split_pack_rows<GTE>(c, c.table + p.tgt_table_off, reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems, p.tgt_elems);
+        }
+        PHASE_STAMP(6);
+        phase_prio(g.stagger, 4);
+        if (p.cam_elems > 0) store_rows_with<GCE>(c, c.table, p.cam_elems, cam_desc, reinterpret_cast<float *>(c.g.cam_obs) + c.out * p.cam_elems);
+        store_masks(c);
+    } else {
     if (!SKIP(64)) fill_scratch(c);
     PHASE_STAMP(6);
     phase_prio(g.stagger, 4);
-    if (!SKIP(128)) { PackDescriptors d; pack_observations<false>(c, d); }
+    if (!SKIP(128)) { if (early_desc) pack_observations<true>(c, pack_desc); else pack_observations<false>(c, pack_desc); }
+    }
     PHASE_STAMP(7);
     if (mode != MODE_OBSERVE) store_dynamic(c);
     PHASE_STAMP(8);
@@ -2348,6 +2511,7 @@ __device__ __forceinline__ void split_view_range(Ctx<ObsT> &c) {
 // one team's rows through the descriptor table (pack_rows_f32, one block): descriptors before the first store
 template <int G, typename ObsT>
 __device__ __forceinline__ void split_pack_rows(const Ctx<ObsT> &c, const uint32_t *table, float *dst, int elems) {
+    if constexpr (sizeof(ObsT) == 4) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int nv = elems / 4;
     const uint4 *tab = reinterpret_cast<const uint4 *>(table);
@@ -2361,10 +2525,35 @@ __device__ __forceinline__ void split_pack_rows(const Ctx<ObsT> &c, const uint32
 #pragma unroll
     for (int k = 0; k < G; ++k) { const int i = c.lane + 64 * k; if (i < nv) stream_store(chunk(d[k]), &out[i]); }
     for (int i = c.lane + 64 * G; i < nv; i += 64) stream_store(chunk(tab[i]), &out[i]);
+    }
 }
 
-template <typename ObsT, typename Shape, int FLOW>
-__global__ __launch_bounds__(128, 4) __attribute__((amdgpu_num_sgpr(96)))
+// ... in two halves: the descriptors of a lane's first G chunks now, the rows later (other stores in between)
+template <int G, typename ObsT>
+__device__ __forceinline__ void load_row_descriptors(const Ctx<ObsT> &c, const uint32_t *table, int elems, uint4 (&d)[G > 0 ? G : 1]) {
+    const int nv = elems / 4;
+    const uint4 *tab = reinterpret_cast<const uint4 *>(table);
+#pragma unroll
+    for (int k = 0; k < G; ++k) { const int i = c.lane + 64 * k; d[k] = tab[i < nv ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < G; ++k) asm volatile("" : "+v"(d[k].x), "+v"(d[k].y), "+v"(d[k].z), "+v"(d[k].w));
+}
+template <int G, typename ObsT>
+__device__ __forceinline__ void store_rows_with(const Ctx<ObsT> &c, const uint32_t *table, int elems, const uint4 (&d)[G > 0 ? G : 1], float *dst) {
+    if constexpr (sizeof(ObsT) == 4) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int nv = elems / 4;
+    const uint4 *tab = reinterpret_cast<const uint4 *>(table);
+    f32x4 *out = reinterpret_cast<f32x4 *>(dst);
+    auto chunk = [&](const uint4 &x) { return f32x4{gather_one(c, x.x), gather_one(c, x.y), gather_one(c, x.z), gather_one(c, x.w)}; };
+#pragma unroll
+    for (int k = 0; k < G; ++k) { const int i = c.lane + 64 * k; if (i < nv) stream_store(chunk(d[k]), &out[i]); }
+    for (int i = c.lane + 64 * G; i < nv; i += 64) stream_store(chunk(tab[i]), &out[i]);
+    }
+}
+
+template <typename ObsT, typename Shape, int FLOW, int EPW = 1>      // EPW: environments per workgroup (wave pairs)
+__global__ __launch_bounds__(128 * EPW, 4) __attribute__((amdgpu_num_sgpr(96)))
 void step_split_kernel(const Params *__restrict__ pp, const Ptrs g) {
     static_assert(sizeof(ObsT) == 4 && (FLOW == FLOW_RANDOM || FLOW == FLOW_ACT_F32), "the two-wave step: f32 observations, a folded flow");
     const Shape shape(pp);
@@ -2376,11 +2565,13 @@ void step_split_kernel(const Params *__restrict__ pp, const Ptrs g) {
         g.ctrl[0] = parity;            // read by the auto-reset launch behind a device-counted interval
     }
     const uint32_t tick = p.dev_tick + g.tick;
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // 0: wave A (cameras), 1: wave B (targets)
-    const int64_t env = (int64_t)blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int role = wave & 1, pair = wave >> 1;      // role 0: wave A (cameras), 1: wave B (targets)
+    const int64_t env = (int64_t)blockIdx.x * EPW + pair;
+    if (env >= g.N) return;
     phase_prio(g.stagger, 0);
     const Ptrs &gk = kernarg_ptrs(g);
-    Ctx<ObsT> c(p, gk, smem, lane, env, FLOW);
+    Ctx<ObsT> c(p, gk, smem + pair * p.lds_wave_bytes, lane, env, FLOW);
 #ifdef MATE_PHASE_CLOCKS      // per-wave stamps: slots 0-7 wave A, 8-15 wave B (tools/split_phases.py)
 #define SPLIT_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + role * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -2406,6 +2597,12 @@ void step_split_kernel(const Params *__restrict__ pp, const Ptrs g) {
         DrawRole r = draw_role(c);
         const bool target_lane = lane >= p.Nc && lane < p.Nc + p.Nt;
         if (role == 0 ? (r.kind == 1 && target_lane) : (r.kind == 2 || (r.kind == 1 && !target_lane))) r.kind = 0;
+        if (c.act_prefetched()) {
+            StepDraws act = prefetch_action(c);
+            asm volatile("" : "+v"(act.a0), "+v"(act.a1));
+            if (role == 0) (void)step_draws(c, tick, nullptr, &r);
+            draws = act;
+        } else
         if (role == 0 || c.mode() == MODE_STEP_RANDOM) draws = step_draws(c, tick, nullptr, &r);
     }
     // the batched auto-reset's idle environments: decided from the record in registers, by both waves alike

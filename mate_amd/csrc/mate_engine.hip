@@ -65,7 +65,7 @@ static void pick_image_kernels(StepFn *rollout, PolicyFn *rollout_greedy, int *i
 static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no_image, StepFn *step, StepFn *rollout, PolicyFn *policy, PolicyFn *rollout_greedy,
                          int *specialised, int *image, StepFn *split) {
     *specialised = 0; *image = 0;
-    split[FLOW_ANY] = split[FLOW_RANDOM] = split[FLOW_ACT_F32] = nullptr;      // the two-wave step (step_split_kernel): f32 observations, the folded flows
+    for (int i = 0; i < 6; ++i) split[i] = nullptr;      // the two-wave step (step_split_kernel): f32 observations, the folded flows; [3 + flow]: two environments per workgroup
     if (!generic) {
 #define X(C, T, O)                                                                                                  \
     if (Nc == C && Nt == T && No == O) {                                                                            \
@@ -74,7 +74,9 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no
         step[FLOW_RANDOM] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                            \
         step[FLOW_ACT_F32] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, FixedShape<C, T, O, false>, FLOW_ACT_F32>;                          \
         if (!f64) { split[FLOW_RANDOM] = (StepFn)step_split_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                                \
-                    split[FLOW_ACT_F32] = (StepFn)step_split_kernel<float, FixedShape<C, T, O, false>, FLOW_ACT_F32>; }                            \
+                    split[FLOW_ACT_F32] = (StepFn)step_split_kernel<float, FixedShape<C, T, O, false>, FLOW_ACT_F32>;                              \
+                    split[3 + FLOW_RANDOM] = (StepFn)step_split_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM, 2>;                         \
+                    split[3 + FLOW_ACT_F32] = (StepFn)step_split_kernel<float, FixedShape<C, T, O, false>, FLOW_ACT_F32, 2>; }                     \
         rollout[0] = f64 ? (StepFn)rollout_kernel<double, FixedShape<C, T, O, true>> : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>>; \
         rollout[1] = f64 ? rollout[0] : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                                   \
         *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, FixedShape<C, T, O, true>> : (PolicyFn)greedy_policy_kernel<float, FixedShape<C, T, O, false>>; \
@@ -88,7 +90,8 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no
     step[FLOW_ANY] = f64 ? (StepFn)step_kernel<double, AnyShape> : (StepFn)step_kernel<float, AnyShape>;
     step[FLOW_RANDOM] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, AnyShape, FLOW_RANDOM>;
     step[FLOW_ACT_F32] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, AnyShape, FLOW_ACT_F32>;
-    if (!f64) { split[FLOW_RANDOM] = (StepFn)step_split_kernel<float, AnyShape, FLOW_RANDOM>; split[FLOW_ACT_F32] = (StepFn)step_split_kernel<float, AnyShape, FLOW_ACT_F32>; }
+    if (!f64) { split[FLOW_RANDOM] = (StepFn)step_split_kernel<float, AnyShape, FLOW_RANDOM>; split[FLOW_ACT_F32] = (StepFn)step_split_kernel<float, AnyShape, FLOW_ACT_F32>;
+                split[3 + FLOW_RANDOM] = (StepFn)step_split_kernel<float, AnyShape, FLOW_RANDOM, 2>; split[3 + FLOW_ACT_F32] = (StepFn)step_split_kernel<float, AnyShape, FLOW_ACT_F32, 2>; }
     rollout[0] = f64 ? (StepFn)rollout_kernel<double, AnyShape> : (StepFn)rollout_kernel<float, AnyShape>;
     rollout[1] = f64 ? rollout[0] : (StepFn)rollout_kernel<float, AnyShape, FLOW_RANDOM>;
     *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, AnyShape> : (PolicyFn)greedy_policy_kernel<float, AnyShape>;
@@ -120,7 +123,7 @@ static Switches read_switches() {
     w.zoom_iterate = flag("MATE_ZOOM_ITERATE");
     w.policy_split = flag("MATE_POLICY_SPLIT");
     w.no_image = flag("MATE_NO_IMAGE");
-    if (const char *v = getenv("MATE_STEP_SPLIT")) w.step_split = atoi(v) != 0;
+    if (const char *v = getenv("MATE_STEP_SPLIT")) w.step_split = atoi(v);      // 1: one environment per workgroup, 2: two
     return w;
 }
 
@@ -147,8 +150,8 @@ struct mate_engine {
     int image = 0;                         // the fused rollouts (random-policy flow, greedy) run their row-image compilation ...
     size_t image_wave_bytes = 0;           // ... whose per-environment LDS slice is this
     PolicyFn policy_fn = nullptr, rollout_greedy_fn = nullptr;
-    StepFn split_fn[3] = {nullptr, nullptr, nullptr};      // step_split_kernel per flow (two waves per environment), or null
-    bool split_on = false;                                 // ... and whether launch_step uses it (MATE_STEP_SPLIT, or the batch is one resident generation)
+    StepFn split_fn[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // step_split_kernel per flow (two waves per environment), or null; [3 + flow]: two environments per workgroup
+    int split_on = 0;                                      // ... and whether launch_step uses it (MATE_STEP_SPLIT, or the batch is one resident generation)
     StepFn step_fn[3] = {nullptr, nullptr, nullptr}, rollout_fn[2] = {nullptr, nullptr};   // kernels chosen at create: shape-specialised when compiled for these counts; step_fn[flow]
     int last_flow = 0;
     bool flow_generic = false;                        // MATE_FLOW_GENERIC=1: every launch runs the FLOW_ANY kernel (tests)
@@ -382,15 +385,18 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         // environments run 15-30 % faster without)
         hipDeviceProp_t prop;
         const int64_t cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
-        const int digits = e->sw.stagger >= 0 ? e->sw.stagger : (((num_envs + 3) / 4 <= 4 * cus) ? 33210 : 0);
+        // (round 4: with the rows leaving early the priorities cost 3 % at the headline batch on the boxes measured -- off unless asked for)
+        const int digits = e->sw.stagger >= 0 ? e->sw.stagger : 0;
+        // the two-wave step: where it measured faster -- batches of at most 8 environments per CU (half a generation of the one-wave
+        // kernel: 2048 environments on 256 CUs, -3 % random policy, -8 % caller's actions; at 4096 it is 17 % slower)
+        if (e->sw.step_split < 0) e->sw.step_split = (Nc > 0 && num_envs <= 8 * cus) ? 1 : 0;
         g.stagger = 0;
         if (digits > 0) {
             int d = digits;
             for (int phase = 4; phase >= 0; --phase, d /= 10) g.stagger |= ((d % 10) & 3) << (2 * phase);
             g.stagger |= (int32_t)0x40000000;
         }
-        // the two-wave step: until measured otherwise only on request (MATE_STEP_SPLIT=1)
-        e->split_on = e->sw.step_split > 0 && Nc > 0;
+        e->split_on = (e->sw.step_split > 0 && Nc > 0) ? (e->sw.step_split >= 2 ? 2 : 1) : 0;
     }
     do {
         if ((rc = dev_alloc(e, &g.stat, N * p.SW))) break;
@@ -804,9 +810,12 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
         else if (mode == MODE_STEP) flow = FLOW_ACT_F32;      // caller-supplied real-valued actions, f32 or f64 per team
     }
     e->last_flow = flow;
-    if (e->split_on && e->split_fn[flow]) {      // two waves per environment: one 128-thread workgroup each
-        if (ev0) hipExtLaunchKernelGGL(e->split_fn[flow], dim3((unsigned)e->N), dim3(128), e->step_lds / 4, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
-        else hipLaunchKernelGGL(e->split_fn[flow], dim3((unsigned)e->N), dim3(128), e->step_lds / 4, stream, (const Params *)e->d_params, (const Ptrs)g);
+    if (e->split_on && e->split_fn[flow]) {      // two waves per environment: one 128-thread workgroup each (or two environments per 256-thread workgroup)
+        const int epw = e->split_on;
+        const StepFn fn = e->split_fn[(epw == 2 ? 3 : 0) + flow];
+        const dim3 grid((unsigned)((e->N + epw - 1) / epw)), block(128 * epw);
+        if (ev0) hipExtLaunchKernelGGL(fn, grid, block, epw * (e->step_lds / 4), stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
+        else hipLaunchKernelGGL(fn, grid, block, epw * (e->step_lds / 4), stream, (const Params *)e->d_params, (const Ptrs)g);
     }
     else if (ev0) hipExtLaunchKernelGGL(e->step_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
     else hipLaunchKernelGGL(e->step_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, (const Params *)e->d_params, (const Ptrs)g);   // (capturable)
@@ -1340,6 +1349,11 @@ extern "C" int mate_engine_block_alloc(int32_t device, int64_t bytes, void **ptr
     HIP_TRY(hipMemGetAllocationGranularity(&granularity, &prop, hipMemAllocationGranularityMinimum));
     if (granularity == 0 || kBlockChunk % granularity != 0) return fail(MATE_EHIP, "block_alloc: allocation granularity %zu does not divide 2 MiB", granularity);
     const size_t n = ((size_t)bytes + kBlockChunk - 1) / kBlockChunk, total = n * kBlockChunk;
+    {   // refuse at once what the device cannot hold (creating chunk after chunk until the driver says no takes minutes for a terabyte)
+        size_t free_bytes = 0, total_bytes = 0;
+        HIP_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
+        if (total > free_bytes) return fail(MATE_ENOMEM, "block_alloc: %zu bytes asked for, %zu free on device %d", total, free_bytes, device);
+    }
     void *va = nullptr;
     HIP_TRY(hipMemAddressReserve(&va, total, kBlockChunk, nullptr, 0));
     ScatteredBlock blk{device, total, {}};
@@ -1484,9 +1498,11 @@ extern "C" int mate_engine_block_free(void *ptr) {
         const hipError_t err = hipMemRelease(h);
         if (err != hipSuccess && first == hipSuccess) first = err;
     }
-    // MATE_BLOCK_KEEP_RANGE=1: the former workaround -- the virtual range stays reserved for the life of the process
-    static const bool keep_range = [] { const char *v = getenv("MATE_BLOCK_KEEP_RANGE"); return v && atoi(v) != 0; }();
-    if (!keep_range) {
+    // The virtual range stays reserved for the life of the process (address space only: 2^47 bytes of it, a block is a few GB)
+    // unless MATE_BLOCK_FREE_RANGE=1: with every chunk properly unmapped a range handed out AGAIN still lost rows of the next
+    // rollout in two of four runs of the GPU suite (tools/va_reuse.hip is the minimal repro).
+    static const bool free_range = [] { const char *v = getenv("MATE_BLOCK_FREE_RANGE"); return v && atoi(v) != 0; }();
+    if (free_range) {
         const hipError_t err = hipMemAddressFree(ptr, blk.bytes);
         if (err != hipSuccess && first == hipSuccess) first = err;
     }

@@ -393,7 +393,7 @@ def test_two_wave_step_equals_one_wave_step(workload, n):
     else:
         cfg = read_config(workload, max_episode_steps=9)
     outs = []
-    for split in ('0', '1'):
+    for split in ('0', '1', '2'):             # one wave per environment; two, one environment per workgroup; two, two environments per workgroup
         os.environ['MATE_STEP_SPLIT'] = split
         try:
             eng = Engine(cfg, n, seed=31, first_env_index=7)
@@ -437,6 +437,7 @@ def test_two_wave_step_equals_one_wave_step(workload, n):
         outs.append(rec)
         assert (eng.state_dict()['episode'] >= 3).all()
         del stepper, eng
-    for i, (a, b) in enumerate(zip(*outs)):
-        for x, y in zip(a, b):
-            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), i
+    for other in outs[1:]:
+        for i, (a, b) in enumerate(zip(outs[0], other)):
+            for x, y in zip(a, b):
+                assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), i

@@ -10,7 +10,7 @@ from mate_amd.engine import Engine  # noqa: E402
 workload = sys.argv[1] if len(sys.argv) > 1 else 'MATE-4v8-9.yaml'
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 flow = sys.argv[3] if len(sys.argv) > 3 else 'random'
-os.environ['MATE_STEP_SPLIT'] = '1'
+os.environ.setdefault('MATE_STEP_SPLIT', '1')
 eng = Engine(read_config(workload), batch, seed=0)
 eng.reset()
 cam = torch.rand((batch, eng.num_cameras, 2), device='cuda') * 4 - 2
