@@ -257,6 +257,16 @@ int mate_engine_step_versus_greedy(mate_engine *engine, int32_t team, const mate
  * stops there (done = 2 in its later scalar rows, counted by mate_engine_idle_steps) and, with auto_reset, starts a new
  * episode before the next call.  Philox draws only (no policy tape).  Bit-identical to `steps` calls of
  * mate_engine_step_greedy. */
+/* auto_reset == MATE_RESET_PIPELINED: restarts taken off the critical path.  Greedy-vs-Greedy episodes last ~1.2 k steps, so a few
+ * hundred of 8192 environments finish in every launch and their reset -- placement, one occlusion table per camera, first view:
+ * three latency-bound launches, ~0.25 ms -- otherwise sits between two rollout launches.  Here the reset of what launch n
+ * finished is enqueued on a stream of the engine's own behind launch n and runs UNDER launch n + 1; a restarted environment joins
+ * launch n + 2 (its `done` word carries a hand-over tag: no launch ever steps or stores an environment a concurrent reset owns,
+ * so results do not depend on timing -- the same calls with MATE_PIPELINED_SERIAL=1, which runs the resets on the caller's
+ * stream, give the same bytes).  A finished environment idles through the rest of its launch and all of the next one (scalar
+ * rows done = 2, counted by mate_engine_idle_steps).  Any other entry point of the handle first waits for the resets in flight
+ * and turns the tags back into plain live environments. */
+#define MATE_RESET_PIPELINED (-1)
 int mate_engine_rollout_greedy(mate_engine *engine, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream);
 /* FrameSkip(frame_skip = steps) over MultiCamera / MultiTarget (examples/utils/wrappers.py:301-323: the same action for
  * `frame_skip` env.step calls; every example trainer's make_env applies it last) in ONE launch: the caller's `team` repeats

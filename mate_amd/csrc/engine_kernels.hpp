@@ -213,7 +213,14 @@ struct Ptrs {
     int32_t obs_mode;             // bits 0-1 camera team, bits 2-3 target team: 0 plain, 1 EnhancedObservation, 2 SharedFieldOfView
     int32_t rotate_prio;          // rollout kernel: rotate the wave priorities (fair SIMD shares, see rollout_kernel)
     int32_t store_shifted;        // row-image rollouts: the line-aligned form of the row stores (image_store_form; mate_engine_set_store_form)
+    // Pipelined restarts of the fused Greedy rollouts (mate_engine_rollout_greedy, auto_reset = MATE_RESET_PIPELINED): the reset of
+    // what launch n finished runs on a side stream UNDER launch n + 1, and a restarted environment joins launch n + 2.  The
+    // record's `done` word carries the hand-over: kDoneTag | parity << 3 = "restarted, live from the next launch of this list
+    // parity on"; any launch of the other parity -- the one the reset runs under -- leaves such an environment alone (no step, no
+    // store), so what a launch does never depends on how far the concurrent reset has come.
+    int32_t pipelined;
 };
+constexpr int32_t kDoneTag = 4;
 
 #ifdef MATE_PHASE_CLOCKS
 #define PHASE_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -2312,62 +2319,36 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     // shapes with one round of sector pairs: the tracked bits and the warehouses from the round's ballot, in registers
     const bool reg_tail = p.sector_rounds <= 1 && mode != MODE_OBSERVE && !SKIP(8) && !SKIP(32);
     int tracked_reg = 0, inside_reg = -1;
-    // The folded flows of the compiled shapes: THE TARGET ROWS LEAVE RIGHT BEHIND THE VISIBILITY PHASE, ahead of the goals and the
-    // rewards.  A launch of the headline batch writes 30 MB, and a kernel ends when its last store is acknowledged: with every row
-    // stored at the very end of every wave's chain the whole batch's stores arrived within a few microseconds of each other and
-    // the launch lasted as long as they took to drain, whatever the chain in front of them cost (four trims of that chain -- 3 % of
-    // its instructions and five LDS hand-offs -- changed the launch by 0.0 us).  The target rows are two thirds of the bytes and
-    // need only the range tests' verdicts and the kinematics; what _assign_goals may still change in them -- a target's cargo
-    // flag, goal and empty-warehouse bits when it picks up, delivers or learns of an empty warehouse: rare -- is repaired by
-    // packing them once more behind the goals (same values as the late packer: the rows are a pure function of scratch and flags).
+    // (Measured and dropped in round 4, profiles/r04_step_early_rows.txt: the target rows -- two thirds of a step's bytes, which need
+    // only the range tests and the kinematics -- packed and stored right behind the visibility phase, ahead of the goals, and packed
+    // once more in the rare step in which _assign_goals changed a cargo flag or a goal bit: 12.7-12.8 us against 12.4-12.5 us.  The
+    // launch does not end with the drain of its stores, nor with the mean wave's chain -- four trims of that chain, 3 % of its
+    // instructions and five LDS hand-offs, changed it by 0.0 us -- but with the YOUNGEST wave of each SIMD: lifetimes p50 20.5 k,
+    // p99 26 k, max 28 k cycles, the slow waves slow in every phase alike.)
     PackDescriptors pack_desc;
     constexpr int GCE = Shape::kHeldGC, GTE = Shape::kHeldGT;
-    uint4 cam_desc[GCE > 0 ? GCE : 1];
     const bool early_desc = FLOW != FLOW_ANY && Shape::kGreedyHeld && GCE + GTE <= 8 && packs_rows_f32(c);      // (wave-uniform; elsewhere the held registers cost the eighth wave per SIMD)
-    const bool early_rows = early_desc && reg_tail && !SKIP(64) && !SKIP(128);
-    int gw_packed = 0;
     if (reg_tail) {
         RangeRoles none;
         uint32_t seen_unused;
         unsigned long long sector_ballot = 0ull;
         update_view<false, false>(c, tick, S_TRANSMIT, true, none, seen_unused, nullptr, &sector_ballot);
-        if (early_rows) {
-            // the camera rows' descriptors before the first store (loads and stores share one in-order counter), held across the goals
-            load_row_descriptors<GCE>(c, c.table, p.cam_elems, cam_desc);
-            wave_sync();                               // (the range flags and mask words of update_view, which skipped its tail)
-            if (lane < p.Nt) gw_packed = c.ti(lane, TI_GW) & 0xffffff;
-            fill_scratch(c);
-            split_pack_rows<GTE>(c, c.table + p.tgt_table_off, reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems, p.tgt_elems);
-        }
         view_tail_regs(c, sector_ballot, tracked_reg, inside_reg);
     } else
     if (!SKIP(8)) update_view(c, tick, S_TRANSMIT, true);
     PHASE_STAMP(4);
     phase_prio(g.stagger, 3);
-    // (otherwise: the packer's descriptors on their way -- L2 / L1: every wave reads the same table -- while the goals, the rewards
-    // and the gather scratch are made)
-    if (early_desc && !early_rows) load_pack_descriptors(c, pack_desc);
+    // the packer's descriptors on their way (L2 / L1: every wave reads the same table) while the goals, the rewards and the gather
+    // scratch are made
+    if (early_desc) load_pack_descriptors(c, pack_desc);
     if (mode == MODE_OBSERVE) score_only(c, g.scalars);
     else if (reg_tail) assign_and_score(c, tick, g.scalars, &tracked_reg, &inside_reg);
     else if (!SKIP(32)) assign_and_score(c, tick, g.scalars);
     PHASE_STAMP(5);
-    if (early_rows) {
-        const bool changed = __ballot(lane < p.Nt && (c.ti(lane, TI_GW) & 0xffffff) != gw_packed) != 0ull;
-        if (changed) {                                 // rare: a pick-up, a delivery, a newly known empty warehouse
-            fill_scratch(c);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the rows' first version has arrived before the second leaves)
-            split_pack_rows<GTE>(c, c.table + p.tgt_table_off, reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems, p.tgt_elems);
-        }
-        PHASE_STAMP(6);
-        phase_prio(g.stagger, 4);
-        if (p.cam_elems > 0) store_rows_with<GCE>(c, c.table, p.cam_elems, cam_desc, reinterpret_cast<float *>(c.g.cam_obs) + c.out * p.cam_elems);
-        store_masks(c);
-    } else {
     if (!SKIP(64)) fill_scratch(c);
     PHASE_STAMP(6);
     phase_prio(g.stagger, 4);
     if (!SKIP(128)) { if (early_desc) pack_observations<true>(c, pack_desc); else pack_observations<false>(c, pack_desc); }
-    }
     PHASE_STAMP(7);
     if (mode != MODE_OBSERVE) store_dynamic(c);
     PHASE_STAMP(8);
@@ -2521,30 +2502,6 @@ __device__ __forceinline__ void split_pack_rows(const Ctx<ObsT> &c, const uint32
     for (int k = 0; k < G; ++k) { const int i = c.lane + 64 * k; d[k] = tab[i < nv ? i : 0]; }
 #pragma unroll
     for (int k = 0; k < G; ++k) asm volatile("" : "+v"(d[k].x), "+v"(d[k].y), "+v"(d[k].z), "+v"(d[k].w));
-    auto chunk = [&](const uint4 &x) { return f32x4{gather_one(c, x.x), gather_one(c, x.y), gather_one(c, x.z), gather_one(c, x.w)}; };
-#pragma unroll
-    for (int k = 0; k < G; ++k) { const int i = c.lane + 64 * k; if (i < nv) stream_store(chunk(d[k]), &out[i]); }
-    for (int i = c.lane + 64 * G; i < nv; i += 64) stream_store(chunk(tab[i]), &out[i]);
-    }
-}
-
-// ... in two halves: the descriptors of a lane's first G chunks now, the rows later (other stores in between)
-template <int G, typename ObsT>
-__device__ __forceinline__ void load_row_descriptors(const Ctx<ObsT> &c, const uint32_t *table, int elems, uint4 (&d)[G > 0 ? G : 1]) {
-    const int nv = elems / 4;
-    const uint4 *tab = reinterpret_cast<const uint4 *>(table);
-#pragma unroll
-    for (int k = 0; k < G; ++k) { const int i = c.lane + 64 * k; d[k] = tab[i < nv ? i : 0]; }
-#pragma unroll
-    for (int k = 0; k < G; ++k) asm volatile("" : "+v"(d[k].x), "+v"(d[k].y), "+v"(d[k].z), "+v"(d[k].w));
-}
-template <int G, typename ObsT>
-__device__ __forceinline__ void store_rows_with(const Ctx<ObsT> &c, const uint32_t *table, int elems, const uint4 (&d)[G > 0 ? G : 1], float *dst) {
-    if constexpr (sizeof(ObsT) == 4) {
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const int nv = elems / 4;
-    const uint4 *tab = reinterpret_cast<const uint4 *>(table);
-    f32x4 *out = reinterpret_cast<f32x4 *>(dst);
     auto chunk = [&](const uint4 &x) { return f32x4{gather_one(c, x.x), gather_one(c, x.y), gather_one(c, x.z), gather_one(c, x.w)}; };
 #pragma unroll
     for (int k = 0; k < G; ++k) { const int i = c.lane + 64 * k; if (i < nv) stream_store(chunk(d[k]), &out[i]); }

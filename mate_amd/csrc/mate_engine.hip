@@ -146,6 +146,13 @@ struct mate_engine {
     bool dev_tick = false;     // mate_engine_device_tick: the step counter lives on the device (graph-replayable launches)
     int dev_interval = 1;      // ... and the auto-reset interval every step() must then use
     int pending_interval = 0;  // auto_reset value of the batched-reset interval in progress (steps_since_reset > 0)
+    // pipelined restarts (mate_engine_rollout_greedy with auto_reset = MATE_RESET_PIPELINED): the side stream the resets run on, the
+    // event behind the last rollout launch, one event per list parity behind the reset that consumed that list
+    bool pipelined = false;          // records may carry "restarted" tags (Ptrs::pipelined): leave_pipelined() before anything else runs
+    bool pipelined_serial = false;   // MATE_PIPELINED_SERIAL=1: the same protocol with the resets on the CALLER's stream (the tests' reference)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_launch = nullptr, ev_reset[2] = {nullptr, nullptr};
+    bool reset_in_flight[2] = {false, false};
     size_t step_lds = 0, reset_lds = 0;
     int image = 0;                         // the fused rollouts (random-policy flow, greedy) run their row-image compilation ...
     size_t image_wave_bytes = 0;           // ... whose per-environment LDS slice is this
@@ -181,7 +188,9 @@ static void note_stream(mate_engine *e, hipStream_t stream) {
     if (e->launched && stream != e->last_stream) e->multi_stream = true;
     e->last_stream = stream; e->launched = true;
 }
+static int leave_pipelined(mate_engine *e, hipStream_t stream);
 static hipError_t wait_for_launches(mate_engine *e) {
+    if (e->pipelined && leave_pipelined(e, e->last_stream) != MATE_OK) return hipErrorUnknown;      // (resets still running on the side stream)
     hipError_t err = e->multi_stream ? hipErrorInvalidHandle : hipStreamSynchronize(e->last_stream);
     if (err != hipSuccess) { (void)hipGetLastError(); e->last_stream = nullptr; err = hipDeviceSynchronize(); }
     if (err == hipSuccess) e->multi_stream = false;
@@ -470,6 +479,12 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
 extern "C" int mate_engine_destroy(mate_engine *e) {
     if (!e) return MATE_OK;
     (void)hipSetDevice(e->device);
+    if (e->side) {                                   // pipelined restarts: nothing of ours may still run when the memory goes
+        (void)hipStreamSynchronize(e->side);
+        (void)hipStreamDestroy(e->side);
+        if (e->ev_launch) (void)hipEventDestroy(e->ev_launch);
+        for (int q = 0; q < 2; ++q) if (e->ev_reset[q]) (void)hipEventDestroy(e->ev_reset[q]);
+    }
     for (auto &ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (void *ptr : e->allocs) (void)hipFree(ptr);
     delete e;
@@ -678,6 +693,7 @@ static int launch_reset(mate_engine *e, Ptrs g, int kind, int phases, hipStream_
 
 extern "C" int mate_engine_reset(mate_engine *e, const uint8_t *env_mask_dev, const mate_step_io *io, void *stream) {
     if (!e) return fail(MATE_EINVAL, "null engine");
+    { const int rc_ = leave_pipelined(e, (hipStream_t)stream); if (rc_ != MATE_OK) return rc_; }
     HIP_TRY(hipSetDevice(e->device));
     Ptrs g = e->g;
     apply_io(g, io);
@@ -698,6 +714,7 @@ extern "C" int mate_engine_reset(mate_engine *e, const uint8_t *env_mask_dev, co
 extern "C" int mate_engine_reset_tape(mate_engine *e, const uint8_t *env_mask_dev, const mate_step_io *io, const double *tape_dev,
                                       int32_t tape_len, int32_t *draws_used_dev, void *stream) {
     if (!e) return fail(MATE_EINVAL, "null engine");
+    { const int rc_ = leave_pipelined(e, (hipStream_t)stream); if (rc_ != MATE_OK) return rc_; }
     if (!tape_dev || tape_len < 1) return fail(MATE_EINVAL, "reset_tape needs a tape");
     HIP_TRY(hipSetDevice(e->device));
     Ptrs g = e->g;
@@ -712,6 +729,7 @@ extern "C" int mate_engine_reset_tape(mate_engine *e, const uint8_t *env_mask_de
 
 extern "C" int mate_engine_rebuild_luts(mate_engine *e, void *stream) {
     if (!e) return fail(MATE_EINVAL, "null engine");
+    { const int rc_ = leave_pipelined(e, (hipStream_t)stream); if (rc_ != MATE_OK) return rc_; }
     HIP_TRY(hipSetDevice(e->device));
     Ptrs g = e->g;
     apply_io(g, nullptr);
@@ -744,8 +762,23 @@ static int flush_pending(mate_engine *e, int key, hipStream_t stream) {
 
 // Device-resident step counter: see Params::dev_tick.  enable = k >= 1: the host's tick goes to the device and stays there,
 // every step() must use auto_reset = k; disable: the stream is drained and the counter comes back.
+// Leaving the pipelined-restart mode (any other entry point): the caller's stream waits for the resets still in flight on the
+// side stream, and the "restarted" tags in the records become plain live environments.
+static int leave_pipelined(mate_engine *e, hipStream_t stream) {
+    if (!e->pipelined) return MATE_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    for (int q = 0; q < 2; ++q)
+        if (e->reset_in_flight[q]) { HIP_TRY(hipStreamWaitEvent(stream, e->ev_reset[q], 0)); e->reset_in_flight[q] = false; }
+    hipLaunchKernelGGL(untag_kernel, dim3((unsigned)((e->N + 255) / 256)), dim3(256), 0, stream, (const Params *)e->d_params, (const Ptrs)e->g);
+    HIP_TRY(hipGetLastError());
+    e->pipelined = false;
+    note_stream(e, stream);
+    return MATE_OK;
+}
+
 extern "C" int mate_engine_device_tick(mate_engine *e, int32_t enable, void *stream_) {
     if (!e) return fail(MATE_EINVAL, "null engine");
+    { const int rc_ = leave_pipelined(e, (hipStream_t)stream_); if (rc_ != MATE_OK) return rc_; }
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
     note_stream(e, stream);
@@ -773,6 +806,7 @@ extern "C" int mate_engine_device_tick(mate_engine *e, int32_t enable, void *str
 
 static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int auto_reset, hipStream_t stream) {
     if (!e) return fail(MATE_EINVAL, "null engine");
+    { const int rc_ = leave_pipelined(e, stream); if (rc_ != MATE_OK) return rc_; }
     if (!e->was_reset) return fail(MATE_ESTATE, "step()/observe() called before reset() (or import_state)");
     if (e->dev_tick && mode != MODE_OBSERVE && auto_reset != e->dev_interval)
         return fail(MATE_ESTATE, "with a device-resident step counter (mate_engine_device_tick) step() needs auto_reset = %d: the auto-reset launch advances it", e->dev_interval);
@@ -853,6 +887,7 @@ extern "C" int mate_engine_step_random(mate_engine *e, const mate_step_io *io, i
 }
 extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_) {
     if (!e) return fail(MATE_EINVAL, "null engine");
+    { const int rc_ = leave_pipelined(e, (hipStream_t)stream_); if (rc_ != MATE_OK) return rc_; }
     if (!e->was_reset) return fail(MATE_ESTATE, "rollout called before reset() (or import_state)");
     if (e->dev_tick) return fail(MATE_ESTATE, "not available while the step counter is device-resident (mate_engine_device_tick)");
     if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
@@ -1028,10 +1063,34 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
+    const bool pipelined = auto_reset == MATE_RESET_PIPELINED;
+    if (pipelined && (per_step || e->dev_tick)) return fail(MATE_EINVAL, "pipelined restarts (auto_reset = MATE_RESET_PIPELINED) belong to the fused rollouts");
+    if (auto_reset < 0 && !pipelined) return fail(MATE_EINVAL, "auto_reset = %d", auto_reset);
+    if (!pipelined) { const int rc_ = leave_pipelined(e, stream); if (rc_ != MATE_OK) return rc_; }
     note_stream(e, stream);
     { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | (per_step ? kStepFlow : kRolloutFlow)) : auto_reset, stream); if (rc != MATE_OK) return rc; }
+    if (pipelined && !e->side) {
+        {   // the LOWEST priority the device offers (MATE_PIPELINED_PRIORITY=0: default priority): the resets' latency-bound workgroups
+            // should take the slots the rollout launch leaves free -- its tail --, not displace its workgroups
+            int least = 0, greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const char *pv = getenv("MATE_PIPELINED_PRIORITY");
+            if (pv && atoi(pv) == 0) HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+            else HIP_TRY(hipStreamCreateWithPriority(&e->side, hipStreamNonBlocking, least));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_launch, hipEventDisableTiming));
+        for (int q = 0; q < 2; ++q) HIP_TRY(hipEventCreateWithFlags(&e->ev_reset[q], hipEventDisableTiming));
+        const char *v = getenv("MATE_PIPELINED_SERIAL");
+        e->pipelined_serial = v && atoi(v) != 0;
+    }
+    if (pipelined && !e->pipelined) {                // entering the mode: both lists empty, nothing in flight
+        HIP_TRY(hipMemsetAsync(e->g.done_count, 0, 2 * sizeof(int32_t), stream));
+        e->reset_in_flight[0] = e->reset_in_flight[1] = false;
+        e->pipelined = true;
+    }
     Ptrs g = e->g;
     apply_io(g, io);
+    g.pipelined = pipelined ? 1 : 0;
     if ((e->p.Nc > 0 && !g.cam_obs) || !g.tgt_obs || !g.scalars) return fail(MATE_EINVAL, "rollout_greedy needs the observation and scalar outputs");
     if (g.obs_mode != 0 || g.xdesc) return fail(MATE_EINVAL, "rollout_greedy packs plain observations (no fused transform / team mode)");
     if (team_caller == 0 && e->p.Nc == 0) return fail(MATE_EINVAL, "the scenario has no cameras to act for");
@@ -1048,7 +1107,10 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     g.rotate_prio = e->sw.rollout_rotate;
     // the finished-episode list: the rollout flows keep it for the immediate restart only (a batched restart finds the finished
     // ones by their flag); the per-step flow lists in both modes, like step()
-    if (per_step ? auto_reset == 0 : auto_reset != 1) g.done_count = nullptr;
+    if (per_step ? auto_reset == 0 : (auto_reset != 1 && !pipelined)) g.done_count = nullptr;
+    // pipelined restarts: this launch appends to list `parity`, which the reset launched two calls ago has consumed and cleared; the
+    // environments that reset restarted carry this parity's tag and go live now
+    if (pipelined && e->reset_in_flight[e->parity]) { HIP_TRY(hipStreamWaitEvent(stream, e->ev_reset[e->parity], 0)); e->reset_in_flight[e->parity] = false; }
     PolicyPtrs q = e->q;
     std::memset(&q.tape, 0, sizeof(q.tape));
     q.caller_team = team_caller;
@@ -1083,7 +1145,20 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
         }
         return MATE_OK;
     }
-    if (auto_reset == 1) {
+    if (pipelined) {
+        // the reset of what THIS launch finishes (list `parity`): on the side stream, behind this launch, under the next one
+        hipStream_t rs = e->pipelined_serial ? stream : e->side;
+        if (!e->pipelined_serial) { HIP_TRY(hipEventRecord(e->ev_launch, stream)); HIP_TRY(hipStreamWaitEvent(rs, e->ev_launch, 0)); }
+        Ptrs r = e->g;
+        apply_io(r, nullptr);
+        r.pipelined = 1;
+        int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, rs, true);
+        if (rc != MATE_OK) return rc;
+        HIP_TRY(hipMemsetAsync(e->g.done_count + e->parity, 0, sizeof(int32_t), rs));      // (the list is consumed: the launch after next appends to it afresh)
+        if (!e->pipelined_serial) { HIP_TRY(hipEventRecord(e->ev_reset[e->parity], rs)); e->reset_in_flight[e->parity] = true; }
+        e->last_stream = stream;                     // (launch_reset noted the side stream: the accessors wait through leave_pipelined)
+        e->parity ^= 1;
+    } else if (auto_reset == 1) {
         Ptrs r = e->g;
         apply_io(r, nullptr);     // state and the engine's own masks: the agents of the next rollout act on the fresh view
         int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream, true);
@@ -1126,6 +1201,7 @@ extern "C" int mate_engine_observe(mate_engine *e, const mate_step_io *io, void 
 
 extern "C" int mate_engine_export_state(mate_engine *e, double *dst_dev, void *stream) {
     if (!e || !dst_dev) return fail(MATE_EINVAL, "null argument");
+    { const int rc_ = leave_pipelined(e, (hipStream_t)stream); if (rc_ != MATE_OK) return rc_; }
     HIP_TRY(hipSetDevice(e->device));
     note_stream(e, (hipStream_t)stream);
     hipLaunchKernelGGL(export_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->d_params, e->g, dst_dev);
@@ -1136,6 +1212,7 @@ extern "C" int mate_engine_export_state(mate_engine *e, double *dst_dev, void *s
 extern "C" int mate_engine_import_state(mate_engine *e, const double *src_dev, void *stream) {
     if (!e || !src_dev) return fail(MATE_EINVAL, "null argument");
     if (e->dev_tick) return fail(MATE_ESTATE, "import_state while the step counter is device-resident (mate_engine_device_tick)");
+    { const int rc_ = leave_pipelined(e, (hipStream_t)stream); if (rc_ != MATE_OK) return rc_; }
     HIP_TRY(hipSetDevice(e->device));
     note_stream(e, (hipStream_t)stream);
     hipLaunchKernelGGL(import_kernel, dim3((unsigned)((e->N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->d_params, e->g, src_dev);
@@ -1238,6 +1315,7 @@ extern "C" int mate_engine_soft_coverage(mate_engine *e, const uint32_t *masks_d
     if (e->p.Nc == 0) return fail(MATE_EINVAL, "no cameras in this scenario");
     if (e->p.Nt > kAuxMaxTargets) return fail(MATE_EINVAL, "soft_coverage: at most %d targets", kAuxMaxTargets);
     if (!e->g.lut_knots_outer) return fail(MATE_ESTATE, "outer boundary not enabled (mate_engine_enable_outer_boundary)");
+    { const int rc_ = leave_pipelined(e, (hipStream_t)stream); if (rc_ != MATE_OK) return rc_; }
     if (!e->was_reset) return fail(MATE_ESTATE, "soft_coverage called before reset() (or import_state)");
     HIP_TRY(hipSetDevice(e->device));
     const int64_t items = e->N * e->p.Nc;

@@ -497,13 +497,14 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
     // see step_kernel -- the host keeps dev_tick = dev_group = 0 in the record while it counts itself)
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) {
         const int32_t parity = (int32_t)((p.dev_group + (uint32_t)g.parity) & 1u);
-        g.done_count[parity ^ 1] = 0;
+        if (!g.pipelined) g.done_count[parity ^ 1] = 0;      // (pipelined restarts: the other list is being consumed right now; its reset clears it)
         g.ctrl[0] = parity;
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t env_raw = (int64_t)blockIdx.x * 4 + wave;
     const bool in_batch = env_raw < g.N;
     const int64_t env = in_batch ? env_raw : g.N - 1;
+    bool untouched = false;          // pipelined restarts: not live at entry, see below (wave-uniform)
     const Ptrs &gk = kernarg_ptrs(g);
     const int pol_bytes = policy_slice_bytes(q.PW, p.Nc, p.Nt);
     unsigned char *pol_base = smem + 4 * p.lds_wave_bytes + wave * pol_bytes;
@@ -518,7 +519,23 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         const double *src = q.pol + env * q.PW;
         for (int k = lane; k < q.PW; k += 64) a.f[k] = src[k];
         build_entities(c);
-        if (in_batch) list_finished_at_entry(c);
+        if (g.pipelined) {
+            // pipelined restarts (Ptrs::pipelined): an environment tagged for this launch's list parity goes live; one that is not
+            // live at entry -- tagged for the other parity, or finished and in the hands of the reset running under this launch --
+            // is left alone: no step and, at the end, no store (the reset may be rewriting its records right now)
+            const int d = c.ei(EI_DONE);
+            const int32_t parity = (int32_t)((p.dev_group + (uint32_t)g.parity) & 1u);
+            const bool mine = (d & kDoneTag) && ((d >> 3) & 1) == parity;
+            untouched = in_batch && d != 0 && !mine;
+            if (d == 1 && in_batch && lane == 0 && g.done_count) {      // finished under auto_reset = 0 earlier, never listed: list it, and say so in the record itself
+                const int slot = atomicAdd(g.done_count + parity, 1);
+                g.done_list[(int64_t)parity * g.N + slot] = (int32_t)env;
+                reinterpret_cast<int32_t *>(g.dyn + env * p.DW + p.DF)[p.Nt * TI_STRIDE + EI_DONE] = 3;
+            }
+            wave_sync();
+            if (mine && lane == 0) c.ei(EI_DONE) = 0;
+        }
+        else if (in_batch) list_finished_at_entry(c);
         wave_sync();
     }
     constexpr bool IMAGE = Shape::kImage;   // row-image mode (engine_kernels.hpp: image_statics)
@@ -630,7 +647,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         g.phase_clocks[env * 16 + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_first;
     }
 #endif
-    if (in_batch) {
+    if (in_batch && !untouched) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
         store_dynamic(c);
         double *dst = q.pol + env * q.PW;

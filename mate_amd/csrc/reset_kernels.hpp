@@ -208,7 +208,8 @@ __device__ __forceinline__ void reset_place(Ctx<ObsT> &c, double *placed /* [5][
             }
         }
     }
-    c.ei(EI_EPSTEP) = 0; c.ei(EI_DONE) = 0;
+    // (pipelined restarts: live from the next launch with this reset's list parity on, see Ptrs::pipelined)
+    c.ei(EI_EPSTEP) = 0; c.ei(EI_DONE) = c.g.pipelined ? (kDoneTag | ((c.g.parity & 1) << 3)) : 0;
     if (c.g.reset_draws) c.g.reset_draws[c.env] = (int32_t)((rng.tape && rng.n > rng.tape_len) ? -1 : (int32_t)rng.n);
 }
 
@@ -583,6 +584,15 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
             if (phases & (PH_PLACE | PH_VIEW)) store_dynamic(c);
         }
     }
+}
+
+// Leaving the pipelined-restart mode: every "restarted, live from launch parity q on" tag becomes a plain live environment.
+__global__ void untag_kernel(const Params *__restrict__ pp, const Ptrs g) {
+    const Params &p = *pp;
+    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= g.N) return;
+    int32_t *e = reinterpret_cast<int32_t *>(g.dyn + env * p.DW + p.DF) + p.Nt * TI_STRIDE;
+    if (e[EI_DONE] & kDoneTag) e[EI_DONE] = 0;
 }
 
 // seed(): every counter that enters a Philox counter word goes back to zero, so that (seed, environment index) alone

@@ -250,9 +250,14 @@ class Engine:
             check(status)
         return self.camera_obs, self.target_obs, self.scalars
 
+    RESET_PIPELINED = -1     # MATE_RESET_PIPELINED (include/mate_engine.h)
+
     def rollout_greedy(self, steps, auto_reset=True, want_masks=False):
         """`steps` fused (agents act, environment steps) iterations of the on-device Greedy policies (enable_policies()
-        first).  Same rollout-shaped tensors as rollout_random."""
+        first).  Same rollout-shaped tensors as rollout_random.  auto_reset = 'pipelined' (Engine.RESET_PIPELINED): the reset of
+        what a launch finishes runs on the engine's side stream under the next launch, restarted environments join the one after."""
+        if auto_reset == 'pipelined':
+            auto_reset = self.RESET_PIPELINED
         return self._run_rollout(self.lib.mate_engine_rollout_greedy, steps, auto_reset, want_masks)
 
     def rollout_versus_greedy(self, team, joint_action, steps, auto_reset=True, want_masks=False):

@@ -1,0 +1,81 @@
+"""Pipelined restarts of the fused Greedy rollouts (mate_engine_rollout_greedy, auto_reset = MATE_RESET_PIPELINED): the reset of what
+launch n finishes runs on the engine's side stream under launch n + 1, restarted environments join launch n + 2."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cfg, n, K, launches, serial, seed=9):
+    from mate_amd.engine import Engine
+    os.environ['MATE_PIPELINED_SERIAL'] = '1' if serial else '0'
+    try:
+        eng = Engine(cfg, n, seed=seed, first_env_index=3)
+        eng.enable_policies()
+        eng.reset()
+        rec = []
+        for _ in range(launches):
+            cam, tgt, sc = eng.rollout_greedy(K, auto_reset='pipelined', want_masks=True)
+            rec.append((cam.clone(), tgt.clone(), sc.clone(), eng._rollout['masks'][:K].clone()))
+        idle = eng.idle_steps()
+        state = eng.export_state().clone()           # (any other entry point: waits for the resets in flight, clears the hand-over tags)
+    finally:
+        os.environ.pop('MATE_PIPELINED_SERIAL', None)
+    return eng, rec, state, idle
+
+
+@pytest.mark.parametrize('workload,n', [('MATE-8v8-9.yaml', 203), ('MATE-4v8-9.yaml', 130)])
+def test_pipelined_restarts_equal_their_serial_form_and_join_two_launches_later(workload, n):
+    """The concurrent form (resets on the side stream, under the next launch) against the same protocol with the resets on the
+    caller's stream (MATE_PIPELINED_SERIAL=1): every row and the final state bit for bit -- what a launch does never depends on how
+    far the concurrent reset has come.  And the protocol itself: an environment whose episode ends in launch n idles through the
+    rest of n and all of n + 1 and steps again from the first row of n + 2, in a fresh episode."""
+    from mate_amd.config import read_config
+    cfg = read_config(workload, max_episode_steps=17)
+    K, launches = 8, 14
+    _, conc, state_c, idle_c = _run(cfg, n, K, launches, serial=False)
+    eng, ser, state_s, idle_s = _run(cfg, n, K, launches, serial=True)
+    for a, b in zip(conc, ser):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+    assert torch.equal(state_c.view(torch.uint8), state_s.view(torch.uint8)) and idle_c == idle_s
+    done = torch.stack([r[2][:, :, 2] for r in conc]).cpu().numpy()          # [launch][step][env]: 0 running, 1 the step that ended the episode, 2 idle
+    finished = 0
+    for ln in range(launches - 2):
+        ended = (done[ln] == 1).any(axis=0)
+        finished += int(ended.sum())
+        assert (done[ln + 1][:, ended] == 2).all()                           # the reset owns them for the whole next launch
+        assert (done[ln + 2][0, ended] != 2).all()                           # ... and they are live again in the one after
+        for env in np.nonzero(ended)[0][:8]:
+            r = int(np.argmax(done[ln][:, env] == 1))
+            assert (done[ln][r + 1:, env] == 2).all()
+    assert finished >= 2 * n                                                 # the time limit (17) ended every episode, more than once
+    sd = {k: state_s[:, off:off + (int(np.prod(shape)) if shape else 1)].cpu().numpy() for k, (off, shape) in eng.export_fields.items()}
+    assert set(np.unique(sd['done'])) <= {0.0, 1.0, 3.0}                     # no hand-over tag survives the mode
+    assert (sd['episode'] >= 3).all()
+    # the ordinary flows carry on from there
+    cam, tgt, sc = eng.rollout_greedy(K, auto_reset=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tgt).all() and (sc[0, :, 2] != 2).sum() >= n // 2
+
+
+def test_pipelined_mode_changes_nothing_while_no_episode_ends():
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-4v8-9.yaml')
+    outs = []
+    for mode in (True, 'pipelined'):
+        eng = Engine(cfg, 96, seed=4)
+        eng.enable_policies()
+        eng.reset()
+        rec = []
+        for _ in range(4):
+            rec.append([t.clone() for t in eng.rollout_greedy(6, auto_reset=mode)])
+        rec.append([eng.export_state().clone()])
+        outs.append(rec)
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
