@@ -220,8 +220,10 @@ int mate_engine_rollout_random(mate_engine *engine, const mate_step_io *io, int3
 /* On-device rule-based policies: the reference's GreedyCameraAgent / GreedyTargetAgent
  * (mate/agents/greedy.py:13-227, 229-365) for every agent of every environment, acting on the same
  * partial observations (own state, opponents gated by the view masks of the previous step, teammates'
- * messages).  mate_engine_policy_enable() must precede the reset()/step() whose view they first act on; it fails with
- * MATE_EINVAL for more than 8 cameras (one lane per sender-recipient pair of camera agents).
+ * messages).  mate_engine_policy_enable() must precede the reset()/step() whose view they first act on.  Any scenario the
+ * engine takes (up to 16 cameras and 16 targets): the camera agents' message exchange runs one lane per sender-recipient pair,
+ * in as many rounds of 64 pairs as the cameras need; the fused rollouts need the workgroup's four environments -- step
+ * records + agents' memory -- to fit the 160 KiB LDS (MATE_EINVAL otherwise, mate_engine_step_greedy still works).
  * mate_engine_step_greedy() = group_step of both teams (observe, two-phase message exchange, act;
  * mate/wrappers/single_team.py:79-92) + step().  `tape` (device arrays, any member NULL = Philox):
  * recorded draws of the agents, for parity runs.  (mate_engine_policy_enable also tabulates the camera agents' 20-iteration

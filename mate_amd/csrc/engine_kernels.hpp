@@ -1355,21 +1355,6 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     update_view<false>(c, tick, stream, predrawn, none);
 }
 
-// real_coverage_rate = (tracked and with bounty) / (with bounty), mean_transport_rate = delayed episode reward / (reward scale x
-// delivered), normalised reward = reward / max team episode reward (environment.py:966-979, 661): lane 0, 1, 2 each make one
-struct MetricQuotients { double q; };
-__device__ __forceinline__ MetricQuotients metric_quotients(int lane, int n_both, int n_bounty, double epd, double reward_scale, int delivered, double r, double max_team_reward) {
-    double num = r, den = max_team_reward;
-    bool valid = lane == 2;
-    if (lane == 0) { num = (double)n_both; den = (double)n_bounty; valid = n_bounty > 0; }
-    else if (lane == 1) { num = epd; den = reward_scale * (double)delivered; valid = delivered > 0; }
-    if (!valid) { num = 0.0; den = 1.0; }
-    MetricQuotients m;
-    m.q = lane <= 2 ? div_nz(num, den) : 0.0;
-    if (!valid) m.q = 0.0;
-    return m;
-}
-
 // The order-dependent part of _assign_goals (environment.py:1278-1318: the warehouses' remaining cargo is shared), on ONE lane,
 // for the targets standing in a warehouse (c.inside); dense and delayed rewards of the deliveries are added to `reward` / `delayed`.
 template <typename ObsT>
@@ -1486,22 +1471,15 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
     const int n_tracked = __popcll(__ballot(tr));
     const int n_bounty = __popcll(__ballot(with_bounty));
     const int n_both = __popcll(__ballot(tr && with_bounty));
-    // The three quotients of the metric record (real coverage rate, mean transport rate, normalised reward) on lanes 0, 1, 2 -- ONE
-    // division's dependent chain instead of three in a row on lane 0, for numbers nothing later in the step reads (same operands,
-    // same IEEE division: same bits).  Every lane reads the record words BEFORE lane 0 rewrites them below (program order).
-    const double epd_all = c.ep_delayed() + delayed;
-    const int delivered_all = c.ei(EI_DELIVERED);
-    const double r_all = p.sparse_reward ? delayed : reward;
-    const MetricQuotients mq = metric_quotients(lane, n_both, n_bounty, epd_all, p.reward_scale, delivered_all, r_all, p.max_team_reward);
-    if (c.has_scalars() && scalars_out && (lane == 1 || lane == 2)) scalars_out[c.out * 8 + (lane == 1 ? 5 : 7)] = (float)mq.q;
     if (lane == 0) {
         const double epr = c.ep_reward() + reward;
-        const double epd = epd_all;
+        const double epd = c.ep_delayed() + delayed;
         c.ep_reward() = epr; c.ep_delayed() = epd;
-        const int delivered = delivered_all;
+        const int delivered = c.ei(EI_DELIVERED);
         const double coverage = div_by_count((double)n_tracked, p.Nt);
-        const double real_cov = mq.q;
-        const double r = r_all;
+        const double real_cov = n_bounty > 0 ? div_nz((double)n_both, (double)n_bounty) : 0.0;
+        const double transport = delivered > 0 ? div_nz(epd, p.reward_scale * (double)delivered) : 0.0;
+        const double r = p.sparse_reward ? delayed : reward;
         const int ep_step = c.ei(EI_EPSTEP) + 1;
         c.ei(EI_EPSTEP) = ep_step;
         const bool awaiting = c.ei(EI_AWAITING) || c.ei(EI_AWAITING + 1) || c.ei(EI_AWAITING + 2) || c.ei(EI_AWAITING + 3);
@@ -1512,7 +1490,7 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
         if (c.has_scalars() && scalars_out) {
             float *o = scalars_out + c.out * 8;
             o[0] = (float)(-r); o[1] = (float)r; o[2] = (float)done; o[3] = (float)coverage;
-            o[4] = (float)real_cov; o[6] = (float)delivered;      // ([5], [7]: lanes 1 and 2, above)
+            o[4] = (float)real_cov; o[5] = (float)transport; o[6] = (float)delivered; o[7] = (float)div_nz(r, p.max_team_reward);
         }
         if (done && c.g.done_count) {
             const int parity = c.list_parity();
@@ -2177,28 +2155,22 @@ __device__ __forceinline__ int assign_and_score_held(Ctx<ObsT> &c, uint32_t tick
     const int n_bounty = __popcll(__ballot(with_bounty));
     const int n_both = __popcll(__ballot(tracked && with_bounty));
     int done = 0;
-    // (the metric record's three quotients on lanes 0, 1, 2: metric_quotients; lane 0's sums and counters broadcast as scalars)
-    const double epd0 = h.ep_delayed + delayed;
-    const double epd_all = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(epd0)), __builtin_amdgcn_readfirstlane(__double2loint(epd0)));
-    const int delivered_all = __builtin_amdgcn_readfirstlane(h.delivered);
-    const double r_all = p.sparse_reward ? delayed : reward;
-    const MetricQuotients mq = metric_quotients(lane, n_both, n_bounty, epd_all, p.reward_scale, delivered_all, r_all, p.max_team_reward);
-    if (scalars_out && (lane == 1 || lane == 2)) scalars_out[c.out * 8 + (lane == 1 ? 5 : 7)] = (float)mq.q;
     if (lane == 0) {
         const double epr = h.ep_reward + reward;
-        const double epd = epd_all;
+        const double epd = h.ep_delayed + delayed;
         h.ep_reward = epr; h.ep_delayed = epd;
         const int delivered = h.delivered;
         const double coverage = div_by_count((double)n_tracked, p.Nt);
-        const double real_cov = mq.q;
-        const double r = r_all;
+        const double real_cov = n_bounty > 0 ? div_nz((double)n_both, (double)n_bounty) : 0.0;
+        const double transport = delivered > 0 ? div_nz(epd, p.reward_scale * (double)delivered) : 0.0;
+        const double r = p.sparse_reward ? delayed : reward;
         const int ep_step = h.epstep + 1;
         h.epstep = ep_step; h.tick = (int)(tick + 1u);
         done = !(ep_step <= p.max_episode_steps && h.awaiting);
         if (scalars_out) {
             float *o = scalars_out + c.out * 8;
             o[0] = (float)(-r); o[1] = (float)r; o[2] = (float)done; o[3] = (float)coverage;
-            o[4] = (float)real_cov; o[6] = (float)delivered;      // ([5], [7]: lanes 1 and 2, above)
+            o[4] = (float)real_cov; o[5] = (float)transport; o[6] = (float)delivered; o[7] = (float)div_nz(r, p.max_team_reward);
         }
         if (done) {                                            // rare: the record's flag, the restart list, the statistics
             c.ei(EI_DONE) = c.g.done_count ? 3 : 1;            // (3: on the list of the next reset launch, see assign_and_score)

@@ -937,8 +937,6 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
 static int policy_enable(mate_engine *e) {
     if (e->policy_ready) return MATE_OK;
     const Params &p = e->p;
-    // one lane per (sender, recipient) pair of camera agents, one Philox block per lane for its message delay
-    if (p.Nc > 8) return fail(MATE_EINVAL, "the on-device greedy agents support at most 8 cameras (%d asked for)", p.Nc);
     PolicyPtrs &q = e->q;
     q.PF = p.Nc * p.Nt * 2 + p.Nc * 2 + p.Nt * 4;
     q.PI = p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + 3 * p.Nt + 1;

@@ -151,6 +151,8 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
                                                    long long *acc = nullptr, long long *t_prev = nullptr, bool publish = true) {
 #ifdef MATE_PHASE_CLOCKS
 #define POL_STAMP(i) do { if (acc) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); acc[i] += t_now - *t_prev; *t_prev = t_now; } } while (0)
+#elif defined(MATE_ISA_MARKS)
+#define POL_STAMP(i) asm volatile("; ==== MATE_GREEDY_PHASE " #i)
 #else
 #define POL_STAMP(i) do { } while (0)
 #endif
@@ -226,9 +228,12 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     POL_STAMP(8);
 
     // ------------------------------------------------------------------ communicate
-    // cameras: send_responses (greedy.py:158-190), one lane per (sender, recipient)
-    if (lane < Nc * Nc) {
-        const int s = (int)(((float)lane + 0.5f) * p.inv_Nc), c = lane - s * Nc;
+    // cameras: send_responses (greedy.py:158-190), one lane per (sender, recipient) -- one round of pairs up to 8 cameras, up to
+    // four for the 16 the engine takes (the pair's message delay: the lane's own Philox word in the first round, one more block
+    // keyed by the pair's index beyond)
+    const bool one_round = Nc * Nc <= 64;
+    auto send_pair = [&](int k) {
+        const int s = (int)(((float)k + 0.5f) * p.inv_Nc), c = k - s * Nc;
         int bits = 0;
         int d = a.delay(s, c) - 1;
         if (d < 0) d = 0;
@@ -243,14 +248,28 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
                 int v;
                 if (q.tape.cam_delay) v = q.tape.cam_delay[(env * Nc + s) * Nc + c];
                 else { const int lo = q.memory_period / 4, hi = 2 * q.memory_period;        // randint(6, 50)
-                       v = lo + (int)((w_delay * (uint32_t)(hi - lo)) >> 16); }
+                       uint32_t w = w_delay;
+                       if (k >= 64) w = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_STEP, (uint32_t)k).x & 0xffffu;
+                       v = lo + (int)((w * (uint32_t)(hi - lo)) >> 16); }
                 d = v;
             }
         }
         a.delay(s, c) = d;
         a.send_bits(s, c) = bits;
-        if (bits < 0) a.neighbor(c, s) = 1;                 // receive_responses: the recipient learns its neighbour (greedy.py:192-226);
-    }                                                       // (every lane read neighbor(s, c) above before any lane writes here)
+        // receive_responses: the recipient learns its neighbour (greedy.py:192-226).  One round of pairs: every lane has read
+        // neighbor(s, c) above before any lane writes here (one wave, one instruction stream, LDS operations in order)
+        if (one_round && bits < 0) a.neighbor(c, s) = 1;
+    };
+    if (lane < Nc * Nc) send_pair(lane);
+    if (!one_round)
+        for (int k = lane + 64; k < Nc * Nc; k += 64) send_pair(k);
+    if (!one_round) {                                       // several rounds: behind EVERY round's reads
+        wave_sync();
+        for (int k = lane; k < Nc * Nc; k += 64) {
+            const int s = (int)(((float)k + 0.5f) * p.inv_Nc), c = k - s * Nc;
+            if (a.send_bits(s, c) < 0) a.neighbor(c, s) = 1;
+        }
+    }
     wave_sync();
     // ... and the positions of the targets it was told about; then the tracking candidates: distance camera -> remembered
     // position, +inf when forgotten or out of reach (greedy.py:115-127)
@@ -566,6 +585,9 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
     const long long t_first = t_prev, r_first = (long long)__builtin_amdgcn_s_memrealtime();
 #define GREEDY_STAMP(i) do { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
 #define GREEDY_ACC acc, &t_prev
+#elif defined(MATE_ISA_MARKS)      // tools/isa_phases.py: phase boundaries as comments in the -S output (no instruction is emitted)
+#define GREEDY_STAMP(i) asm volatile("; ==== MATE_GREEDY_PHASE " #i)
+#define GREEDY_ACC nullptr, nullptr
 #else
 #define GREEDY_STAMP(i) do { } while (0)
 #define GREEDY_ACC nullptr, nullptr

@@ -315,8 +315,9 @@ class Engine:
         # slowest seen: the classes lie at ~4.2, ~5.0 and 5.4-6.1).  Its transient footprint is bounded three ways: 45 % of what is
         # free (two ranks that share a GPU in a test must both fit), MATE_BLOCK_GIB (default 96) GiB in absolute terms, and
         # MATE_BLOCK_SECONDS (default 3) of wall time -- a learner whose model already holds most of the HBM gets a short search,
-        # not an out-of-memory error.  Everything but the winner is freed at the end (mate_engine_block_free gives the memory AND the
-        # address range back).
+        # not an out-of-memory error.  The wall-time bound covers BOTH blocks of a reserve_rollout (the camera block's candidates
+        # take what the target block's search left, at least one).  Everything but the winner is freed at the end
+        # (mate_engine_block_free: the physical memory comes back, the address range stays reserved).
         row_bytes = nbytes // (shape[0] * shape[1])
         tries = (sw['candidates'] or 6) if nbytes >= (128 << 20) and row_bytes % 16 == 0 else 1
         free = torch.cuda.mem_get_info(self.device)[0]
@@ -327,7 +328,7 @@ class Engine:
             tries = max(tries, int(budget // (nbytes + spacer_bytes)))
         tries = max(1, min(tries, int(free // (2 * nbytes))))
         import time
-        t0 = time.perf_counter()
+        t0 = getattr(self, '_reserve_t0', None) or time.perf_counter()      # (reserve_rollout's start: one time budget for both blocks)
         best, rates, held, spacers = None, [], [], []
         for _ in range(tries):
             try:
@@ -348,10 +349,10 @@ class Engine:
                 best = (rate, block)
             if len(rates) > 1 and best[0] >= 1.28 * min(rates):
                 break
+            if time.perf_counter() - t0 > sw['deep_seconds']:
+                break
             if deep:
                 if rate >= (5350.0 if nbytes >= (1 << 30) else 5100.0):      # (a short block's probe is a short launch: its ramp weighs more)
-                    break
-                if time.perf_counter() - t0 > sw['deep_seconds']:
                     break
                 try:
                     spacers.append(_native.HeldMemory(self.device_index, spacer_bytes))      # (moves the allocation on; never mapped, never touched)
@@ -372,7 +373,7 @@ class Engine:
         buf = getattr(self, '_rollout', None)
         if buf is None or buf['steps'] < steps or (want_masks and buf['masks'] is None):     # a shorter rollout fills a prefix
             import time
-            t0 = time.perf_counter()
+            t0 = self._reserve_t0 = time.perf_counter()
             N, Nc, Nt, L = self.num_envs, self.num_cameras, self.num_targets, self.layout
             self._rollout = None
             with torch.cuda.device(self.device):
@@ -395,6 +396,7 @@ class Engine:
             check(self.lib.mate_engine_set_store_form(self._h, int(shifted)))
             torch.cuda.synchronize(self.device)
             self.reserve_seconds = time.perf_counter() - t0
+            self._reserve_t0 = None
         return buf
 
     def _run_rollout(self, entry_point, steps, auto_reset, want_masks):

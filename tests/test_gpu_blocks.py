@@ -149,9 +149,8 @@ def test_block_probe_and_candidate_search():
 
 def test_rows_survive_block_churn():
     """Blocks allocated and freed over and over, then a fused rollout into fresh ones: every row arrives (a virtual range handed
-    out again after a free once lost rows of the last step: block_free had unmapped the whole block with ONE hipMemUnmap although it
-    had been mapped chunk by chunk, which retired the first chunk's mapping only -- it now unmaps per chunk and gives the range
-    back, so reuse of a range is exactly what this test provokes)."""
+    out again after a free lost rows of the last step -- translations of a virtual address outlive hipMemUnmap on this driver,
+    tools/va_reuse.hip -- so block_free releases the memory and keeps the range reserved: no range is ever mapped twice)."""
     from mate_amd import _native
     from mate_amd.config import read_config
     from mate_amd.engine import Engine
@@ -178,8 +177,8 @@ def test_rows_survive_block_churn():
 
 
 def test_block_free_returns_the_memory():
-    """Blocks allocated and freed: the device's free memory comes back (every chunk unmapped and released, the address range
-    given back), also after the candidate search of reserve_rollout, which frees everything but the winners."""
+    """Blocks allocated and freed: the device's free memory comes back (every chunk unmapped and released; the address range stays
+    reserved), also after the candidate search of reserve_rollout, which frees everything but the winners."""
     import gc
     from mate_amd import _native
     from mate_amd.config import read_config

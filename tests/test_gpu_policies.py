@@ -281,20 +281,76 @@ def test_fused_greedy_rollout_equals_single_steps(config, n, kw):
     assert idled == bool(kw)         # the time-limit case did end episodes inside a rollout
 
 
-def test_policies_refuse_more_than_eight_cameras():
-    """The camera agents' message exchange runs one lane per (sender, recipient) pair: scenarios with more than 8 cameras are refused
-    loudly by mate_engine_policy_enable, not stepped wrongly (the environment itself takes up to 16)."""
-    from mate_amd._native import EngineError
+def _twelve_cameras(**overrides):
+    """MATE-8v8-9 with four more cameras (12: three rounds of (sender, recipient) pairs, three of sector pairs)."""
     from mate_amd.config import read_config
+    cfg = read_config('MATE-8v8-9.yaml', **overrides)
+    cfg['camera']['location_random_range'] = list(cfg['camera']['location_random_range']) + [
+        [300.0, 400.0, 300.0, 400.0], [300.0, 400.0, -400.0, -300.0], [-400.0, -300.0, -400.0, -300.0], [-400.0, -300.0, 300.0, 400.0]]
+    return cfg
+
+
+def test_greedy_agents_with_more_than_eight_cameras_vs_oracle(oracle_lib):
+    """Twelve camera agents (the message exchange then takes three rounds of (sender, recipient) pairs; rounds 1-3 lifted the engine's
+    16-camera limit to the agents in round 4): closed loop against the oracle's restatement of the reference agents on recorded
+    draws -- joint actions 1e-8, masks / goals / bounties exact -- and, on Philox draws, the fused rollout against single steps."""
+    O = oracle_lib
     from mate_amd.engine import Engine
-    cfg = read_config('MATE-8v8-9.yaml')
-    cfg['camera']['location_random_range'] = list(cfg['camera']['location_random_range']) + [[-300.0, -200.0, -300.0, -200.0]]
-    eng = Engine(cfg, 8, seed=1)
-    assert eng.num_cameras == 9
-    eng.reset()                                # nine cameras step fine ...
-    eng.step_random()
-    with pytest.raises(EngineError, match='at most 8 cameras'):
-        eng.enable_policies()                  # ... but not with the on-device greedy agents
+    cfg = _twelve_cameras()
+    n, steps = 40, 90
+    eng = Engine(cfg, n, seed=23, first_env_index=77, obs_dtype=torch.float32)
+    assert eng.num_cameras == 12 and not eng.specialised
+    eng.enable_policies()
+    eng.reset()
+    torch.cuda.synchronize()
+    batch = O.OracleBatch(U.oracle_proto_from_config(cfg, O), n, seed=23, first_env_index=77)
+    batch.reset(threads=4)
+    Nc, Nt = eng.num_cameras, eng.num_targets
+    envs = [batch.env(e) for e in range(n)]
+    for e in range(n):
+        for c in range(Nc):
+            envs[e].set_lut(c, *eng.lut_read(e, c))
+    agents = [O.GreedyPolicies() for _ in range(n)]
+    rng = np.random.RandomState(6)
+    reset_u = rng.random_sample((n, Nt, 2))
+    dev = eng.device
+    worst, messages = 0.0, 0
+    for s in range(steps):
+        t = {'camera_resample_u': rng.random_sample((n, Nc)), 'camera_sample_u': rng.random_sample((n, Nc, 2)),
+             'camera_delay': rng.randint(6, 50, size=(n, Nc, Nc)).astype(np.int32),
+             'target_choice_u': rng.random_sample((n, Nt)), 'target_resample_u': rng.random_sample((n, Nt)),
+             'target_sample_u': rng.random_sample((n, Nt, 2)), 'target_reset_sample_u': reset_u}
+        tape_ct, goal_u = rng.random_sample((n, Nc, Nt)), rng.random_sample((n, Nt))
+        eng.step_greedy(policy_tape={k: torch.from_numpy(v).to(dev) for k, v in t.items()}, tape_ct=torch.from_numpy(tape_ct).to(dev),
+                        tape_goal=torch.from_numpy(goal_u).to(dev), auto_reset=False)
+        cam_act, tgt_act = (a.cpu().numpy() for a in eng.policy_actions())
+        for e in range(n):
+            ca, ta = agents[e].act(envs[e], t['camera_resample_u'][e], t['camera_sample_u'][e], t['camera_delay'][e],
+                                   t['target_choice_u'][e], t['target_resample_u'][e], t['target_sample_u'][e], reset_u[e])
+            worst = max(worst, float(np.abs(ta - tgt_act[e]).max()), float(np.abs(ca - cam_act[e]).max()))
+            envs[e].step(ca, ta, tape_ct[e], goal_u[e])
+        assert worst < 1e-8, (s, worst)
+        masks = eng.unpack_masks()
+        assert np.array_equal(masks['camera_target_view_mask'], batch.gather('camera_target_view_mask').reshape(n, Nc, Nt) != 0), s
+        sd = eng.state_dict()
+        for k in ('tgt_goals', 'bounties', 'freights', 'num_delivered_cargoes'):
+            ref = batch.gather(k)
+            assert np.array_equal(sd[k].reshape(ref.shape), ref), (k, s)
+        assert np.abs(sd['tgt_x'] - batch.gather('tgt_x')).max() < 1e-8
+    # Philox draws (a pair beyond the 64th takes its message delay from a block keyed by the pair's index): fused == single steps
+    a, b = Engine(_twelve_cameras(), 22, seed=9), Engine(_twelve_cameras(), 22, seed=9)
+    for e in (a, b):
+        e.enable_policies()
+        e.reset()
+    for rnd in range(2):
+        cam, tgt, sc = a.rollout_greedy(12, auto_reset=False)
+        for r in range(12):
+            b.step_greedy(auto_reset=False)
+            assert torch.equal(cam[r], b.camera_obs) and torch.equal(tgt[r], b.target_obs) and torch.equal(sc[r], b.scalars), (rnd, r)
+        assert torch.equal(a.export_state(), b.export_state())
+        ca, ta = a.policy_actions()
+        cb, tb = b.policy_actions()
+        assert torch.equal(ca, cb) and torch.equal(ta, tb) and float(ca.abs().sum()) > 0.0
 
 
 @pytest.mark.parametrize('switch,auto_reset', [('MATE_ZOOM_ITERATE', 1), ('MATE_POLICY_SPLIT', 1), ('MATE_POLICY_SPLIT', 4)])

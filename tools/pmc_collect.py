@@ -49,7 +49,7 @@ def main():
             d = os.path.join(out, f'raw_{name}_{gi}')
             cmd = ['rocprofv3', '--kernel-trace', '--pmc'] + group + ['--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
                                                                      'python3', os.path.join(root, 'bench.py'), '--reps', '1', '--rep-warmup', '1',
-                                                                     '--no-cpu-baseline', '--no-extras', '--no-other-configs'] + args
+                                                                     '--no-cpu-baseline', '--no-extras', '--no-other-configs', '--no-side-measurements'] + args
             with open(os.path.join(out, f'{name}_{gi}.log'), 'w') as log:
                 subprocess.call(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, cwd=root)
             for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
