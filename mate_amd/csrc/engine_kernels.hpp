@@ -1822,11 +1822,18 @@ __device__ __forceinline__ void image_statics(Ctx<ObsT> &c) {
     if constexpr (sizeof(ObsT) == 4) {
     const Params &p = c.p;
     const int lane = c.lane;
-    const float *si = reinterpret_cast<const float *>(c.g.scratch_init);        // [1] = 1, [2..4] counts, [5..12] warehouses, [13] = 75, [14 + i] = i
     for (int i = lane; i < (p.Nc + p.Nt) * 13; i += 64) {                        // preserved block of every row (environment.py:499-501, 941)
         const int row = (int)(((float)i + 0.5f) * (1.0f / 13.0f)), col = i - row * 13;
         const int agent = row < p.Nc ? row : row - p.Nc;
-        const float v = si[col < 3 ? 2 + col : col == 3 ? 14 + agent : col + 1];
+        // [Nc, Nt, No, agent index, the four warehouses' centres (+,+) (-,+) (-,-) (+,-) (constants.py:70-72), their half width]: made here --
+        // read from the constants table in global memory, three dependent round trips to L2 stood at the head of every launch
+        float v;
+        if (col < 4) v = (float)(col == 0 ? p.Nc : col == 1 ? p.Nt : col == 2 ? p.No : agent);
+        else if (col < 12) {
+            const int k = col - 4, w = k >> 1;
+            const bool plus = (k & 1) ? w < 2 : (w == 0 || w == 3);
+            v = plus ? (float)kWarehouseCenter : -(float)kWarehouseCenter;
+        } else v = (float)kWarehouseRadius;
         (row < p.Nc ? c.img_cam_row(row) : c.img_tgt_row(agent))[col] = v;
     }
     if (lane < p.Nc) {                                                           // Camera.state(private), entities.py:313-324
@@ -2657,6 +2664,12 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     const int64_t env = (int64_t)blockIdx.x * 4 + wave;
     if (env >= g.N) return;
     const Ptrs &gk = kernarg_ptrs(g);     // launch arguments read where they are used (see step_kernel)
+#ifdef MATE_PHASE_CLOCKS      // the launch's prologue, in s_memtime ticks since the wave began: slots 8..11 (tools/rollout_prologue.py), 12 the epilogue
+    const long long t_wave = (long long)__builtin_amdgcn_s_memtime();
+#define PROLOGUE_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime() - t_wave; } while (0)
+#else
+#define PROLOGUE_STAMP(i) do { } while (0)
+#endif
     {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env);
         load_records(c);
@@ -2665,6 +2678,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         list_finished_at_entry(c);
         wave_sync();
     }
+    PROLOGUE_STAMP(8);
     // The observation descriptors of this lane are the same for every step: loaded once and held in 32 VGPRs (the
     // headline batch runs 4 waves per SIMD, the register file has room), which takes the table's two global-load
     // round trips out of every step's pack phase.
@@ -2681,8 +2695,10 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
         range_roles(c, roles);
         pin_roles(roles);
+        PROLOGUE_STAMP(9);
         if constexpr (IMAGE) image_statics(c);
     }
+    PROLOGUE_STAMP(10);
     NearCarry near{};                       // the collision screen of the step to come, made by the range tests of the step before
     if constexpr (Shape::kHoldRoles) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
@@ -2723,6 +2739,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         held_load(c, h);
         finished = __builtin_amdgcn_readfirstlane((int)(c.ei(EI_DONE) != 0));
     }
+    PROLOGUE_STAMP(11);
     // (Measured and dropped: the four waves of a workgroup -- one per SIMD of a CU, their environments' records all in this
     // workgroup's LDS -- handing their environments on to each other after every quarter of the launch, so that every SIMD of
     // the CU works on all sixteen environments.  It removed every dependence of a wave's pace on its environment (occlusion
@@ -2841,11 +2858,17 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         g.phase_clocks[env * 16 + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_first;
     }
 #endif
+#ifdef MATE_PHASE_CLOCKS
+    const long long t_epilogue = (long long)__builtin_amdgcn_s_memtime();
+#endif
     {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env);
         if constexpr (HELDSTATE) held_store(c, h);
         store_dynamic(c);
     }
+#ifdef MATE_PHASE_CLOCKS
+    if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + 12] = (long long)__builtin_amdgcn_s_memtime() - t_epilogue;
+#endif
 }
 
 }  // namespace mate

@@ -130,9 +130,13 @@ def test_one_rank_runs_every_collective_of_the_sharded_path_on_rccl():
         st = line['startup']
         assert len(st['startup_s']) == 1 and st['startup_s'][0] > 0 and 0 < st['reserve_rollout_s'][0] < 30.0
     assert forced['startup']['process_group_s'][0] > 0.0
-    ratio = forced['value'] / plain['value']
-    print(f"forced collectives {forced['value']:.4g} vs plain {plain['value']:.4g} env-steps/s: {ratio:.3f}; start-up {forced['startup']}")
-    assert 0.97 <= ratio <= 1.06, (forced['value'], plain['value'])
+    # what the collectives cost: the share of the timed region spent inside the rollout kernel (end-to-end rate / kernel rate), which
+    # does not depend on where each process's observation blocks happened to land (the two values themselves differ by that, up to
+    # 10 % between two processes on a box with mixed memory): within 3 % of the plain run's
+    share = [line['roofline']['end_to_end_frac'] / line['roofline']['frac'] for line in (forced, plain)]
+    print(f"forced collectives {forced['value']:.4g} vs plain {plain['value']:.4g} env-steps/s; kernel share of the region {share[0]:.3f} vs {share[1]:.3f}; "
+          f"start-up {forced['startup']}")
+    assert share[0] >= share[1] - 0.03 and 0.85 <= forced['value'] / plain['value'] <= 1.18, (share, forced['value'], plain['value'])
 
 
 def test_time_limited_episodes_reach_the_gathered_statistics(tmp_path):
