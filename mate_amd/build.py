@@ -84,7 +84,7 @@ def build_tools(verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
     built = []
-    for name in ('store_roof', 'store_bits', 'store_contig', 'store_vmm', 'region_bw', 'valu_rates', 'chunk_order', 'dispatch_probe', 'va_reuse'):
+    for name in ('store_roof', 'store_bits', 'store_contig', 'store_vmm', 'region_bw', 'valu_rates', 'chunk_order', 'dispatch_probe', 'va_reuse', 'store_layout'):
         src, out = os.path.join(tools, name + '.hip'), os.path.join(tools, name)
         if not os.path.exists(src) or (os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src)):
             continue
