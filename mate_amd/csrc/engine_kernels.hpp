@@ -1102,8 +1102,22 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorE
     bool overflow;
     double limit = segment_interp(w, e.x, overflow);
     if (overflow) {
-        const int start = (int)w[0].y, count = (int)w[1].x;
+        int start = (int)w[0].y, count = (int)w[1].x;
         const double2 *knots = c.g.lut_knots + e.lc * c.p.kmax;
+        // A degree with more knots than the quarter scheme takes (two or more obstacles' arcs in one degree): the same three-pivot
+        // selection first narrows it -- one round trip per level, 65 knots in one, 257 in two -- instead of the general path's
+        // dependent binary search (ten round trips).  A launch of 4096 one-step waves lasts as long as its slowest wave, and with
+        // one such lookup in a thousand there is one in (almost) every launch: it WAS the slowest wave, 14 k cycles in this phase
+        // against 5.4 k.
+        while (count > kQuarterKnots && count <= 4 * 256 + 1) {
+            const int q = (count + 2) / 4, last = count - 1;
+            const double a1 = knots[start + (q < last ? q : last)].x;
+            const double a2 = knots[start + (2 * q < last ? 2 * q : last)].x;
+            const double a3 = knots[start + (3 * q < last ? 3 * q : last)].x;
+            const int base = e.x >= a3 ? 3 * q : (e.x >= a2 ? 2 * q : (e.x >= a1 ? q : 0));
+            start += base;
+            count = (q + 1 < count - base) ? q + 1 : count - base;
+        }
         if (count >= 2 && count <= kQuarterKnots) {
             const int q = (count + 2) / 4, last = count - 1;                          // q = ceil((count - 1) / 4) <= kDegSlots - 1
             const double a1 = knots[start + (q < last ? q : last)].x;

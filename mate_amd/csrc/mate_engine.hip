@@ -396,6 +396,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         const int64_t cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
         // (round 4: with the rows leaving early the priorities cost 3 % at the headline batch on the boxes measured -- off unless asked for)
         const int digits = e->sw.stagger >= 0 ? e->sw.stagger : 0;
+
         // the two-wave step: where it measured faster -- batches of at most 8 environments per CU (half a generation of the one-wave
         // kernel: 2048 environments on 256 CUs, -3 % random policy, -8 % caller's actions; at 4096 it is 17 % slower)
         if (e->sw.step_split < 0) e->sw.step_split = (Nc > 0 && num_envs <= 8 * cus) ? 1 : 0;

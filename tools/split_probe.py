@@ -10,7 +10,7 @@ from mate_amd.engine import Engine  # noqa: E402
 workload = sys.argv[1] if len(sys.argv) > 1 else 'MATE-4v8-9.yaml'
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 staggers = sys.argv[3:] or ['default']
-for split in ('0', '1', '2', '0', '1', '2'):
+for split in os.environ.get('SPLITS', '0 1 2 0 1 2').split():
     for stagger in staggers:
         os.environ['MATE_STEP_SPLIT'] = split
         if stagger != 'default':
