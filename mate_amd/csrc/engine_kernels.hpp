@@ -105,12 +105,15 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
     p.off_img = off; off += image ? (p.cam_elems + p.tgt_elems) * 4 : 0;
     p.lds_wave_bytes = off;
 }
-// Shapes the row-image mode is compiled for: f32 rows in whole 16-byte chunks, one round of sector pairs, at most three of
-// range pairs (the lane roles are held in registers), and 16 environments per CU still resident (160 KiB of LDS).
+// Shapes the row-image mode is compiled for: f32 rows in whole 16-byte chunks -- or, a small target block (at most 512 floats), in
+// whole 8-byte chunks: MATE-4v2-9's two target rows are 202 floats, so an environment's block begins on an 8-byte boundary only --,
+// one round of sector pairs, at most three of range pairs (the lane roles are held in registers), and 16 environments per CU still
+// resident (160 KiB of LDS).
 constexpr bool image_fits(int Nc, int Nt, int No) {
     Params p{};
     fill_shape(p, Nc, Nt, No, false, true);
-    return Nc > 0 && p.cam_elems % 4 == 0 && p.tgt_elems % 4 == 0 && p.cam_elems <= 4 * 128 && p.tgt_elems <= 4 * 384 &&      // (image_store's unrolled rounds)
+    const bool tgt16 = p.tgt_elems % 4 == 0 && p.tgt_elems <= 4 * 384, tgt8 = p.tgt_elems % 2 == 0 && p.tgt_elems <= 512;
+    return Nc > 0 && p.cam_elems % 4 == 0 && (tgt16 || tgt8) && p.cam_elems <= 4 * 128 &&      // (image_store's unrolled rounds)
            p.sector_rounds == 1 && p.range_rounds <= 3 && p.lds_wave_bytes <= 10 * 1024;
 }
 
@@ -1959,17 +1962,31 @@ __device__ __forceinline__ void image_store_form(const Ctx<ObsT> &c, uint32_t ca
     // part of the slice, or zeros past the workgroup's LDS, and stores nothing; only the first round needs the lower bound and
     // only the rounds that can reach the row's end the upper one)
     const f32x4 *from_c = src_c - sc, *from_t = src_t - st;
+    // a target block of whole 8-byte chunks only (image_fits: at most 512 floats, four rounds; never shifted: its rows begin on
+    // 8-byte boundaries that alternate with the environment's parity)
+    const bool tgt8 = (p.tgt_elems % 4) != 0;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int GT2 = 4;
+    const int nv2 = p.tgt_elems / 2;
+    f32x2 vt2[GT2];
     f32x4 vc[GC], vt[GT];
 #pragma unroll
     for (int k = 0; k < GC; ++k) if (64 * k - slack < nvc) vc[k] = from_c[lane + 64 * k];
+    if (tgt8) {
+        const f32x2 *from_t2 = reinterpret_cast<const f32x2 *>(c.img + p.cam_elems);
+#pragma unroll
+        for (int k = 0; k < GT2; ++k) if (64 * k < nv2) vt2[k] = from_t2[lane + 64 * k];
+    } else {
 #pragma unroll
     for (int k = 0; k < GT; ++k) if (64 * k - slack < nvt) vt[k] = from_t[lane + 64 * k];
+    }
     // The blocks' base pointers come from the kernel-argument segment (a scalar load): first USED here, behind the LDS reads, so
     // that one wait covers both -- used earlier, the reads would queue up behind the pointers' round trip (+350 cycles per step).
     // (as integers through the barrier, and back as GLOBAL pointers: a generic pointer out of an asm stores through flat_store)
     typedef __attribute__((address_space(1))) f32x4 global_f32x4;
     uint64_t cam_base = reinterpret_cast<uint64_t>(c.g.cam_obs), tgt_base = reinterpret_cast<uint64_t>(c.g.tgt_obs);
-    asm volatile("" : "+s"(cam_base), "+s"(tgt_base), "+v"(vt[0]));
+    if (tgt8) asm volatile("" : "+s"(cam_base), "+s"(tgt_base), "+v"(vt2[0]));
+    else asm volatile("" : "+s"(cam_base), "+s"(tgt_base), "+v"(vt[0]));
     // (what comes out of an asm counts as divergent: say again that it is not, or the row arithmetic runs on the vector unit)
     cam_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(cam_base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)cam_base);
     tgt_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(tgt_base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)tgt_base);
@@ -1980,10 +1997,17 @@ __device__ __forceinline__ void image_store_form(const Ctx<ObsT> &c, uint32_t ca
         const bool inside = (k > 0 || lane >= sc) && (64 * (k + 1) <= nvc || lane + 64 * k - sc < nvc);
         if (inside) stream_store(vc[k], &to_c[lane + 64 * k]);
     }
+    if (tgt8) {
+        typedef __attribute__((address_space(1))) f32x2 global_f32x2;
+        global_f32x2 *to_t2 = (global_f32x2 *)(tgt_base + (uint64_t)c.out * (uint64_t)(p.tgt_elems * 4));
+#pragma unroll
+        for (int k = 0; k < GT2; ++k) if (64 * k < nv2) { if (lane + 64 * k < nv2) stream_store(vt2[k], &to_t2[lane + 64 * k]); }
+    } else {
 #pragma unroll
     for (int k = 0; k < GT; ++k) if (64 * k - slack < nvt) {
         const bool inside = (k > 0 || lane >= st) && (64 * (k + 1) <= nvt || lane + 64 * k - st < nvt);
         if (inside) stream_store(vt[k], &to_t[lane + 64 * k]);
+    }
     }
     }
 }
