@@ -46,7 +46,11 @@
  *   MATE_BLOCK_FREE_RANGE=1  mate_engine_block_free also gives the block's virtual address range back (hipMemAddressFree) instead
  *                            of keeping it reserved for the life of the process (read once, at the first block_free).  Unsafe on
  *                            this driver: a range handed out again lost stores of the next kernel (tools/va_reuse.hip)
- * Read by the Python host (mate_amd/engine.py), once, when an Engine object is built -- they steer where
+ *   MATE_PIPELINED_SERIAL=1  pipelined restarts (MATE_RESET_PIPELINED) with the resets on the caller's stream: the reference form
+ *                            the tests compare the concurrent one with; MATE_PIPELINED_PRIORITY=0: the side stream at the default
+ *                            priority instead of the device's lowest (both read when the mode is first entered)
+ * Read by the Python host: MATE_ENGINE_LIB=<path> (mate_amd/_native.py: another build of this library, e.g. the profiling build
+ * lib/libmate_engine_prof.so), and (mate_amd/engine.py), once, when an Engine object is built -- they steer where
  * Engine.reserve_rollout puts the [steps][N][...] observation blocks of the fused rollouts, never what is written there:
  *   MATE_PLAIN_BLOCKS=1      blocks from torch.zeros instead of mate_engine_block_alloc
  *   MATE_BLOCK_CANDIDATES=n  at most n candidates probed per block (default 6; the deep search of the target block: as

@@ -270,3 +270,25 @@ def test_zoom_table_interpolation_matches_the_iteration_over_the_whole_range():
     err = np.abs(got - iterate(K))
     assert err.max() < 1e-11, err.max()               # (4e-12 for K < 10, where the function bends most; 1.5e-13 above K = 100)
     assert np.median(err) < 2e-13 and err[K > 100.0].max() < 5e-13
+
+
+def test_every_environment_switch_is_documented_in_the_header():
+    """Every MATE_* environment variable the library (getenv in csrc/) or the Python host (mate_amd/*.py) reads is listed in
+    include/mate_engine.h -- the one place an integrator looks."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, 'include', 'mate_engine.h')).read()
+    names = set()
+    for name in os.listdir(os.path.join(root, 'mate_amd', 'csrc')):
+        if not name.endswith(('.hip', '.hpp')):
+            continue
+        text = open(os.path.join(root, 'mate_amd', 'csrc', name)).read()
+        names |= set(re.findall(r'getenv\("(MATE_[A-Z0-9_]+)"\)', text))
+        names |= set(re.findall(r'flag\("(MATE_[A-Z0-9_]+)"\)', text))
+    for name in ('engine.py', '_native.py', 'build.py', 'environment.py'):
+        text = open(os.path.join(root, 'mate_amd', name)).read()
+        names |= set(re.findall(r"""(?:environ|env)(?:\.get\(|\[)['"](MATE_[A-Z0-9_]+)['"]""", text))
+        names |= set(re.findall(r"""['"](MATE_[A-Z0-9_]+)['"] in env""", text))
+    assert len(names) >= 15, names
+    missing = sorted(n for n in names if n not in header)
+    assert not missing, missing
