@@ -80,6 +80,9 @@ WORKLOAD = 'MATE-4v8-9.yaml'
 BATCH_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 HBM_PEAK_MEASURED_GBS = 6290.0   # device-to-device copy on this pool (tools/pmc_calibrate.py, profiles/README.md)
+# `--rollout 0` (one launch per step in the main timed region): every 17th step_kernel launch carries dispatch events (a stride
+# coprime to the reset interval).  The per_step_launch side measurement times its kernel in a pass of its own, see there.
+STEP_SAMPLE = 17
 
 
 def algorithmic_bytes(Nc, Nt, No):
@@ -191,7 +194,7 @@ def parse_args(argv=None):
                     help='steps fused per launch (rollout_kernel / rollout_greedy_kernel); 0 = one launch per step; -1 (default) = 256 '
                          '(random) / 48 (greedy) while the batch is at most 64 / 32 environment-waves per CU, else 0 (the fused '
                          'kernels trade occupancy for registers and LDS); capped so that the [R][N][...] buffers stay under --buffer-gib')
-    ap.add_argument('--step-reset-interval', type=int, default=8,
+    ap.add_argument('--step-reset-interval', type=int, default=32,
                     help='one launch per step (per_step_launch / external_actions / --rollout 0 with the random policy): restart finished '
                          'environments with one reset launch per k steps (1 = a reset launch behind every step); a finished environment idles at most k - 1 steps')
     ap.add_argument('--stats-interval', type=int, default=8, help='launches between two episode-statistics gathers inside the timed loop (0 = none)')
@@ -541,7 +544,7 @@ def main():
     # ... and, whatever W is, at least ~0.25 s of the timed region's own launches: the GPU raises its clocks under load, and a
     # 20-step region lasts 0.2 ms (reported as `warmup_extra_steps`; W itself is honoured above)
     extra_steps = 0
-    eng.kernel_time(enable=1 if R > 0 else 16)     # ... with the dispatch-event launch path of the timed region (events created, runtime warmed)
+    eng.kernel_time(enable=1 if R > 0 else STEP_SAMPLE)     # ... with the dispatch-event launch path of the timed region (events created, runtime warmed)
     t_warm = time.perf_counter()
     while (extra_steps < 4 * args.steps) if args.deterministic else (time.perf_counter() - t_warm < 0.25):
         chunk = min(args.steps, 8 * R) if R > 0 else 64      # back to back like the timed region (sustained, not boost, clocks)
@@ -564,7 +567,7 @@ def main():
     startup['startup_s'] = time.perf_counter() - t_main      # everything of this rank's main() before the first pass through the measuring loop
     rep_ms, rep_executed, kernel_times = [], [], []
     for rep in range(max(0, args.rep_warmup) + max(1, args.reps)):
-        eng.kernel_time(enable=1 if R > 0 else 16)   # HIP-event pair around (every 16th) launch of the dominant kernel
+        eng.kernel_time(enable=1 if R > 0 else STEP_SAMPLE)   # HIP-event pair around every launch of the dominant kernel (every 17th one-step launch)
         # a region shorter than the gather interval gathers the episodes finished BEFORE it (see run): the marker of what that
         # gather may read is recorded here, behind the previous repetition's last launch -- an event record in front of the
         # region's only launch delays it by 4 us (tools/region_probe.py); the gather itself is enqueued inside the region
@@ -625,17 +628,25 @@ def main():
                 runner = lambda n: [step() for _ in range(n)]     # noqa: E731
             runner(max(args.graph_steps, 1) * 2)
             times = []
-            for _ in range(3):
-                eng.kernel_time(enable=16)
+            for _ in range(3):          # the rate: no dispatch events anywhere (they cost the host 4-5 us per launch)
+                eng.kernel_time(enable=False)
                 barrier()
                 idle1 = eng.idle_steps()
                 t1 = time.perf_counter()
                 runner(k2)
                 barrier()
                 e2 = time.perf_counter() - t1
+                times.append((e2, args.batch * k2 - (eng.idle_steps() - idle1)))
+            e2, ex2 = sorted(times)[1]
+            # the kernel's own duration: a separate pass with a dispatch-event pair on EVERY launch.  Sampled every k-th launch
+            # among event-less ones (rounds 1-3: every 16th), a launch's start stamp is taken while its event-less predecessor is
+            # still draining: the figure came out 1.5-2 us ABOVE the end-to-end time per step of the same loop
+            km2 = 0.0
+            if name == 'per_step_launch':
+                eng.kernel_time(enable=1)
+                runner(512)
+                barrier()
                 km2, _ = eng.kernel_time(enable=False)
-                times.append((e2, args.batch * k2 - (eng.idle_steps() - idle1), km2))
-            e2, ex2, km2 = sorted(times)[1]
             b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
             extras[name] = {'value': ex2 * world / e2, 'unit': 'env-steps/s', 'steps': k2, 'ms_per_step': e2 / k2 * 1e3,
                             'kernel': 'step_kernel', 'kernel_avg_us': km2 * 1e3,
