@@ -20,7 +20,8 @@ caller-owned device buffer, the step + auto-reset launch pairs replayed from one
 
 Timing: W untimed warm-up steps (plus one untimed launch of every launch shape of the timed region, so that no
 buffer is allocated and no kernel is first loaded inside it), then the timed region of EXACTLY K steps, bracketed by a
-barrier + torch.cuda.synchronize() on both sides, is run `--rep-warmup` (3) untimed + `--reps` (5) timed times and the MEDIAN
+barrier + torch.cuda.synchronize() on both sides, is run `--rep-warmup` (3) untimed + `--reps` (5; 21 when the region is one
+short launch, e.g. the driver's `--steps 20`: 0.17 ms) timed times and the MEDIAN
 of the timed ones is reported (`ms_per_step` x `steps` = the median repetition; every timed repetition is listed in `rep_ms`).
 
 `--gpus N` (N > 1) started without a torchrun environment launches the N ranks itself (a `torch.distributed.run`
@@ -175,7 +176,9 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2048)
     ap.add_argument('--warmup', type=int, default=128)
-    ap.add_argument('--reps', type=int, default=5, help='repetitions of the timed region; the median is reported')
+    ap.add_argument('--reps', type=int, default=0,
+                    help='repetitions of the timed region; the median is reported (default 0 = 5, or 21 when the region is a single short launch -- '
+                         'under a millisecond: one preempted host thread moves a median of five)')
     ap.add_argument('--rep-warmup', type=int, default=3,
                     help='untimed repetitions of the whole measuring loop (region + its bookkeeping) before the timed ones: the first '
                          'passes through that loop are slower than its steady state (clocks, lazily loaded code), whatever ran before')
@@ -563,6 +566,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.reps <= 0:
+        args.reps = 21 if (R > 0 and args.steps <= R and args.steps * args.batch <= (1 << 18)) else 5
     from mate_amd.distributed import reduce_job
     startup['startup_s'] = time.perf_counter() - t_main      # everything of this rank's main() before the first pass through the measuring loop
     rep_ms, rep_executed, kernel_times = [], [], []
