@@ -376,7 +376,7 @@ int mate_engine_last_flow(const mate_engine *engine);
  * range stays reserved (address space only; MATE_BLOCK_FREE_RANGE above).  The pointer must come from block_alloc; the CALLER
  * has waited for every launch that reads or writes the block -- the library does not synchronise here.  A failed block_alloc / block_probe / block_free reports through its return code
  * only: HIP's sticky last-error is cleared, so the caller's next launch check does not see it. */
-/* The form of the row stores of the row-image rollouts (MATE-4v8-9, MATE-4v8-0, MATE-4v2-9 under mate_engine_rollout_random): 0 (default) the
+/* The form of the row stores of the row-image rollouts (MATE-4v8-9, MATE-4v8-0, MATE-4v2-9, MATE-Navigation under mate_engine_rollout_random): 0 (default) the
  * rows' 16-byte chunks as they lie -- 1.3-2 % faster where the blocks take the rows fast, i.e. where the arithmetic bounds a launch
  * --, 1 every store instruction an aligned kilobyte -- 3 % faster where they do not (mate_engine_block_probe of the target block
  * below ~4.8 TB/s: the stores bound the launch).  Same rows either way.  Engine.reserve_rollout sets it from what it probed. */

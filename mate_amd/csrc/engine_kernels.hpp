@@ -91,7 +91,7 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
     int off = 0;
     p.off_st = off; off += shape_round_up(p.SW * 8, 16);
     p.off_dy = off; off += shape_round_up(p.DW * 8, 16);
-    p.off_tmp = off; off += shape_round_up((Nc + 3 * Nt + 64) * 8, 16);
+    p.off_tmp = off; off += shape_round_up((Nc + 3 * Nt + (Nc > 0 ? 64 : 0)) * 8, 16);      // (sight^2 | step vectors | the 64 predrawn transmittance uniforms: cameras only)
     p.off_scratch = off; off += image ? 0 : shape_round_up(p.nscratch * obs_size, 16);
     p.off_mask = off; off += shape_round_up(p.MW * 4, 16);
     p.off_misc = off; off += shape_round_up((4 * Nt + 8) * 4, 16);
@@ -112,9 +112,10 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
 constexpr bool image_fits(int Nc, int Nt, int No) {
     Params p{};
     fill_shape(p, Nc, Nt, No, false, true);
-    const bool tgt16 = p.tgt_elems % 4 == 0 && p.tgt_elems <= 4 * 384, tgt8 = p.tgt_elems % 2 == 0 && p.tgt_elems <= 512;
-    return Nc > 0 && p.cam_elems % 4 == 0 && (tgt16 || tgt8) && p.cam_elems <= 4 * 128 &&      // (image_store's unrolled rounds)
-           p.sector_rounds == 1 && p.range_rounds <= 3 && p.lds_wave_bytes <= 10 * 1024;
+    const bool tgt16 = p.tgt_elems % 4 == 0 && p.tgt_elems <= 4 * 441, tgt8 = p.tgt_elems % 2 == 0 && p.tgt_elems <= 512;
+    // (one round of sector pairs, or none: MATE-Navigation has no camera -- eight targets among 32 obstacles, 320 range pairs in five rounds)
+    return p.cam_elems % 4 == 0 && (tgt16 || tgt8) && p.cam_elems <= 4 * 128 &&      // (image_store's unrolled rounds: 3 x 64 camera chunks, 7 x 64 - 7 target chunks)
+           p.sector_rounds <= 1 && p.range_rounds <= 5 && p.lds_wave_bytes <= 10 * 1024;
 }
 
 // Kernel shape policies: AnyShape reads every constant from the device-resident Params on demand;
@@ -144,7 +145,7 @@ template <int NC, int NT, int NO, bool F64, bool IMAGE = false>
 struct FixedShape {
     static constexpr bool kImage = IMAGE;
     static_assert(!IMAGE || (!F64 && image_fits(NC, NT, NO)), "row-image mode: f32 observations of a shape that fits");
-    static constexpr bool kHoldRoles = shape_range_rounds(NC, NT, NO) <= 3;      // 5 words per round: fits beside the held descriptors
+    static constexpr bool kHoldRoles = shape_range_rounds(NC, NT, NO) <= (IMAGE ? 5 : 3);      // 5 words per round: three rounds fit beside the held descriptors, five where the row image needs none
     static constexpr bool kGreedyRoles = shape_range_rounds(NC, NT, NO) <= 4;    // rollout_greedy_kernel: MATE-8v8-9's four rounds too
     // observation descriptors the fused rollouts hold per lane: all chunks of the shape's rows (up to twelve uint4)
     static constexpr int kRowsC = (NC * (13 + 9 + 5 * NT + 4 * NO + 7 * NC) / 4 + 63) / 64, kRowsT = (NT * (13 + 14 + 7 * NC + 4 * NO + 5 * NT) / 4 + 63) / 64;
@@ -423,7 +424,7 @@ __device__ __forceinline__ void load_records(Ctx<ObsT> &c) {
 // while they are in flight (all co-resident waves of a SIMD start together: without this they idle through the
 // HBM latency together and then contend for the VALU together), then the data is committed to LDS.
 struct StepDraws { double a0, a1; };
-constexpr int kNearWords = 4;                     // (= kRoleRounds, declared further down with the range-test roles)
+constexpr int kNearWords = 5;                     // (= kRoleRounds, declared further down with the range-test roles)
 struct DrawCarry { uint32_t z, w, block; };      // second half of the lane's Philox block of the even tick, for the odd tick behind it
 // What a lane draws is the same at every step of a launch: its stream and index, whether it draws at all, and -- an agent -- the
 // bounds of its two action components.  The fused rollout derives it once and holds it (22 vector instructions per step).
@@ -856,7 +857,7 @@ struct SectorEval { bool seen, need; double rn, x; int64_t lc; };      // rn: th
 // whether that is the diagonal, and the squared limit (sight + the other's radius)^2 -- all static inside an episode.
 // The fused rollout, which is VALU-bound, computes them once per launch and keeps them in registers (`HELD`); the
 // single-step kernel derives them in place.
-constexpr int kRoleRounds = 4;       // (the fused random-policy rollout holds up to three -- Shape::kHoldRoles: a fourth, MATE-8v8-9's 200 range pairs,
+constexpr int kRoleRounds = 5;       // (five: MATE-Navigation's row-image rollout; the fused random-policy rollout of the other shapes holds up to three -- Shape::kHoldRoles: a fourth, MATE-8v8-9's 200 range pairs,
                                      // measured no faster there at 126 of the 128 registers a wave may hold -- the fused Greedy rollout all four)
 // Sensor.perceive (entities.py:229-232), `distance <= sight_range + radius`, is first tried on the f32 shadow of the entity
 // table: with positions rounded to f32 the distance is off by at most 1.3e-4 and the squared distance by at most
@@ -1006,7 +1007,7 @@ __device__ __forceinline__ void near_seed(const Ctx<ObsT> &c, const RangeRoles &
 
 // Camera.perceive (entities.py:491-505) up to the occlusion lookup.
 __device__ __forceinline__ int sector_role(const Params &p, int q) {      // camera | other << 8 | is_target << 16, or -1
-    if (q >= p.n_sector) return -1;
+    if (q < 0 || q >= p.n_sector) return -1;      // (q < 0: the "last sector round" of a scenario without cameras)
     int cam, other; bool is_target;
     if (q < p.bit_cc) { cam = (int)(((float)q + 0.5f) * p.inv_Nt); other = q - cam * p.Nt; is_target = true; }
     else { const int r = q - p.bit_cc; cam = (int)(((float)r + 0.5f) * p.inv_Nc); other = r - cam * p.Nc; is_target = false; }

@@ -343,7 +343,7 @@ def test_idle_rows_of_a_fused_rollout_are_marked_and_never_written(policy):
     assert torch.equal(info['skipped'], idle) and torch.equal(done, sc[..., 2] == 1)
 
 
-@pytest.mark.parametrize('workload,n', [('MATE-4v8-9.yaml', 301), ('MATE-4v8-0.yaml', 130), ('MATE-4v2-9.yaml', 67)])
+@pytest.mark.parametrize('workload,n', [('MATE-4v8-9.yaml', 301), ('MATE-4v8-0.yaml', 130), ('MATE-4v2-9.yaml', 67), ('MATE-Navigation.yaml', 131)])
 def test_row_image_rollout_equals_descriptor_rollout(workload, n):
     """The fused random-policy rollout of the shapes with a row-image compilation (observation rows resident in LDS, every
     visibility lane writes its own block) against the same kernel packing through the descriptor table (MATE_NO_IMAGE=1,
