@@ -21,7 +21,9 @@
  * changes results (each selects between implementations the tests hold bit-identical, except MATE_ZOOM_ITERATE,
  * see below).  They exist for tests and measurements:
  *   MATE_GENERIC=1           run the generic kernels even for a (cameras, targets, obstacles) shape with a compiled
- *                            specialisation (mate_layout.specialised reports which one runs)
+ *                            specialisation (mate_layout.specialised reports which one runs).  Compiled: the shapes of all
+ *                            seventeen scenarios the reference ships (csrc/shape_groups.hpp); a generic fused rollout runs
+ *                            at less than half the rate of a specialised one
  *   MATE_FLOW_GENERIC=1      run the kernel that reads every launch switch at run time instead of the ones compiled
  *                            for the common flows (mate_engine_last_flow)
  *   MATE_STAGGER=<digits>    wave priorities of the single-step kernel at its five phase boundaries, one decimal digit
@@ -50,7 +52,8 @@
  *                            the tests compare the concurrent one with; MATE_PIPELINED_PRIORITY=0: the side stream at the default
  *                            priority instead of the device's lowest (both read when the mode is first entered)
  * Read by the Python host: MATE_ENGINE_LIB=<path> (mate_amd/_native.py: another build of this library, e.g. the profiling build
- * lib/libmate_engine_prof.so), and (mate_amd/engine.py), once, when an Engine object is built -- they steer where
+ * lib/libmate_engine_prof.so); MATE_BUILD_JOBS=<n> (mate_amd/build.py: parallel hipcc processes, default one per translation
+ * unit up to the CPU count); and (mate_amd/engine.py), once, when an Engine object is built -- they steer where
  * Engine.reserve_rollout puts the [steps][N][...] observation blocks of the fused rollouts, never what is written there:
  *   MATE_PLAIN_BLOCKS=1      blocks from torch.zeros instead of mate_engine_block_alloc
  *   MATE_BLOCK_CANDIDATES=n  at most n candidates probed per block (default 6; the deep search of the target block: as

@@ -11,7 +11,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'mate_engine.hip')
-DEPS = [SRC] + [os.path.join(HERE, 'csrc', f) for f in ('engine_kernels.hpp', 'reset_kernels.hpp', 'policy_kernels.hpp', 'aux_kernels.hpp', 'device_math.hpp')] + [
+DEPS = [SRC] + [os.path.join(HERE, 'csrc', f) for f in ('engine_kernels.hpp', 'reset_kernels.hpp', 'policy_kernels.hpp', 'aux_kernels.hpp', 'device_math.hpp',
+                                                          'shape_groups.hpp', 'shape_group.inc', 'shape_group.hip')] + [
     os.path.join(os.path.dirname(HERE), 'include', 'mate_engine.h')]
 OUT = os.path.join(HERE, 'lib', 'libmate_engine.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
@@ -42,19 +43,52 @@ def parse_resources(text):
     return kernels
 
 
+N_SHAPE_GROUPS = 6      # csrc/shape_groups.hpp: the compiled scenario shapes in six groups, one translation unit each
+
+
+def _compile_and_link(out, extra=(), verbose=False, remarks=False):
+    """The engine as seven translation units compiled in parallel -- mate_engine.hip (host side, generic kernels, reset) and one
+    shape_group.hip per group of compiled scenario shapes -- and linked into `out`.  Returns the compilers' stderr (remarks)."""
+    import concurrent.futures
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objdir = os.path.join(os.path.dirname(OUT), 'obj', os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(objdir, exist_ok=True)
+    compile_flags = [f for f in FLAGS if f != '-shared'] + list(extra) + ['-DMATE_SPLIT_BUILD'] + (['-Rpass-analysis=kernel-resource-usage'] if remarks else [])
+    units = [(SRC, [], os.path.join(objdir, 'mate_engine.o'))]
+    units += [(os.path.join(HERE, 'csrc', 'shape_group.hip'), [f'-DMATE_SHAPE_GROUP={k}'], os.path.join(objdir, f'shape_group_{k}.o')) for k in range(N_SHAPE_GROUPS)]
+
+    def compile_unit(unit):
+        src, defs, obj = unit
+        cmd = [hipcc] + compile_flags + defs + ['-c', '-o', obj, src]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        done = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+        return cmd, done
+
+    workers = max(1, min(len(units), int(os.environ.get('MATE_BUILD_JOBS', '0')) or (os.cpu_count() or 2)))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
+        results = list(pool.map(compile_unit, units))
+    text = ''
+    for cmd, done in results:
+        if done.returncode != 0:
+            sys.stderr.write(done.stderr)
+            raise subprocess.CalledProcessError(done.returncode, cmd)
+        text += done.stderr
+    link = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + [u[2] for u in units]
+    if verbose:
+        print(' '.join(link), flush=True)
+    done = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    if done.returncode != 0:
+        sys.stderr.write(done.stderr)
+        raise subprocess.CalledProcessError(done.returncode, link)
+    return text
+
+
 def build_engine(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-o', OUT, SRC]
-    if verbose:
-        print(' '.join(cmd))
-    done = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
-    if done.returncode != 0:
-        sys.stderr.write(done.stderr)
-        raise subprocess.CalledProcessError(done.returncode, cmd)
-    kernels = parse_resources(done.stderr)
+    kernels = parse_resources(_compile_and_link(OUT, verbose=verbose, remarks=True))
     with open(RESOURCES, 'w') as f:
         json.dump(kernels, f, indent=1, sort_keys=True)
     # A kernel that needs private scratch memory (a spilled register, an outlined helper that takes the environment
@@ -70,11 +104,7 @@ def build_profiling(verbose=False):
     """The profiling build (per-wave s_memtime stamps at the phase boundaries, -DMATE_PHASE_CLOCKS): lib/libmate_engine_prof.so,
     selected with MATE_ENGINE_LIB by tools/*_phases.py.  Never loaded by the package itself."""
     out = os.path.join(HERE, 'lib', 'libmate_engine_prof.so')
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + ['-DMATE_PHASE_CLOCKS', '-o', out, SRC]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    _compile_and_link(out, extra=['-DMATE_PHASE_CLOCKS'], verbose=verbose)
     return out
 
 

@@ -40,58 +40,58 @@ static int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) { (void)hipGetLastError(); return fail(MATE_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); }    \
     } while (0)
 
-using StepFn = void (*)(const Params *, const Ptrs);
-using PolicyFn = void (*)(const Params *, const Ptrs, const PolicyPtrs);
+#include "shape_groups.hpp"
 
-// Scenario shapes (cameras, targets, obstacles) with a compiled specialisation of the step kernel: the
-// shapes of the reference's shipped scenarios (mate/assets/*.yaml); any other shape runs the generic kernel.
-#define MATE_SHAPES(X) X(4, 8, 9) X(4, 2, 9) X(8, 8, 9) X(4, 8, 0) X(0, 8, 32)
+// Without -DMATE_SPLIT_BUILD (a plain `hipcc mate_engine.hip`, as the experiment scripts under tools/ do) the shape groups are
+// compiled right here, one after the other; mate_amd/build.py compiles them as translation units of their own, in parallel.
+#ifndef MATE_SPLIT_BUILD
+#define MATE_SHAPE_GROUP 0
+#include "shape_group.inc"
+#undef MATE_SHAPE_GROUP
+#define MATE_SHAPE_GROUP 1
+#include "shape_group.inc"
+#undef MATE_SHAPE_GROUP
+#define MATE_SHAPE_GROUP 2
+#include "shape_group.inc"
+#undef MATE_SHAPE_GROUP
+#define MATE_SHAPE_GROUP 3
+#include "shape_group.inc"
+#undef MATE_SHAPE_GROUP
+#define MATE_SHAPE_GROUP 4
+#include "shape_group.inc"
+#undef MATE_SHAPE_GROUP
+#define MATE_SHAPE_GROUP 5
+#include "shape_group.inc"
+#undef MATE_SHAPE_GROUP
+#endif
 
-// step[flow]: the launch-flag specialisations (enum Flow) exist for f32 observations, the product path; f64
-// observations (the parity mirror) run the generic flow everywhere.
+// Kernels per (scenario shape, observation type): a compiled specialisation where one exists -- every scenario the reference
+// ships, shape_groups.hpp -- else the generic kernels.  step[flow]: the launch-flag specialisations (enum Flow) exist for f32
+// observations, the product path; f64 observations (the parity mirror) run the generic flow everywhere.
 // `image`: the row-image compilation of the fused random-policy rollout (engine_kernels.hpp: image_statics) where the shape has
 // one.  (The fused Greedy rollout keeps the descriptor packer: with the agents' memory next to a 6 KB row image only three
 // workgroups fit a CU -- 3072 of the 4096 environments of a MATE-4v8-9 batch resident -- and a second pass costs more than
-// the packer's instructions.  rollout_greedy_kernel compiles in row-image mode all the same, for the day the slices shrink.)
-template <int C, int T, int O>
-static void pick_image_kernels(StepFn *rollout, PolicyFn *rollout_greedy, int *image) {
-    (void)rollout_greedy;
-    if constexpr (image_fits(C, T, O)) {
-        rollout[1] = (StepFn)rollout_kernel<float, FixedShape<C, T, O, false, true>, FLOW_RANDOM>;
-        *image = 1;
-    }
-}
-
+// the packer's instructions.)
 static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no_image, StepFn *step, StepFn *rollout, PolicyFn *policy, PolicyFn *rollout_greedy,
                          int *specialised, int *image, StepFn *split) {
     *specialised = 0; *image = 0;
-    for (int i = 0; i < 6; ++i) split[i] = nullptr;      // the two-wave step (step_split_kernel): f32 observations, the folded flows; [3 + flow]: two environments per workgroup
+    for (int i = 0; i < 3; ++i) split[i] = nullptr;      // the two-wave step (step_split_kernel): f32 observations, the folded flows
     if (!generic) {
-#define X(C, T, O)                                                                                                  \
-    if (Nc == C && Nt == T && No == O) {                                                                            \
-        *specialised = 1;                                                                                           \
-        step[FLOW_ANY] = f64 ? (StepFn)step_kernel<double, FixedShape<C, T, O, true>> : (StepFn)step_kernel<float, FixedShape<C, T, O, false>>;   \
-        step[FLOW_RANDOM] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                            \
-        step[FLOW_ACT_F32] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, FixedShape<C, T, O, false>, FLOW_ACT_F32>;                          \
-        if (!f64) { split[FLOW_RANDOM] = (StepFn)step_split_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                                \
-                    split[FLOW_ACT_F32] = (StepFn)step_split_kernel<float, FixedShape<C, T, O, false>, FLOW_ACT_F32>;                              \
-                    split[3 + FLOW_RANDOM] = (StepFn)step_split_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM, 2>;                         \
-                    split[3 + FLOW_ACT_F32] = (StepFn)step_split_kernel<float, FixedShape<C, T, O, false>, FLOW_ACT_F32, 2>; }                     \
-        rollout[0] = f64 ? (StepFn)rollout_kernel<double, FixedShape<C, T, O, true>> : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>>; \
-        rollout[1] = f64 ? rollout[0] : (StepFn)rollout_kernel<float, FixedShape<C, T, O, false>, FLOW_RANDOM>;                                   \
-        *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, FixedShape<C, T, O, true>> : (PolicyFn)greedy_policy_kernel<float, FixedShape<C, T, O, false>>; \
-        *rollout_greedy = f64 ? (PolicyFn)rollout_greedy_kernel<double, FixedShape<C, T, O, true>> : (PolicyFn)rollout_greedy_kernel<float, FixedShape<C, T, O, false>>; \
-        if (!f64 && !no_image) pick_image_kernels<C, T, O>(rollout, rollout_greedy, image);                         \
-        return;                                                                                                     \
-    }
-        MATE_SHAPES(X)
-#undef X
+        KernelSet k{};
+        if (pick_kernels_group0(Nc, Nt, No, f64, no_image, &k) || pick_kernels_group1(Nc, Nt, No, f64, no_image, &k) ||
+            pick_kernels_group2(Nc, Nt, No, f64, no_image, &k) || pick_kernels_group3(Nc, Nt, No, f64, no_image, &k) ||
+            pick_kernels_group4(Nc, Nt, No, f64, no_image, &k) || pick_kernels_group5(Nc, Nt, No, f64, no_image, &k)) {
+            for (int i = 0; i < 3; ++i) { step[i] = k.step[i]; split[i] = k.split[i]; }
+            rollout[0] = k.rollout[0]; rollout[1] = k.rollout[1];
+            *policy = k.policy; *rollout_greedy = k.rollout_greedy;
+            *specialised = 1; *image = k.image;
+            return;
+        }
     }
     step[FLOW_ANY] = f64 ? (StepFn)step_kernel<double, AnyShape> : (StepFn)step_kernel<float, AnyShape>;
     step[FLOW_RANDOM] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, AnyShape, FLOW_RANDOM>;
     step[FLOW_ACT_F32] = f64 ? step[FLOW_ANY] : (StepFn)step_kernel<float, AnyShape, FLOW_ACT_F32>;
-    if (!f64) { split[FLOW_RANDOM] = (StepFn)step_split_kernel<float, AnyShape, FLOW_RANDOM>; split[FLOW_ACT_F32] = (StepFn)step_split_kernel<float, AnyShape, FLOW_ACT_F32>;
-                split[3 + FLOW_RANDOM] = (StepFn)step_split_kernel<float, AnyShape, FLOW_RANDOM, 2>; split[3 + FLOW_ACT_F32] = (StepFn)step_split_kernel<float, AnyShape, FLOW_ACT_F32, 2>; }
+    if (!f64) { split[FLOW_RANDOM] = (StepFn)step_split_kernel<float, AnyShape, FLOW_RANDOM>; split[FLOW_ACT_F32] = (StepFn)step_split_kernel<float, AnyShape, FLOW_ACT_F32>; }
     rollout[0] = f64 ? (StepFn)rollout_kernel<double, AnyShape> : (StepFn)rollout_kernel<float, AnyShape>;
     rollout[1] = f64 ? rollout[0] : (StepFn)rollout_kernel<float, AnyShape, FLOW_RANDOM>;
     *policy = f64 ? (PolicyFn)greedy_policy_kernel<double, AnyShape> : (PolicyFn)greedy_policy_kernel<float, AnyShape>;
@@ -123,7 +123,7 @@ static Switches read_switches() {
     w.zoom_iterate = flag("MATE_ZOOM_ITERATE");
     w.policy_split = flag("MATE_POLICY_SPLIT");
     w.no_image = flag("MATE_NO_IMAGE");
-    if (const char *v = getenv("MATE_STEP_SPLIT")) w.step_split = atoi(v);      // 1: one environment per workgroup, 2: two
+    if (const char *v = getenv("MATE_STEP_SPLIT")) w.step_split = atoi(v) != 0;
     return w;
 }
 
@@ -157,7 +157,7 @@ struct mate_engine {
     int image = 0;                         // the fused rollouts (random-policy flow, greedy) run their row-image compilation ...
     size_t image_wave_bytes = 0;           // ... whose per-environment LDS slice is this
     PolicyFn policy_fn = nullptr, rollout_greedy_fn = nullptr;
-    StepFn split_fn[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // step_split_kernel per flow (two waves per environment), or null; [3 + flow]: two environments per workgroup
+    StepFn split_fn[3] = {nullptr, nullptr, nullptr};      // step_split_kernel per flow (two waves per environment), or null
     int split_on = 0;                                      // ... and whether launch_step uses it (MATE_STEP_SPLIT, or the batch is one resident generation)
     StepFn step_fn[3] = {nullptr, nullptr, nullptr}, rollout_fn[2] = {nullptr, nullptr};   // kernels chosen at create: shape-specialised when compiled for these counts; step_fn[flow]
     int last_flow = 0;
@@ -406,7 +406,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
             for (int phase = 4; phase >= 0; --phase, d /= 10) g.stagger |= ((d % 10) & 3) << (2 * phase);
             g.stagger |= (int32_t)0x40000000;
         }
-        e->split_on = (e->sw.step_split > 0 && Nc > 0) ? (e->sw.step_split >= 2 ? 2 : 1) : 0;
+        e->split_on = (e->sw.step_split > 0 && Nc > 0) ? 1 : 0;
     }
     do {
         if ((rc = dev_alloc(e, &g.stat, N * p.SW))) break;
@@ -845,12 +845,11 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
         else if (mode == MODE_STEP) flow = FLOW_ACT_F32;      // caller-supplied real-valued actions, f32 or f64 per team
     }
     e->last_flow = flow;
-    if (e->split_on && e->split_fn[flow]) {      // two waves per environment: one 128-thread workgroup each (or two environments per 256-thread workgroup)
-        const int epw = e->split_on;
-        const StepFn fn = e->split_fn[(epw == 2 ? 3 : 0) + flow];
-        const dim3 grid((unsigned)((e->N + epw - 1) / epw)), block(128 * epw);
-        if (ev0) hipExtLaunchKernelGGL(fn, grid, block, epw * (e->step_lds / 4), stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
-        else hipLaunchKernelGGL(fn, grid, block, epw * (e->step_lds / 4), stream, (const Params *)e->d_params, (const Ptrs)g);
+    if (e->split_on && e->split_fn[flow]) {      // two waves per environment: one 128-thread workgroup each
+        const StepFn fn = e->split_fn[flow];
+        const dim3 grid((unsigned)e->N), block(128);
+        if (ev0) hipExtLaunchKernelGGL(fn, grid, block, e->step_lds / 4, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
+        else hipLaunchKernelGGL(fn, grid, block, e->step_lds / 4, stream, (const Params *)e->d_params, (const Ptrs)g);
     }
     else if (ev0) hipExtLaunchKernelGGL(e->step_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
     else hipLaunchKernelGGL(e->step_fn[flow], dim3(blocks), dim3(256), e->step_lds, stream, (const Params *)e->d_params, (const Ptrs)g);   // (capturable)

@@ -4,7 +4,7 @@
 # the one-launch-per-step rate measured in the same run.
 out=${1:-/dev/stdout}
 {
-for spec in "MATE-4v2-9.yaml 4096 random" "MATE-4v8-9.yaml 4096 random" "MATE-4v8-9.yaml 16384 random" "MATE-4v8-9.yaml 65536 random" "MATE-8v8-9.yaml 8192 random" "MATE-8v8-9.yaml 8192 greedy" "MATE-4v8-0.yaml 8192 random" "MATE-4v8-0.yaml 65536 random" "MATE-Navigation.yaml 4096 random" "MATE-Navigation.yaml 32768 random"; do
+for spec in "MATE-2v4-0.yaml 4096 random" "MATE-4v4-9.yaml 4096 random" "MATE-8v8-0.yaml 4096 random" "MATE-4v2-9.yaml 4096 random" "MATE-4v8-9.yaml 4096 random" "MATE-4v8-9.yaml 16384 random" "MATE-4v8-9.yaml 65536 random" "MATE-8v8-9.yaml 8192 random" "MATE-8v8-9.yaml 8192 greedy" "MATE-4v8-0.yaml 8192 random" "MATE-4v8-0.yaml 65536 random" "MATE-Navigation.yaml 4096 random" "MATE-Navigation.yaml 32768 random"; do
   set -- $spec
   python bench.py --workload $1 --batch $2 --policy $3 --steps 1024 --warmup 128 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | python -c "
 import json,sys
