@@ -303,6 +303,8 @@ struct Ctx {
     const double *act_cam = nullptr, *act_tgt = nullptr;   // FLOW_GREEDY: this step's joint actions in LDS ([Nc][2], [Nt][2])
     float *pub = nullptr, *img = nullptr;                  // row-image mode: public-state table, observation rows (Params::off_pub / off_img)
 
+    bool pivots = true;           // sector_resolve: use the pivot angles of an overflow record (kernels at their register limit -- the generic
+                                  // fused rollouts, the fused Greedy rollouts -- take the two-trip quarter path instead: same bracket, same limit)
     bool statics_done = false;    // fused rollouts, steps after the first: what never changes inside an episode (static
                                   // mask words and flags, obstacle / capacity slots of the scratch) is in LDS already
 
@@ -827,6 +829,11 @@ __device__ __forceinline__ double segment_interp(const double2 (&w)[kDegWords], 
     return sl * (x - x0) + y0;
 }
 constexpr int kDegSlots = 5;
+// Overflow records (first angle NaN): [NaN, first knot] [knot count, pivot stride q] [pivot 1, pivot 2] ... [pivot 7, pivot 8]: eight
+// pivot angles = the angles of the degree's knots q, 2q, ... 8q (+inf past the last), q = ceil((count - 1) / 9) <= kDegSlots - 1, so
+// that the query's bracket lies among the five knots from (number of pivots <= query) * q on; stride 0 = no pivots (general path).
+constexpr int kPivotKnots = 9 * (kDegSlots - 1) + 1;      // 37
+__host__ __device__ constexpr int pivot_stride(int count) { return (count - 1 + 8) / 9; }
 constexpr int kQuarterKnots = 4 * (kDegSlots - 1) + 1;
 __device__ __forceinline__ int degree_of(double x) {
     int d = (int)floor(x + 180.0);
@@ -1113,6 +1120,22 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorE
         // dependent binary search (ten round trips).  A launch of 4096 one-step waves lasts as long as its slowest wave, and with
         // one such lookup in a thousand there is one in (almost) every launch: it WAS the slowest wave, 14 k cycles in this phase
         // against 5.4 k.
+        // Eight PIVOT ANGLES ride in the overflow record itself (kPivotKnots; the builders write the angles of knots q, 2q, ... 8q of
+        // the degree, q = ceil((count - 1) / 9), +inf beyond the last): up to 37 knots -- every degree but the rarest -- the
+        // bracketing five are fetched at once, ONE round trip behind the record's instead of two (pivots, then knots).  A step in
+        // which any pair overflows waits for the slowest lane: 30 % of the steps of MATE-4v8-9, nearly all of the heaviest
+        // environments', which set the length of a short launch.
+        if (c.pivots && count >= 2 && count <= kPivotKnots && w[1].y > 0.0) {
+            const int q = (int)w[1].y, last = count - 1;
+            const double pv[8] = {w[2].x, w[2].y, w[3].x, w[3].y, w[4].x, w[4].y, w[5].x, w[5].y};
+            int nle = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nle += pv[i] <= e.x ? 1 : 0;
+            const int base = nle * q;
+#pragma unroll
+            for (int i = 0; i < kDegSlots; ++i) w[i] = knots[start + (base + i < last ? base + i : last)];
+            limit = degree_interp(w, e.x, overflow);
+        } else {
         while (count > kQuarterKnots && count <= 4 * 256 + 1) {
             const int q = (count + 2) / 4, last = count - 1;
             const double a1 = knots[start + (q < last ? q : last)].x;
@@ -1133,6 +1156,7 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorE
             limit = degree_interp(w, e.x, overflow);
         } else {
             limit = lut_lookup(knots, c.g.lut_bucket + e.lc * c.p.nbucket, c.g.lut_count[e.lc], e.x);
+        }
         }
     }
     // `relative.norm <= sight_range_at(angle) * (1 + 1e-6)` (entities.py:505) on squares, the root inside the rounding rim
@@ -2802,6 +2826,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW);
         c.out = (int64_t)r * g.N + env_r;
         c.statics_done = stepped;
+        c.pivots = Shape::kGreedyHeld;      // (the compiled shapes; the generic kernel has no registers to spare)
         if (HELDSTATE ? finished != 0 : c.ei(EI_DONE) != 0) {
             if (lane_r == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
             if (lane_r == 0 && g.idle_steps) g.idle_steps[env_r] += 1;      // a slot of the rollout, not an executed step

@@ -1360,7 +1360,16 @@ extern "C" int mate_engine_lut_write(mate_engine *e, int64_t env, int32_t camera
             }
         } else {
             for (int i = 0; i < kDegWords; ++i) { rec[i].x = NAN; rec[i].y = 0.0; }
-            if (phis[start] == (double)(d - 180) && increasing) { rec[0].y = (double)start; rec[1].x = (double)(endk - start + 1); }   // burst path
+            if (phis[start] == (double)(d - 180) && increasing) {                                                  // burst path: first knot, count, pivot stride, eight pivots
+                const int count = endk - start + 1, last = count - 1;
+                const int q = count <= kPivotKnots ? pivot_stride(count) : 0;
+                rec[0].y = (double)start; rec[1].x = (double)count; rec[1].y = (double)q;
+                for (int i = 0; i < 4; ++i) {
+                    const int ka = (2 * i + 1) * q, kb = (2 * i + 2) * q;
+                    rec[2 + i].x = q > 0 && ka <= last ? phis[start + ka] : inf;
+                    rec[2 + i].y = q > 0 && kb <= last ? phis[start + kb] : inf;
+                }
+            }
             else rec[1].x = 0.0;                                                                                   // general path
         }
     }

@@ -608,6 +608,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         c.out = (int64_t)r * g.N + env_r;
         c.act_cam = act_cam; c.act_tgt = act_tgt;
         c.statics_done = stepped;
+        c.pivots = false;                    // (at the register limit: the quarter path's two round trips)
         const bool active = in_batch && c.ei(EI_DONE) == 0;
         if (g.rotate_prio) {
             const int turn = (r + wave_slot) & 3;

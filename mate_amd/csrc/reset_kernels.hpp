@@ -450,9 +450,15 @@ __device__ __forceinline__ bool build_lut(Ctx<ObsT> &c, int cam, double *keys, d
                 if (idx < endk) degree_record_set(rec, i, okeys[idx], ovals[idx], (ovals[idx + 1] - ovals[idx]) / (okeys[idx + 1] - okeys[idx]));
                 else degree_record_set(rec, i, inf, 0.0, 0.0);
             }
-        } else {                                   // overflow: (NaN, first knot) (knots of the degree incl. the next integer one, -)
+        } else {                                   // overflow: (NaN, first knot) (knots of the degree incl. the next integer one, pivot stride) + 8 pivot angles
+            const int count = endk - start + 1, last = count - 1;
+            const int q = count <= kPivotKnots ? pivot_stride(count) : 0;
             rec[0] = make_double2(__longlong_as_double(0x7ff8000000000000ll), (double)start);
-            rec[1] = make_double2((double)(endk - start + 1), 0.0);
+            rec[1] = make_double2((double)count, (double)q);
+            for (int i = 0; i < 4; ++i) {
+                const int ka = (2 * i + 1) * q, kb = (2 * i + 2) * q;
+                rec[2 + i] = make_double2(q > 0 && ka <= last ? okeys[start + ka] : inf, q > 0 && kb <= last ? okeys[start + kb] : inf);
+            }
         }
     }
     __syncthreads();
