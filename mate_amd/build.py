@@ -126,7 +126,18 @@ def build_tools(verbose=False):
     return built
 
 
+def build_variant(name, defines, verbose=False):
+    """An experiment build, lib/libmate_engine_<name>.so with extra -D flags (A/B partners of tools/rollout_ab.py and of
+    MATE_ENGINE_LIB=...; never loaded by the package itself)."""
+    out = os.path.join(HERE, 'lib', 'libmate_engine_%s.so' % name)
+    _compile_and_link(out, extra=list(defines), verbose=verbose)
+    return out
+
+
 if __name__ == '__main__':
+    if '--variant' in sys.argv:      # python -m mate_amd.build --variant NAME -DFLAG[=V] ...
+        build_variant(sys.argv[sys.argv.index('--variant') + 1], [a for a in sys.argv if a.startswith('-D')], verbose=True)
+        sys.exit(0)
     build_engine(force='--force' in sys.argv, verbose=True)
     if '--tools' in sys.argv:
         build_tools(verbose=True)
