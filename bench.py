@@ -192,11 +192,12 @@ def parse_args(argv=None):
                     help='fused rollouts: restart finished environments after every k-th launch (1 = after every launch; default: about every '
                          '128 steps for the random policy (k = 128 // launch length), 2 for Greedy vs Greedy, whose ~1.2k-step episodes end '
                          'somewhere in the batch at every step)')
-    ap.add_argument('--buffer-gib', type=float, default=8.0, help='cap of the rollout-shaped output buffers [R][N][...] (limits --rollout)')
+    ap.add_argument('--buffer-gib', type=float, default=48.0, help='cap of the rollout-shaped output buffers [R][N][...] (limits --rollout; 48 of the 288 GiB: 64-step launches of 65536 x MATE-4v8-9)')
     ap.add_argument('--rollout', type=int, default=-1,
-                    help='steps fused per launch (rollout_kernel / rollout_greedy_kernel); 0 = one launch per step; -1 (default) = 256 '
-                         '(random) / 48 (greedy) while the batch is at most 64 / 32 environment-waves per CU, else 0 (the fused '
-                         'kernels trade occupancy for registers and LDS); capped so that the [R][N][...] buffers stay under --buffer-gib')
+                    help='steps fused per launch (rollout_kernel / rollout_greedy_kernel); 0 = one launch per step; -1 (default) = 256 / 128 / 64 '
+                         '(random: the longest of which the timed region holds eight) / 48 (greedy), at every batch size (rounds 1-3 went back to '
+                         'one launch per step beyond 64 environment-waves per CU, which the fused kernels have since overtaken there too: '
+                         '65536 x MATE-4v8-9 7.3e8 against 5.7e8 env-steps/s); capped so that the [R][N][...] buffers stay under --buffer-gib')
     ap.add_argument('--step-reset-interval', type=int, default=32,
                     help='one launch per step (per_step_launch / external_actions / --rollout 0 with the random policy): restart finished '
                          'environments with one reset launch per k steps (1 = a reset launch behind every step); a finished environment idles at most k - 1 steps')
@@ -476,11 +477,9 @@ def main():
     if args.policy == 'external':
         R = 0
     if R < 0:
-        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
-        R = 32 if args.batch <= (64 if args.policy == 'random' else 32) * cus else 0
-        if R and args.policy == 'random':       # longer launches while the timed region still holds eight of them
+        if args.policy == 'random':             # longer launches while the timed region still holds eight of them
             R = next((r for r in (256, 128, 64) if args.steps // r >= 8), 32)
-        elif R:                                 # Greedy vs Greedy: 48 steps (longer launches lose more to the idle slots of finished
+        else:                                   # Greedy vs Greedy: 48 steps (longer launches lose more to the idle slots of finished
             R = 48 if args.steps >= 8 * 48 else 32     # episodes than they save in launches; measured 16 .. 96)
     if R > 0:        # rollout buffers [R][N][...] capped (default 8 GiB of the 288)
         R = max(1, min(R, args.steps, (int(args.buffer_gib * (1 << 30))) // (args.batch * b_obs)))

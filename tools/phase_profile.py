@@ -14,13 +14,16 @@ from mate_amd.engine import Engine  # noqa: E402
 
 workload = sys.argv[1] if len(sys.argv) > 1 else 'MATE-4v8-9.yaml'
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # runtime phase mask (mate_engine_debug_skip; 255: launch + records + state store only)
 eng = Engine(read_config(workload), batch, seed=0)
+eng.lib.mate_engine_debug_skip.argtypes = [ctypes.c_void_p, ctypes.c_int32]
 eng.reset()
 for _ in range(50):
     eng.step_random(auto_reset=True)
 buf = torch.zeros((batch, 16), dtype=torch.int64, device='cuda')
 eng.lib.mate_engine_debug_phase_clocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 eng.lib.mate_engine_debug_phase_clocks(eng._h, ctypes.c_void_p(buf.data_ptr()))
+eng.lib.mate_engine_debug_skip(eng._h, skip)
 names = ['table+sync', 'load', 'simulate', 'view', 'assign', 'scratch', 'pack', 'store']
 acc = np.zeros(8)
 spans = []

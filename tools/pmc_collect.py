@@ -30,8 +30,11 @@ CASES = {
     'headline20': ('rollout_kernel', 20, 4096, ['--rollout', '20', '--steps', '20', '--warmup', '20', '--rollout-reset-interval', '6']),
     'step': ('step_kernel', 1, 4096, ['--rollout', '0', '--steps', '512', '--warmup', '64']),
     'c3': ('rollout_greedy_kernel', 48, 8192, ['--workload', 'MATE-8v8-9.yaml', '--batch', '8192', '--policy', 'greedy', '--rollout', '48', '--steps', '384', '--warmup', '48']),
-    'c4shard': ('rollout_kernel', 128, 8192, ['--workload', 'MATE-4v8-0.yaml', '--batch', '8192', '--rollout', '128', '--steps', '512', '--warmup', '128']),
+    'c4shard': ('rollout_kernel', 256, 8192, ['--workload', 'MATE-4v8-0.yaml', '--batch', '8192', '--rollout', '256', '--steps', '1024', '--warmup', '256']),
     'c5shard': ('rollout_kernel', 256, 4096, ['--workload', 'MATE-Navigation.yaml', '--batch', '4096', '--rollout', '256', '--steps', '1024', '--warmup', '256']),
+    # BASELINE configs 4 and 5 whole on ONE GPU (sixteen / eight generations of resident waves)
+    'c4full': ('rollout_kernel', 64, 65536, ['--workload', 'MATE-4v8-0.yaml', '--batch', '65536', '--rollout', '64', '--steps', '256', '--warmup', '64']),
+    'c5full': ('rollout_kernel', 64, 32768, ['--workload', 'MATE-Navigation.yaml', '--batch', '32768', '--rollout', '64', '--steps', '256', '--warmup', '64']),
 }
 
 
