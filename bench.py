@@ -44,7 +44,8 @@ Rank 0 prints ONE JSON line (see the driver contract).  Extra objects:
   other_configs the other BASELINE.json configurations that fit one GPU, timed for about a second each after the
                 headline in the default N = 1 run: config 3 (MATE-8v8-9 x 8192, on-device Greedy vs Greedy, fused
                 48-step launches), the per-GPU shard of config 4 (MATE-4v8-0 x 8192) and of config 5
-                (MATE-Navigation x 4096), each with its dominant kernel's dispatch-event average and roofline fraction.
+                (MATE-Navigation x 4096), and the WHOLE batches of configs 4 and 5 (65536 / 32768 environments) on this one
+                GPU, each with its dominant kernel's dispatch-event average and roofline fraction.
 
   reset_amortised  what the driver's region never contains: all environments of the random-policy batch hit the time limit together
                 every max_episode_steps + 1 steps and restart in one whole-batch reset; `value_with_resets` = the headline with
@@ -311,11 +312,13 @@ def measure_other_config(torch, device_index, spec, seconds, buffer_gib):
     steps), timed for about `seconds` of back-to-back launches after an untimed pass and 0.25 s of clock warm-up."""
     from mate_amd.config import read_config
     from mate_amd.engine import Engine
-    workload, batch, policy, label = spec
+    workload, batch, policy, label = spec[:4]
     eng = Engine(read_config(workload), batch, device=device_index, seed=0, first_env_index=0)
     b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
     b_obs = 4 * (eng.num_cameras * eng.camera_obs_dim + eng.num_targets * eng.target_obs_dim) + 48
     cap = int(buffer_gib * (1 << 30)) // (batch * b_obs)
+    if len(spec) > 4:
+        cap = min(cap, spec[4])
     if policy == 'greedy':
         eng.enable_policies()
         R, resets, fn, kernel = min(48, cap), 2, eng.rollout_greedy, 'rollout_greedy_kernel'
@@ -401,6 +404,9 @@ OTHER_CONFIGS = (
     ('MATE-8v8-9.yaml', 8192, 'greedy', 'BASELINE config 3'),
     ('MATE-4v8-0.yaml', 8192, 'random', 'BASELINE config 4, the shard of one of its 8 GPUs'),
     ('MATE-Navigation.yaml', 4096, 'random', 'BASELINE config 5, the shard of one of its 8 GPUs'),
+    # the same two configurations WHOLE on this one GPU (sixteen / eight generations of resident waves; launches of 64 steps: 19 / 17 GB of rows)
+    ('MATE-4v8-0.yaml', 65536, 'random', 'BASELINE config 4, its whole batch on ONE GPU', 64),
+    ('MATE-Navigation.yaml', 32768, 'random', 'BASELINE config 5, its whole batch on ONE GPU', 64),
 )
 
 
