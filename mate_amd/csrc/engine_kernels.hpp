@@ -227,8 +227,8 @@ struct Ptrs {
 constexpr int32_t kDoneTag = 4;
 
 #ifdef MATE_PHASE_CLOCKS
-#define PHASE_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#define SUB_STAMP(c, i) do { if ((c).lane == 0 && (c).g.phase_clocks) (c).g.phase_clocks[(c).env * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define PHASE_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * kClockStride + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define SUB_STAMP(c, i) do { if ((c).lane == 0 && (c).g.phase_clocks) (c).g.phase_clocks[(c).env * kClockStride + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #elif defined(MATE_ISA_MARKS)      // tools/isa_phases.py: phase boundaries of step_kernel as comments in the -S output (no instruction is emitted)
 #define PHASE_STAMP(i) asm volatile("; ==== MATE_STEP_PHASE " #i)
 #define SUB_STAMP(c, i) asm volatile("; ==== MATE_STEP_SUB " #i)
@@ -236,6 +236,25 @@ constexpr int32_t kDoneTag = 4;
 #define PHASE_STAMP(i) do { } while (0)
 #define SUB_STAMP(c, i) do { } while (0)
 #endif
+#ifdef MATE_SUB_CLOCKS
+constexpr int kClockStride = 32;      // stamps per environment in Ptrs::phase_clocks
+#else
+constexpr int kClockStride = 16;
+#endif
+// Sub-phase accumulators of the fused rollout (python -m mate_amd.build --variant sub -DMATE_PHASE_CLOCKS -DMATE_SUB_CLOCKS;
+// tools/rollout_subphases.py): cycles summed over a launch's steps into Ctx::sub[0..7] (sub[15]: the previous stamp), events counted
+// in the stamp buffer itself.
+#if defined(MATE_PHASE_CLOCKS) && defined(MATE_SUB_CLOCKS)
+#define SUB_ACC(c, i) do { if ((c).sub) { const long long t_sub = (long long)__builtin_amdgcn_s_memtime(); (c).sub[i] += t_sub - (c).sub[15]; (c).sub[15] = t_sub; } } while (0)
+// (slots 24..31 of the environment's 32: callable under divergent control flow)
+#define SUB_COUNT(c, i, cond) do { const unsigned long long b_sub = __ballot(cond); \
+    if ((c).sub && b_sub != 0ull && (c).lane == __ffsll((long long)b_sub) - 1 && (c).g.phase_clocks) \
+        atomicAdd(reinterpret_cast<unsigned long long *>((c).g.phase_clocks) + (c).env * kClockStride + 24 + (i), 1ull); } while (0)
+#else
+#define SUB_ACC(c, i) do { } while (0)
+#define SUB_COUNT(c, i, cond) do { } while (0)
+#endif
+#define SUB_START(c) do { if ((c).sub) (c).sub[15] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
 // Phase-keyed issue priority.  The SIMD arbiter serves its oldest wave first, so the four co-resident
 // environment-waves of a SIMD finish one after the other and the last one runs its tail alone, with nobody
@@ -303,6 +322,7 @@ struct Ctx {
     const double *act_cam = nullptr, *act_tgt = nullptr;   // FLOW_GREEDY: this step's joint actions in LDS ([Nc][2], [Nt][2])
     float *pub = nullptr, *img = nullptr;                  // row-image mode: public-state table, observation rows (Params::off_pub / off_img)
 
+    long long *sub = nullptr;     // (profiling variant: SUB_ACC / SUB_COUNT)
     bool pivots = true;           // sector_resolve: use the pivot angles of an overflow record (kernels at their register limit -- the generic
                                   // fused rollouts, the fused Greedy rollouts -- take the two-trip quarter path instead: same bracket, same limit)
     bool statics_done = false;    // fused rollouts, steps after the first: what never changes inside an episode (static
@@ -1112,6 +1132,7 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorE
     if (!e.need) return e.seen;
     bool overflow;
     double limit = segment_interp(w, e.x, overflow);
+    SUB_COUNT(c, 1, overflow);                           // ... with a lookup in a degree that overflows its record
     if (overflow) {
         int start = (int)w[0].y, count = (int)w[1].x;
         const double2 *knots = c.g.lut_knots + e.lc * c.p.kmax;
@@ -1340,9 +1361,13 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
             sector_fetch(c, pending, w);
         }
         SUB_STAMP(c, 13);
+        SUB_ACC(c, 0);                                   // sector geometry + fetch issued
+        SUB_COUNT(c, 0, pending.need);                   // steps with an occlusion lookup
         range_tests();
+        SUB_ACC(c, 1);                                   // range tests
         if (last >= 0) {
             const bool seen = sector_resolve(c, pending, w);
+            SUB_ACC(c, 2);                               // wait for the record + interpolation (+ overflow trips)
             if (!c.image() && last * 64 + lane < p.n_sector) set_flag(c, last * 64 + lane, seen);
             seen_out |= (uint32_t)seen;
             const unsigned long long b = __ballot(seen);
@@ -2320,7 +2345,7 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
 #ifdef MATE_PHASE_CLOCKS
     if (lane == 0 && g.phase_clocks) {
-        g.phase_clocks[env * 16 + 0] = t_begin;
+        g.phase_clocks[env * kClockStride + 0] = t_begin;
     }
 #endif
     PHASE_STAMP(1);
@@ -2395,7 +2420,7 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     if (mode != MODE_OBSERVE) store_dynamic(c);
     PHASE_STAMP(8);
 #ifdef MATE_PHASE_CLOCKS
-    if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
+    if (lane == 0 && g.phase_clocks) g.phase_clocks[env * kClockStride + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
 #endif
 }
 
@@ -2572,7 +2597,7 @@ void step_split_kernel(const Params *__restrict__ pp, const Ptrs g) {
     const Ptrs &gk = kernarg_ptrs(g);
     Ctx<ObsT> c(p, gk, smem + pair * p.lds_wave_bytes, lane, env, FLOW);
 #ifdef MATE_PHASE_CLOCKS      // per-wave stamps: slots 0-7 wave A, 8-15 wave B (tools/split_phases.py)
-#define SPLIT_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + role * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define SPLIT_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * kClockStride + role * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SPLIT_STAMP(i) do { } while (0)
 #endif
@@ -2729,7 +2754,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     const Ptrs &gk = kernarg_ptrs(g);     // launch arguments read where they are used (see step_kernel)
 #ifdef MATE_PHASE_CLOCKS      // the launch's prologue, in s_memtime ticks since the wave began: slots 8..11 (tools/rollout_prologue.py), 12 the epilogue
     const long long t_wave = (long long)__builtin_amdgcn_s_memtime();
-#define PROLOGUE_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + (i)] = (long long)__builtin_amdgcn_s_memtime() - t_wave; } while (0)
+#define PROLOGUE_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * kClockStride + (i)] = (long long)__builtin_amdgcn_s_memtime() - t_wave; } while (0)
 #else
 #define PROLOGUE_STAMP(i) do { } while (0)
 #endif
@@ -2779,6 +2804,9 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     const int wave_slot = (int)(hw_id & 15u);
 #ifdef MATE_PHASE_CLOCKS
     long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // cycles per phase summed over the steps of this launch
+#ifdef MATE_SUB_CLOCKS
+    long long sub[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (SUB_ACC: 0..7 cycles of sub-phases, 15 the previous stamp)
+#endif
     long long t_prev = (long long)__builtin_amdgcn_s_memtime();
     const long long t_first = t_prev, r_first = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -2867,10 +2895,16 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
             ROLL_STAMP(2);
             uint32_t seen = 0u;
             unsigned long long sector_ballot = 0ull;
+#ifdef MATE_SUB_CLOCKS
+            c.sub = sub;
+#endif
+            SUB_START(c);
             if (!(MATE_ABLATE & 8)) update_view<true, true>(c, tick, S_TRANSMIT, true, roles, seen, &near, &sector_ballot);
+            SUB_ACC(c, 3);                               // mask words, static bits
             if (MATE_DOUBLE & 8) { uint32_t again; update_view<true, true>(c, tick, S_TRANSMIT, true, roles, again, &near, &sector_ballot); seen |= again; }
             bool tracked; int inside;
             view_tail_held(c, sector_ballot, h, tracked, inside);
+            SUB_ACC(c, 4);                               // tracked bits, warehouses
             ROLL_STAMP(3);
             if (!(MATE_ABLATE & 16)) finished = assign_and_score_held(c, tick, g.scalars, h, tracked, inside);
             ROLL_STAMP(4);
@@ -2912,18 +2946,22 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     }
 #ifdef MATE_PHASE_CLOCKS
     if (lane == 0 && g.phase_clocks)
-        for (int i = 0; i < 8; ++i) g.phase_clocks[env * 16 + i] = acc[i];
+        for (int i = 0; i < 8; ++i) g.phase_clocks[env * kClockStride + i] = acc[i];
     if (lane == 0 && g.phase_clocks) {      // clock calibration: s_memtime ticks against the constant 100 MHz counter
         uint32_t hwid, xccid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xccid));
-        g.phase_clocks[env * 16 + 13] = ((long long)xccid << 32) | (long long)hwid;
-        g.phase_clocks[env * 16 + 14] = (long long)__builtin_amdgcn_s_memtime() - t_first;
-        g.phase_clocks[env * 16 + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_first;
+        g.phase_clocks[env * kClockStride + 13] = ((long long)xccid << 32) | (long long)hwid;
+        g.phase_clocks[env * kClockStride + 14] = (long long)__builtin_amdgcn_s_memtime() - t_first;
+        g.phase_clocks[env * kClockStride + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_first;
     }
 #endif
 #ifdef MATE_PHASE_CLOCKS
     const long long t_epilogue = (long long)__builtin_amdgcn_s_memtime();
+#ifdef MATE_SUB_CLOCKS
+    if (lane == 0 && g.phase_clocks)
+        for (int i = 0; i < 8; ++i) g.phase_clocks[env * kClockStride + 16 + i] = sub[i];
+#endif
 #endif
     {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env);
@@ -2931,7 +2969,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         store_dynamic(c);
     }
 #ifdef MATE_PHASE_CLOCKS
-    if (lane == 0 && g.phase_clocks) g.phase_clocks[env * 16 + 12] = (long long)__builtin_amdgcn_s_memtime() - t_epilogue;
+    if (lane == 0 && g.phase_clocks) g.phase_clocks[env * kClockStride + 12] = (long long)__builtin_amdgcn_s_memtime() - t_epilogue;
 #endif
 }
 

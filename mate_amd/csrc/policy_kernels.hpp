@@ -665,9 +665,9 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
     }
 #ifdef MATE_PHASE_CLOCKS
     if (in_batch && lane == 0 && g.phase_clocks) {
-        for (int i = 0; i < 13; ++i) g.phase_clocks[env * 16 + i] = acc[i];
-        g.phase_clocks[env * 16 + 14] = (long long)__builtin_amdgcn_s_memtime() - t_first;
-        g.phase_clocks[env * 16 + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_first;
+        for (int i = 0; i < 13; ++i) g.phase_clocks[env * kClockStride + i] = acc[i];
+        g.phase_clocks[env * kClockStride + 14] = (long long)__builtin_amdgcn_s_memtime() - t_first;
+        g.phase_clocks[env * kClockStride + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_first;
     }
 #endif
     if (in_batch && !untouched) {
