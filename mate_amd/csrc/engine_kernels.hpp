@@ -855,10 +855,16 @@ constexpr int kDegSlots = 5;
 constexpr int kPivotKnots = 9 * (kDegSlots - 1) + 1;      // 37
 __host__ __device__ constexpr int pivot_stride(int count) { return (count - 1 + 8) / 9; }
 constexpr int kQuarterKnots = 4 * (kDegSlots - 1) + 1;
-__device__ __forceinline__ int degree_of(double x) {
-    int d = (int)floor(x + 180.0);
-    d = d < 0 ? 0 : (d > 359 ? 359 : d);
-    if (x < (double)(d - 180)) d -= 1;                // x + 180 rounded up across an integer
+// The records' cells: kCellsPerDegree per degree (round 4: two -- a cell holds the knots from the last one at or below its start on,
+// so one in 115 cells of a MATE-4v8-9 table overflows its record instead of one in 24, and the slowest waves of a launch are the
+// ones that overflow at almost every step, tools/rollout_subphases.py).  Cell starts c / kCellsPerDegree - 180 are exact in f64.
+constexpr int kCellsPerDegree = 2;
+constexpr int kLutCells = 360 * kCellsPerDegree;
+__host__ __device__ __forceinline__ double cell_start(int c) { return (double)c * (1.0 / kCellsPerDegree) - 180.0; }
+__device__ __forceinline__ int degree_of(double x) {      // the cell of angle x
+    int d = (int)floor((x + 180.0) * (double)kCellsPerDegree);
+    d = d < 0 ? 0 : (d > kLutCells - 1 ? kLutCells - 1 : d);
+    if (x < cell_start(d)) d -= 1;                    // x + 180 rounded up across a cell boundary
     return d < 0 ? 0 : d;
 }
 __device__ __forceinline__ double degree_interp(const double2 (&w)[kDegWords], double x, bool &overflow) {      // (plain knots in w[0 .. kDegSlots))
@@ -1118,9 +1124,9 @@ template <typename ObsT>
 __device__ __forceinline__ void sector_fetch(const Ctx<ObsT> &c, const SectorEval &e, double2 (&w)[kDegWords]) {
     if (e.need) {
 #ifdef MATE_LUT_FAKE      // experiment build: every lookup reads the same (cache-resident) record -- what the real fetch's latency costs
-        const double2 *rec = c.g.lut_deg + (0 * e.lc * 360 + degree_of(e.x)) * kDegWords;
+        const double2 *rec = c.g.lut_deg + (0 * e.lc * kLutCells + degree_of(e.x)) * kDegWords;
 #else
-        const double2 *rec = c.g.lut_deg + (e.lc * 360 + degree_of(e.x)) * kDegWords;
+        const double2 *rec = c.g.lut_deg + (e.lc * kLutCells + degree_of(e.x)) * kDegWords;
 #endif
 #pragma unroll
         for (int i = 0; i < kDegWords; ++i) w[i] = rec[i];
@@ -1320,7 +1326,7 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
             q_first = cand[lane];
             first = sector_eval<true>(c, q_first, tick, stream, predrawn);
             if (first.need) {
-                const double2 *rec = c.g.lut_deg + (first.lc * 360 + degree_of(first.x)) * kDegWords;
+                const double2 *rec = c.g.lut_deg + (first.lc * kLutCells + degree_of(first.x)) * kDegWords;
                 asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:92" : "+v"(touch0), "+v"(touch1) : "v"(rec) : "memory");
             }
         }

@@ -414,7 +414,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         if ((rc = dev_alloc(e, &g.lut_knots, N * std::max(Nc, 1) * (size_t)p.kmax, false))) break;
         if ((rc = dev_alloc(e, &g.lut_bucket, N * std::max(Nc, 1) * (size_t)p.nbucket))) break;
         if ((rc = dev_alloc(e, &g.lut_count, N * std::max(Nc, 1)))) break;
-        if ((rc = dev_alloc(e, &g.lut_deg, N * std::max(Nc, 1) * (size_t)360 * kDegWords, false))) break;
+        if ((rc = dev_alloc(e, &g.lut_deg, N * std::max(Nc, 1) * (size_t)kLutCells * kDegWords, false))) break;
         if ((rc = dev_alloc(e, &g.done_count, (size_t)2))) break;
         if ((rc = dev_alloc(e, &g.done_list, 2 * N))) break;
         if ((rc = dev_alloc(e, &g.flag_count, (size_t)4))) break;
@@ -1341,17 +1341,25 @@ extern "C" int mate_engine_lut_write(mate_engine *e, int64_t env, int32_t camera
         bucket[d] = (uint16_t)j;
     }
     const int64_t lc = env * e->p.Nc + camera;
-    // per-degree records (same rule as the device builder in reset_kernels.hpp)
-    std::vector<double2> deg((size_t)360 * kDegWords);
+    // per-cell records (same rule as the device builder in reset_kernels.hpp: a cell's knots from the last one at or below its
+    // start up to, not including, the first one at or above the next cell's start)
+    std::vector<double2> deg((size_t)kLutCells * kDegWords);
     const double inf = INFINITY;
-    for (int d = 0; d < 360; ++d) {
-        const int start = bucket[d], endk = bucket[d + 1];
-        double2 *rec = deg.data() + (size_t)d * kDegWords;
+    for (int cell = 0; cell < kLutCells; ++cell) {
+        const int d = cell / kCellsPerDegree, sub = cell - d * kCellsPerDegree;
+        int start = bucket[d];                                   // last knot with angle <= d - 180
+        if (sub > 0) { const double a = cell_start(cell); while (start + 1 < n && phis[start + 1] <= a) ++start; }
+        int endk = bucket[d + 1];
+        if (sub < kCellsPerDegree - 1) { const double a = cell_start(cell + 1); endk = start; while (endk + 1 < n && phis[endk] < a) ++endk; }
+        double2 *rec = deg.data() + (size_t)cell * kDegWords;
         double *words = reinterpret_cast<double *>(rec);
-        // a caller's table may repeat an angle (np.interp repairs the infinite slope): such a degree takes the general path
-        bool increasing = true;
+        // a caller's table may repeat an angle (np.interp repairs the infinite slope): such a cell takes the general path; so does
+        // one whose degree does not start on a knot (real tables have a knot on every integer degree, and the closing knot of a
+        // degree's last cell is taken from there)
+        bool increasing = endk > start;
         for (int idx = start; idx < endk; ++idx) increasing = increasing && phis[idx + 1] > phis[idx];
-        if (endk - start + 1 <= kDegSlots && phis[start] == (double)(d - 180) && increasing) {
+        increasing = increasing && phis[bucket[d]] == (double)(d - 180) && phis[start] <= cell_start(cell) && phis[endk] >= cell_start(cell + 1);
+        if (endk - start + 1 <= kDegSlots && increasing) {
             for (int i = 0; i < kDegSlots - 1; ++i) {
                 const int idx = start + i;
                 words[3 * i] = idx < endk ? phis[idx] : inf;
@@ -1360,7 +1368,7 @@ extern "C" int mate_engine_lut_write(mate_engine *e, int64_t env, int32_t camera
             }
         } else {
             for (int i = 0; i < kDegWords; ++i) { rec[i].x = NAN; rec[i].y = 0.0; }
-            if (phis[start] == (double)(d - 180) && increasing) {                                                  // burst path: first knot, count, pivot stride, eight pivots
+            if (increasing) {                                                  // burst path: first knot, count, pivot stride, eight pivots
                 const int count = endk - start + 1, last = count - 1;
                 const int q = count <= kPivotKnots ? pivot_stride(count) : 0;
                 rec[0].y = (double)start; rec[1].x = (double)count; rec[1].y = (double)q;
@@ -1373,7 +1381,7 @@ extern "C" int mate_engine_lut_write(mate_engine *e, int64_t env, int32_t camera
             else rec[1].x = 0.0;                                                                                   // general path
         }
     }
-    HIP_TRY(hipMemcpy(e->g.lut_deg + lc * 360 * kDegWords, deg.data(), sizeof(double2) * deg.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->g.lut_deg + lc * kLutCells * kDegWords, deg.data(), sizeof(double2) * deg.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->g.lut_knots + lc * e->p.kmax, knots.data(), sizeof(double2) * (size_t)n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->g.lut_bucket + lc * e->p.nbucket, bucket.data(), sizeof(uint16_t) * bucket.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->g.lut_count + lc, &n, sizeof(n), hipMemcpyHostToDevice));

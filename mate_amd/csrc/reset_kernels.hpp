@@ -281,8 +281,8 @@ __device__ __forceinline__ bool build_lut(Ctx<ObsT> &c, int cam, double *keys, d
         if (tid == 0) { knots[0] = make_double2(-180.0, 0.0); knots[1] = make_double2(180.0, 0.0); *knot_count = 2; }
         if (outer) { __syncthreads(); return false; }
         for (int d = tid; d < p.nbucket; d += nthreads) bucket[d] = d >= 360 ? 1 : 0;
-        for (int d = tid; d < 360; d += nthreads) {
-            double2 *rec = c.g.lut_deg + (lc * 360 + d) * kDegWords;
+        for (int d = tid; d < kLutCells; d += nthreads) {
+            double2 *rec = c.g.lut_deg + (lc * kLutCells + d) * kDegWords;
             degree_record_set(rec, 0, -180.0, 0.0, 0.0);      // (one segment from -180 to 180, range 0)
             for (int i = 1; i < kDegSlots - 1; ++i) degree_record_set(rec, i, __longlong_as_double(0x7ff0000000000000ll), 0.0, 0.0);
         }
@@ -441,9 +441,23 @@ __device__ __forceinline__ bool build_lut(Ctx<ObsT> &c, int cam, double *keys, d
     if (outer) { __syncthreads(); return false; }                          // boundary_between(outer=True) only reads the knots
     for (int d = tid; d < p.nbucket; d += nthreads) bucket[d] = d <= 361 ? lbucket[d] : (uint16_t)m;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
-    for (int d = tid; d < 360; d += nthreads) {       // per-degree records of the fast lookup path
-        const int start = lbucket[d], endk = lbucket[d + 1];
-        double2 *rec = c.g.lut_deg + (lc * 360 + d) * kDegWords;
+    for (int cell = tid; cell < kLutCells; cell += nthreads) {       // per-cell records of the fast lookup path
+        // the cell's knots: from the last one at or below its start (a cell that starts on an integer degree starts on a knot) up to,
+        // not including, the first one at or above the next cell's start, which closes the last segment
+        const int d = cell / kCellsPerDegree, sub = cell - d * kCellsPerDegree;
+        int start = lbucket[d];
+        if (sub > 0) {
+            const double a = cell_start(cell);
+            while (okeys[start] < a) ++start;
+            if (okeys[start] != a) --start;
+        }
+        int endk = lbucket[d + 1];
+        if (sub < kCellsPerDegree - 1) {
+            const double a = cell_start(cell + 1);
+            endk = start;
+            while (okeys[endk] < a) ++endk;
+        }
+        double2 *rec = c.g.lut_deg + (lc * kLutCells + cell) * kDegWords;
         if (endk - start + 1 <= kDegSlots) {
             for (int i = 0; i < kDegSlots - 1; ++i) {          // the degree's knots as segments (np.interp's slope, its own division)
                 const int idx = start + i;
