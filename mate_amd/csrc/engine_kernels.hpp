@@ -820,8 +820,9 @@ __device__ __noinline__ double lut_lookup(const double2 *knots, const uint16_t *
     return res;
 }
 
-// Fast path: one 96-byte record per (camera, degree): the up to four knots of that degree as SEGMENTS (angle, range, slope to the
-// next knot -- the last one's to the next integer-degree knot), +inf angles in the unused slots: one dependent memory round
+// Fast path: one 96-byte record per (camera, cell of 1 / kCellsPerDegree degrees): the up to four knots of that cell -- from the last
+// one at or below its start on -- as SEGMENTS (angle, range, slope to the next knot -- the last one's to the first knot of the
+// next cell), +inf angles in the unused slots: one dependent memory round
 // trip, and np.interp (`slope * (x - xp[j]) + fp[j]`, slope = (fp[j+1] - fp[j]) / (xp[j+1] - xp[j])) without its division --
 // the builders make it once per table, with the same IEEE division, so the product and the sum see the same bits.  (Angles
 // of a table increase strictly, so the slopes are finite and np.interp's NaN repairs never apply; a query below the next
@@ -2174,6 +2175,8 @@ __device__ __forceinline__ void simulate_targets_held(Ctx<ObsT> &c, const StepDr
         const double desx = ox + vx, desy = oy + vy;
         uint64_t todo = near_field(p, carried, t);
         bool n_known = true;
+        SUB_ACC(c, 5);                                   // targets: the step vector
+        SUB_COUNT(c, 2, todo != 0ull);                   // steps with a collision candidate
         while (todo) {
             const int k = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -2185,9 +2188,11 @@ __device__ __forceinline__ void simulate_targets_held(Ctx<ObsT> &c, const StepDr
             if (n != 0.0 && fma(dy, dy, dx * dx) > reach * reach * (1.0 + 1e-12)) continue;
             obstruct_tangential(ox, oy, vx, vy, n, n_known, cx, cy, cr);
         }
+        SUB_ACC(c, 6);                                   // targets: the candidates' circles
         const double nx = clip_uniform(ox + vx, -kTerrain, kTerrain);   // entities.py:664-666
         const double ny = clip_uniform(oy + vy, -kTerrain, kTerrain);
         const bool colliding = (fabs(nx - desx) > 1e-6) || (fabs(ny - desy) > 1e-6);  // entities.py:668
+        SUB_COUNT(c, 3, colliding);                      // steps in which a target was deflected
         h.x = nx; h.y = ny;
         const int slot = c.tgt_slot(t);
         c.ex[slot] = nx; c.ey[slot] = ny; c.exf[slot] = (float)nx; c.eyf[slot] = (float)ny;
@@ -2897,13 +2902,15 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         if constexpr (HELDSTATE) {
             if (!(MATE_ABLATE & 2)) simulate_cameras_held(c, draws, h);
             ROLL_STAMP(1);
-            if (!(MATE_ABLATE & 4)) simulate_targets_held(c, draws, near, h);
-            ROLL_STAMP(2);
-            uint32_t seen = 0u;
-            unsigned long long sector_ballot = 0ull;
 #ifdef MATE_SUB_CLOCKS
             c.sub = sub;
 #endif
+            SUB_START(c);
+            if (!(MATE_ABLATE & 4)) simulate_targets_held(c, draws, near, h);
+            SUB_ACC(c, 7);                               // targets: clip, entity table
+            ROLL_STAMP(2);
+            uint32_t seen = 0u;
+            unsigned long long sector_ballot = 0ull;
             SUB_START(c);
             if (!(MATE_ABLATE & 8)) update_view<true, true>(c, tick, S_TRANSMIT, true, roles, seen, &near, &sector_ballot);
             SUB_ACC(c, 3);                               // mask words, static bits

@@ -25,12 +25,13 @@ eng.rollout_random(R)
 torch.cuda.synchronize()
 raw = buf.cpu().numpy().astype(np.float64)
 t = raw[:, :8] / R
-sub = raw[:, 16:21] / R
-cnt = raw[:, 24:26] / R
+sub = raw[:, 16:24] / R
+cnt = raw[:, 24:28] / R
 tot = t.sum(axis=1)
 names = ['draws', 'cameras', 'targets', 'view', 'assign', 'scratch', 'pack', 'loop']
-subn = ['sector geometry + fetch issue', 'range tests', 'record wait + interpolation', 'mask words', 'tracked bits']
-cntn = ['steps with a lookup', 'steps with an overflowing degree']
+subn = ['view: sector geometry + fetch issue', 'view: range tests', 'view: record wait + interpolation', 'view: mask words', 'view: tracked bits',
+        'targets: step vector', 'targets: candidate circles', 'targets: clip + table']
+cntn = ['steps with a lookup', 'steps with an overflowing degree', 'steps with a collision candidate', 'steps with a deflected target']
 order = np.argsort(tot)
 groups = [('all waves', order), ('fastest 10 %', order[:batch // 10]), ('middle 10 %', order[batch * 45 // 100: batch * 55 // 100]),
           ('slowest 10 %', order[-(batch // 10):]), ('slowest 1 %', order[-max(4, batch // 100):]), ('slowest 8', order[-8:])]
@@ -40,7 +41,7 @@ print('%-32s' % 'total' + ''.join('%14.0f' % tot[g[1]].mean() for g in groups))
 for i, n in enumerate(names):
     print('%-32s' % n + ''.join('%14.0f' % t[g[1], i].mean() for g in groups))
 for i, n in enumerate(subn):
-    print('%-32s' % ('  view: ' + n) + ''.join('%14.0f' % sub[g[1], i].mean() for g in groups))
+    print('%-34s' % ('  ' + n)[:34] + ''.join('%14.0f' % sub[g[1], i].mean() for g in groups))
 for i, n in enumerate(cntn):
     print('%-32s' % n[:32] + ''.join('%14.2f' % cnt[g[1], i].mean() for g in groups))
 wv = (buf.cpu().numpy()[:, 13] & 0xf)
