@@ -481,10 +481,52 @@ class Engine:
         check(self.lib.mate_engine_observe(self._h, ctypes.byref(io), self._stream()))
         return self.camera_obs, self.target_obs
 
-    def export_state(self):
-        out = torch.empty((self.num_envs, self.layout.export_width), dtype=torch.float64, device=self.device)
+    def export_state(self, out=None):
+        if out is None:
+            out = torch.empty((self.num_envs, self.layout.export_width), dtype=torch.float64, device=self.device)
         check(self.lib.mate_engine_export_state(self._h, ctypes.c_void_p(out.data_ptr()), self._stream()))
         return out
+
+    # One copy per step for the N = 1 NumPy API (mate_amd.environment): the output tensors and an export_state buffer become views of
+    # ONE device allocation, and fetch_host() brings a step's results over in a single transfer (five blocking copies of a few KB each
+    # were a third of that API's 250 us per step).
+    def stage_outputs(self):
+        """Re-home camera_obs / target_obs / scalars / masks (and a state-export buffer) in one flat device buffer.  Call before
+        the first reset; the tensors keep their names, shapes and dtypes."""
+        parts = [('camera_obs', self.camera_obs), ('target_obs', self.target_obs), ('scalars', self.scalars), ('masks', self.masks),
+                 ('state', torch.empty((self.num_envs, self.layout.export_width), dtype=torch.float64, device=self.device))]
+        offsets, total = [], 0
+        for _, t in parts:
+            offsets.append(total)
+            total += -(-t.numel() * t.element_size() // 256) * 256
+        flat = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        self._staged = {'flat': flat, 'views': {}}
+        for (name, t), off in zip(parts, offsets):
+            nbytes = t.numel() * t.element_size()
+            view = flat[off:off + nbytes].view(t.dtype).view(t.shape)
+            self._staged['views'][name] = (off, nbytes, t.dtype, tuple(t.shape))
+            if name == 'state':
+                self._staged['state'] = view
+            else:
+                setattr(self, name, view)
+        self.__dict__.pop('_random_io', None)
+
+    _NP = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32}
+
+    def fetch_host(self):
+        """(after stage_outputs) the current state exported + ONE device-to-host copy: dict of NumPy arrays camera_obs, target_obs,
+        scalars, masks, state -- views of one host buffer, valid until the next call."""
+        self.export_state(out=self._staged['state'])
+        host = self._staged['flat'].cpu().numpy()
+        return {name: host[off:off + nbytes].view(self._NP[dtype]).reshape(shape)
+                for name, (off, nbytes, dtype, shape) in self._staged['views'].items()}
+
+    def state_dict_from(self, flat):
+        """state_dict() of an already fetched [N, export_width] f64 array."""
+        if getattr(self, '_export_slices', None) is None:
+            self._export_slices = [(name, off, int(np.prod(shape)) if shape else 1, (self.num_envs,) + tuple(shape))
+                                   for name, (off, shape) in self.export_fields.items()]
+        return {name: flat[:, off:off + n].reshape(shape) for name, off, n, shape in self._export_slices}
 
     def import_state(self, flat):
         flat = flat.to(device=self.device, dtype=torch.float64).contiguous()
@@ -494,12 +536,7 @@ class Engine:
 
     def state_dict(self):
         """All state fields as numpy arrays [N, ...] (host copy)."""
-        flat = self.export_state().cpu().numpy()
-        out = {}
-        for name, (off, shape) in self.export_fields.items():
-            n = int(np.prod(shape)) if shape else 1
-            out[name] = flat[:, off:off + n].reshape((self.num_envs,) + tuple(shape))
-        return out
+        return self.state_dict_from(self.export_state().cpu().numpy())
 
     def load_state_dict(self, fields):
         flat = self.export_state().cpu().numpy()
@@ -566,9 +603,10 @@ class Engine:
         return int(self.lib.mate_engine_last_flow(self._h))
 
     # decoded masks ------------------------------------------------------------
-    def unpack_masks(self, masks=None):
-        """Packed u32 words -> dict of boolean numpy arrays [N, ...] (environment.py:475-494 names)."""
-        words = (self.masks if masks is None else masks).cpu().numpy().astype(np.uint32)
+    def unpack_masks(self, masks=None, words_host=None):
+        """Packed u32 words -> dict of boolean numpy arrays [N, ...] (environment.py:475-494 names).  `words_host`: the words as a
+        NumPy array already on the host (fetch_host)."""
+        words = (words_host if words_host is not None else (self.masks if masks is None else masks).cpu().numpy()).astype(np.uint32)
         N, Nc, Nt, No = self.num_envs, self.num_cameras, self.num_targets, self.num_obstacles
         bits = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool).reshape(N, -1)
         L = self.layout

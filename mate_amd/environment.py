@@ -291,6 +291,9 @@ class MultiAgentTracking(_ScenarioMixin, _EnvBase, metaclass=EnvMeta):
         self._device_index, self._obs_dtype = device, obs_dtype
         self._seed_value = 0
         self.engine = Engine(self.config, 1, device=device, seed=0, obs_dtype=obs_dtype)
+        self.engine.stage_outputs()          # one device-to-host copy per step (Engine.fetch_host)
+        Na = self.engine.num_cameras * consts.CAMERA_ACTION_DIM + self.engine.num_targets * consts.TARGET_ACTION_DIM
+        self._act_dev = torch.zeros(Na, dtype=torch.float64, device=self.engine.device)      # ... and one host-to-device copy of the joint action
         self.num_cameras, self.num_targets, self.num_obstacles = self.engine.num_cameras, self.engine.num_targets, self.engine.num_obstacles
         self._setup_spaces()
         Nc, Nt, No = self.num_cameras, self.num_targets, self.num_obstacles
@@ -394,10 +397,12 @@ class MultiAgentTracking(_ScenarioMixin, _EnvBase, metaclass=EnvMeta):
         """Fresh observations + the metrics of joint_observation (environment.py:966-979), computed here in f64 from the
         exported state and masks as the reference computes them (the engine's own scalar record is f32: the batched
         product dtype)."""
-        self._cache = self._masks = None
-        cam = self.engine.camera_obs[0].to(torch.float64).cpu().numpy() if self.num_cameras else np.zeros((0, self.camera_observation_dim))
-        tgt = self.engine.target_obs[0].to(torch.float64).cpu().numpy()
-        scalars = self.engine.scalars[0].cpu().numpy()
+        host = self.engine.fetch_host()
+        self._cache = {k: v[0] for k, v in self.engine.state_dict_from(host['state']).items()}
+        self._masks = {k: v[0] for k, v in self.engine.unpack_masks(words_host=host['masks']).items()}
+        cam = host['camera_obs'][0].astype(np.float64) if self.num_cameras else np.zeros((0, self.camera_observation_dim))
+        tgt = host['target_obs'][0].astype(np.float64)
+        scalars = host['scalars'][0].copy()
         f = self._fields()
         tracked = self.tracked_bits.astype(bool)
         with_bounty = f['bounties'] > 0
@@ -474,10 +479,11 @@ class MultiAgentTracking(_ScenarioMixin, _EnvBase, metaclass=EnvMeta):
         tgt_act = np.asarray(target_joint_action, dtype=np.float64).reshape(self.num_targets, consts.TARGET_ACTION_DIM)
         assert np.isfinite(cam_act).all(), f'Got unexpected joint action {cam_act}.'
         assert np.isfinite(tgt_act).all(), f'Got unexpected joint action {tgt_act}.'
-        dev = self.engine.device
         tape_ct, tape_goal = self._tapes()
-        self.engine.step(torch.from_numpy(cam_act[None]).to(dev), torch.from_numpy(tgt_act[None]).to(dev), tape_ct=tape_ct, tape_goal=tape_goal,
-                         auto_reset=False)
+        nc = cam_act.size
+        self._act_dev.copy_(torch.from_numpy(np.concatenate([cam_act.ravel(), tgt_act.ravel()])))
+        self.engine.step(self._act_dev[:nc].view(1, self.num_cameras, consts.CAMERA_ACTION_DIM), self._act_dev[nc:].view(1, self.num_targets, consts.TARGET_ACTION_DIM),
+                         tape_ct=tape_ct, tape_goal=tape_goal, auto_reset=False)
         return self._finish_step()
 
     def _finish_step(self):
