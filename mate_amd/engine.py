@@ -517,7 +517,12 @@ class Engine:
         """(after stage_outputs) the current state exported + ONE device-to-host copy: dict of NumPy arrays camera_obs, target_obs,
         scalars, masks, state -- views of one host buffer, valid until the next call."""
         self.export_state(out=self._staged['state'])
-        host = self._staged['flat'].cpu().numpy()
+        pinned = self._staged.get('pinned')
+        if pinned is None:
+            pinned = self._staged['pinned'] = torch.empty(self._staged['flat'].shape, dtype=torch.uint8, pin_memory=True)
+        pinned.copy_(self._staged['flat'], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        host = pinned.numpy().copy()          # (the caller keeps views of it; the pinned buffer is rewritten by the next call)
         return {name: host[off:off + nbytes].view(self._NP[dtype]).reshape(shape)
                 for name, (off, nbytes, dtype, shape) in self._staged['views'].items()}
 
