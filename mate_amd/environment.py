@@ -295,7 +295,6 @@ class MultiAgentTracking(_ScenarioMixin, _EnvBase, metaclass=EnvMeta):
         Na = self.engine.num_cameras * consts.CAMERA_ACTION_DIM + self.engine.num_targets * consts.TARGET_ACTION_DIM
         self._act_dev = torch.zeros(Na, dtype=torch.float64, device=self.engine.device)      # ... and one host-to-device copy of the joint action,
         self._act_host = torch.zeros(Na, dtype=torch.float64, pin_memory=True)               # from page-locked memory
-        self._act_np = self._act_host.numpy()
         self.num_cameras, self.num_targets, self.num_obstacles = self.engine.num_cameras, self.engine.num_targets, self.engine.num_obstacles
         self._setup_spaces()
         Nc, Nt, No = self.num_cameras, self.num_targets, self.num_obstacles
@@ -483,8 +482,9 @@ class MultiAgentTracking(_ScenarioMixin, _EnvBase, metaclass=EnvMeta):
         assert np.isfinite(tgt_act).all(), f'Got unexpected joint action {tgt_act}.'
         tape_ct, tape_goal = self._tapes()
         nc = cam_act.size
-        self._act_np[:nc] = cam_act.ravel()
-        self._act_np[nc:] = tgt_act.ravel()
+        act_np = self._act_host.numpy()
+        act_np[:nc] = cam_act.ravel()
+        act_np[nc:] = tgt_act.ravel()
         self._act_dev.copy_(self._act_host, non_blocking=True)      # (stream-ordered before the step; the next call rewrites the host buffer only after fetch_host's synchronise)
         self.engine.step(self._act_dev[:nc].view(1, self.num_cameras, consts.CAMERA_ACTION_DIM), self._act_dev[nc:].view(1, self.num_targets, consts.TARGET_ACTION_DIM),
                          tape_ct=tape_ct, tape_goal=tape_goal, auto_reset=False)
