@@ -43,6 +43,7 @@ for e in range(n):                       # identical occlusion tables on both si
 MASKS = ['camera_target_view_mask', 'target_camera_view_mask', 'target_obstacle_view_mask', 'target_target_view_mask', 'camera_camera_view_mask']
 INTS = ['tgt_colliding', 'tgt_goals', 'freights', 'bounties', 'remaining_cargoes', 'awaiting_cargo_counts', 'num_delivered_cargoes', 'episode_step']
 bad = np.zeros(n, dtype=bool)
+first_bad = {}                           # environment -> (step, what differed first)
 worst = 0.0
 t0 = time.time()
 rows = None
@@ -58,12 +59,18 @@ for s in range(steps):
     masks = eng.unpack_masks(mask_words)
     for m in MASKS:
         ref = batch.gather(m) != 0
-        bad |= (masks[m].reshape(ref.shape) != ref).reshape(n, -1).any(axis=1)
+        now = (masks[m].reshape(ref.shape) != ref).reshape(n, -1).any(axis=1)
+        for e in np.nonzero(now & ~bad)[0]:
+            first_bad.setdefault(int(e), (s, m))
+        bad |= now
     if (fused > 1 and (s % fused == fused - 1 or s == steps - 1)) or (fused == 1 and (s % 10 == 9 or s == steps - 1)):    # state is current at launch ends
         sdg = eng.state_dict()
         for k in INTS:
             ref = batch.gather(k)
-            bad |= (sdg[k].reshape(ref.shape) != ref).reshape(n, -1).any(axis=1)
+            now = (sdg[k].reshape(ref.shape) != ref).reshape(n, -1).any(axis=1)
+            for e in np.nonzero(now & ~bad)[0]:
+                first_bad.setdefault(int(e), (s, k))
+            bad |= now
         good = ~bad
         worst = max(worst, float(np.abs(sdg['tgt_x'] - batch.gather('tgt_x'))[good].max()), float(np.abs(sdg['tgt_y'] - batch.gather('tgt_y'))[good].max()))
 oc, ot = batch.observe()
@@ -73,3 +80,5 @@ last_scalars = rows[2][(steps - 1) % fused] if fused > 1 else eng.scalars
 rew_equal = bool(np.array_equal(last_scalars[:, 1].cpu().numpy()[~bad], batch.gather('reward_tgt').astype(np.float32)[~bad]))
 print(f'{workload} ({"fused " + str(fused) + "-step launches" if fused > 1 else "one launch per step"}): {n} envs x {steps} steps = {n * steps} env-steps in {time.time() - t0:.0f} s; environments that ever diverged: {int(bad.sum())}; '
       f'max |position error| on the rest {worst:.2e}; final target-obs error {obs_err:.2e}; rewards equal: {rew_equal}')
+if first_bad:
+    print('  first differences (environment: step, field):', '; '.join(f'{e}: {st}, {what}' for e, (st, what) in sorted(first_bad.items())))
