@@ -567,9 +567,9 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if distributed:
+        if distributed:          # (one rank: the barrier is the synchronisation itself; a second one would only add its own 3-4 us to a 0.16 ms region)
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     if args.reps <= 0:
         args.reps = 21 if (R > 0 and args.steps <= R and args.steps * args.batch <= (1 << 18)) else 5
