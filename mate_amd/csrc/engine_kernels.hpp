@@ -170,7 +170,7 @@ struct Ptrs {
     double *dyn;                  // [N][DW] (8-byte words: DF doubles then NI ints)
     double2 *lut_knots;           // [N][Nc][kmax]  (phi, rho)
     uint16_t *lut_bucket;         // [N][Nc][nbucket]
-    double2 *lut_deg;             // [N][Nc][360][kDegWords] per-degree segment records (fast lookup path)
+    double2 *lut_deg;             // [N][Nc][kLutCells][kDegWords] per-cell segment records (fast lookup path; kCellsPerDegree cells per degree)
     int32_t *lut_count;           // [N][Nc]
     double2 *lut_knots_outer;     // optional (mate_engine_enable_outer_boundary): [N][Nc][kmax_outer] knots of Camera.boundary_outer
     int32_t *lut_count_outer;     // [N][Nc]
