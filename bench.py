@@ -14,9 +14,11 @@ eight such launches, or K itself when K is smaller -- the driver's `--steps 20` 
 keeps an environment's records in LDS across the R steps and writes every step's observations,
 rewards and masks to [R][N][...] buffers; an environment whose episode ends inside a rollout
 idles until the reset launch that follows it, and those idle slots are NOT counted in `value`);
-`--rollout 0` launches step_kernel once per step, and the default run reports that mode too
-(`per_step_launch`), as well as the learner-in-the-loop flow (`external_actions`: step(actions) with the joint actions in a
-caller-owned device buffer, the step + auto-reset launch pairs replayed from one HIP graph).
+`--rollout 0` launches step_kernel once per step.  The default run also reports the flows a LEARNER calls, one launch per
+step (`learner_flows`, measure_learner_flows: `per_step_launch`, `external_actions` = step(actions) with the joint actions in a
+caller-owned device buffer rewritten by a policy kernel before every step, `versus_greedy` = MultiCamera(GreedyTargetAgent) with the
+opponents on the device, and the same batch as two groups on two streams), each replayed from HIP graphs, at 4096, 16 384 and
+65 536 environments; the headline batch's entries also stand at the top level of the line.
 
 Timing: W untimed warm-up steps (plus one untimed launch of every launch shape of the timed region, so that no
 buffer is allocated and no kernel is first loaded inside it), then the timed region of EXACTLY K steps, bracketed by a
@@ -80,8 +82,9 @@ sys.path.insert(0, ROOT)
 
 WORKLOAD = 'MATE-4v8-9.yaml'
 BATCH_PER_GPU = 4096
+LEARNER_BATCHES = (4096, 16384, 65536)     # `learner_flows` of the default line: the per-step flows at the batches a learner on one MI355X runs
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
-HBM_PEAK_MEASURED_GBS = 6290.0   # device-to-device copy on this pool (tools/pmc_calibrate.py, profiles/README.md)
+HBM_PEAK_MEASURED_GBS = 6290.0   # device-to-device copy on this pool (tools/pmc_calibrate.py, profiles/README.md); the line reports the rate measured IN the run (measure_hbm_copy_peak)
 # `--rollout 0` (one launch per step in the main timed region): every 17th step_kernel launch carries dispatch events (a stride
 # coprime to the reset interval).  The per_step_launch side measurement times its kernel in a pass of its own, see there.
 STEP_SAMPLE = 17
@@ -326,7 +329,7 @@ def measure_other_config(torch, device_index, spec, seconds, buffer_gib):
         R = next((r for r in (256, 128, 64, 32) if r <= cap), max(1, cap))
         resets, fn, kernel = max(1, 128 // R), eng.rollout_random, 'rollout_kernel'
     eng.reset()
-    eng.reserve_rollout(R)
+    eng.reserve_rollout(R, search='deep')
     for _ in range(2 * resets):
         fn(R, auto_reset=resets)
     torch.cuda.synchronize()
@@ -397,6 +400,146 @@ def measure_n1_api(torch, steps=1500):
            'value': len(history) / elapsed, 'unit': 'env-steps/s', 'steps': len(history), 'seconds': elapsed,
            'reference_numpy': 1101.0, 'reference_note': 'mate/evaluate.py FPS of the reference on one core of the build container (BASELINE.md section 2)'}
     env.close()
+    return out
+
+
+def measure_hbm_copy_peak(torch, device_index, gib=1.0, reps=5):
+    """The rate of a plain device-to-device copy ON THIS BOX, in this run: a 1 GiB tensor copied `reps` times, the median of the
+    timed copies, read + write bytes per second (the figure `roofline.peak_measured` used to take from a constant measured on
+    another box of the pool)."""
+    n = int(gib * (1 << 30))
+    with torch.cuda.device(device_index):
+        a = torch.empty(n, dtype=torch.uint8, device='cuda')
+        b = torch.empty_like(a)
+        a.zero_()
+        b.copy_(a)
+        torch.cuda.synchronize()
+        rates = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            rates.append(2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del a, b
+        torch.cuda.empty_cache()
+    return sorted(rates)[len(rates) // 2]
+
+
+def measure_learner_flows(torch, device_index, workload, batch, graph_steps, reset_interval, world=1):
+    """The flows a learner calls, one launch (or one launch + the learner's own kernel) per step, at `batch` environments:
+      per_step_launch   step_random: the engine's step kernel back to back, no caller kernel in between
+      external_actions  step(actions): the joint actions in a caller-owned f32 buffer that a stand-in policy kernel rewrites before
+                        every step (mate/environment.py:590-676 behind a learner), `graph_steps` (policy, step) pairs per HIP graph
+      versus_greedy     MultiCamera(GreedyTargetAgent) (mate/wrappers/single_team.py:245-264; every examples/*/camera/config.py): the
+                        learner's stand-in policy kernel writes the camera team's joint action, the on-device greedy targets act and
+                        the environment steps in ONE launch (step_greedy_kernel)
+      external_actions_two_groups   the same batch as two half-batch engines on two streams, graphs replayed alternately -- a learner
+                        that alternates between two groups of environments (double-buffered sampling): one group's step runs under
+                        the other group's policy and launch ramp
+    each timed over whole graphs (median of three passes), with one reset launch per `reset_interval` steps; idle slots of finished
+    environments are excluded from `value`.  `kernel_avg_us` / `roofline_frac`: a separate pass of direct launches with a
+    dispatch-event pair on every launch."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config(workload)
+    G = max(int(graph_steps), reset_interval)
+    G -= G % reset_interval
+    steps = max(G, (1024 if batch <= 16384 else 256) // G * G)
+    out = {'batch': batch, 'workload': workload, 'steps': steps, 'reset_interval': reset_interval, 'graph_steps': G}
+
+    def timed(run, idle, n_envs):
+        run(2 * G)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(3):
+            i0, t0 = idle(), time.perf_counter()
+            run(steps)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            times.append((dt, n_envs * steps - (idle() - i0)))
+        return sorted(times)[1]
+
+    def entry(eng, dt, executed, kernel=None, km=0.0, flow=None):
+        b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
+        e = {'value': executed * world / dt, 'unit': 'env-steps/s', 'us_per_step': dt / steps * 1e6,
+             'end_to_end_frac': b_alg * executed / dt / 1e9 / HBM_PEAK_GBS}
+        if kernel:
+            e.update({'kernel': kernel, 'kernel_avg_us': km * 1e3, 'roofline_frac': b_alg * batch / (km * 1e-3) / 1e9 / HBM_PEAK_GBS if km > 0 else 0.0})
+        if flow:
+            e['flow'] = flow
+        return e
+
+    with torch.cuda.device(device_index):
+        # ---- step_random, direct launches (the host enqueues ahead of the GPU from 4096 environments on)
+        eng = Engine(cfg, batch, device=device_index, seed=0)
+        eng.reset()
+        dt, ex = timed(lambda n: [eng.step_random(auto_reset=reset_interval) for _ in range(n)], eng.idle_steps, batch)
+        eng.kernel_time(enable=1)
+        for _ in range(256):
+            eng.step_random(auto_reset=reset_interval)
+        torch.cuda.synchronize()
+        km, _ = eng.kernel_time(enable=False)
+        out['per_step_launch'] = entry(eng, dt, ex, 'step_kernel', km)
+        # ---- step(actions) from a HIP graph
+        ext = ExternalActions(torch, eng, G, reset_interval)
+        dt, ex = timed(ext.run, eng.idle_steps, batch)
+        out['external_actions'] = entry(eng, dt, ex, flow=f'step(actions): f32 joint actions rewritten by a policy kernel in a caller-owned device buffer before every step; '
+                                                              f'{ext.graph_steps} (policy kernel, step) pairs + one reset launch per {reset_interval} steps per HIP graph replay')
+        ext.stepper.close()
+        eng.close()
+        del ext, eng
+        torch.cuda.empty_cache()
+        # ---- learner versus the on-device greedy opponents
+        eng = Engine(cfg, batch, device=device_index, seed=0)
+        if eng.num_cameras:
+            eng.enable_policies()
+            eng.reset()
+            mine = (torch.rand((batch, eng.num_cameras, 2), device=eng.device) * 2 - 1) * torch.tensor([5.0, 2.5], device=eng.device)
+            st = eng.make_stepper(mine, None, auto_reset=reset_interval, graph_steps=G, between=lambda: mine.mul_(-1.0), versus='camera')
+            dt, ex = timed(st.run, eng.idle_steps, batch)
+            st.close()
+            eng.kernel_time(enable=1)
+            for _ in range(256):
+                eng.step_versus_greedy('camera', mine, auto_reset=reset_interval)
+            torch.cuda.synchronize()
+            km, _ = eng.kernel_time(enable=False)
+            out['versus_greedy'] = entry(eng, dt, ex, 'step_greedy_kernel' if eng.last_flow == 4 else 'rollout_greedy_kernel (one step)', km,
+                                         flow='MultiCamera(GreedyTargetAgent): the learner\'s stand-in policy (one elementwise kernel) writes the camera team\'s joint action, '
+                                              'the greedy targets act and the environment steps in one launch; executed env-steps (idle slots of finished episodes excluded)')
+            del st, mine
+        eng.close()
+        del eng
+        torch.cuda.empty_cache()
+        # ---- two half-batch groups on two streams
+        if batch % 2 == 0 and batch >= 2048:
+            half = batch // 2
+            streams = [torch.cuda.Stream(device=device_index), torch.cuda.Stream(device=device_index)]
+            engs, exts = [], []
+            for gi in range(2):
+                with torch.cuda.stream(streams[gi]):
+                    e = Engine(cfg, half, device=device_index, seed=0, first_env_index=gi * half)
+                    e.reset()
+                    engs.append(e)
+                    exts.append(ExternalActions(torch, e, G, reset_interval))
+            torch.cuda.synchronize()
+
+            def run_two(n):
+                for _ in range(n // G):
+                    for gi in range(2):
+                        with torch.cuda.stream(streams[gi]):
+                            exts[gi].run(G)
+
+            dt, ex = timed(run_two, lambda: engs[0].idle_steps() + engs[1].idle_steps(), batch)
+            out['external_actions_two_groups'] = entry(engs[0], dt, ex, flow=f'two engines of {half} environments (global indices 0.. and {half}..) on two streams, their HIP graphs replayed alternately: '
+                                                                                'us_per_step = per step of the WHOLE batch')
+            for x in exts:
+                x.stepper.close()
+            for e in engs:
+                e.close()
+            del exts, engs
+            torch.cuda.empty_cache()
     return out
 
 
@@ -506,6 +649,8 @@ def main():
     rollout = lambda n, auto_reset=True: rollout_fn(n, auto_reset=rollout_resets)     # noqa: E731
     gather = StatsGather(torch, dist, distributed, eng, host_staged=host_staged) if args.stats_interval > 0 else None
 
+    gather_inside = [False]      # a short region's one gather: its marker BEHIND the region's last launch (it carries the region's own episodes) instead of ahead of the region
+
     def run(steps, timed=False):
         """exactly `steps` env.step()s of the whole batch"""
         if external is not None:
@@ -520,11 +665,11 @@ def main():
             # last one, where its copy + collective would sit between the kernel's end and the region's closing synchronise
             # (15 us of a 200 us region at the driver's `--steps 20`)
             short = timed and gather is not None and len(lengths) < args.stats_interval
-            if short and not gather.marked:
+            if short and not gather.marked and not gather_inside[0]:
                 gather.mark()            # (an event record: the copy + collective are enqueued behind the first launch, below,
             for i, n in enumerate(lengths):          # so that the host prepares them while the GPU already runs it)
                 rollout(n, auto_reset=True)
-                if timed and gather is not None and ((i + 1) % args.stats_interval == 0 or (short and i == 0)):
+                if timed and gather is not None and ((i + 1) % args.stats_interval == 0 or (short and i == (len(lengths) - 1 if gather_inside[0] else 0))):
                     gather.submit()
         else:
             every = args.stats_interval * 128
@@ -541,7 +686,9 @@ def main():
     torch.cuda.synchronize()
     startup['first_reset_s'] = time.perf_counter() - t_phase
     if R > 0:
-        eng.reserve_rollout(R)       # [R][N][...] output buffers: allocated here, never inside the timed region
+        # [R][N][...] output buffers: allocated here, never inside the timed region.  This process owns the GPU, so it asks for the
+        # deep search of the observation blocks (seconds, and a transient footprint of up to 45 % of the free HBM: Engine.reserve_rollout)
+        eng.reserve_rollout(R, search='deep')
         startup['reserve_rollout_s'] = eng.reserve_seconds
     run(args.warmup)
     # one untimed pass over every launch shape of the timed region (kernel code objects loaded, graphs instantiated)
@@ -575,13 +722,19 @@ def main():
         args.reps = 21 if (R > 0 and args.steps <= R and args.steps * args.batch <= (1 << 18)) else 5
     from mate_amd.distributed import reduce_job
     startup['startup_s'] = time.perf_counter() - t_main      # everything of this rank's main() before the first pass through the measuring loop
+    short_region = (R > 0 and -(-args.steps // R) < args.stats_interval) or (R == 0 and external is None and args.steps < args.stats_interval * 128)
     rep_ms, rep_executed, kernel_times = [], [], []
-    for rep in range(max(0, args.rep_warmup) + max(1, args.reps)):
+    inside_ms, inside_executed = [], []      # the same repetitions once more with the short region's gather marker INSIDE the region (see gather_inside)
+    n_main = max(0, args.rep_warmup) + max(1, args.reps)
+    n_inside = max(1, args.reps) if (gather is not None and short_region and R > 0 and not args.dump) else 0
+    for rep_index in range(n_main + n_inside):
+        rep = rep_index if rep_index < n_main else n_main       # (the second pass needs no warm-up repetitions of its own)
+        gather_inside[0] = rep_index >= n_main
         eng.kernel_time(enable=1 if R > 0 else STEP_SAMPLE)   # HIP-event pair around every launch of the dominant kernel (every 17th one-step launch)
         # a region shorter than the gather interval gathers the episodes finished BEFORE it (see run): the marker of what that
         # gather may read is recorded here, behind the previous repetition's last launch -- an event record in front of the
         # region's only launch delays it by 4 us (tools/region_probe.py); the gather itself is enqueued inside the region
-        if gather is not None and ((R > 0 and -(-args.steps // R) < args.stats_interval) or (R == 0 and external is None and args.steps < args.stats_interval * 128)):
+        if gather is not None and short_region and not gather_inside[0]:
             gather.mark()
         barrier()
         idle0 = eng.idle_steps()
@@ -602,8 +755,14 @@ def main():
             if gather is not None:
                 gather.count = 0
             continue                                  # an untimed pass through the measuring loop
+        if gather_inside[0]:
+            kernel_times.pop()
+            inside_ms.append(elapsed * 1e3)
+            inside_executed.append(executed)
+            continue
         rep_ms.append(elapsed * 1e3)
         rep_executed.append(executed)
+    gather_inside[0] = False
     order = sorted(range(len(rep_ms)), key=lambda i: rep_ms[i])
     mid = order[len(order) // 2]                      # the median repetition (upper median for an even count)
     elapsed, executed = rep_ms[mid] * 1e-3, rep_executed[mid]
@@ -625,53 +784,8 @@ def main():
                     'scalars': eng.scalars.cpu(), 'episode_stats': eng.episode_stats.cpu(), 'idle_steps': eng.idle_steps(),
                     'last_rollout_scalars': (eng._rollout['scalars'].cpu() if getattr(eng, '_rollout', None) else None)},
                    f'{args.dump}.rank{rank}.pt')
-    extras = {}
-    if not args.no_extras and args.policy == 'random' and R > 0 and not args.dump:
-        # the same workload with one step_kernel launch per step, and with externally supplied actions (learner in the loop)
-        k2 = min(max(args.steps, 256), 1024)
-        k2 -= k2 % 64                            # whole reset intervals and whole graphs
-        for name in ('per_step_launch', 'external_actions'):
-            if name == 'external_actions':
-                ext = ExternalActions(torch, eng, args.graph_steps, args.step_reset_interval)
-                runner = ext.run
-            else:
-                runner = lambda n: [step() for _ in range(n)]     # noqa: E731
-            runner(max(args.graph_steps, 1) * 2)
-            times = []
-            for _ in range(3):          # the rate: no dispatch events anywhere (they cost the host 4-5 us per launch)
-                eng.kernel_time(enable=False)
-                barrier()
-                idle1 = eng.idle_steps()
-                t1 = time.perf_counter()
-                runner(k2)
-                barrier()
-                e2 = time.perf_counter() - t1
-                times.append((e2, args.batch * k2 - (eng.idle_steps() - idle1)))
-            e2, ex2 = sorted(times)[1]
-            # the kernel's own duration: a separate pass with a dispatch-event pair on EVERY launch.  Sampled every k-th launch
-            # among event-less ones (rounds 1-3: every 16th), a launch's start stamp is taken while its event-less predecessor is
-            # still draining: the figure came out 1.5-2 us ABOVE the end-to-end time per step of the same loop
-            km2 = 0.0
-            if name == 'per_step_launch':
-                eng.kernel_time(enable=1)
-                runner(512)
-                barrier()
-                km2, _ = eng.kernel_time(enable=False)
-            b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
-            extras[name] = {'value': ex2 * world / e2, 'unit': 'env-steps/s', 'steps': k2, 'ms_per_step': e2 / k2 * 1e3,
-                            'kernel': 'step_kernel', 'kernel_avg_us': km2 * 1e3,
-                            'roofline_frac': (b_alg * args.batch / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS) if km2 > 0 else 0.0,
-                            'end_to_end_frac': b_alg * ex2 / e2 / 1e9 / HBM_PEAK_GBS}
-            extras[name]['reset_interval'] = args.step_reset_interval
-            if km2 <= 0:                         # launches replayed from a graph carry no dispatch events
-                del extras[name]['kernel_avg_us'], extras[name]['roofline_frac']
-            if name == 'external_actions':
-                extras[name]['flow'] = ((f'step(actions): f32 joint actions rewritten by a policy kernel in a caller-owned device buffer before every step; '
-                                         f'{ext.graph_steps} (policy kernel, step) pairs + one reset launch per {args.step_reset_interval} steps per HIP graph replay')
-                                        if args.graph_steps > 0 else 'step(actions), direct launches')
-                ext.stepper.close()
-
     if rank == 0:
+        copy_peak = measure_hbm_copy_peak(torch, local_rank) if not args.dump else HBM_PEAK_MEASURED_GBS
         total_envs = args.batch * world
         value = executed / elapsed            # == total_envs * steps / elapsed unless environments idled for a batched reset
         b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
@@ -701,8 +815,10 @@ def main():
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
                 'traffic': measured_traffic(kernel, steps_per_launch, args.batch) if (headline_case and float(steps_per_launch).is_integer()) else None,
-                'traffic_unit': 'bytes per launch (rocprofv3 2*FETCH_SIZE + WRITE_SIZE of this kernel at this launch length, profiles/latest_pmc.json)',
-                'peak_measured': HBM_PEAK_MEASURED_GBS, 'frac_of_measured_peak': achieved / HBM_PEAK_MEASURED_GBS,
+                'traffic_unit': 'bytes per launch (rocprofv3 2*FETCH_SIZE + WRITE_SIZE of this kernel at this launch length)',
+                'traffic_source': 'profiles/latest_pmc.json: PMC passes of the builder on a box of the same pool (tools/pmc_collect.py), NOT collected in this run',
+                'peak_measured': copy_peak, 'frac_of_measured_peak': achieved / copy_peak,
+                'peak_measured_source': 'device-to-device copy of 1 GiB on this box in this run, median of 5 (read + write bytes)',
                 'kernel': '%s<float, %s, %s>' % (kernel, 'FixedShape' if eng.specialised else 'AnyShape', ('FLOW_ANY', 'FLOW_RANDOM', 'FLOW_ACT_F32', 'FLOW_GREEDY')[flow]),
                 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches, 'env_steps_per_launch': args.batch * steps_per_launch,
                 'algorithmic_bytes_per_launch': bytes_per_launch,
@@ -717,15 +833,23 @@ def main():
             'episode_stats': {'mean_target_reward': float(stats[0]), 'mean_coverage_rate': float(stats[1]),
                               'mean_delivered': float(stats[2]), 'gathered_in_loop': gathered_stats},
         }
-        line.update(extras)
         line['startup'] = startup_line
-        short_region = (R > 0 and -(-args.steps // R) < args.stats_interval) or (R == 0 and external is None and args.steps < args.stats_interval * 128)
         line['episode_stats']['stats_gather'] = (
             'none' if gather is None else
             'region shorter than the gather interval: ONE gather per repetition, copy + collective enqueued on the side stream inside the region behind its '
             'first launch; the marker of what it may read is recorded BEFORE the region (behind the previous repetition), so it carries the episodes '
             'finished before this region, not its own' if short_region else
             f'every {args.stats_interval} launches inside the region, each behind the launch whose episodes it carries')
+        if inside_ms:      # the same region under the other definition, so that both stand in one line
+            order_i = sorted(range(len(inside_ms)), key=lambda i: inside_ms[i])
+            mid_i = order_i[len(order_i) // 2]
+            line['gather_marker'] = {
+                'before': {'value': value, 'ms_per_step': elapsed / args.steps * 1e3},
+                'inside': {'value': inside_executed[mid_i] / (inside_ms[mid_i] * 1e-3), 'ms_per_step': inside_ms[mid_i] / args.steps,
+                           'rep_ms': [round(v, 4) for v in inside_ms]},
+                'note': '`value` is the `before` form: the one statistics gather of a region shorter than the gather interval reads what finished BEFORE the region '
+                        '(marker recorded behind the previous repetition, copy + collective under the region\'s launch).  `inside`: the marker behind the region\'s last launch '
+                        '-- the gather carries the region\'s own episodes, and its copy + collective sit between the kernel\'s end and the closing synchronise'}
         line['config']['backend'] = ('gloo (ranks may share a GPU; statistics staged through the host)' if host_staged else 'nccl (RCCL)') if distributed else 'single process'
         line['config']['collectives'] = ('forced on one rank: barrier, side-stream all_gather, job reduction' if args.force_collectives and world == 1
                                          else 'barrier, side-stream all_gather, job reduction' if distributed else 'none (one rank)')
@@ -738,6 +862,18 @@ def main():
             eng._rollout = None
             torch.cuda.empty_cache()
             line['other_configs'] = [measure_other_config(torch, local_rank, spec, args.other_seconds, args.buffer_gib) for spec in OTHER_CONFIGS]
+        if world == 1 and not args.no_extras and args.policy == 'random' and R > 0 and not args.dump:
+            # the learner-facing per-step flows, at this run's batch and -- the default line -- at the two larger
+            # batches a learner on one MI355X runs; the headline batch's entries also stand at the top level of the line
+            eng.close()
+            eng._rollout = None
+            torch.cuda.empty_cache()
+            batches = [args.batch] + ([b for b in LEARNER_BATCHES if b != args.batch] if default_case else [])
+            flows = [measure_learner_flows(torch, local_rank, args.workload, b, args.graph_steps, args.step_reset_interval) for b in batches]
+            line['learner_flows'] = flows
+            for key in ('per_step_launch', 'external_actions', 'versus_greedy'):
+                if key in flows[0]:
+                    line[key] = dict(flows[0][key], batch=args.batch, reset_interval=args.step_reset_interval)
         if default_case and not args.no_side_measurements and not args.dump:
             line['n1_api'] = measure_n1_api(torch)
         if not args.no_cpu_baseline and world == 1 and args.policy == 'random' and args.workload == WORKLOAD:

@@ -38,6 +38,9 @@
  *                            row-image compilation (same rows; tests compare the two)
  *   MATE_POLICY_SPLIT=1      mate_engine_step_greedy / _step_versus_greedy as two launches (the agents' kernel, then the step
  *                            kernel) even where the fused one-launch form applies (same results; tests compare the two)
+ *   MATE_STEP_GREEDY_ROLLOUT=1  the one-launch form of mate_engine_step_greedy / _step_versus_greedy on the fused rollout kernel with a
+ *                            single step (rounds 3-4) instead of step_greedy_kernel (policy_kernels.hpp: the per-step kernel's own
+ *                            sequence with the agents in front; same results, tests compare the two)
  *   MATE_STEP_SPLIT=0|1      the per-step kernel of the folded flows (step_random / step with real-valued actions, f32 observations)
  *                            as one wave per environment (0) or two (1: cameras, sector tests and goals on one wave, targets
  *                            and range tests on the other; engine_kernels.hpp: step_split_kernel); default: by what measured
@@ -48,6 +51,9 @@
  *   MATE_BLOCK_FREE_RANGE=1  mate_engine_block_free also gives the block's virtual address range back (hipMemAddressFree) instead
  *                            of keeping it reserved for the life of the process (read once, at the first block_free).  Unsafe on
  *                            this driver: a range handed out again lost stores of the next kernel (tools/va_reuse.hip)
+ *   MATE_BLOCK_DEAD_GIB=g    address space [GiB] that freed blocks may keep reserved per process (default 4096 of the 131072 a process
+ *                            has): beyond it mate_engine_block_alloc fails with MATE_ENOMEM and the caller uses plain device memory
+ *                            (read once, at the first block_alloc)
  *   MATE_PIPELINED_SERIAL=1  pipelined restarts (MATE_RESET_PIPELINED) with the resets on the caller's stream: the reference form
  *                            the tests compare the concurrent one with; MATE_PIPELINED_PRIORITY=0: the side stream at the default
  *                            priority instead of the device's lowest (both read when the mode is first entered)
@@ -56,11 +62,13 @@
  * unit up to the CPU count); and (mate_amd/engine.py), once, when an Engine object is built -- they steer where
  * Engine.reserve_rollout puts the [steps][N][...] observation blocks of the fused rollouts, never what is written there:
  *   MATE_PLAIN_BLOCKS=1      blocks from torch.zeros instead of mate_engine_block_alloc
- *   MATE_BLOCK_CANDIDATES=n  at most n candidates probed per block (default 6; the deep search of the target block: as
- *                            many as its memory and time bounds allow)
- *   MATE_BLOCK_DEEP=0        no deep search (candidates separated by unmapped 12 GB spacers) for the target block
- *   MATE_BLOCK_SECONDS=s     wall-time bound of the deep search (default 3)
- *   MATE_BLOCK_GIB=g         bound of its transient footprint in GiB (default 96; always at most 45 % of the free memory)
+ *   MATE_BLOCK_CANDIDATES=n  at most n candidates probed per block (default 3, allocated side by side; 6 and -- for the target block --
+ *                            as many as the memory and time bounds allow in a deep search; n <= 1: one block, unprobed)
+ *   MATE_BLOCK_DEEP=1        the deep search (candidates separated by unmapped 12 GB spacers: a walk through the device's memory)
+ *                            for the target block even when reserve_rollout is not asked for it (search='deep': bench.py does;
+ *                            off by default since round 5 -- a co-resident learner should not see 45 % of the HBM vanish for seconds)
+ *   MATE_BLOCK_SECONDS=s     wall-time bound of the search (default 0.3; deep: 3)
+ *   MATE_BLOCK_GIB=g         bound of the deep search's transient footprint in GiB (default 96; always at most 45 % of the free memory)
  *   MATE_STORE_FORM=0|1      force the form of the row stores (mate_engine_set_store_form) instead of choosing by the probed rate
  */
 #ifndef MATE_ENGINE_H
@@ -365,7 +373,9 @@ int mate_engine_kernel_time(mate_engine *engine, int32_t enable, double *avg_ms,
 /* Which compilation of the step kernel the last step()/step_random() launch ran: 0 = the generic flow (every launch
  * switch read on the device), 1 = the on-device random policy flow, 2 = the f32-continuous-actions flow.  1 and 2 are
  * the same code with the switches folded at compile time (no tapes, no discrete actions, plain observations, all four
- * outputs present, immediate auto-reset); results are bit-identical.  MATE_FLOW_GENERIC=1 forces 0. */
+ * outputs present, immediate auto-reset); results are bit-identical.  MATE_FLOW_GENERIC=1 forces 0.
+ * After a launch with the on-device agents: 3 = rollout_greedy_kernel (the fused rollouts; a per-step call under
+ * MATE_STEP_GREEDY_ROLLOUT=1), 4 = step_greedy_kernel (the one-launch form of step_greedy / step_versus_greedy). */
 int mate_engine_last_flow(const mate_engine *engine);
 
 /* Device memory for the [steps][N][...] observation blocks of the fused rollouts (mate_step_io.camera_obs_dev /

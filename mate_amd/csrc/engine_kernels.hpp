@@ -299,6 +299,7 @@ enum Flow : int {
     FLOW_RANDOM = 1,    // step_random: on-device uniform policy, Philox draws, plain observations, all outputs present
     FLOW_ACT_F32 = 2,   // step: real-valued joint actions (f32 or f64, per team: Ptrs::act_f64), Philox draws, plain observations, all outputs present
     FLOW_GREEDY = 3,    // rollout_greedy_kernel: joint actions of the on-device Greedy agents, handed over in LDS
+    FLOW_STEP_GREEDY = 4,   // step_greedy_kernel (policy_kernels.hpp): ONE (agents act, environment steps) iteration per launch with the per-step flows' semantics
 };
 
 template <typename ObsT>
@@ -356,8 +357,8 @@ struct Ctx {
     // (one of the two summands is always zero: the host keeps dev_group = 0 while it counts itself and passes parity = 0 otherwise)
     __device__ __forceinline__ int32_t list_parity() const { return (int32_t)((p.dev_group + (uint32_t)g.parity) & 1u); }
     // launch switches (constants in the specialised flows)
-    __device__ __forceinline__ int mode() const { return flow == FLOW_RANDOM ? (int)MODE_STEP_RANDOM : (flow == FLOW_ACT_F32 || flow == FLOW_GREEDY) ? (int)MODE_STEP : g.mode; }
-    __device__ __forceinline__ bool act_from_lds() const { return flow == FLOW_GREEDY; }
+    __device__ __forceinline__ int mode() const { return flow == FLOW_RANDOM ? (int)MODE_STEP_RANDOM : (flow == FLOW_ACT_F32 || flow == FLOW_GREEDY || flow == FLOW_STEP_GREEDY) ? (int)MODE_STEP : g.mode; }
+    __device__ __forceinline__ bool act_from_lds() const { return flow == FLOW_GREEDY || flow == FLOW_STEP_GREEDY; }
     // FLOW_ACT_F32 (the single-step kernels): an agent's lane fetches its own action together with the records, into the StepDraws
     // the kinematics read anyway (prefetch_action) -- read where it is used, behind the LDS commit, the load's round trip to
     // L2 / HBM lay bare on every wave's critical path (1.4 us of a 14 us step)
@@ -371,7 +372,7 @@ struct Ctx {
     __device__ __forceinline__ const double *tape_goal() const { return flow != FLOW_ANY ? nullptr : g.tape_goal; }
     __device__ __forceinline__ int obs_mode() const { return flow != FLOW_ANY ? 0 : g.obs_mode; }
     __device__ __forceinline__ const uint2 *xdesc() const { return flow != FLOW_ANY ? nullptr : g.xdesc; }
-    __device__ __forceinline__ bool freeze_done() const { return flow == FLOW_GREEDY ? false : g.freeze_done != 0; }
+    __device__ __forceinline__ bool freeze_done() const { return (flow == FLOW_GREEDY || flow == FLOW_STEP_GREEDY) ? false : g.freeze_done != 0; }
     __device__ __forceinline__ bool has_scratch_init() const { return flow != FLOW_ANY ? true : g.scratch_init != nullptr; }
     __device__ __forceinline__ bool has_cam_obs() const { return flow != FLOW_ANY ? true : g.cam_obs != nullptr; }
     __device__ __forceinline__ bool has_tgt_obs() const { return flow != FLOW_ANY ? true : g.tgt_obs != nullptr; }

@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -73,8 +74,9 @@ static int fail(int code, const char *fmt, ...) {
 // workgroups fit a CU -- 3072 of the 4096 environments of a MATE-4v8-9 batch resident -- and a second pass costs more than
 // the packer's instructions.)
 static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no_image, StepFn *step, StepFn *rollout, PolicyFn *policy, PolicyFn *rollout_greedy,
-                         int *specialised, int *image, StepFn *split) {
+                         int *specialised, int *image, StepFn *split, PolicyFn *step_greedy) {
     *specialised = 0; *image = 0;
+    *step_greedy = f64 ? nullptr : (PolicyFn)step_greedy_kernel<float, AnyShape>;
     for (int i = 0; i < 3; ++i) split[i] = nullptr;      // the two-wave step (step_split_kernel): f32 observations, the folded flows
     if (!generic) {
         KernelSet k{};
@@ -83,7 +85,7 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no
             pick_kernels_group4(Nc, Nt, No, f64, no_image, &k) || pick_kernels_group5(Nc, Nt, No, f64, no_image, &k)) {
             for (int i = 0; i < 3; ++i) { step[i] = k.step[i]; split[i] = k.split[i]; }
             rollout[0] = k.rollout[0]; rollout[1] = k.rollout[1];
-            *policy = k.policy; *rollout_greedy = k.rollout_greedy;
+            *policy = k.policy; *rollout_greedy = k.rollout_greedy; *step_greedy = k.step_greedy;
             *specialised = 1; *image = k.image;
             return;
         }
@@ -110,6 +112,7 @@ struct Switches {
     bool policy_split = false;     // MATE_POLICY_SPLIT=1: step_greedy / step_versus_greedy as two launches (agents' kernel, step kernel) even when the fused one-launch form applies
     int step_split = -1;           // MATE_STEP_SPLIT=0 / 1: the one-wave / two-wave form of the per-step kernel in the folded flows (-1: by batch size)
     bool zoom_iterate = false;     // MATE_ZOOM_ITERATE=1: the greedy camera agents iterate the zoom solve (greedy.py:139-145) instead of reading its table
+    bool step_greedy_rollout = false;   // MATE_STEP_GREEDY_ROLLOUT=1: the one-launch form of step_greedy / step_versus_greedy on rollout_greedy_kernel with one step (round 3) instead of step_greedy_kernel
 };
 static Switches read_switches() {
     Switches w;
@@ -122,6 +125,7 @@ static Switches read_switches() {
     if (const char *v = getenv("MATE_ROLLOUT_ROTATE")) w.rollout_rotate = atoi(v);
     w.zoom_iterate = flag("MATE_ZOOM_ITERATE");
     w.policy_split = flag("MATE_POLICY_SPLIT");
+    w.step_greedy_rollout = flag("MATE_STEP_GREEDY_ROLLOUT");
     w.no_image = flag("MATE_NO_IMAGE");
     if (const char *v = getenv("MATE_STEP_SPLIT")) w.step_split = atoi(v) != 0;
     return w;
@@ -157,6 +161,7 @@ struct mate_engine {
     int image = 0;                         // the fused rollouts (random-policy flow, greedy) run their row-image compilation ...
     size_t image_wave_bytes = 0;           // ... whose per-environment LDS slice is this
     PolicyFn policy_fn = nullptr, rollout_greedy_fn = nullptr;
+    PolicyFn step_greedy_fn = nullptr;     // step_greedy_kernel: the per-step flows with the on-device agents as ONE launch (f32 observations), or null
     StepFn split_fn[3] = {nullptr, nullptr, nullptr};      // step_split_kernel per flow (two waves per environment), or null
     int split_on = 0;                                      // ... and whether launch_step uses it (MATE_STEP_SPLIT, or the batch is one resident generation)
     StepFn step_fn[3] = {nullptr, nullptr, nullptr}, rollout_fn[2] = {nullptr, nullptr};   // kernels chosen at create: shape-specialised when compiled for these counts; step_fn[flow]
@@ -193,7 +198,8 @@ static hipError_t wait_for_launches(mate_engine *e) {
     if (e->pipelined && leave_pipelined(e, e->last_stream) != MATE_OK) return hipErrorUnknown;      // (resets still running on the side stream)
     hipError_t err = e->multi_stream ? hipErrorInvalidHandle : hipStreamSynchronize(e->last_stream);
     if (err != hipSuccess) { (void)hipGetLastError(); e->last_stream = nullptr; err = hipDeviceSynchronize(); }
-    if (err == hipSuccess) e->multi_stream = false;
+    // everything launched so far has drained: the bookkeeping starts afresh (the next launch, on whatever stream, is the only one in flight)
+    if (err == hipSuccess) { e->multi_stream = false; e->launched = false; }
     return err;
 }
 
@@ -370,7 +376,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.first_env = (uint32_t)first_env_index;
     e->step_lds = 4 * (size_t)p.lds_wave_bytes;
     e->sw = read_switches();
-    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->sw.generic, e->sw.no_image, e->step_fn, e->rollout_fn, &e->policy_fn, &e->rollout_greedy_fn, &e->specialised, &e->image, e->split_fn);
+    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->sw.generic, e->sw.no_image, e->step_fn, e->rollout_fn, &e->policy_fn, &e->rollout_greedy_fn, &e->specialised, &e->image, e->split_fn, &e->step_greedy_fn);
     { Params pi = p; fill_shape(pi, Nc, Nt, No, false, true); e->image_wave_bytes = e->image ? (size_t)pi.lds_wave_bytes : (size_t)p.lds_wave_bytes; }
     e->flow_generic = e->sw.flow_generic;
     if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }
@@ -934,6 +940,11 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
     return MATE_OK;
 }
 
+// LDS per workgroup of the two one-launch forms of a step with the on-device agents
+static size_t fused_rollout_lds(const mate_engine *e) { return 4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt) + 1024; }
+static size_t step_greedy_lds(const mate_engine *e) { return 4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)step_greedy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt, e->p.MW); }
+static bool use_step_greedy(const mate_engine *e) { return e->step_greedy_fn && !e->sw.step_greedy_rollout && step_greedy_lds(e) <= 160 * 1024; }
+
 static int policy_enable(mate_engine *e) {
     if (e->policy_ready) return MATE_OK;
     const Params &p = e->p;
@@ -941,6 +952,7 @@ static int policy_enable(mate_engine *e) {
     q.PF = p.Nc * p.Nt * 2 + p.Nc * 2 + p.Nt * 4;
     q.PI = p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + 3 * p.Nt + 1;
     q.PW = q.PF + (q.PI + 1) / 2;
+    q.caller_team = -1;
     q.memory_period = 25;      // greedy.py:21
     q.noise_scale = 0.5;       // greedy.py:236
     q.lds_bytes = round_up((q.PW + policy_staging_words(p.Nc, p.Nt) + p.SW + p.DW) * 8 + p.MW * 4 + 4, 16);   // (+ one mask word of slack: seen_mask reads two)
@@ -979,6 +991,8 @@ static int policy_enable(mate_engine *e) {
         if (fused <= 160 * 1024)
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rollout_greedy_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused);
     }
+    if (err == hipSuccess && e->step_greedy_fn && step_greedy_lds(e) <= 160 * 1024)
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->step_greedy_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_greedy_lds(e));
     if (err != hipSuccess) return fail(MATE_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(err));
     e->policy_ready = true;
     return MATE_OK;
@@ -993,14 +1007,18 @@ extern "C" int mate_engine_policy_enable(mate_engine *e) {
 
 static int rollout_with_policies(mate_engine *e, int team_caller, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_, bool per_step = false);
 
+
 // team_caller: -1 = both teams are the on-device agents; 0 / 1 = the camera / target team's joint action is the caller's
 static int step_with_policies(mate_engine *e, int team_caller, const mate_step_io *io, const mate_policy_tape *tape, int32_t auto_reset, hipStream_t stream) {
     if (!e) return fail(MATE_EINVAL, "null engine");
+    // (pipelined restarts still in flight rewrite records, masks and `done` tags on the side stream: the agents' kernel of the
+    // two-launch form reads all three, so the mode is left HERE, not only in launch_step behind it)
+    { const int rc_ = leave_pipelined(e, stream); if (rc_ != MATE_OK) return rc_; }
     // One launch (agents + step fused, rollout_greedy_kernel with one step) unless something needs the two-launch form: recorded
     // agent draws, tapes of the step itself, fused observation post-processing, a missing output, a workgroup that does not fit
     if (e->policy_ready && e->was_reset && !e->sw.policy_split && !tape && io && !io->tape_camera_target_dev && !io->tape_goal_dev &&
         e->g.obs_mode == 0 && !e->g.xdesc && (io->camera_obs_dev || e->p.Nc == 0) && io->target_obs_dev && io->scalars_dev && !e->p.obs_f64 &&
-        4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt) + 1024 <= 160 * 1024 &&
+        (use_step_greedy(e) || fused_rollout_lds(e) <= 160 * 1024) &&
         (team_caller < 0 || (team_caller == 0 ? io->camera_actions_dev : io->target_actions_dev)))
         return rollout_with_policies(e, team_caller, io, 1, auto_reset, (void *)stream, true);
     if (!e->was_reset) return fail(MATE_ESTATE, "step_greedy called before reset() (or import_state)");
@@ -1014,6 +1032,7 @@ static int step_with_policies(mate_engine *e, int team_caller, const mate_step_i
     note_stream(e, stream);
     PolicyPtrs q = e->q;
     std::memset(&q.tape, 0, sizeof(q.tape));
+    q.caller_team = team_caller;      // (the agents of the caller's team do not act: greedy_policy_body)
     if (tape) {
         q.tape.cam_binom_u = tape->camera_resample_u_dev; q.tape.cam_sample_u = tape->camera_sample_u_dev;
         q.tape.cam_delay = tape->camera_delay_dev; q.tape.tgt_choice_u = tape->target_choice_u_dev;
@@ -1096,7 +1115,11 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
         return fail(MATE_EINVAL, "rollout_versus_greedy needs the %s team's joint action", team_caller == 0 ? "camera" : "target");
     if (team_caller >= 0 && (((g.act_discrete & 1) && team_caller == 0 && !g.cam_grid) || ((g.act_discrete & 2) && team_caller == 1 && !g.tgt_grid)))
         return fail(MATE_ESTATE, "discrete actions passed before mate_engine_set_action_grids");
-    const size_t lds = 4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt) + 1024;
+    // the per-step flows run step_greedy_kernel (step_kernel's sequence with the agents in front) where it exists; the fused
+    // rollouts -- and MATE_STEP_GREEDY_ROLLOUT=1 -- rollout_greedy_kernel
+    const bool light = per_step && use_step_greedy(e);
+    const PolicyFn fn = light ? e->step_greedy_fn : e->rollout_greedy_fn;
+    const size_t lds = light ? step_greedy_lds(e) : fused_rollout_lds(e);
     if (lds > 160 * 1024) return fail(MATE_EINVAL, "rollout_greedy: %zu bytes of LDS per workgroup do not fit", lds);
     g.mode = MODE_STEP; g.reset_kind = -1; g.rollout_steps = steps;
     g.parity = e->dev_tick ? 0 : e->parity;
@@ -1122,9 +1145,9 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
         }
         ev0 = e->events[e->events_used].first; ev1 = e->events[e->events_used].second; ++e->events_used;
     }
-    e->last_flow = FLOW_GREEDY;
-    if (ev0) hipExtLaunchKernelGGL(e->rollout_greedy_fn, dim3(blocks), dim3(256), lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g, (const PolicyPtrs)q);
-    else hipLaunchKernelGGL(e->rollout_greedy_fn, dim3(blocks), dim3(256), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const PolicyPtrs)q);   // (capturable)
+    e->last_flow = light ? FLOW_STEP_GREEDY : FLOW_GREEDY;
+    if (ev0) hipExtLaunchKernelGGL(fn, dim3(blocks), dim3(256), lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g, (const PolicyPtrs)q);
+    else hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), lds, stream, (const Params *)e->d_params, (const Ptrs)g, (const PolicyPtrs)q);   // (capturable)
     HIP_TRY(hipGetLastError());
     if (!e->dev_tick) e->tick += (uint32_t)steps;
     if (per_step) {
@@ -1150,11 +1173,14 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
         Ptrs r = e->g;
         apply_io(r, nullptr);
         r.pipelined = 1;
+        const bool multi_before = e->multi_stream;
         int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, rs, true);
         if (rc != MATE_OK) return rc;
         HIP_TRY(hipMemsetAsync(e->g.done_count + e->parity, 0, sizeof(int32_t), rs));      // (the list is consumed: the launch after next appends to it afresh)
         if (!e->pipelined_serial) { HIP_TRY(hipEventRecord(e->ev_reset[e->parity], rs)); e->reset_in_flight[e->parity] = true; }
-        e->last_stream = stream;                     // (launch_reset noted the side stream: the accessors wait through leave_pipelined)
+        // (launch_reset noted the side stream: the accessors order it through leave_pipelined's event waits, so it neither becomes
+        // the stream they wait for nor counts as a second stream of the CALLER's -- which would turn every accessor into a device-wide wait)
+        e->last_stream = stream; e->multi_stream = multi_before;
         e->parity ^= 1;
     } else if (auto_reset == 1) {
         Ptrs r = e->g;
@@ -1427,6 +1453,7 @@ namespace {
 struct ScatteredBlock { int device; size_t bytes; std::vector<hipMemGenericAllocationHandle_t> chunks; };
 std::mutex g_blocks_mutex;
 std::map<void *, ScatteredBlock> g_blocks;
+std::atomic<int64_t> g_dead_range_bytes{0};      // address ranges of freed blocks that stay reserved (block_free)
 constexpr size_t kBlockChunk = (size_t)2 << 20;      // smaller chunks cost TLB reach (1 MiB: 4.1-4.7 TB/s), larger ones scatter less
 }  // namespace
 
@@ -1447,6 +1474,13 @@ extern "C" int mate_engine_block_alloc(int32_t device, int64_t bytes, void **ptr
         HIP_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
         if (total > free_bytes) return fail(MATE_ENOMEM, "block_alloc: %zu bytes asked for, %zu free on device %d", total, free_bytes, device);
     }
+    // Address ranges of freed blocks stay reserved (block_free): refuse new blocks once a process has retired more than
+    // MATE_BLOCK_DEAD_GIB (default 4096 GiB of the 2^47-byte address space) -- a loop that reallocates rollout buffers forever
+    // gets an error it can read (the Python host then falls back to plain memory), not an address space that runs dry.
+    static const int64_t dead_cap = [] { const char *v = getenv("MATE_BLOCK_DEAD_GIB"); return (int64_t)(v ? atof(v) : 4096.0) << 30; }();
+    if (g_dead_range_bytes.load() + (int64_t)total > dead_cap && g_dead_range_bytes.load() > 0)
+        return fail(MATE_ENOMEM, "block_alloc: %lld GiB of address space are held by freed blocks (limit MATE_BLOCK_DEAD_GIB = %lld): use plain device memory",
+                    (long long)(g_dead_range_bytes.load() >> 30), (long long)(dead_cap >> 30));
     void *va = nullptr;
     HIP_TRY(hipMemAddressReserve(&va, total, kBlockChunk, nullptr, 0));
     ScatteredBlock blk{device, total, {}};
@@ -1598,7 +1632,7 @@ extern "C" int mate_engine_block_free(void *ptr) {
     if (free_range) {
         const hipError_t err = hipMemAddressFree(ptr, blk.bytes);
         if (err != hipSuccess && first == hipSuccess) first = err;
-    }
+    } else g_dead_range_bytes += (int64_t)blk.bytes;      // (bounded: block_alloc refuses beyond MATE_BLOCK_DEAD_GIB)
     if (first != hipSuccess) {
         (void)hipGetLastError();
         return fail(MATE_EHIP, "block_free: %s", hipGetErrorString(first));

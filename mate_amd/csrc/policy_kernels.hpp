@@ -149,6 +149,13 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
                                                    const int32_t *di, const uint32_t *mk,
                                                    int wave, int lane, int64_t env, bool active, double *lds_cam_act, double *lds_tgt_act,
                                                    long long *acc = nullptr, long long *t_prev = nullptr, bool publish = true) {
+    // Which teams' agents act (wave-uniform): both under step_greedy / rollout_greedy; under MultiCamera / MultiTarget
+    // (q.caller_team = the learner's team, single_team.py:245-264) ONLY THE OPPONENTS -- the reference's wrapper holds no agents
+    // for the learner's team, and its joint action is the caller's.  A team that does not act keeps its memory as it is (its
+    // agent.reset at the first call of an episode still runs: `fresh` below), so what the acting team does never depends on it:
+    // every draw is keyed by (environment, tick, stream, lane).  The camera agents are three quarters of this function's chain
+    // (11.5 k of a 32 k-cycle learner-versus-greedy step at 4096 x MATE-4v8-9 before; the camera learner's step skips them).
+    const bool cams = q.caller_team != 0, tgts = q.caller_team != 1;
 #ifdef MATE_PHASE_CLOCKS
 #define POL_STAMP(i) do { if (acc) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); acc[i] += t_now - *t_prev; *t_prev = t_now; } } while (0)
 #elif defined(MATE_ISA_MARKS)
@@ -186,12 +193,13 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         return (uint32_t)(w >> (b & 31)) & ((1u << Nt) - 1u);
     };
     const double threshold = 1.1 * p.rmax;                  // filterout_beyond_range / the tracking reach: 110 % of the range
-    if (lane < Nc) a.near_bits(lane) = 0;
+    if (cams && lane < Nc) a.near_bits(lane) = 0;
     if (fresh) {                                            // GreedyCameraAgent.reset (greedy.py:43-61)
         if (lane < Nc) { a.prev_action(lane, 0) = 0.0; a.prev_action(lane, 1) = 0.0; a.has_state(lane) = 1; }
         for (int k = lane; k < Nc * Nc; k += 64) { a.i[Nc * Nt + k] = 0; a.i[Nc * Nt + Nc * Nc + k] = 0; }   // delay, neighbor
     }
     wave_sync();
+    if (cams || fresh)
     for (int k = lane; k < Nc * Nt; k += 64) {              // process_messages of the observation (greedy.py:100-113)
         const int c = (int)(((float)k + 0.5f) * p.inv_Nt), t = k - c * Nt;
         const bool s = sees(c, t);
@@ -204,7 +212,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         if (norm2(x - cam_x(c), y - cam_y(c)) < threshold) atomicOr(&a.near_bits(c), 1 << t);
     }
     const int tl = lane - 32;
-    if (tl >= 0 && tl < Nt) {                               // GreedyTargetAgent.reset / process_messages (greedy.py:262-283,326-332)
+    if ((tgts || fresh) && tl >= 0 && tl < Nt) {            // GreedyTargetAgent.reset / process_messages (greedy.py:262-283,326-332)
         const int t = tl;
         const int gw = di[t * TI_STRIDE + TI_GW];
         const int state_goal = (gw & 0xff) - 1;
@@ -232,6 +240,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     // four for the 16 the engine takes (the pair's message delay: the lane's own Philox word in the first round, one more block
     // keyed by the pair's index beyond)
     const bool one_round = Nc * Nc <= 64;
+    if (cams) {
     auto send_pair = [&](int k) {
         const int s = (int)(((float)k + 0.5f) * p.inv_Nc), c = k - s * Nc;
         int bits = 0;
@@ -288,9 +297,10 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         a.pair_dist(c, t) = dn;
     }
     if (lane < Nc && (a.has_state(lane) || seen_mask(lane))) a.has_state(lane) = 0;   // message2send.clear()
+    }
     // targets: broadcast non-empty warehouse sets (greedy.py:334-358).  Every lane's reads precede every lane's writes: one wave,
     // one instruction stream, LDS operations in order.
-    if (tl >= 0 && tl < Nt) {
+    if (tgts && tl >= 0 && tl < Nt) {
         int set = a.tgt_nonempty(tl);
         for (int s = 0; s < Nt; ++s) if (a.tgt_need(s)) set &= a.tgt_nonempty(s);
         a.tgt_nonempty(tl) = set;
@@ -304,7 +314,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     int best = -1;
     double theta = 0.0, orientation = 0.0, min_va = 0.0, best_orientation = 0.0, best_va = 0.0, K = 0.0;
     bool solve = false;
-    if (lane < Nc) {
+    if (cams && lane < Nc) {
         const int c = lane;
         const double phi = dy[c];
         theta = dy[Nc + c];
@@ -333,9 +343,9 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         }
     }
     POL_STAMP(12);
-    if (lane < Nc && solve) best_va = clipd(zoom_lookup(q, K), min_va, 180.0);      // greedy.py:139-146, tabulated (zoom_lookup)
+    if (cams && lane < Nc && solve) best_va = clipd(zoom_lookup(q, K), min_va, 180.0);      // greedy.py:139-146, tabulated (zoom_lookup)
     POL_STAMP(9);
-    if (lane < Nc) {                                        // part 2: the action
+    if (cams && lane < Nc) {                                // part 2: the action
         const int c = lane;
         double a0, a1;
         if (best >= 0) {
@@ -356,7 +366,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         if (lds_cam_act) { lds_cam_act[2 * c] = a0; lds_cam_act[2 * c + 1] = a1; }
         if (active && publish) { q.cam_act[(env * Nc + c) * 2] = a0; q.cam_act[(env * Nc + c) * 2 + 1] = a1; }
     }
-    if (tl >= 0 && tl < Nt) {                               // GreedyTargetAgent.act (greedy.py:285-324)
+    if (tgts && tl >= 0 && tl < Nt) {                       // GreedyTargetAgent.act (greedy.py:285-324)
         const int t = tl;
         const int gw = di[t * TI_STRIDE + TI_GW];
         const int state_goal = (gw & 0xff) - 1;
@@ -531,22 +541,32 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
     double *act_cam = a.f + (q.PW + policy_staging_words(p.Nc, p.Nt)), *act_tgt = act_cam + 2 * p.Nc;
     {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
-        load_records(c);
-        wave_sync();
-        const uint32_t *m = q.masks + env * p.MW;                 // the view the previous step / reset left
-        for (int i = lane; i < p.MW; i += 64) c.mask[i] = m[i];
-        const double *src = q.pol + env * q.PW;
-        for (int k = lane; k < q.PW; k += 64) a.f[k] = src[k];
-        build_entities(c);
+        // pipelined restarts (Ptrs::pipelined): an environment tagged for this launch's list parity goes live; one that is not
+        // live at entry -- tagged for the other parity, or finished and in the hands of the reset running under this launch --
+        // is left alone: no step and, at the end, no store (the reset may be rewriting its records right now).  Whether it is
+        // live is decided from ONE 4-byte load of the record's `done` word, ahead of everything else: every value the concurrent
+        // reset can leave there (finished, listed, tagged for the other parity) reads "not mine", so the verdict does not depend
+        // on how far that reset has come, and nothing else of such an environment -- records, masks, agents' memory -- is read.
+        int d_entry = 0;
+        bool mine = false;
+        const int32_t parity = (int32_t)((p.dev_group + (uint32_t)g.parity) & 1u);
         if (g.pipelined) {
-            // pipelined restarts (Ptrs::pipelined): an environment tagged for this launch's list parity goes live; one that is not
-            // live at entry -- tagged for the other parity, or finished and in the hands of the reset running under this launch --
-            // is left alone: no step and, at the end, no store (the reset may be rewriting its records right now)
-            const int d = c.ei(EI_DONE);
-            const int32_t parity = (int32_t)((p.dev_group + (uint32_t)g.parity) & 1u);
-            const bool mine = (d & kDoneTag) && ((d >> 3) & 1) == parity;
-            untouched = in_batch && d != 0 && !mine;
-            if (d == 1 && in_batch && lane == 0 && g.done_count) {      // finished under auto_reset = 0 earlier, never listed: list it, and say so in the record itself
+            const volatile int32_t *done_word = reinterpret_cast<const volatile int32_t *>(g.dyn + env * p.DW + p.DF) + p.Nt * TI_STRIDE + EI_DONE;
+            d_entry = __builtin_amdgcn_readfirstlane(*done_word);
+            mine = (d_entry & kDoneTag) && ((d_entry >> 3) & 1) == parity;
+            untouched = d_entry != 0 && !mine;      // (a wave past the end of the batch mirrors environment N - 1: the same rule)
+        }
+        if (!untouched) {
+            load_records(c);
+            wave_sync();
+            const uint32_t *m = q.masks + env * p.MW;                 // the view the previous step / reset left
+            for (int i = lane; i < p.MW; i += 64) c.mask[i] = m[i];
+            const double *src = q.pol + env * q.PW;
+            for (int k = lane; k < q.PW; k += 64) a.f[k] = src[k];
+            build_entities(c);
+        } else if (lane == 0) c.ei(EI_DONE) = d_entry;               // (all the step loop reads of it: "not live")
+        if (g.pipelined) {
+            if (d_entry == 1 && in_batch && lane == 0 && g.done_count) {      // finished under auto_reset = 0 earlier, never listed: list it, and say so in the record itself
                 const int slot = atomicAdd(g.done_count + parity, 1);
                 g.done_list[(int64_t)parity * g.N + slot] = (int32_t)env;
                 reinterpret_cast<int32_t *>(g.dyn + env * p.DW + p.DF)[p.Nt * TI_STRIDE + EI_DONE] = 3;
@@ -680,6 +700,138 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
             for (int k = lane; k < 2 * p.Nt; k += 64) q.tgt_act[env * 2 * p.Nt + k] = act_tgt[k];
         }
     }
+}
+
+// =============================================================================================
+// ONE (agents act, environment steps) iteration per launch: mate_engine_step_greedy / _step_versus_greedy (MultiCamera / MultiTarget,
+// mate/wrappers/single_team.py:245-264 -- the flow of every examples/*/config.py: the learner plays one team at every step).
+//
+// Round 3 ran these flows on rollout_greedy_kernel with a single step: one launch, but a launch that pays the fused rollout's
+// prologue -- lane roles, the seed of the carried collision screen, up to twelve held descriptor chunks: work that amortises over
+// tens of steps -- in front of its only step, at four waves per SIMD (98-128 registers): 24 us at 4096 x MATE-4v8-9 where the
+// agents' kernel and step_kernel take 9 + 15 as two launches, 91 us at 16 384.  This kernel is step_kernel's own sequence -- the
+// records, the agents' memory and the previous view loaded under the Philox draws, the light packer, eight waves per SIMD where
+// the registers allow -- with greedy_policy_body between the entity table and the kinematics and the joint actions handed over in
+// LDS (FLOW_STEP_GREEDY).  Same phase functions, same bytes as the two-launch form and as the fused rollout with one step (tested).
+// LDS per workgroup: 4 step slices, then 4 x (agents' memory + staging + joint actions + the previous step's mask words).
+// (compiled for every shipped shape but MATE-1v2-*: with one camera and two targets the register allocator leaves 36-48 bytes of
+// private scratch, which costs ~5 us per launch -- mate_amd/build.py refuses such a kernel; those two scenarios keep the one-step
+// rollout_greedy_kernel form)
+constexpr bool step_greedy_compiled(int Nc, int Nt, int /*No*/) { return !(Nc == 1 && Nt == 2); }
+__host__ __device__ constexpr int step_greedy_slice_bytes(int PW, int Nc, int Nt, int MW) { return policy_slice_bytes(PW, Nc, Nt) + shape_round_up(MW * 4 + 4, 16); }
+
+template <typename ObsT, typename Shape>
+__global__ __launch_bounds__(256, 4) __attribute__((amdgpu_num_sgpr(96)))   // (eight waves per SIMD, as step_kernel)
+void step_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q_arg) {
+    const PolicyPtrs &q = kernarg_policy_ptrs(q_arg);
+    const Shape shape(pp);
+    const Params &p = shape.get();
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) {      // (tick and list parity: launch arguments or the device-resident counter, see step_kernel)
+        const int32_t parity = (int32_t)((p.dev_group + (uint32_t)g.parity) & 1u);
+        g.done_count[parity ^ 1] = 0;
+        g.ctrl[0] = parity;
+    }
+    const uint32_t tick = p.dev_tick + g.tick;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int64_t env = (int64_t)blockIdx.x * 4 + wave;
+    if (env >= g.N) return;                                          // (the four waves of a workgroup never synchronise)
+    const Ptrs &gk = kernarg_ptrs(g);
+    Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_STEP_GREEDY);
+    const int pol_bytes = step_greedy_slice_bytes(q.PW, p.Nc, p.Nt, p.MW);
+    unsigned char *pol_base = smem + 4 * p.lds_wave_bytes + wave * pol_bytes;
+    PolCtx<ObsT> a(p, q, pol_base);
+    double *act_cam = a.f + (q.PW + policy_staging_words(p.Nc, p.Nt)), *act_tgt = act_cam + 2 * p.Nc;
+    uint32_t *mk = reinterpret_cast<uint32_t *>(act_tgt + 2 * p.Nt);      // the view the previous step / reset left (the agents' observation gate)
+    // the agents' memory and the previous view on their way together with the records (load_records_with_draws issues those and
+    // runs the step's Philox draws under all of it)
+    const double *pol_src = q.pol + env * q.PW;
+    double pw0 = pol_src[lane < q.PW ? lane : 0], pw1 = 0.0, pw2 = 0.0;
+    if (q.PW > 64) pw1 = pol_src[lane + 64 < q.PW ? lane + 64 : 0];
+    if (q.PW > 128) pw2 = pol_src[lane + 128 < q.PW ? lane + 128 : 0];
+    uint32_t mw0 = q.masks[env * p.MW + (lane < p.MW ? lane : 0)];
+    asm volatile("" : "+v"(pw0), "+v"(pw1), "+v"(pw2), "+v"(mw0));
+#ifdef MATE_PHASE_CLOCKS      // per-wave stamps (tools/versus_phases.py): 0 begin, 1 records, 2 entity table, 3 agents, 4 kinematics, 5 view, 6 goals, 7 rows, 8 end;
+    const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();      // 9-13: the agents' sub-phases (observe, zoom, actions, communicate, choose)
+    long long pol_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pol_prev = 0;
+#define SG_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * kClockStride + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define SG_ACC pol_acc, &pol_prev
+#else
+#define SG_STAMP(i) do { } while (0)
+#define SG_ACC nullptr, nullptr
+#endif
+    SG_STAMP(0);
+    const StepDraws draws = load_records_with_draws(c, tick, true);
+    if (lane < q.PW) a.f[lane] = pw0;
+    if (lane + 64 < q.PW) a.f[lane + 64] = pw1;
+    if (lane + 128 < q.PW) a.f[lane + 128] = pw2;
+    for (int k = lane + 192; k < q.PW; k += 64) a.f[k] = pol_src[k];
+    if (lane < p.MW) mk[lane] = mw0;
+    for (int k = lane + 64; k < p.MW; k += 64) mk[k] = q.masks[env * p.MW + k];
+    if (lane == 0) mk[p.MW] = 0u;                                        // (seen_mask reads two words)
+    wave_sync();
+    if (c.ei(EI_DONE) != 0) {        // finished: waiting for the reset launch (immediate: behind this one; batched: at the interval's end) -- no agents, no step
+        if (lane == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
+        if (lane == 0 && g.idle_steps) g.idle_steps[env] += 1;
+        if (lane == 0 && g.done_count && c.ei(EI_DONE) == 1) {          // finished under auto_reset = 0 earlier: not on the list yet
+            const int parity = c.list_parity();
+            const int slot = atomicAdd(g.done_count + parity, 1);
+            g.done_list[(int64_t)parity * g.N + slot] = (int32_t)env;
+            reinterpret_cast<int32_t *>(g.dyn + env * p.DW + p.DF)[p.Nt * TI_STRIDE + EI_DONE] = 3;
+        }
+        return;
+    }
+    SG_STAMP(1);
+    build_entities(c);
+    wave_sync();
+    SG_STAMP(2);
+#ifdef MATE_PHASE_CLOCKS
+    pol_prev = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, mk, wave, lane, env, true, act_cam, act_tgt, SG_ACC, false);
+    wave_sync();
+    if (q.caller_team >= 0) {
+        load_caller_actions(c, q.caller_team, act_cam, act_tgt);
+        wave_sync();
+    }
+    c.act_cam = act_cam; c.act_tgt = act_tgt;
+    SG_STAMP(3);
+    simulate_cameras(c, draws, true);
+    simulate_targets(c, draws);
+    SG_STAMP(4);
+    const bool reg_tail = p.sector_rounds <= 1;
+    int tracked_reg = 0, inside_reg = -1;
+    PackDescriptors pack_desc;
+    constexpr int GCE = Shape::kHeldGC, GTE = Shape::kHeldGT;
+    const bool early_desc = Shape::kGreedyHeld && GCE + GTE <= 8 && packs_rows_f32(c);
+    if (reg_tail) {
+        RangeRoles none;
+        uint32_t seen_unused;
+        unsigned long long sector_ballot = 0ull;
+        update_view<false, false>(c, tick, S_TRANSMIT, true, none, seen_unused, nullptr, &sector_ballot);
+        view_tail_regs(c, sector_ballot, tracked_reg, inside_reg);
+    } else update_view(c, tick, S_TRANSMIT, true);
+    SG_STAMP(5);
+    if (early_desc) load_pack_descriptors(c, pack_desc);
+    if (reg_tail) assign_and_score(c, tick, g.scalars, &tracked_reg, &inside_reg);
+    else assign_and_score(c, tick, g.scalars);
+    SG_STAMP(6);
+    fill_scratch(c);
+    if (early_desc) pack_observations<true>(c, pack_desc); else pack_observations<false>(c, pack_desc);
+    SG_STAMP(7);
+    store_dynamic(c);
+    double *dst = q.pol + env * q.PW;
+    for (int k = lane; k < q.PW; k += 64) dst[k] = a.f[k];
+    // what mate_engine_policy_actions reads: this step's joint actions (the caller's team's as decoded)
+    for (int k = lane; k < 2 * p.Nc; k += 64) q.cam_act[env * 2 * p.Nc + k] = act_cam[k];
+    for (int k = lane; k < 2 * p.Nt; k += 64) q.tgt_act[env * 2 * p.Nt + k] = act_tgt[k];
+    SG_STAMP(8);
+#ifdef MATE_PHASE_CLOCKS
+    if (lane == 0 && g.phase_clocks) {
+        for (int i = 8; i < 13; ++i) g.phase_clocks[env * kClockStride + 1 + i] = pol_acc[i];
+        g.phase_clocks[env * kClockStride + 15] = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
+    }
+#endif
 }
 
 }  // namespace mate

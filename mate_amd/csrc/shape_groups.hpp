@@ -25,6 +25,7 @@ struct KernelSet {
     StepFn split[3];           // step_split_kernel per flow, or null
     StepFn rollout[2];         // [0] generic flow, [1] FLOW_RANDOM (the row-image compilation where the shape has one)
     PolicyFn policy, rollout_greedy;
+    PolicyFn step_greedy;      // step_greedy_kernel (f32 observations), or null
     int image;
 };
 

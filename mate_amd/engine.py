@@ -266,6 +266,8 @@ class Engine:
         the on-device greedy opponents act anew on every frame.  Rollout-shaped tensors; the caller sums the reward rows."""
         team = {'camera': 0, 'target': 1}.get(team, team)
         assert team in (0, 1)
+        if auto_reset == 'pipelined':
+            auto_reset = self.RESET_PIPELINED
         steps = int(steps)
         buf = self.reserve_rollout(steps, want_masks)
         io, keep = self._io(cam_act=joint_action if team == 0 else None, tgt_act=joint_action if team == 1 else None)
@@ -288,9 +290,13 @@ class Engine:
         env = os.environ
         return {
             'plain': env.get('MATE_PLAIN_BLOCKS') == '1',
-            'candidates': int(env['MATE_BLOCK_CANDIDATES']) if 'MATE_BLOCK_CANDIDATES' in env else None,
-            'deep': env.get('MATE_BLOCK_DEEP', '1') != '0',
-            'deep_seconds': float(env.get('MATE_BLOCK_SECONDS', '3.0')),
+            # (0 or less: no search at all -- one block, unprobed)
+            'candidates': max(1, int(env['MATE_BLOCK_CANDIDATES'])) if 'MATE_BLOCK_CANDIDATES' in env else None,
+            # the deep search (candidates separated by 12 GB spacers, a transient footprint of up to 45 % of the free memory) is
+            # OPT-IN: reserve_rollout(search='deep') -- bench.py asks for it -- or MATE_BLOCK_DEEP=1; by default a few candidates side
+            # by side within 0.3 s
+            'deep': env.get('MATE_BLOCK_DEEP', '0') != '0',
+            'seconds': float(env['MATE_BLOCK_SECONDS']) if 'MATE_BLOCK_SECONDS' in env else None,
             'deep_gib': float(env.get('MATE_BLOCK_GIB', '96')),
             'store_form': env.get('MATE_STORE_FORM', 'auto'),
         }
@@ -319,9 +325,11 @@ class Engine:
         # take what the target block's search left, at least one).  Everything but the winner is freed at the end
         # (mate_engine_block_free: the physical memory comes back, the address range stays reserved).
         row_bytes = nbytes // (shape[0] * shape[1])
-        tries = (sw['candidates'] or 6) if nbytes >= (128 << 20) and row_bytes % 16 == 0 else 1
+        search = getattr(self, '_block_search', None) or ('deep' if sw['deep'] else 'shallow')
+        tries = (sw['candidates'] or (6 if search == 'deep' else 3)) if nbytes >= (128 << 20) and row_bytes % 16 == 0 and search != 'none' else 1
         free = torch.cuda.mem_get_info(self.device)[0]
-        deep = deep and tries > 1 and sw['deep']
+        deep = deep and tries > 1 and search == 'deep'
+        seconds = sw['seconds'] if sw['seconds'] is not None else (3.0 if search == 'deep' else 0.3)
         spacer_bytes = 12 << 30
         budget = min(0.45 * free, sw['deep_gib'] * (1 << 30))
         if deep and sw['candidates'] is None:      # (an explicit count bounds the deep search too)
@@ -349,7 +357,7 @@ class Engine:
                 best = (rate, block)
             if len(rates) > 1 and best[0] >= 1.28 * min(rates):
                 break
-            if time.perf_counter() - t0 > sw['deep_seconds']:
+            if time.perf_counter() - t0 > seconds:
                 break
             if deep:
                 if rate >= (5350.0 if nbytes >= (1 << 30) else 5100.0):      # (a short block's probe is a short launch: its ramp weighs more)
@@ -363,13 +371,20 @@ class Engine:
         del spacers
         return block.tensor(self.obs_dtype, shape).zero_(), rates
 
-    def reserve_rollout(self, steps, want_masks=False):
+    def reserve_rollout(self, steps, want_masks=False, search=None):
         """Allocate the rollout-shaped output buffers ([steps][N][...]) now, so that a later rollout of up to `steps`
         steps allocates nothing (a training loop or a timed region calls this once up front).  Rows a launch does not
         write -- the observation rows of an environment that had finished earlier in the launch -- keep whatever they
         held; its scalar rows say done = 2.  `Engine.reserve_seconds` says how long the last (re)allocation took, candidate
-        search included; `Engine.block_rates` = [target block's candidates, camera block's candidates] in GB/s."""
+        search included; `Engine.block_rates` = [target block's candidates, camera block's candidates] in GB/s.
+        `search`: where the observation blocks come from -- 'shallow' (default: the fastest of up to three candidates allocated
+        side by side, at most 0.3 s), 'deep' (the walk through the device's memory described in _observation_block: seconds,
+        and a transient footprint of up to 45 % of the free HBM -- for a process that owns the GPU, e.g. bench.py), 'none' (one
+        block, unprobed).  Every candidate that loses keeps its address range reserved (mate_engine_block_free), bounded per
+        process by MATE_BLOCK_DEAD_GIB."""
         steps = int(steps)
+        assert search in (None, 'shallow', 'deep', 'none')
+        self._block_search = search
         buf = getattr(self, '_rollout', None)
         if buf is None or buf['steps'] < steps or (want_masks and buf['masks'] is None):     # a shorter rollout fills a prefix
             import time

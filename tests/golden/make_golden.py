@@ -15,6 +15,7 @@ Fixture families:
   kat_scalar.npz                     F3 normalize_angle / polar clamp (utils.py:155,223-229)
   kat_perceive.npz                   F3 Camera.perceive on crafted geometry (entities.py:491-511)
   reset_<cfg>_s<seed>.npz            F1 reset() with EVERY random draw on a tape (environment.py:679-834)
+  chain_<cfg>_s<seed>.npz            the example trainers' whole wrapper chain for a camera learner (examples/ippo/camera/config.py:19-51)
 
 Random draws are captured by replacing each RandomState with a recording proxy
 (the reference source is not modified): every in-sector `binomial(1, tau)` draw
@@ -805,8 +806,130 @@ def xform_fixture(trace_name, steps):
     print(f'xform_{trace_name[6:]}: {steps} steps, {os.path.getsize(path) / 1024:.0f} KiB')
 
 
+def chain_fixture(name, config, seed, learner_steps, frame_skip=5, levels=5, coefficients=None, reduction='mean'):
+    """The wrapper chain every example trainer's make_env builds for a camera learner (examples/ippo/camera/config.py:19-51, and its
+    qmix / mappo / ... siblings): base -> DiscreteCamera(levels) -> MultiCamera(GreedyTargetAgent(seed=0)) -> RelativeCoordinates ->
+    RescaledObservation -> RepeatedRewardIndividualDone -> AuxiliaryCameraRewards(coverage_rate, 'mean') -> FrameSkip(5), all of them
+    the REFERENCE's own classes from mate.wrappers -- except FrameSkip, which lives in examples/utils/wrappers.py:254-323 behind
+    `ray` imports: it is restated here as what it does (the same action for `frame_skip` env.step calls, rewards summed, stop when
+    all(dones)).  Recorded per FRAME: the learner's grid indices, the opponents' joint action and every random draw (environment
+    and agents), the chain's camera observations (relative + rescaled), the shaped and raw rewards, dones, masks, state; per
+    LEARNER STEP: the FrameSkip sums and the observation it returns."""
+    import mate.wrappers.single_team as single_team
+    coefficients = coefficients or {'coverage_rate': 1.0}
+    base = mate.make('MultiAgentTracking-v0', config=config, reward_type='dense')
+    disc = mate.DiscreteCamera(base, levels=levels)
+    multi = mate.MultiCamera(disc, target_agent=GreedyTargetAgent(seed=0))
+    chain = mate.AuxiliaryCameraRewards(mate.RepeatedRewardIndividualDone(mate.RescaledObservation(mate.RelativeCoordinates(multi))),
+                                        coefficients=coefficients, reduction=reduction)
+    chain.seed(seed)
+    tgt_agents = multi.opponent_agents_ordered
+    gym.spaces.Box.sample = _recording_box_sample
+    for agent in tgt_agents:
+        agent._np_random = AgentRNG(agent.np_random, AGENT_LOG, None)
+    AGENT_LOG.clear()
+    opponent_actions = []
+    real_group_step = single_team.group_step
+
+    def recording_group_step(env, agents, observation, infos=None, **kwargs):
+        action = real_group_step(env, agents, observation, infos, **kwargs)
+        opponent_actions.append(np.asarray(action, dtype=np.float64))
+        return action
+
+    single_team.group_step = recording_group_step
+    try:
+        cam_obs = chain.reset()
+        for agent in tgt_agents:
+            agent._np_random._who = ('tgt', agent.index)
+        reset_draws = drain_agent_log([], tgt_agents)
+        log = []
+        install_proxies(base, log)
+        Nc, Nt, No = base.num_cameras, base.num_targets, base.num_obstacles
+        out = {
+            'config_file': np.str_(config), 'seed': np.int64(seed), 'policy': np.str_('chain'),
+            'num_cameras': np.int64(Nc), 'num_targets': np.int64(Nt), 'num_obstacles': np.int64(No),
+            'transmittance': np.float64(base.obstacle_transmittance), 'max_episode_steps': np.int64(base.max_episode_steps),
+            'sparse_reward': np.bool_(base._sparse_reward), 'freight_scale': np.float64(base.freight_scale),
+            'bounty_scale': np.float64(base.bounty_scale), 'reward_scale': np.float64(base.reward_scale),
+            'max_target_team_episode_reward': np.float64(base.max_target_team_episode_reward),
+            'target_step_size': np.float64(base.target_step_size),
+            'frame_skip': np.int64(frame_skip), 'discrete_levels': np.int64(levels),
+            'camera_action_grid': disc.normalized_action_grid,
+            'aux_keys': np.asarray(list(coefficients.keys())), 'aux_coefficients': np.asarray(list(coefficients.values()), dtype=np.float64),
+            'aux_reduction': np.str_(reduction),
+            'agent/tgt_reset_sample_u': reset_draws['tgt_sample_u'],
+        }
+        for k, v in snapshot_static(base).items():
+            out['static/' + k] = v
+        for k, v in snapshot_dynamic(base).items():
+            out['reset/' + k] = v
+        out['reset/chain_cam_obs'] = np.asarray(cam_obs, dtype=np.float64)
+        per_step, per_skip = {}, {}
+
+        def push(store, key, value):
+            store.setdefault(key, []).append(np.asarray(value))
+
+        rng = np.random.RandomState(seed + 1000)
+        finished = False
+        for ls in range(learner_steps):
+            cam_idx = rng.randint(0, levels ** 2, size=Nc)
+            fragment_rewards, frames = [], 0
+            for f in range(frame_skip):                      # FrameSkip.step (examples/utils/wrappers.py:301-323)
+                log.clear()
+                observations, rewards, dones, infos = chain.step(cam_idx)
+                fragment_rewards.append(rewards)
+                frames += 1
+                tape_ct, _, goal_u, goal_k, goal_j = drain_log(base, log)
+                for k, v in drain_agent_log([], tgt_agents).items():
+                    if k.startswith('tgt_'):
+                        push(per_step, 'agent_' + k, v)
+                push(per_step, 'cam_idx', cam_idx)
+                push(per_step, 'cam_act', np.asarray(disc.action((cam_idx, None))[0], dtype=np.float64).reshape(Nc, 2))
+                push(per_step, 'tgt_act', opponent_actions.pop().reshape(Nt, 2))
+                assert not opponent_actions
+                push(per_step, 'tape_ct', tape_ct)
+                push(per_step, 'goal_u', goal_u)
+                push(per_step, 'goal_k', goal_k)
+                push(per_step, 'goal_j', goal_j)
+                push(per_step, 'chain_cam_obs', np.asarray(observations, dtype=np.float64))
+                push(per_step, 'chain_reward_cam', np.asarray(rewards, dtype=np.float64))
+                push(per_step, 'reward_cam', infos[0]['raw_reward'])
+                push(per_step, 'coverage_rate', infos[0]['coverage_rate'])
+                push(per_step, 'done', bool(dones[0]))
+                push(per_step, 'learner_step', ls)
+                for k, v in snapshot_dynamic(base).items():
+                    push(per_step, k, v)
+                if all(dones):
+                    finished = True
+                    break
+            push(per_skip, 'cam_idx', cam_idx)
+            push(per_skip, 'frames', frames)
+            push(per_skip, 'reward_cam', np.sum(fragment_rewards, axis=0))
+            push(per_skip, 'chain_cam_obs', np.asarray(observations, dtype=np.float64))
+            push(per_skip, 'done', bool(dones[0]))
+            if finished:
+                break
+    finally:
+        single_team.group_step = real_group_step
+        gym.spaces.Box.sample = _ORIG_BOX_SAMPLE
+    for k, v in per_step.items():
+        out['step/' + k] = np.stack(v)
+    for k, v in per_skip.items():
+        out['skip/' + k] = np.stack(v)
+    out.pop('step/state', None)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    nsteps = len(per_step['done'])
+    print(f'{name}: {len(per_skip["done"])} learner steps = {nsteps} frames, delivered={int(out["step/num_delivered_cargoes"][-1])}, '
+          f'in-sector draws={int(np.isfinite(out["step/tape_ct"]).sum())}, mean shaped reward={float(out["step/chain_reward_cam"].mean()):.3f}, '
+          f'{os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def main():
     check_binomial_model()
+    if sys.argv[1:] == ['chain']:
+        chain_fixture('chain_4v8-9_s15', 'MATE-4v8-9.yaml', 15, learner_steps=13)
+        return
     if sys.argv[1:] == ['agents']:
         make_trace('greedy_4v8-9_s5', 'MATE-4v8-9.yaml', 5, 'greedy', 300, record_agents=True)
         make_trace('greedy_8v8-9_s6', 'MATE-8v8-9.yaml', 6, 'greedy', 200, record_agents=True)

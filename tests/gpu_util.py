@@ -26,7 +26,12 @@ def fixture_state(fx, prefix='reset/', index=None):
 
 def engine_from_fixture(fx, num_envs=3, obs_dtype=torch.float64, seed=0):
     """Engine whose every environment holds the fixture's post-reset state and occlusion tables."""
-    eng = Engine(config_of_fixture(fx), num_envs, seed=seed, obs_dtype=obs_dtype)
+    return load_fixture_state(Engine(config_of_fixture(fx), num_envs, seed=seed, obs_dtype=obs_dtype), fx)
+
+
+def load_fixture_state(eng, fx):
+    """Every environment of `eng` takes the fixture's post-reset state and occlusion tables."""
+    num_envs = eng.num_envs
     st = fixture_state(fx)
     fields = {k: np.broadcast_to(v, (num_envs,) + v.shape) for k, v in st.items()}
     fields['tick'] = np.zeros(num_envs)

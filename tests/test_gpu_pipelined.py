@@ -79,3 +79,44 @@ def test_pipelined_mode_changes_nothing_while_no_episode_ends():
     for a, b in zip(*outs):
         for x, y in zip(a, b):
             assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+
+
+@pytest.mark.parametrize('form', ['two_launch_tape', 'one_launch', 'versus_rollout'])
+def test_per_step_flows_behind_pipelined_rollouts_wait_for_the_resets_in_flight(form):
+    """Every other entry point first waits for the resets in flight on the side stream (include/mate_engine.h).  The two-launch
+    form of step_greedy -- recorded agent draws -- used to launch the AGENTS' kernel before anything had left the pipelined mode
+    (round 4's advisor finding): its agents read records, masks and `done` tags the side-stream reset was still writing.  The
+    concurrent form must equal the serial one (MATE_PIPELINED_SERIAL=1: resets on the caller's stream), bit for bit, for the
+    two-launch form, the one-launch form and the FrameSkip rollout with auto_reset = 'pipelined' spelled as the C enum's name."""
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=11)
+    n, outs = 160, []
+    for serial in (False, True):
+        os.environ['MATE_PIPELINED_SERIAL'] = '1' if serial else '0'
+        try:
+            eng = Engine(cfg, n, seed=21)
+            eng.enable_policies()
+            eng.reset()
+            rec = []
+            gen = torch.Generator(device='cuda')
+            gen.manual_seed(77)
+            for _ in range(6):
+                eng.rollout_greedy(6, auto_reset='pipelined')
+                if form == 'two_launch_tape':
+                    tape = {'camera_resample_u': torch.rand((n, 4), device='cuda', generator=gen, dtype=torch.float64)}
+                    eng.step_greedy(policy_tape=tape, auto_reset=True)
+                elif form == 'one_launch':
+                    eng.step_greedy(auto_reset=True)
+                else:
+                    mine = torch.full((n, 4, 2), 1.5, device='cuda')
+                    eng.rollout_versus_greedy('camera', mine, 3, auto_reset='pipelined')
+                    eng.step_greedy(auto_reset=True)
+                rec.append((eng.scalars.clone(), eng.masks.clone(), eng.target_obs.clone(), eng.export_state().clone()))
+        finally:
+            os.environ.pop('MATE_PIPELINED_SERIAL', None)
+        outs.append(rec)
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+    assert (outs[0][-1][3][:, -2] >= 2).all()          # episodes ended and restarted under the launches

@@ -353,13 +353,16 @@ def test_greedy_agents_with_more_than_eight_cameras_vs_oracle(oracle_lib):
         assert torch.equal(ca, cb) and torch.equal(ta, tb) and float(ca.abs().sum()) > 0.0
 
 
-@pytest.mark.parametrize('switch,auto_reset', [('MATE_ZOOM_ITERATE', 1), ('MATE_POLICY_SPLIT', 1), ('MATE_POLICY_SPLIT', 4)])
+@pytest.mark.parametrize('switch,auto_reset', [('MATE_ZOOM_ITERATE', 1), ('MATE_POLICY_SPLIT', 1), ('MATE_POLICY_SPLIT', 4),
+                                               ('MATE_STEP_GREEDY_ROLLOUT', 1), ('MATE_STEP_GREEDY_ROLLOUT', 4)])
 def test_policy_implementation_switches_give_the_same_episodes(switch, auto_reset):
     """Two implementation choices of the on-device Greedy agents, selected at create by an environment switch:
     MATE_ZOOM_ITERATE=1 runs the reference's 20-iteration zoom solve (agents/greedy.py:139-145) instead of its tabulation --
     joint actions within 1e-10 degrees, the episodes (masks, goals, rewards) identical; MATE_POLICY_SPLIT=1 runs
     step_greedy / step_versus_greedy as two launches (agents' kernel, step kernel) instead of the fused one -- bit for bit,
-    also with batched resets (auto_reset = 4: the idle rows of finished environments included)."""
+    also with batched resets (auto_reset = 4: the idle rows of finished environments included); MATE_STEP_GREEDY_ROLLOUT=1 runs
+    the one-launch form on the fused rollout kernel with a single step (rounds 3-4) instead of step_greedy_kernel (round 5):
+    bit for bit as well."""
     from mate_amd.config import read_config
     from mate_amd.engine import Engine
     cfg = read_config('MATE-8v8-9.yaml', max_episode_steps=40)
@@ -388,7 +391,7 @@ def test_policy_implementation_switches_give_the_same_episodes(switch, auto_rese
         rec.append((eng.export_state().clone(),))
         runs.append(rec)
         assert (idle_rows > 0) == (auto_reset > 1)
-    exact = switch == 'MATE_POLICY_SPLIT'
+    exact = switch != 'MATE_ZOOM_ITERATE'
     for a, b in zip(*runs):
         if exact:
             assert all(torch.equal(x.view(torch.uint8), y.view(torch.uint8)) for x, y in zip(a, b))

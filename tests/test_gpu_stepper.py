@@ -109,6 +109,8 @@ def _census(workload, n, steps, fused, own_tables, oracle_lib, seed=99, first=12
     bad = np.zeros(n, dtype=bool)
     worst = 0.0
     rows = None
+    obs_bad = np.zeros(n, dtype=bool)          # an f32 row element off by more than 1e-5 relative, at ANY step, in EITHER team's rows
+    rew_bad = np.zeros(n, dtype=bool)          # a step reward that is not the oracle's, at any step
     for s in range(steps):
         if fused > 1:
             if s % fused == 0:
@@ -121,6 +123,15 @@ def _census(workload, n, steps, fused, own_tables, oracle_lib, seed=99, first=12
         for m in MASKS:
             ref = batch.gather(m) != 0
             bad |= (masks[m].reshape(ref.shape) != ref).reshape(n, -1).any(axis=1)
+        # both teams' rows and the reward of EVERY step (inside a fused launch: its row r), not only the last one's target rows
+        oc, ot = batch.observe(threads=threads)
+        co = (rows[0][s % fused] if fused > 1 else eng.camera_obs).cpu().numpy()
+        to = (rows[1][s % fused] if fused > 1 else eng.target_obs).cpu().numpy()
+        sc = (rows[2][s % fused] if fused > 1 else eng.scalars).cpu().numpy()
+        if eng.num_cameras:
+            obs_bad |= (np.abs(co - oc) > 1e-5 * np.maximum(1.0, np.abs(oc))).reshape(n, -1).any(axis=1)
+        obs_bad |= (np.abs(to - ot) > 1e-5 * np.maximum(1.0, np.abs(ot))).reshape(n, -1).any(axis=1)
+        rew_bad |= sc[:, 1] != batch.gather('reward_tgt').astype(np.float32)
         if (fused > 1 and (s % fused == fused - 1 or s == steps - 1)) or fused == 1:
             sdg = eng.state_dict()
             for k in INTS:
@@ -128,12 +139,9 @@ def _census(workload, n, steps, fused, own_tables, oracle_lib, seed=99, first=12
                 bad |= (sdg[k].reshape(ref.shape) != ref).reshape(n, -1).any(axis=1)
             good = ~bad
             worst = max(worst, float(np.abs(sdg['tgt_x'] - batch.gather('tgt_x'))[good].max()), float(np.abs(sdg['tgt_y'] - batch.gather('tgt_y'))[good].max()))
-    _, ot = batch.observe(threads=threads)
-    to = (rows[1][(steps - 1) % fused] if fused > 1 else eng.target_obs).cpu().numpy()
-    sc = (rows[2][(steps - 1) % fused] if fused > 1 else eng.scalars).cpu().numpy()
     good = ~bad
-    obs_ok = bool(np.all(np.abs(to - ot)[good] <= 1e-5 * np.maximum(1.0, np.abs(ot))[good]))
-    rew_ok = bool(np.array_equal(sc[:, 1][good], batch.gather('reward_tgt').astype(np.float32)[good]))
+    obs_ok = not bool(obs_bad[good].any())
+    rew_ok = not bool(rew_bad[good].any())
     return int(bad.sum()), worst, obs_ok, rew_ok
 
 

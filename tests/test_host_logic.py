@@ -156,10 +156,17 @@ def test_kernels_need_no_scratch_and_keep_full_occupancy():
     assert len(step) >= 24 and any('soft_coverage' in k for k in kernels) and any('greedy_policy' in k for k in kernels)
     for name, r in kernels.items():
         assert r['ScratchSize'] == 0 and r['Dynamic Stack'] == 'False', name
+    # SGPRs parked in VGPR lanes, by kernel: none anywhere but in the two folded flows of MATE-8v8-9, which sit at the SGPR limit
+    # (5 in the random-policy flow, 9 in the caller's-actions flow today; two more would be a regression worth looking at)
+    spill_allowance = {'FixedShapeILi8ELi8ELi9ELb0ELb0EEELi1E': 6, 'FixedShapeILi8ELi8ELi9ELb0ELb0EEELi2E': 10}
     for name, r in step.items():
-        # (a few SGPRs parked in VGPR lanes are tolerated -- the 8v8-9 flows sit at the SGPR limit: 9 in the caller's-actions flow --
-        # as long as nothing reaches scratch memory and the occupancy holds)
-        assert r['TotalSGPRs'] <= 96 and r['VGPRs'] <= 64 and r['SGPRs Spill'] <= 12 and r['VGPRs Spill'] == 0 and r['Occupancy'] == 8, (name, r)
+        allowed = next((v for k, v in spill_allowance.items() if k in name), 0)
+        assert r['TotalSGPRs'] <= 96 and r['VGPRs'] <= 64 and r['SGPRs Spill'] <= allowed and r['VGPRs Spill'] == 0 and r['Occupancy'] == 8, (name, r)
+    # step_greedy_kernel (the per-step flows with the on-device agents): full occupancy for every compiled shape but MATE-8v8-9
+    fused = {k: r for k, r in kernels.items() if 'step_greedy_kernel' in k}
+    assert len(fused) >= 15
+    for name, r in fused.items():
+        assert r['VGPRs Spill'] == 0 and r['Occupancy'] >= (7 if ('Li8ELi8ELi9E' in name or 'AnyShape' in name) else 8), (name, r)
 
 
 def test_auxiliary_target_rewards_on_a_replayed_trace():
