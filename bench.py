@@ -206,6 +206,8 @@ def parse_args(argv=None):
                     help='one launch per step (per_step_launch / external_actions / --rollout 0 with the random policy): restart finished '
                          'environments with one reset launch per k steps (1 = a reset launch behind every step); a finished environment idles at most k - 1 steps')
     ap.add_argument('--stats-interval', type=int, default=8, help='launches between two episode-statistics gathers inside the timed loop (0 = none)')
+    ap.add_argument('--versus-reset-interval', type=int, default=64,
+                    help='learner_flows / versus_greedy: one restart of the finished environments per this many steps (Greedy episodes end after ~1.2 k steps)')
     ap.add_argument('--graph-steps', type=int, default=64, help='external policy: step + auto-reset pairs captured per HIP graph (0 = direct launches)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the per_step_launch / external_actions side measurements')
@@ -427,7 +429,27 @@ def measure_hbm_copy_peak(torch, device_index, gib=1.0, reps=5):
     return sorted(rates)[len(rates) // 2]
 
 
-def measure_learner_flows(torch, device_index, workload, batch, graph_steps, reset_interval, world=1):
+def measure_hbm_fill_peak(torch, device_index, gib=1.0, reps=5):
+    """... and of a plain fill (write-only, like the observation rows the dominant kernels stream out): 1 GiB zeroed `reps` times, median."""
+    n = int(gib * (1 << 30)) // 4
+    with torch.cuda.device(device_index):
+        a = torch.empty(n, dtype=torch.float32, device='cuda')
+        a.zero_()
+        torch.cuda.synchronize()
+        rates = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            a.zero_()
+            e1.record()
+            torch.cuda.synchronize()
+            rates.append(4.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del a
+        torch.cuda.empty_cache()
+    return sorted(rates)[len(rates) // 2]
+
+
+def measure_learner_flows(torch, device_index, workload, batch, graph_steps, reset_interval, versus_reset_interval, world=1):
     """The flows a learner calls, one launch (or one launch + the learner's own kernel) per step, at `batch` environments:
       per_step_launch   step_random: the engine's step kernel back to back, no caller kernel in between
       external_actions  step(actions): the joint actions in a caller-owned f32 buffer that a stand-in policy kernel rewrites before
@@ -438,8 +460,10 @@ def measure_learner_flows(torch, device_index, workload, batch, graph_steps, res
       external_actions_two_groups   the same batch as two half-batch engines on two streams, graphs replayed alternately -- a learner
                         that alternates between two groups of environments (double-buffered sampling): one group's step runs under
                         the other group's policy and launch ramp
-    each timed over whole graphs (median of three passes), with one reset launch per `reset_interval` steps; idle slots of finished
-    environments are excluded from `value`.  `kernel_avg_us` / `roofline_frac`: a separate pass of direct launches with a
+    each timed over whole graphs (median of three passes, all three listed), with one reset launch per `reset_interval` steps
+    (`versus_reset_interval` against the greedy opponents, whose episodes end after ~1.2 k steps: a hundred of 4096 environments per
+    32 steps, and their restart -- placement, occlusion tables, first view: four latency-bound launches -- costs 3.5 us per step at
+    32, half of it at 64); idle slots of finished environments are excluded from `value`.  `kernel_avg_us` / `roofline_frac`: a separate pass of direct launches with a
     dispatch-event pair on every launch."""
     from mate_amd.config import read_config
     from mate_amd.engine import Engine
@@ -459,11 +483,15 @@ def measure_learner_flows(torch, device_index, workload, batch, graph_steps, res
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             times.append((dt, n_envs * steps - (idle() - i0)))
+        passes[:] = [t[0] / steps * 1e6 for t in times]
         return sorted(times)[1]
+
+    passes = []
 
     def entry(eng, dt, executed, kernel=None, km=0.0, flow=None):
         b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
         e = {'value': executed * world / dt, 'unit': 'env-steps/s', 'us_per_step': dt / steps * 1e6,
+             'passes_us_per_step': [round(v, 3) for v in passes],
              'end_to_end_frac': b_alg * executed / dt / 1e9 / HBM_PEAK_GBS}
         if kernel:
             e.update({'kernel': kernel, 'kernel_avg_us': km * 1e3, 'roofline_frac': b_alg * batch / (km * 1e-3) / 1e9 / HBM_PEAK_GBS if km > 0 else 0.0})
@@ -497,17 +525,20 @@ def measure_learner_flows(torch, device_index, workload, batch, graph_steps, res
             eng.enable_policies()
             eng.reset()
             mine = (torch.rand((batch, eng.num_cameras, 2), device=eng.device) * 2 - 1) * torch.tensor([5.0, 2.5], device=eng.device)
-            st = eng.make_stepper(mine, None, auto_reset=reset_interval, graph_steps=G, between=lambda: mine.mul_(-1.0), versus='camera')
+            Gv = max(G, versus_reset_interval) // versus_reset_interval * versus_reset_interval
+            st = eng.make_stepper(mine, None, auto_reset=versus_reset_interval, graph_steps=Gv, between=lambda: mine.mul_(-1.0), versus='camera')
             dt, ex = timed(st.run, eng.idle_steps, batch)
             st.close()
             eng.kernel_time(enable=1)
             for _ in range(256):
-                eng.step_versus_greedy('camera', mine, auto_reset=reset_interval)
+                eng.step_versus_greedy('camera', mine, auto_reset=versus_reset_interval)
             torch.cuda.synchronize()
             km, _ = eng.kernel_time(enable=False)
             out['versus_greedy'] = entry(eng, dt, ex, 'step_greedy_kernel' if eng.last_flow == 4 else 'rollout_greedy_kernel (one step)', km,
                                          flow='MultiCamera(GreedyTargetAgent): the learner\'s stand-in policy (one elementwise kernel) writes the camera team\'s joint action, '
-                                              'the greedy targets act and the environment steps in one launch; executed env-steps (idle slots of finished episodes excluded)')
+                                              'the greedy targets act and the environment steps in one launch; executed env-steps (idle slots of finished episodes excluded); '
+                                              f'one restart of the finished environments per {versus_reset_interval} steps')
+            out['versus_greedy']['reset_interval'] = versus_reset_interval
             del st, mine
         eng.close()
         del eng
@@ -786,6 +817,7 @@ def main():
                    f'{args.dump}.rank{rank}.pt')
     if rank == 0:
         copy_peak = measure_hbm_copy_peak(torch, local_rank) if not args.dump else HBM_PEAK_MEASURED_GBS
+        fill_peak = measure_hbm_fill_peak(torch, local_rank) if not args.dump else None
         total_envs = args.batch * world
         value = executed / elapsed            # == total_envs * steps / elapsed unless environments idled for a batched reset
         b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
@@ -819,6 +851,7 @@ def main():
                 'traffic_source': 'profiles/latest_pmc.json: PMC passes of the builder on a box of the same pool (tools/pmc_collect.py), NOT collected in this run',
                 'peak_measured': copy_peak, 'frac_of_measured_peak': achieved / copy_peak,
                 'peak_measured_source': 'device-to-device copy of 1 GiB on this box in this run, median of 5 (read + write bytes)',
+                'fill_measured': fill_peak, 'fill_measured_source': 'torch zero_() of 1 GiB on this box in this run, median of 5 (write-only, like the rows this kernel streams out)',
                 'kernel': '%s<float, %s, %s>' % (kernel, 'FixedShape' if eng.specialised else 'AnyShape', ('FLOW_ANY', 'FLOW_RANDOM', 'FLOW_ACT_F32', 'FLOW_GREEDY')[flow]),
                 'kernel_avg_us': kernel_ms * 1e3, 'launches_timed': launches, 'env_steps_per_launch': args.batch * steps_per_launch,
                 'algorithmic_bytes_per_launch': bytes_per_launch,
@@ -869,11 +902,11 @@ def main():
             eng._rollout = None
             torch.cuda.empty_cache()
             batches = [args.batch] + ([b for b in LEARNER_BATCHES if b != args.batch] if default_case else [])
-            flows = [measure_learner_flows(torch, local_rank, args.workload, b, args.graph_steps, args.step_reset_interval) for b in batches]
+            flows = [measure_learner_flows(torch, local_rank, args.workload, b, args.graph_steps, args.step_reset_interval, args.versus_reset_interval) for b in batches]
             line['learner_flows'] = flows
             for key in ('per_step_launch', 'external_actions', 'versus_greedy'):
                 if key in flows[0]:
-                    line[key] = dict(flows[0][key], batch=args.batch, reset_interval=args.step_reset_interval)
+                    line[key] = dict({'reset_interval': args.step_reset_interval}, **flows[0][key], batch=args.batch)
         if default_case and not args.no_side_measurements and not args.dump:
             line['n1_api'] = measure_n1_api(torch)
         if not args.no_cpu_baseline and world == 1 and args.policy == 'random' and args.workload == WORKLOAD:

@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'mate_engine.hip')
-DEPS = [SRC] + [os.path.join(HERE, 'csrc', f) for f in ('engine_kernels.hpp', 'reset_kernels.hpp', 'policy_kernels.hpp', 'aux_kernels.hpp', 'device_math.hpp',
+DEPS = [SRC] + [os.path.join(HERE, 'csrc', f) for f in ('engine_kernels.hpp', 'reset_kernels.hpp', 'policy_kernels.hpp', 'aux_kernels.hpp', 'device_math.hpp', 'experiments.hpp',
                                                           'shape_groups.hpp', 'shape_group.inc', 'shape_group.hip')] + [
     os.path.join(os.path.dirname(HERE), 'include', 'mate_engine.h')]
 OUT = os.path.join(HERE, 'lib', 'libmate_engine.so')

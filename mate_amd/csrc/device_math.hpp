@@ -238,6 +238,16 @@ __device__ __forceinline__ void sincos_deg_f32(double deg, float &sn, float &cs)
 // The reference shortens the ray through its polar form (new_norm * (cos a, sin a), a = atan2(v)); that
 // is v * (new_norm / |v|) up to last-place rounding, which is how it is done here (no atan2/sincos).
 // (vx, vy) step vector from origin (ox, oy); n = |v| (recomputed when n_known is false).
+// `Vector2D.norm = value` (utils.py:223-229) the reference's way: the vector is re-made from its polar form, value * (cos, sin) of
+// atan2_deg(v) (utils.py:144-152).  The kernels rescale the vector instead (below); -DMATE_POLAR_CLAMP (python -m mate_amd.build
+// --variant polar -DMATE_POLAR_CLAMP) builds them with THIS on the two places the hot path sets a norm -- the over-long step and the
+// ray truncated by an obstacle -- for the census that weighs the departure (profiles/r05_polar_census.txt).
+__device__ __forceinline__ void set_norm_polar(double &vx, double &vy, double value) {
+    double sn, cs;
+    sincos_deg(atan2_deg(vy, vx), sn, cs);
+    vx = value * cs; vy = value * sn;
+}
+
 __device__ __forceinline__ void obstruct_tangential(double ox, double oy, double &vx, double &vy, double &n, bool &n_known,
                                                     double cx, double cy, double rad) {
     const double relx = cx - ox, rely = cy - oy;
@@ -255,8 +265,14 @@ __device__ __forceinline__ void obstruct_tangential(double ox, double oy, double
             const double cand = rel_norm * cosv - half_chord;
             const double new_norm = cand > 0.0 ? cand : 0.0;
             if (new_norm < n) {
+#ifdef MATE_POLAR_CLAMP
+                double tvx = vx, tvy = vy;
+                set_norm_polar(tvx, tvy, new_norm);
+                const double rx = (ox + tvx) - cx, ry = (oy + tvy) - cy;
+#else
                 const double scale = div_nz(new_norm, n);
                 const double rx = (ox + vx * scale) - cx, ry = (oy + vy * scale) - cy;
+#endif
                 const double s = div_nz((n - new_norm) * half_chord, rad * rad);
                 vx = vx + rx * s; vy = vy + ry * s;
                 n_known = false;

@@ -9,6 +9,19 @@
 #pragma once
 #include "device_math.hpp"
 
+// Measurement hooks (phases compiled out or executed twice, a fake occlusion record, plain row stores): experiment builds only --
+// experiments.hpp says what each does.  The shipped library sees the defaults below: every phase once, the real record,
+// non-temporal row stores.
+#if defined(MATE_ABLATE) || defined(MATE_DOUBLE) || defined(MATE_LUT_FAKE) || defined(MATE_STORE_PLAIN)
+#include "experiments.hpp"
+#else
+#define MATE_PHASE(bit, ...) do { __VA_ARGS__; } while (0)
+#define MATE_PHASE_AGAIN(bit, ...) do { } while (0)
+#define MATE_ZOOM_ITERATIONS 20
+#define MATE_LUT_TABLE_OF(lc) (lc)
+#define MATE_ROW_STORE(v, dst) __builtin_nontemporal_store((v), (dst))
+#endif
+
 namespace mate {
 
 enum Mode : int32_t { MODE_STEP = 0, MODE_STEP_RANDOM = 1, MODE_OBSERVE = 2 };
@@ -697,8 +710,12 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
             // `step.norm = step_size` (entities.py:649-650) goes through the polar form in the reference
             // (s*(cos, sin) of atan2(a)); rescaling the vector is the same quantity to within the
             // last-place noise a device atan2/sincos would add anyway, at a tenth of the instructions.
+#ifdef MATE_POLAR_CLAMP
+            set_norm_polar(vx, vy, step_size); n = step_size;
+#else
             const double k = div_nz(step_size, n);
             vx = ax * k; vy = ay * k; n = step_size;
+#endif
         }
         desx = ox + vx; desy = oy + vy;
         if (!carried) { c.snorm(t) = n; if (!ballot_screen) { c.near(t) = 0; c.near(p.Nt + t) = 0; } }
@@ -1125,11 +1142,7 @@ __device__ __forceinline__ SectorEval sector_eval_held(Ctx<ObsT> &c, const Range
 template <typename ObsT>
 __device__ __forceinline__ void sector_fetch(const Ctx<ObsT> &c, const SectorEval &e, double2 (&w)[kDegWords]) {
     if (e.need) {
-#ifdef MATE_LUT_FAKE      // experiment build: every lookup reads the same (cache-resident) record -- what the real fetch's latency costs
-        const double2 *rec = c.g.lut_deg + (0 * e.lc * kLutCells + degree_of(e.x)) * kDegWords;
-#else
-        const double2 *rec = c.g.lut_deg + (e.lc * kLutCells + degree_of(e.x)) * kDegWords;
-#endif
+        const double2 *rec = c.g.lut_deg + (MATE_LUT_TABLE_OF(e.lc) * kLutCells + degree_of(e.x)) * kDegWords;
 #pragma unroll
         for (int i = 0; i < kDegWords; ++i) w[i] = rec[i];
     }
@@ -1433,9 +1446,12 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
 // The order-dependent part of _assign_goals (environment.py:1278-1318: the warehouses' remaining cargo is shared), on ONE lane,
 // for the targets standing in a warehouse (c.inside); dense and delayed rewards of the deliveries are added to `reward` / `delayed`.
 template <typename ObsT>
-__device__ __forceinline__ void goal_logistics(Ctx<ObsT> &c, uint32_t tick, double &reward, double &delayed) {
+__device__ __forceinline__ void goal_logistics(Ctx<ObsT> &c, uint32_t tick, double &reward, double &delayed, uint32_t inside_mask) {
     const Params &p = c.p;
-    for (int t = 0; t < p.Nt; ++t) {
+    // `inside_mask`: bit t = target t stands in a warehouse (the callers' ballot, wave-uniform): the loop visits those targets only, in
+    // ascending order as the reference's does -- one LDS round trip per target in a warehouse (usually one) instead of one per target
+    for (uint32_t todo = inside_mask; todo != 0u; todo &= todo - 1u) {
+        const int t = __ffs((int)todo) - 1;
         const int w = c.inside(t);
         if (w < 0) continue;
         int gw = c.ti(t, TI_GW);
@@ -1522,12 +1538,13 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
         c.ti(lane, TI_BOUNTY) = nb > 0 ? nb : 0;               // environment.py:1276
     }
     const int n_penal = __popcll(__ballot(penal));
-    const bool any_inside = __ballot(lane < p.Nt && inside_lane >= 0) != 0ull;
+    const uint32_t inside_mask = (uint32_t)__ballot(lane < p.Nt && inside_lane >= 0);      // (target t on lane t; at most 16 targets)
+    const bool any_inside = inside_mask != 0u;
     wave_sync();
     double reward = -(double)n_penal, delayed = 0.0;
     if (any_inside) {
         if (lane == 0) {
-            goal_logistics(c, tick, reward, delayed);
+            goal_logistics(c, tick, reward, delayed, inside_mask);
             c.xch(0) = __double2hiint(reward); c.xch(1) = __double2loint(reward);
             c.xch(2) = __double2hiint(delayed); c.xch(3) = __double2loint(delayed);
         }
@@ -1670,24 +1687,11 @@ __device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c) {
     fill_scratch(c, always);
 }
 
-// The observation rows leave through this store.  (MATE_STORE_PLAIN: experiment switch -- plain write-back stores instead of
-// non-temporal ones, tools/store_roof.hip)
+// The observation rows leave through this store: non-temporal (a write-once stream; -9 % kernel time against plain stores)
 template <typename V>
-__device__ __forceinline__ void stream_store(V v, V *dst) {
-#ifdef MATE_STORE_PLAIN
-    *dst = v;
-#else
-    __builtin_nontemporal_store(v, dst);
-#endif
-}
+__device__ __forceinline__ void stream_store(V v, V *dst) { MATE_ROW_STORE(v, dst); }
 template <typename V>
-__device__ __forceinline__ void stream_store(V v, __attribute__((address_space(1))) V *dst) {
-#ifdef MATE_STORE_PLAIN
-    *dst = v;
-#else
-    __builtin_nontemporal_store(v, dst);
-#endif
-}
+__device__ __forceinline__ void stream_store(V v, __attribute__((address_space(1))) V *dst) { MATE_ROW_STORE(v, dst); }
 template <typename ObsT> struct Vec;
 template <> struct Vec<float> { using type = float4; static constexpr int W = 4; };
 template <> struct Vec<double> { using type = double2; static constexpr int W = 2; };
@@ -2172,7 +2176,11 @@ __device__ __forceinline__ void simulate_targets_held(Ctx<ObsT> &c, const StepDr
         const double ox = h.x, oy = h.y;
         double vx = ax, vy = ay;
         double n = norm2(ax, ay);
+#ifdef MATE_POLAR_CLAMP
+        if (n > step_size) { set_norm_polar(vx, vy, step_size); n = step_size; }
+#else
         if (n > step_size) { const double k = div_nz(step_size, n); vx = ax * k; vy = ay * k; n = step_size; }      // entities.py:649-650
+#endif
         const double desx = ox + vx, desy = oy + vy;
         uint64_t todo = near_field(p, carried, t);
         bool n_known = true;
@@ -2231,7 +2239,8 @@ __device__ __forceinline__ int assign_and_score_held(Ctx<ObsT> &c, uint32_t tick
     }
     const int n_penal = __popcll(__ballot(penal));
     double reward = -(double)n_penal, delayed = 0.0;
-    if (__ballot(inside >= 0) != 0ull) {                       // rare: through the LDS record, with the shared serial code
+    const unsigned long long inside_lanes = __ballot(inside >= 0);      // (target t on lane Nc + t)
+    if (inside_lanes != 0ull) {                                // rare: through the LDS record, with the shared serial code
         if (is_target) {
             c.ti(t, TI_BOUNTY) = h.bounty; c.ti(t, TI_FREIGHT) = h.freight; c.ti(t, TI_GW) = h.gw;
             c.ti(t, TI_TSTEPS) = h.tsteps; c.ti(t, TI_TRSTEPS) = h.trsteps;
@@ -2239,7 +2248,7 @@ __device__ __forceinline__ int assign_and_score_held(Ctx<ObsT> &c, uint32_t tick
         }
         wave_sync();
         if (lane == 0) {
-            goal_logistics(c, tick, reward, delayed);
+            goal_logistics(c, tick, reward, delayed, (uint32_t)(inside_lanes >> p.Nc));
             c.xch(0) = __double2hiint(reward); c.xch(1) = __double2loint(reward);
             c.xch(2) = __double2hiint(delayed); c.xch(3) = __double2loint(delayed);
         }
@@ -2889,70 +2898,64 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
 #define ROLL_STAMP(i) do { } while (0)
 #endif
         ROLL_STAMP(7);         // loop overhead: from the end of the previous step to here
-#ifndef MATE_ABLATE            // experiment builds (tools/ablate_rollout.sh): a phase compiled out, to weigh it
-#define MATE_ABLATE 0
-#endif
-#ifndef MATE_DOUBLE            // experiment builds (tools/double_phase.sh): an idempotent phase executed TWICE -- the difference of the
-#define MATE_DOUBLE 0          // dynamic instruction counters against the plain build is that phase's exact share, on real data
-#endif
         StepDraws draws{0.0, 0.0};
         pin_draw_role(draws_of_lane);
-        if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick, &carry, &draws_of_lane);
-        if (MATE_DOUBLE & 1) { DrawCarry again = carry; again.block = 0xffffffffu; const StepDraws d2 = step_draws(c, tick, &again); draws.a0 += 0.0 * d2.a0; }
+        MATE_PHASE(1, draws = step_draws(c, tick, &carry, &draws_of_lane));
+        MATE_PHASE_AGAIN(1, DrawCarry again = carry; again.block = 0xffffffffu; const StepDraws d2 = step_draws(c, tick, &again); draws.a0 += 0.0 * d2.a0);
         ROLL_STAMP(0);
         if constexpr (HELDSTATE) {
-            if (!(MATE_ABLATE & 2)) simulate_cameras_held(c, draws, h);
+            MATE_PHASE(2, simulate_cameras_held(c, draws, h));
             ROLL_STAMP(1);
 #ifdef MATE_SUB_CLOCKS
             c.sub = sub;
 #endif
             SUB_START(c);
-            if (!(MATE_ABLATE & 4)) simulate_targets_held(c, draws, near, h);
+            MATE_PHASE(4, simulate_targets_held(c, draws, near, h));
             SUB_ACC(c, 7);                               // targets: clip, entity table
             ROLL_STAMP(2);
             uint32_t seen = 0u;
             unsigned long long sector_ballot = 0ull;
             SUB_START(c);
-            if (!(MATE_ABLATE & 8)) update_view<true, true>(c, tick, S_TRANSMIT, true, roles, seen, &near, &sector_ballot);
+            MATE_PHASE(8, update_view<true, true>(c, tick, S_TRANSMIT, true, roles, seen, &near, &sector_ballot));
             SUB_ACC(c, 3);                               // mask words, static bits
-            if (MATE_DOUBLE & 8) { uint32_t again; update_view<true, true>(c, tick, S_TRANSMIT, true, roles, again, &near, &sector_ballot); seen |= again; }
+            MATE_PHASE_AGAIN(8, uint32_t again; update_view<true, true>(c, tick, S_TRANSMIT, true, roles, again, &near, &sector_ballot); seen |= again);
             bool tracked; int inside;
             view_tail_held(c, sector_ballot, h, tracked, inside);
             SUB_ACC(c, 4);                               // tracked bits, warehouses
             ROLL_STAMP(3);
-            if (!(MATE_ABLATE & 16)) finished = assign_and_score_held(c, tick, g.scalars, h, tracked, inside);
+            MATE_PHASE(16, finished = assign_and_score_held(c, tick, g.scalars, h, tracked, inside));
             ROLL_STAMP(4);
-            if (!(MATE_ABLATE & 32)) { image_targets_held(c, h, last_gw); image_blocks(c, roles, seen); }
+            MATE_PHASE(32, image_targets_held(c, h, last_gw); image_blocks(c, roles, seen));
             ROLL_STAMP(5);
             // (measured and dropped: the rows of step r leaving in the MIDDLE of step r + 1, behind its occlusion wait, so that their
             // acknowledgements have a whole step before the next wait instead of 40 % of one -- no faster)
-            if (!(MATE_ABLATE & 64)) { image_store(c, cam_low, tgt_low); store_masks(c); }
+            MATE_PHASE(64, image_store(c, cam_low, tgt_low); store_masks(c));
             wave_sync();
             stepped = true;
             ROLL_STAMP(6);
             continue;
         }
-        if (!(MATE_ABLATE & 2)) simulate_cameras(c, draws, true);
-        if (MATE_DOUBLE & 2) { wave_sync(); simulate_cameras(c, StepDraws{0.0, 0.0}, true); }      // (a zero action: the same instructions, the same state)
+        MATE_PHASE(2, simulate_cameras(c, draws, true));
+        MATE_PHASE_AGAIN(2, wave_sync(); simulate_cameras(c, StepDraws{0.0, 0.0}, true));      // (a zero action: the same instructions, the same state)
         ROLL_STAMP(1);
-        if (!(MATE_ABLATE & 4)) simulate_targets(c, draws, Shape::kHoldRoles ? &near : nullptr);
+        MATE_PHASE(4, simulate_targets(c, draws, Shape::kHoldRoles ? &near : nullptr));
         ROLL_STAMP(2);
         uint32_t seen = 0u;
-        if (!(MATE_ABLATE & 8)) update_view<Shape::kHoldRoles, true>(c, tick, S_TRANSMIT, true, roles, seen, Shape::kHoldRoles ? &near : nullptr);
-        if (MATE_DOUBLE & 8) { uint32_t again; update_view<Shape::kHoldRoles, true>(c, tick, S_TRANSMIT, true, roles, again, Shape::kHoldRoles ? &near : nullptr); seen |= again; }
+        MATE_PHASE(8, update_view<Shape::kHoldRoles, true>(c, tick, S_TRANSMIT, true, roles, seen, Shape::kHoldRoles ? &near : nullptr));
+        MATE_PHASE_AGAIN(8, uint32_t again; update_view<Shape::kHoldRoles, true>(c, tick, S_TRANSMIT, true, roles, again, Shape::kHoldRoles ? &near : nullptr); seen |= again);
         ROLL_STAMP(3);
-        if (!(MATE_ABLATE & 16)) assign_and_score(c, tick, g.scalars);
+        MATE_PHASE(16, assign_and_score(c, tick, g.scalars));
         ROLL_STAMP(4);
         if constexpr (IMAGE) {
-            if (!(MATE_ABLATE & 32)) { image_targets(c, last_gw); image_blocks(c, roles, seen); }
+            MATE_PHASE(32, image_targets(c, last_gw); image_blocks(c, roles, seen));
             ROLL_STAMP(5);
-            if (!(MATE_ABLATE & 64)) { image_store(c, cam_low, tgt_low); store_masks(c); }
-            if (MATE_DOUBLE & 32) { int gw2 = last_gw; image_targets(c, gw2); image_blocks(c, roles, seen); }
-            if (MATE_DOUBLE & 64) { wave_sync(); image_store(c, cam_low, tgt_low); }
+            MATE_PHASE(64, image_store(c, cam_low, tgt_low); store_masks(c));
+            MATE_PHASE_AGAIN(32, int gw2 = last_gw; image_targets(c, gw2); image_blocks(c, roles, seen));
+            MATE_PHASE_AGAIN(64, wave_sync(); image_store(c, cam_low, tgt_low));
         } else {
-        if (!(MATE_ABLATE & 32)) fill_scratch(c, last_gw);
+        MATE_PHASE(32, fill_scratch(c, last_gw));
         ROLL_STAMP(5);
-        if (!(MATE_ABLATE & 64)) pack_observations<true>(c, held);
+        MATE_PHASE(64, pack_observations<true>(c, held));
         }
         wave_sync();
         stepped = true;

@@ -53,9 +53,6 @@ struct PolicyPtrs {
 //   mem[c][t][2] | prev_action[c][2] | tgt_prev_xy[t][2] | tgt_prev_noise[t][2]
 // i32 part
 //   t2f[c][t] | delay[s][c] | neighbor[c][s] | has_state[c] | tgt_goal[t] | tgt_nonempty[t] | tgt_need[t] | episode
-#ifndef MATE_ABLATE            // experiment builds (tools/ablate_rollout.sh)
-#define MATE_ABLATE 0
-#endif
 
 template <typename ObsT>
 struct PolCtx {
@@ -111,7 +108,7 @@ __device__ __forceinline__ double sin_deg_0_90(double deg) {
 // depth -- was no faster: the solving wave shares its SIMD with three others and is issue-bound, not latency-bound.)
 __device__ __forceinline__ double zoom_fixed_point(double Kc) {
     double b = 180.0;
-    for (int it = 0; it < ((MATE_ABLATE & 256) ? 1 : 20); ++it) {
+    for (int it = 0; it < MATE_ZOOM_ITERATIONS; ++it) {
         const double half = b * 0.5;
         const double y = 1.0 + sin_deg_0_90(half < 90.0 ? half : 90.0);
         double r = __builtin_amdgcn_rcp(y);
@@ -644,7 +641,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
             continue;
         }
         // (the joint actions stay in LDS; the last executed step's are published once, at the end of the launch)
-        if (!(MATE_ABLATE & 128)) greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, c.mask, wave_r, lane_r, env_r, true, act_cam, act_tgt, GREEDY_ACC, false);
+        MATE_PHASE(128, greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, c.mask, wave_r, lane_r, env_r, true, act_cam, act_tgt, GREEDY_ACC, false));
         wave_sync();
         GREEDY_STAMP(10);
         if (q.caller_team >= 0) {
@@ -653,31 +650,29 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         }
         const uint32_t tick = p.dev_tick + g.tick + (uint32_t)r;
         StepDraws draws{0.0, 0.0};
-        if (!(MATE_ABLATE & 1)) draws = step_draws(c, tick, &carry);       // see-through uniforms only (mode() is MODE_STEP)
+        MATE_PHASE(1, draws = step_draws(c, tick, &carry));       // see-through uniforms only (mode() is MODE_STEP)
         GREEDY_STAMP(0);
-        if (!(MATE_ABLATE & 2)) simulate_cameras(c, draws, true);
+        MATE_PHASE(2, simulate_cameras(c, draws, true));
         GREEDY_STAMP(1);
-        if (!(MATE_ABLATE & 4)) simulate_targets(c, draws, ROLES ? &near : nullptr);
+        MATE_PHASE(4, simulate_targets(c, draws, ROLES ? &near : nullptr));
         GREEDY_STAMP(2);
         uint32_t seen = 0u;
-        if (!(MATE_ABLATE & 8)) {
+        MATE_PHASE(8,
             if constexpr (ROLES) update_view<true, true>(c, tick, S_TRANSMIT, true, roles, seen, &near);
-            else { RangeRoles none; update_view<false, true>(c, tick, S_TRANSMIT, true, none); }
-        }
+            else { RangeRoles none; update_view<false, true>(c, tick, S_TRANSMIT, true, none); });
         GREEDY_STAMP(3);
-        if (!(MATE_ABLATE & 16)) assign_and_score(c, tick, g.scalars);
+        MATE_PHASE(16, assign_and_score(c, tick, g.scalars));
         GREEDY_STAMP(4);
         if constexpr (IMAGE) {
-            if (!(MATE_ABLATE & 32)) { image_targets(c, last_gw); image_blocks(c, roles, seen); }
+            MATE_PHASE(32, image_targets(c, last_gw); image_blocks(c, roles, seen));
             GREEDY_STAMP(5);
-            if (!(MATE_ABLATE & 64)) { image_store(c); store_masks(c); }
+            MATE_PHASE(64, image_store(c); store_masks(c));
         } else {
-        if (!(MATE_ABLATE & 32)) fill_scratch(c);
+        MATE_PHASE(32, fill_scratch(c));
         GREEDY_STAMP(5);
-        if (!(MATE_ABLATE & 64)) {
+        MATE_PHASE(64,
             if constexpr (Shape::kGreedyHeld) pack_observations<true>(c, held);
-            else { PackDescriptors now; pack_observations<false>(c, now); }
-        }
+            else { PackDescriptors now; pack_observations<false>(c, now); });
         }
         wave_sync();
         stepped = true;

@@ -23,12 +23,18 @@ GROUPS = [
     ['WRITE_SIZE'],
     ['SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_ACTIVE_INST_VALU', 'SQ_WAIT_INST_ANY'],
     ['SQ_WAIT_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR', 'SQ_ACTIVE_INST_LDS', 'SQ_LDS_BANK_CONFLICT', 'SQ_WAIT_INST_LDS', 'GRBM_GUI_ACTIVE'],
+    # round 5: what the LDS array itself does (SQ_LDS_IDX_ACTIVE = all LDS-array cycles, SQ_LDS_BANK_CONFLICT = the extra ones: their
+    # quotient is the share of array cycles lost to conflicts; MI355X_MICROARCH.md, "LDS"), and how many lanes a vector instruction
+    # has switched on (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, both in quad-cycles: 64 = every lane of every instruction)
+    ['SQ_LDS_IDX_ACTIVE', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_ADDR_CONFLICT', 'SQ_LDS_UNALIGNED_STALL', 'SQ_INSTS_LDS'],
+    ['SQ_THREAD_CYCLES_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VALU', 'SQ_INST_CYCLES_VMEM_WR', 'SQ_INST_CYCLES_VMEM_RD'],
 ]
 # name: (kernel substring, steps per launch, environments, bench arguments)
 CASES = {
     'headline256': ('rollout_kernel', 256, 4096, ['--rollout', '256', '--steps', '1024', '--warmup', '256']),
     'headline20': ('rollout_kernel', 20, 4096, ['--rollout', '20', '--steps', '20', '--warmup', '20', '--rollout-reset-interval', '6']),
     'step': ('step_kernel', 1, 4096, ['--rollout', '0', '--steps', '512', '--warmup', '64']),
+    'step16k': ('step_kernel', 1, 16384, ['--batch', '16384', '--rollout', '0', '--steps', '256', '--warmup', '64']),
     'c3': ('rollout_greedy_kernel', 48, 8192, ['--workload', 'MATE-8v8-9.yaml', '--batch', '8192', '--policy', 'greedy', '--rollout', '48', '--steps', '384', '--warmup', '48']),
     'c4shard': ('rollout_kernel', 256, 8192, ['--workload', 'MATE-4v8-0.yaml', '--batch', '8192', '--rollout', '256', '--steps', '1024', '--warmup', '256']),
     'c5shard': ('rollout_kernel', 256, 4096, ['--workload', 'MATE-Navigation.yaml', '--batch', '4096', '--rollout', '256', '--steps', '1024', '--warmup', '256']),
@@ -72,6 +78,10 @@ def main():
                 entry[c + '_per_env_step'] = entry[c] / envs / steps
             if entry.get('SQ_WAVE_CYCLES'):
                 entry['valu_active_fraction_of_wave_cycles'] = entry['SQ_ACTIVE_INST_VALU'] / entry['SQ_WAVE_CYCLES']
+        if entry.get('SQ_LDS_IDX_ACTIVE'):
+            entry['lds_conflict_share_of_array_cycles'] = entry['SQ_LDS_BANK_CONFLICT'] / entry['SQ_LDS_IDX_ACTIVE']
+        if entry.get('SQ_THREAD_CYCLES_VALU') and entry.get('SQ_ACTIVE_INST_VALU'):
+            entry['mean_active_lanes_per_valu_instruction'] = entry['SQ_THREAD_CYCLES_VALU'] / entry['SQ_ACTIVE_INST_VALU']
         entry['hbm_bytes_per_launch'] = (2.0 * entry.get('FETCH_SIZE', 0.0) + entry.get('WRITE_SIZE', 0.0)) * 1024.0
         summary[f'{kernel}@{steps}' + ('' if name in ('headline256', 'headline20', 'step', 'c3') else ':' + name)] = entry
         print(name, json.dumps({k: (round(v, 1) if isinstance(v, float) else v) for k, v in entry.items()}, sort_keys=True), flush=True)
