@@ -811,15 +811,14 @@ void step_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const Polic
     if (reg_tail) assign_and_score(c, tick, g.scalars, &tracked_reg, &inside_reg);
     else assign_and_score(c, tick, g.scalars);
     SG_STAMP(6);
+    // the records, the agents' memory and the joint actions are final: out before the packer (see step_kernel)
+    store_dynamic(c);
+    { double *dst = q.pol + env * q.PW; for (int k = lane; k < q.PW; k += 64) dst[k] = a.f[k]; }
+    for (int k = lane; k < 2 * p.Nc; k += 64) q.cam_act[env * 2 * p.Nc + k] = act_cam[k];      // what mate_engine_policy_actions reads: this step's joint actions (the caller's team's as decoded)
+    for (int k = lane; k < 2 * p.Nt; k += 64) q.tgt_act[env * 2 * p.Nt + k] = act_tgt[k];
     fill_scratch(c);
     if (early_desc) pack_observations<true>(c, pack_desc); else pack_observations<false>(c, pack_desc);
     SG_STAMP(7);
-    store_dynamic(c);
-    double *dst = q.pol + env * q.PW;
-    for (int k = lane; k < q.PW; k += 64) dst[k] = a.f[k];
-    // what mate_engine_policy_actions reads: this step's joint actions (the caller's team's as decoded)
-    for (int k = lane; k < 2 * p.Nc; k += 64) q.cam_act[env * 2 * p.Nc + k] = act_cam[k];
-    for (int k = lane; k < 2 * p.Nt; k += 64) q.tgt_act[env * 2 * p.Nt + k] = act_tgt[k];
     SG_STAMP(8);
 #ifdef MATE_PHASE_CLOCKS
     if (lane == 0 && g.phase_clocks) {

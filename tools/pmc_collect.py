@@ -54,7 +54,10 @@ def main():
     for name in names:
         kernel, steps, envs, args = CASES[name]
         acc = collections.defaultdict(list)
+        only = os.environ.get('PMC_GROUPS')       # e.g. PMC_GROUPS=4,5: only those counter groups (attribution runs with experiment builds)
         for gi, group in enumerate(GROUPS):
+            if only and str(gi) not in only.split(','):
+                continue
             d = os.path.join(out, f'raw_{name}_{gi}')
             cmd = ['rocprofv3', '--kernel-trace', '--pmc'] + group + ['--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
                                                                      'python3', os.path.join(root, 'bench.py'), '--reps', '1', '--rep-warmup', '1',
