@@ -539,53 +539,103 @@ def measure_learner_flows(torch, device_index, workload, batch, graph_steps, res
                                               'the greedy targets act and the environment steps in one launch; executed env-steps (idle slots of finished episodes excluded); '
                                               f'one restart of the finished environments per {versus_reset_interval} steps')
             out['versus_greedy']['reset_interval'] = versus_reset_interval
-            del st, mine
+            del st
+            # ---- ... and with FrameSkip(5) on top, what every example trainer's make_env ends with (examples/ippo/camera/config.py:
+            # frame_skip = 5; examples/utils/wrappers.py:301-323): ONE launch per learner action (rollout_versus_greedy), direct launches
+            K = 5
+            per = max(1, versus_reset_interval // K)
+            eng.reserve_rollout(K, search='none')
+            launches = max(2 * per, steps // K // per * per)
+
+            def run_skip(n):
+                for _ in range(n):
+                    mine.mul_(-1.0)
+                    eng.rollout_versus_greedy('camera', mine, K, auto_reset=per)
+
+            run_skip(2 * per)
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(3):
+                i0, t0 = eng.idle_steps(), time.perf_counter()
+                run_skip(launches)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                times.append((dt, batch * launches * K - (eng.idle_steps() - i0)))
+            dt, ex = sorted(times)[1]
+            eng.kernel_time(enable=1)
+            run_skip(per)
+            torch.cuda.synchronize()
+            km, _ = eng.kernel_time(enable=False)
+            b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
+            out['versus_greedy_frameskip5'] = {
+                'value': ex * world / dt, 'unit': 'env-steps/s', 'us_per_step': dt / (launches * K) * 1e6, 'us_per_launch': dt / launches * 1e6,
+                'passes_us_per_step': [round(t[0] / (launches * K) * 1e6, 3) for t in times],
+                'end_to_end_frac': b_alg * ex / dt / 1e9 / HBM_PEAK_GBS, 'kernel': 'rollout_greedy_kernel', 'kernel_avg_us': km * 1e3,
+                'roofline_frac': b_alg * batch * K / (km * 1e-3) / 1e9 / HBM_PEAK_GBS if km > 0 else 0.0,
+                'flow': f'FrameSkip({K}) over MultiCamera(GreedyTargetAgent): one policy kernel and ONE fused launch per learner action ({K} frames, the greedy targets '
+                        f'act anew on every frame), direct launches, one restart of the finished environments per {per} launches; executed env-steps'}
+            del mine
         eng.close()
         del eng
         torch.cuda.empty_cache()
-        # ---- two half-batch groups on two streams
+        # ---- two half-batch groups on two streams: step(actions), and the learner versus the greedy opponents
         if batch % 2 == 0 and batch >= 2048:
             half = batch // 2
             # (HIP maps streams onto a handful of hardware queues, and two streams that share one run their graphs one after the
             # other: 23 instead of 13 us per step at 4096 when that happens.  Group 0 stays on the current stream, group 1 takes the
             # best of three fresh streams by a short trial)
             candidates = [torch.cuda.Stream(device=device_index) for _ in range(3)]
-            streams = [torch.cuda.current_stream(device_index), candidates[0]]
-            engs, exts = [], []
-            for gi in range(2):
-                with torch.cuda.stream(streams[gi]):
-                    e = Engine(cfg, half, device=device_index, seed=0, first_env_index=gi * half)
-                    e.reset()
-                    engs.append(e)
-                    exts.append(ExternalActions(torch, e, G, reset_interval))
-            torch.cuda.synchronize()
-
-            def run_two(n):
-                for _ in range(n // G):
-                    for gi in range(2):
-                        with torch.cuda.stream(streams[gi]):
-                            exts[gi].run(G)
-
-            trials = []
-            for cand in candidates:
-                streams[1] = cand
-                run_two(2 * G)
+            for key, versus in (('external_actions_two_groups', False), ('versus_greedy_two_groups', True)):
+                if versus and 'versus_greedy' not in out:      # (a scenario without cameras)
+                    continue
+                streams = [torch.cuda.current_stream(device_index), candidates[0]]
+                engs, steppers, keep = [], [], []
+                interval = versus_reset_interval if versus else reset_interval
+                Gk = max(G, interval) // interval * interval
+                for gi in range(2):
+                    with torch.cuda.stream(streams[gi]):
+                        e = Engine(cfg, half, device=device_index, seed=0, first_env_index=gi * half)
+                        if versus:
+                            e.enable_policies()
+                            e.reset()
+                            mine = (torch.rand((half, e.num_cameras, 2), device=e.device) * 2 - 1) * torch.tensor([5.0, 2.5], device=e.device)
+                            keep.append(mine)
+                            steppers.append(e.make_stepper(mine, None, auto_reset=interval, graph_steps=Gk, between=(lambda m=mine: m.mul_(-1.0)), versus='camera'))
+                        else:
+                            e.reset()
+                            ext = ExternalActions(torch, e, Gk, interval)
+                            keep.append(ext)
+                            steppers.append(ext.stepper)
+                        engs.append(e)
                 torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                run_two(4 * G)
-                torch.cuda.synchronize()
-                trials.append(time.perf_counter() - t0)
-            streams[1] = candidates[trials.index(min(trials))]
-            dt, ex = timed(run_two, lambda: engs[0].idle_steps() + engs[1].idle_steps(), batch)
-            out['external_actions_two_groups'] = entry(engs[0], dt, ex, flow=f'two engines of {half} environments (global indices 0.. and {half}..) on two streams, their HIP graphs replayed alternately: '
-                                                                                'us_per_step = per step of the WHOLE batch')
-            out['external_actions_two_groups']['stream_trials_us_per_step'] = [round(t / (4 * G) * 1e6, 2) for t in trials]
-            for x in exts:
-                x.stepper.close()
-            for e in engs:
-                e.close()
-            del exts, engs
-            torch.cuda.empty_cache()
+
+                def run_two(n):
+                    for _ in range(n // Gk):
+                        for gi in range(2):
+                            with torch.cuda.stream(streams[gi]):
+                                steppers[gi].run(Gk)
+
+                trials = []
+                for cand in candidates:
+                    streams[1] = cand
+                    run_two(2 * Gk)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    run_two(4 * Gk)
+                    torch.cuda.synchronize()
+                    trials.append(time.perf_counter() - t0)
+                streams[1] = candidates[trials.index(min(trials))]
+                dt, ex = timed(run_two, lambda: engs[0].idle_steps() + engs[1].idle_steps(), batch)
+                out[key] = entry(engs[0], dt, ex, flow=f'{"MultiCamera(GreedyTargetAgent)" if versus else "step(actions)"} as two engines of {half} environments (global indices 0.. and {half}..) on two streams, '
+                                                         'their HIP graphs replayed alternately: us_per_step = per step of the WHOLE batch')
+                out[key]['stream_trials_us_per_step'] = [round(t / (4 * Gk) * 1e6, 2) for t in trials]
+                out[key]['reset_interval'] = interval
+                for st in steppers:
+                    st.close()
+                for e in engs:
+                    e.close()
+                del steppers, engs, keep
+                torch.cuda.empty_cache()
     return out
 
 

@@ -942,16 +942,17 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
 
 // LDS per workgroup of the two one-launch forms of a step with the on-device agents
 static size_t fused_rollout_lds(const mate_engine *e) { return 4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt) + 1024; }
-static size_t step_greedy_lds(const mate_engine *e) { return 4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)step_greedy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt, e->p.MW); }
+static size_t step_greedy_lds(const mate_engine *e, bool cameras = true) {
+    return 4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)step_greedy_slice_bytes(e->q.PW, e->q.TW, e->p.Nc, e->p.Nt, e->p.MW, cameras);
+}
 static bool use_step_greedy(const mate_engine *e) { return e->step_greedy_fn && !e->sw.step_greedy_rollout && step_greedy_lds(e) <= 160 * 1024; }
 
 static int policy_enable(mate_engine *e) {
     if (e->policy_ready) return MATE_OK;
     const Params &p = e->p;
     PolicyPtrs &q = e->q;
-    q.PF = p.Nc * p.Nt * 2 + p.Nc * 2 + p.Nt * 4;
-    q.PI = p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + 3 * p.Nt + 1;
-    q.PW = q.PF + (q.PI + 1) / 2;
+    q.TW = pol_target_words(p.Nt);
+    q.PW = pol_record_words(p.Nc, p.Nt);
     q.caller_team = -1;
     q.memory_period = 25;      // greedy.py:21
     q.noise_scale = 0.5;       // greedy.py:236
@@ -1119,7 +1120,8 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     // rollouts -- and MATE_STEP_GREEDY_ROLLOUT=1 -- rollout_greedy_kernel
     const bool light = per_step && use_step_greedy(e);
     const PolicyFn fn = light ? e->step_greedy_fn : e->rollout_greedy_fn;
-    const size_t lds = light ? step_greedy_lds(e) : fused_rollout_lds(e);
+    // (the caller plays the cameras: step_greedy_kernel holds the target agents' section only -- a smaller slice, one more workgroup per CU)
+    const size_t lds = light ? step_greedy_lds(e, team_caller != 0) : fused_rollout_lds(e);
     if (lds > 160 * 1024) return fail(MATE_EINVAL, "rollout_greedy: %zu bytes of LDS per workgroup do not fit", lds);
     g.mode = MODE_STEP; g.reset_kind = -1; g.rollout_steps = steps;
     g.parity = e->dev_tick ? 0 : e->parity;

@@ -38,7 +38,7 @@ struct PolicyPtrs {
     const uint32_t *masks;     // [N][MW] view masks of the previous step / reset
     double *cam_act, *tgt_act; // [N][Nc][2], [N][Nt][2] f64 outputs
     PolicyTape tape;
-    int32_t PF, PI, PW;        // doubles, ints, 8-byte words per record
+    int32_t TW, PW;            // 8-byte words of the target agents' section / of the whole record (pol_target_words, pol_record_words)
     int32_t lds_bytes;         // per wave
     int32_t memory_period;     // 25 (greedy.py:21)
     double noise_scale;        // 0.5 (greedy.py:236)
@@ -49,36 +49,52 @@ struct PolicyPtrs {
                                // joint action (Ptrs::cam_act / tgt_act) for every step of the launch (FrameSkip over MultiCamera / MultiTarget)
 };
 
-// f64 part of the record
-//   mem[c][t][2] | prev_action[c][2] | tgt_prev_xy[t][2] | tgt_prev_noise[t][2]
-// i32 part
-//   t2f[c][t] | delay[s][c] | neighbor[c][s] | has_state[c] | tgt_goal[t] | tgt_nonempty[t] | tgt_need[t] | episode
+// The agents' memory record of one environment, one section per TEAM (round 5: a team the caller plays does not act -- MultiCamera /
+// MultiTarget -- and step_greedy_kernel then neither loads nor stores, nor holds in LDS, that team's section):
+//   target section  f64: tgt_prev_xy[t][2] | tgt_prev_noise[t][2]      i32: tgt_goal[t] | tgt_nonempty[t] | tgt_need[t] | episode
+//   camera section  f64: mem[c][t][2] | prev_action[c][2]              i32: t2f[c][t] | delay[s][c] | neighbor[c][s] | has_state[c] | episode
+// `episode`: the episode whose first call has run the team's agent.reset(observation) (greedy.py:43-61, 262-283) -- per team, so
+// that a team that starts to act in the middle of an episode (the caller alternating step_greedy and step_versus_greedy) resets
+// at ITS first call.
+__host__ __device__ constexpr int pol_target_ints(int Nt) { return 3 * Nt + 1; }
+__host__ __device__ constexpr int pol_target_words(int Nt) { return 4 * Nt + (pol_target_ints(Nt) + 1) / 2; }
+__host__ __device__ constexpr int pol_camera_ints(int Nc, int Nt) { return Nc * Nt + 2 * Nc * Nc + Nc + 1; }
+__host__ __device__ constexpr int pol_camera_words(int Nc, int Nt) { return 2 * Nc * Nt + 2 * Nc + (pol_camera_ints(Nc, Nt) + 1) / 2; }
+__host__ __device__ constexpr int pol_record_words(int Nc, int Nt) { return pol_target_words(Nt) + pol_camera_words(Nc, Nt); }
 
 template <typename ObsT>
 struct PolCtx {
     const Params &p;
     const PolicyPtrs &q;
-    double *f;
-    int32_t *i;
-    __device__ PolCtx(const Params &p_, const PolicyPtrs &q_, unsigned char *base) : p(p_), q(q_) {
+    double *f;                 // the record: [target section | camera section], then the camera agents' per-step scratch
+    double *cf;                // camera section (f + TW)
+    int32_t *ti, *ci, *si;     // the sections' integers; the scratch's integers (f + PW)
+    // `base`: [target section | camera section | scratch] -- or, `cameras` false (step_greedy_kernel with the cameras played by the
+    // caller), the target section alone: no camera accessor is touched then
+    __device__ PolCtx(const Params &p_, const PolicyPtrs &q_, unsigned char *base, bool cameras = true) : p(p_), q(q_) {
         f = reinterpret_cast<double *>(base);
-        i = reinterpret_cast<int32_t *>(f + q.PF);
+        ti = reinterpret_cast<int32_t *>(f + 4 * p.Nt);
+        cf = f + q.TW;
+        ci = reinterpret_cast<int32_t *>(cf + 2 * p.Nc * p.Nt + 2 * p.Nc);
+        si = reinterpret_cast<int32_t *>(f + q.PW);
+        (void)cameras;
     }
-    __device__ double &mem(int c, int t, int k) { return f[(c * p.Nt + t) * 2 + k]; }
-    __device__ double &prev_action(int c, int k) { return f[p.Nc * p.Nt * 2 + c * 2 + k]; }
-    __device__ double &tgt_prev(int t, int k) { return f[p.Nc * p.Nt * 2 + p.Nc * 2 + t * 2 + k]; }
-    __device__ double &tgt_noise(int t, int k) { return f[p.Nc * p.Nt * 2 + p.Nc * 2 + p.Nt * 2 + t * 2 + k]; }
-    __device__ int32_t &t2f(int c, int t) { return i[c * p.Nt + t]; }
-    __device__ int32_t &delay(int s, int c) { return i[p.Nc * p.Nt + s * p.Nc + c]; }
-    __device__ int32_t &neighbor(int c, int s) { return i[p.Nc * p.Nt + p.Nc * p.Nc + c * p.Nc + s]; }
-    __device__ int32_t &has_state(int c) { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + c]; }
-    __device__ int32_t &tgt_goal(int t) { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + t]; }
-    __device__ int32_t &tgt_nonempty(int t) { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + p.Nt + t]; }
-    __device__ int32_t &tgt_need(int t) { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + 2 * p.Nt + t]; }
-    __device__ int32_t &episode() { return i[p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc + 3 * p.Nt]; }
+    __device__ double &tgt_prev(int t, int k) { return f[t * 2 + k]; }
+    __device__ double &tgt_noise(int t, int k) { return f[p.Nt * 2 + t * 2 + k]; }
+    __device__ int32_t &tgt_goal(int t) { return ti[t]; }
+    __device__ int32_t &tgt_nonempty(int t) { return ti[p.Nt + t]; }
+    __device__ int32_t &tgt_need(int t) { return ti[2 * p.Nt + t]; }
+    __device__ int32_t &tgt_episode() { return ti[3 * p.Nt]; }
+    __device__ double &mem(int c, int t, int k) { return cf[(c * p.Nt + t) * 2 + k]; }
+    __device__ double &prev_action(int c, int k) { return cf[p.Nc * p.Nt * 2 + c * 2 + k]; }
+    __device__ int32_t &t2f(int c, int t) { return ci[c * p.Nt + t]; }
+    __device__ int32_t &delay(int s, int c) { return ci[p.Nc * p.Nt + s * p.Nc + c]; }
+    __device__ int32_t &neighbor(int c, int s) { return ci[p.Nc * p.Nt + p.Nc * p.Nc + c * p.Nc + s]; }
+    __device__ int32_t &has_state(int c) { return ci[p.Nc * p.Nt + 2 * p.Nc * p.Nc + c]; }
+    __device__ int32_t &cam_episode() { return ci[p.Nc * p.Nt + 2 * p.Nc * p.Nc + p.Nc]; }
     // scratch past the record (policy_staging_words): message staging, per-camera masks, per-pair distances
-    __device__ int32_t &send_bits(int s, int c) { return i[q.PI + s * p.Nc + c]; }      // bit 31: 'state', bits 0..Nt-1: targets
-    __device__ int32_t &near_bits(int c) { return i[q.PI + p.Nc * p.Nc + c]; }          // targets within 110 % of the range of camera c
+    __device__ int32_t &send_bits(int s, int c) { return si[s * p.Nc + c]; }            // bit 31: 'state', bits 0..Nt-1: targets
+    __device__ int32_t &near_bits(int c) { return si[p.Nc * p.Nc + c]; }                // targets within 110 % of the range of camera c
     __device__ double &pair_dist(int c, int t) { return f[q.PW + (p.Nc * p.Nc + p.Nc) / 2 + 2 + c * p.Nt + t]; }
 };
 // 8-byte words of that scratch: Nc*Nc + Nc ints (possibly starting in the upper half of the record's last word), Nc*Nt doubles
@@ -146,13 +162,12 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
                                                    const int32_t *di, const uint32_t *mk,
                                                    int wave, int lane, int64_t env, bool active, double *lds_cam_act, double *lds_tgt_act,
                                                    long long *acc = nullptr, long long *t_prev = nullptr, bool publish = true) {
-    // Which teams' agents act (wave-uniform): both under step_greedy / rollout_greedy; under MultiCamera / MultiTarget
-    // (q.caller_team = the learner's team, single_team.py:245-264) ONLY THE OPPONENTS -- the reference's wrapper holds no agents
-    // for the learner's team, and its joint action is the caller's.  A team that does not act keeps its memory as it is (its
-    // agent.reset at the first call of an episode still runs: `fresh` below), so what the acting team does never depends on it:
-    // every draw is keyed by (environment, tick, stream, lane).  The camera agents are three quarters of this function's chain
-    // (11.5 k of a 32 k-cycle learner-versus-greedy step at 4096 x MATE-4v8-9 before; the camera learner's step skips them).
-    const bool cams = q.caller_team != 0, tgts = q.caller_team != 1;
+    // Which teams' agents act (wave-uniform, `cams` / `tgts` below): both under step_greedy / rollout_greedy; under MultiCamera /
+    // MultiTarget (q.caller_team = the learner's team, single_team.py:245-264) ONLY THE OPPONENTS -- the reference's wrapper holds no
+    // agents for the learner's team, and its joint action is the caller's.  A team that does not act keeps its memory as it is and
+    // runs its agent.reset at its own first call of an episode (`fresh_c` / `fresh_t`), so what the acting team does never depends
+    // on it: every draw is keyed by (environment, tick, stream, lane).  The camera agents are three quarters of this function's
+    // chain (11.5 k of a 32 k-cycle learner-versus-greedy step at 4096 x MATE-4v8-9 before; the camera learner's step skips them).
 #ifdef MATE_PHASE_CLOCKS
 #define POL_STAMP(i) do { if (acc) { const long long t_now = (long long)__builtin_amdgcn_s_memtime(); acc[i] += t_now - *t_prev; *t_prev = t_now; } } while (0)
 #elif defined(MATE_ISA_MARKS)
@@ -169,7 +184,9 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     const int32_t *env_i = di + Nt * TI_STRIDE;
     const uint32_t tick = (uint32_t)env_i[EI_TICK];
     const uint32_t env_global = p.first_env + (uint32_t)env;
-    const bool fresh = a.episode() != env_i[EI_EPISODE];     // first call of a new episode: agent.reset(observation)
+    const bool cams = q.caller_team != 0, tgts = q.caller_team != 1;      // (which teams act: see below)
+    // a team's first call of a new episode: agent.reset(observation)
+    const bool fresh_c = cams && a.cam_episode() != env_i[EI_EPISODE], fresh_t = tgts && a.tgt_episode() != env_i[EI_EPISODE];
     // this step's draws (see PolicyStream); skipped when every draw comes from the tape
     double u_bern = 0.0, u_s0 = 0.0, u_s1 = 0.0;
     uint32_t w_delay = 0, w_choice = 0;
@@ -191,17 +208,17 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     };
     const double threshold = 1.1 * p.rmax;                  // filterout_beyond_range / the tracking reach: 110 % of the range
     if (cams && lane < Nc) a.near_bits(lane) = 0;
-    if (fresh) {                                            // GreedyCameraAgent.reset (greedy.py:43-61)
+    if (fresh_c) {                                          // GreedyCameraAgent.reset (greedy.py:43-61)
         if (lane < Nc) { a.prev_action(lane, 0) = 0.0; a.prev_action(lane, 1) = 0.0; a.has_state(lane) = 1; }
-        for (int k = lane; k < Nc * Nc; k += 64) { a.i[Nc * Nt + k] = 0; a.i[Nc * Nt + Nc * Nc + k] = 0; }   // delay, neighbor
+        for (int k = lane; k < Nc * Nc; k += 64) { a.ci[Nc * Nt + k] = 0; a.ci[Nc * Nt + Nc * Nc + k] = 0; }   // delay, neighbor
     }
     wave_sync();
-    if (cams || fresh)
+    if (cams)
     for (int k = lane; k < Nc * Nt; k += 64) {              // process_messages of the observation (greedy.py:100-113)
         const int c = (int)(((float)k + 0.5f) * p.inv_Nt), t = k - c * Nt;
         const bool s = sees(c, t);
         int left = 0;
-        if (fresh) { a.mem(c, t, 0) = 0.0; a.mem(c, t, 1) = 0.0; }      // hidden rows of the first observation are zeros
+        if (fresh_c) { a.mem(c, t, 0) = 0.0; a.mem(c, t, 1) = 0.0; }      // hidden rows of the first observation are zeros
         else { left = a.t2f(c, t) - 1; if (left < 0) left = 0; }
         const double x = tx(t), y = ty(t);
         if (s) { left = q.memory_period; a.mem(c, t, 0) = x; a.mem(c, t, 1) = y; }
@@ -209,12 +226,12 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         if (norm2(x - cam_x(c), y - cam_y(c)) < threshold) atomicOr(&a.near_bits(c), 1 << t);
     }
     const int tl = lane - 32;
-    if ((tgts || fresh) && tl >= 0 && tl < Nt) {            // GreedyTargetAgent.reset / process_messages (greedy.py:262-283,326-332)
+    if (tgts && tl >= 0 && tl < Nt) {                       // GreedyTargetAgent.reset / process_messages (greedy.py:262-283,326-332)
         const int t = tl;
         const int gw = di[t * TI_STRIDE + TI_GW];
         const int state_goal = (gw & 0xff) - 1;
         const double step_size = ((capword >> t) & 1ull) ? p.tgt_step * 0.5 : p.tgt_step;
-        if (fresh) {
+        if (fresh_t) {
             a.tgt_prev(t, 0) = tx(t); a.tgt_prev(t, 1) = ty(t);
             double u0, u1;
             if (q.tape.tgt_reset_sample_u) { u0 = q.tape.tgt_reset_sample_u[(env * Nt + t) * 2]; u1 = q.tape.tgt_reset_sample_u[(env * Nt + t) * 2 + 1]; }
@@ -228,7 +245,8 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         const int seen_empty = (gw >> 16) & 0xf;
         if (seen_empty & a.tgt_nonempty(t)) { a.tgt_nonempty(t) &= ~seen_empty; a.tgt_need(t) = 1; }
     }
-    if (lane == 0 && fresh) a.episode() = env_i[EI_EPISODE];
+    if (lane == 0 && fresh_c) a.cam_episode() = env_i[EI_EPISODE];
+    if (lane == 0 && fresh_t) a.tgt_episode() = env_i[EI_EPISODE];
     wave_sync();
     POL_STAMP(8);
 
@@ -713,7 +731,12 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
 // private scratch, which costs ~5 us per launch -- mate_amd/build.py refuses such a kernel; those two scenarios keep the one-step
 // rollout_greedy_kernel form)
 constexpr bool step_greedy_compiled(int Nc, int Nt, int /*No*/) { return !(Nc == 1 && Nt == 2); }
-__host__ __device__ constexpr int step_greedy_slice_bytes(int PW, int Nc, int Nt, int MW) { return policy_slice_bytes(PW, Nc, Nt) + shape_round_up(MW * 4 + 4, 16); }
+// (`cameras` false: the caller plays the cameras -- MultiCamera, the flow of every examples/*/camera/config.py --, so only the target
+// agents act: their section of the memory record, the joint actions and the mask words: 0.7 KB per environment instead of 1.8, and seven
+// workgroups per CU instead of six at MATE-4v8-9)
+__host__ __device__ constexpr int step_greedy_slice_bytes(int PW, int TW, int Nc, int Nt, int MW, bool cameras) {
+    return cameras ? policy_slice_bytes(PW, Nc, Nt) + shape_round_up(MW * 4 + 4, 16) : shape_round_up((TW + 2 * (Nc + Nt)) * 8 + MW * 4 + 4, 16);
+}
 
 template <typename ObsT, typename Shape>
 __global__ __launch_bounds__(256, 4) __attribute__((amdgpu_num_sgpr(96)))   // (eight waves per SIMD, as step_kernel)
@@ -733,17 +756,21 @@ void step_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const Polic
     if (env >= g.N) return;                                          // (the four waves of a workgroup never synchronise)
     const Ptrs &gk = kernarg_ptrs(g);
     Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_STEP_GREEDY);
-    const int pol_bytes = step_greedy_slice_bytes(q.PW, p.Nc, p.Nt, p.MW);
+    // which teams' agents act (wave-uniform): the acting teams' sections of the memory record are loaded, held and stored -- words
+    // [w_lo, w_hi) of [target section | camera section]; with the cameras played by the caller the LDS slice holds nothing else
+    const bool cams = q.caller_team != 0, tgts = q.caller_team != 1;
+    const int w_lo = tgts ? 0 : q.TW, w_hi = cams ? q.PW : q.TW, w_n = w_hi - w_lo;
+    const int pol_bytes = step_greedy_slice_bytes(q.PW, q.TW, p.Nc, p.Nt, p.MW, cams);
     unsigned char *pol_base = smem + 4 * p.lds_wave_bytes + wave * pol_bytes;
-    PolCtx<ObsT> a(p, q, pol_base);
-    double *act_cam = a.f + (q.PW + policy_staging_words(p.Nc, p.Nt)), *act_tgt = act_cam + 2 * p.Nc;
+    PolCtx<ObsT> a(p, q, pol_base, cams);
+    double *act_cam = a.f + (cams ? q.PW + policy_staging_words(p.Nc, p.Nt) : q.TW), *act_tgt = act_cam + 2 * p.Nc;
     uint32_t *mk = reinterpret_cast<uint32_t *>(act_tgt + 2 * p.Nt);      // the view the previous step / reset left (the agents' observation gate)
     // the agents' memory and the previous view on their way together with the records (load_records_with_draws issues those and
     // runs the step's Philox draws under all of it)
-    const double *pol_src = q.pol + env * q.PW;
-    double pw0 = pol_src[lane < q.PW ? lane : 0], pw1 = 0.0, pw2 = 0.0;
-    if (q.PW > 64) pw1 = pol_src[lane + 64 < q.PW ? lane + 64 : 0];
-    if (q.PW > 128) pw2 = pol_src[lane + 128 < q.PW ? lane + 128 : 0];
+    const double *pol_src = q.pol + env * q.PW + w_lo;
+    double pw0 = pol_src[lane < w_n ? lane : 0], pw1 = 0.0, pw2 = 0.0;
+    if (w_n > 64) pw1 = pol_src[lane + 64 < w_n ? lane + 64 : 0];
+    if (w_n > 128) pw2 = pol_src[lane + 128 < w_n ? lane + 128 : 0];
     uint32_t mw0 = q.masks[env * p.MW + (lane < p.MW ? lane : 0)];
     asm volatile("" : "+v"(pw0), "+v"(pw1), "+v"(pw2), "+v"(mw0));
 #ifdef MATE_PHASE_CLOCKS      // per-wave stamps (tools/versus_phases.py): 0 begin, 1 records, 2 entity table, 3 agents, 4 kinematics, 5 view, 6 goals, 7 rows, 8 end;
@@ -757,10 +784,11 @@ void step_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const Polic
 #endif
     SG_STAMP(0);
     const StepDraws draws = load_records_with_draws(c, tick, true);
-    if (lane < q.PW) a.f[lane] = pw0;
-    if (lane + 64 < q.PW) a.f[lane + 64] = pw1;
-    if (lane + 128 < q.PW) a.f[lane + 128] = pw2;
-    for (int k = lane + 192; k < q.PW; k += 64) a.f[k] = pol_src[k];
+    double *pol_lds = a.f + w_lo;
+    if (lane < w_n) pol_lds[lane] = pw0;
+    if (lane + 64 < w_n) pol_lds[lane + 64] = pw1;
+    if (lane + 128 < w_n) pol_lds[lane + 128] = pw2;
+    for (int k = lane + 192; k < w_n; k += 64) pol_lds[k] = pol_src[k];
     if (lane < p.MW) mk[lane] = mw0;
     for (int k = lane + 64; k < p.MW; k += 64) mk[k] = q.masks[env * p.MW + k];
     if (lane == 0) mk[p.MW] = 0u;                                        // (seen_mask reads two words)
@@ -813,7 +841,7 @@ void step_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const Polic
     SG_STAMP(6);
     // the records, the agents' memory and the joint actions are final: out before the packer (see step_kernel)
     store_dynamic(c);
-    { double *dst = q.pol + env * q.PW; for (int k = lane; k < q.PW; k += 64) dst[k] = a.f[k]; }
+    { double *dst = q.pol + env * q.PW + w_lo; for (int k = lane; k < w_n; k += 64) dst[k] = pol_lds[k]; }
     for (int k = lane; k < 2 * p.Nc; k += 64) q.cam_act[env * 2 * p.Nc + k] = act_cam[k];      // what mate_engine_policy_actions reads: this step's joint actions (the caller's team's as decoded)
     for (int k = lane; k < 2 * p.Nt; k += 64) q.tgt_act[env * 2 * p.Nt + k] = act_tgt[k];
     fill_scratch(c);

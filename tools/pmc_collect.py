@@ -39,6 +39,9 @@ CASES = {
     'c4shard': ('rollout_kernel', 256, 8192, ['--workload', 'MATE-4v8-0.yaml', '--batch', '8192', '--rollout', '256', '--steps', '1024', '--warmup', '256']),
     'c5shard': ('rollout_kernel', 256, 4096, ['--workload', 'MATE-Navigation.yaml', '--batch', '4096', '--rollout', '256', '--steps', '1024', '--warmup', '256']),
     # BASELINE configs 4 and 5 whole on ONE GPU (sixteen / eight generations of resident waves)
+    # the learner-versus-greedy step (step_greedy_kernel): a target script of its own, not a bench.py command
+    'versus': ('step_greedy_kernel', 1, 4096, ['4096', '300'], 'tools/versus_target.py'),
+    'versus16k': ('step_greedy_kernel', 1, 16384, ['16384', '200'], 'tools/versus_target.py'),
     'c4full': ('rollout_kernel', 64, 65536, ['--workload', 'MATE-4v8-0.yaml', '--batch', '65536', '--rollout', '64', '--steps', '256', '--warmup', '64']),
     'c5full': ('rollout_kernel', 64, 32768, ['--workload', 'MATE-Navigation.yaml', '--batch', '32768', '--rollout', '64', '--steps', '256', '--warmup', '64']),
 }
@@ -52,16 +55,18 @@ def main():
     env = dict(os.environ, TMPDIR='/tmp')
     summary = {}
     for name in names:
-        kernel, steps, envs, args = CASES[name]
+        kernel, steps, envs, args = CASES[name][:4]
+        script = CASES[name][4] if len(CASES[name]) > 4 else None
         acc = collections.defaultdict(list)
         only = os.environ.get('PMC_GROUPS')       # e.g. PMC_GROUPS=4,5: only those counter groups (attribution runs with experiment builds)
         for gi, group in enumerate(GROUPS):
             if only and str(gi) not in only.split(','):
                 continue
             d = os.path.join(out, f'raw_{name}_{gi}')
-            cmd = ['rocprofv3', '--kernel-trace', '--pmc'] + group + ['--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
-                                                                     'python3', os.path.join(root, 'bench.py'), '--reps', '1', '--rep-warmup', '1',
-                                                                     '--no-cpu-baseline', '--no-extras', '--no-other-configs', '--no-side-measurements'] + args
+            target = (['python3', os.path.join(root, script)] + args) if script else (
+                ['python3', os.path.join(root, 'bench.py'), '--reps', '1', '--rep-warmup', '1', '--no-cpu-baseline', '--no-extras', '--no-other-configs',
+                 '--no-side-measurements'] + args)
+            cmd = ['rocprofv3', '--kernel-trace', '--pmc'] + group + ['--output-format', 'csv', '-d', d, '-o', 'pmc', '--'] + target
             with open(os.path.join(out, f'{name}_{gi}.log'), 'w') as log:
                 subprocess.call(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, cwd=root)
             for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
@@ -86,7 +91,7 @@ def main():
         if entry.get('SQ_THREAD_CYCLES_VALU') and entry.get('SQ_ACTIVE_INST_VALU'):
             entry['mean_active_lanes_per_valu_instruction'] = entry['SQ_THREAD_CYCLES_VALU'] / entry['SQ_ACTIVE_INST_VALU']
         entry['hbm_bytes_per_launch'] = (2.0 * entry.get('FETCH_SIZE', 0.0) + entry.get('WRITE_SIZE', 0.0)) * 1024.0
-        summary[f'{kernel}@{steps}' + ('' if name in ('headline256', 'headline20', 'step', 'c3') else ':' + name)] = entry
+        summary[f'{kernel}@{steps}' + ('' if name in ('headline256', 'headline20', 'step', 'c3', 'versus') else ':' + name)] = entry
         print(name, json.dumps({k: (round(v, 1) if isinstance(v, float) else v) for k, v in entry.items()}, sort_keys=True), flush=True)
     json.dump(summary, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1, sort_keys=True)
 
