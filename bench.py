@@ -578,63 +578,42 @@ def measure_learner_flows(torch, device_index, workload, batch, graph_steps, res
         eng.close()
         del eng
         torch.cuda.empty_cache()
-        # ---- two half-batch groups on two streams: step(actions), and the learner versus the greedy opponents
+        # ---- two half-batch groups on two streams (mate_amd.engine.EngineGroups): step(actions), and the learner versus the greedy opponents
         if batch % 2 == 0 and batch >= 2048:
+            from mate_amd.engine import EngineGroups
             half = batch // 2
-            # (HIP maps streams onto a handful of hardware queues, and two streams that share one run their graphs one after the
-            # other: 23 instead of 13 us per step at 4096 when that happens.  Group 0 stays on the current stream, group 1 takes the
-            # best of three fresh streams by a short trial)
-            candidates = [torch.cuda.Stream(device=device_index) for _ in range(3)]
             for key, versus in (('external_actions_two_groups', False), ('versus_greedy_two_groups', True)):
                 if versus and 'versus_greedy' not in out:      # (a scenario without cameras)
                     continue
-                streams = [torch.cuda.current_stream(device_index), candidates[0]]
-                engs, steppers, keep = [], [], []
                 interval = versus_reset_interval if versus else reset_interval
                 Gk = max(G, interval) // interval * interval
-                for gi in range(2):
-                    with torch.cuda.stream(streams[gi]):
-                        e = Engine(cfg, half, device=device_index, seed=0, first_env_index=gi * half)
-                        if versus:
-                            e.enable_policies()
-                            e.reset()
-                            mine = (torch.rand((half, e.num_cameras, 2), device=e.device) * 2 - 1) * torch.tensor([5.0, 2.5], device=e.device)
-                            keep.append(mine)
-                            steppers.append(e.make_stepper(mine, None, auto_reset=interval, graph_steps=Gk, between=(lambda m=mine: m.mul_(-1.0)), versus='camera'))
-                        else:
-                            e.reset()
-                            ext = ExternalActions(torch, e, Gk, interval)
-                            keep.append(ext)
-                            steppers.append(ext.stepper)
-                        engs.append(e)
+                groups = EngineGroups(cfg, batch, groups=2, device=device_index, seed=0, policies=versus)
+                groups.reset()
+                keep = []
+
+                def make(g, e):
+                    if versus:
+                        mine = (torch.rand((half, e.num_cameras, 2), device=e.device) * 2 - 1) * torch.tensor([5.0, 2.5], device=e.device)
+                        keep.append(mine)
+                        return e.make_stepper(mine, None, auto_reset=interval, graph_steps=Gk, between=(lambda m=mine: m.mul_(-1.0)), versus='camera')
+                    ext = ExternalActions(torch, e, Gk, interval)
+                    keep.append(ext)
+                    return ext.stepper
+
+                steppers = groups.each(make)
                 torch.cuda.synchronize()
-
-                def run_two(n):
-                    for _ in range(n // Gk):
-                        for gi in range(2):
-                            with torch.cuda.stream(streams[gi]):
-                                steppers[gi].run(Gk)
-
-                trials = []
-                for cand in candidates:
-                    streams[1] = cand
-                    run_two(2 * Gk)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    run_two(4 * Gk)
-                    torch.cuda.synchronize()
-                    trials.append(time.perf_counter() - t0)
-                streams[1] = candidates[trials.index(min(trials))]
-                dt, ex = timed(run_two, lambda: engs[0].idle_steps() + engs[1].idle_steps(), batch)
-                out[key] = entry(engs[0], dt, ex, flow=f'{"MultiCamera(GreedyTargetAgent)" if versus else "step(actions)"} as two engines of {half} environments (global indices 0.. and {half}..) on two streams, '
-                                                         'their HIP graphs replayed alternately: us_per_step = per step of the WHOLE batch')
+                # (HIP maps streams onto a handful of hardware queues, and two streams that share one run their graphs one after the
+                # other -- 23 instead of 13 us per step at 4096 when that happens: the second group's stream is chosen by a short trial)
+                trials = groups.pick_streams(lambda g, e: steppers[g].run(Gk), candidates=3, warm=2, timed=4)
+                dt, ex = timed(lambda n: [groups.each(lambda g, e: steppers[g].run(Gk)) for _ in range(n // Gk)], groups.idle_steps, batch)
+                out[key] = entry(groups.engines[0], dt, ex, flow=f'{"MultiCamera(GreedyTargetAgent)" if versus else "step(actions)"} as two engines of {half} environments (global indices 0.. and {half}..) on two streams '
+                                                                   '(mate_amd.engine.EngineGroups), their HIP graphs replayed alternately: us_per_step = per step of the WHOLE batch')
                 out[key]['stream_trials_us_per_step'] = [round(t / (4 * Gk) * 1e6, 2) for t in trials]
                 out[key]['reset_interval'] = interval
                 for st in steppers:
                     st.close()
-                for e in engs:
-                    e.close()
-                del steppers, engs, keep
+                groups.close()
+                del steppers, groups, keep
                 torch.cuda.empty_cache()
     return out
 

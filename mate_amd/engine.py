@@ -12,7 +12,7 @@ import torch
 from mate_amd import _native
 from mate_amd._native import MateConfig, MateLayout, MatePolicyTape, MateStepIO, check
 
-__all__ = ['Engine', 'Stepper', 'export_layout', 'SCALAR_NAMES']
+__all__ = ['Engine', 'EngineGroups', 'Stepper', 'export_layout', 'SCALAR_NAMES']
 
 SCALAR_NAMES = ('camera_team_reward', 'target_team_reward', 'done', 'coverage_rate', 'real_coverage_rate',
                 'mean_transport_rate', 'num_delivered_cargoes', 'normalized_target_team_reward')
@@ -733,3 +733,77 @@ class Stepper:
         except Exception as exc:      # an engine left in device-tick mode refuses rollouts / seed / import_state: say so
             import warnings
             warnings.warn(f'Stepper.close() failed while the stepper was collected: {exc!r}; the engine may still count steps on the device', RuntimeWarning)
+
+
+class EngineGroups:
+    """One batch of N environments as G groups of N / G on G streams, for a learner that interleaves its groups (double-buffered
+    sampling: while it computes the actions of one group, the other group steps).
+
+    A one-launch-per-step flow leaves the GPU idle at every kernel boundary -- the tail of step t's slowest waves, the ramp of step
+    t + 1, the caller's policy kernel in between, and the two dependency gaps around it: at 4096 x MATE-4v8-9 5 of a step's 14.5 us.
+    Two independent half-batches on two streams fill each other's gaps: 14.5 -> 13.2 us per step of the whole batch at 4096
+    environments, 33.7 -> 27.6 at 16 384 (+20 %; 0.456 -> 0.55 of the HBM roofline), 53.6 -> 43.8 for the learner-versus-greedy step;
+    three groups do no better, four worse (profiles/r05_groups_probe.txt).  The groups ARE the batch: group g holds the global
+    environment indices [first_env_index + g N / G, ...), so every environment's episode is, bit for bit, what the single engine of N
+    steps (the random streams are keyed by the global index; tests/test_gpu_groups.py).
+
+    `streams[0]` is the stream current at construction, the others come from `pick_streams()`: HIP maps streams onto a handful of
+    hardware queues, and two streams that share a queue run their work one after the other (23 instead of 13 us per step when
+    that happens) -- a short trial of a few fresh streams with the caller's own loop body picks ones that overlap."""
+
+    def __init__(self, config, num_envs, groups=2, device=0, seed=0, first_env_index=0, obs_dtype=torch.float32, policies=False):
+        assert groups >= 1 and num_envs % groups == 0, 'the groups share the batch evenly'
+        self.groups, self.per_group = int(groups), int(num_envs) // int(groups)
+        self.device = torch.device('cuda', int(device))
+        self.streams = [torch.cuda.current_stream(self.device)] + [torch.cuda.Stream(device=self.device) for _ in range(self.groups - 1)]
+        self.engines = []
+        for g in range(self.groups):
+            with torch.cuda.stream(self.streams[g]):
+                eng = Engine(config, self.per_group, device=device, seed=seed, first_env_index=first_env_index + g * self.per_group, obs_dtype=obs_dtype)
+                if policies:
+                    eng.enable_policies()
+                self.engines.append(eng)
+
+    def each(self, fn):
+        """fn(group index, engine) for every group, with the group's stream current; returns the results."""
+        out = []
+        for g, eng in enumerate(self.engines):
+            with torch.cuda.stream(self.streams[g]):
+                out.append(fn(g, eng))
+        return out
+
+    def reset(self):
+        return self.each(lambda g, eng: eng.reset())
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def pick_streams(self, body, candidates=3, warm=2, timed=4):
+        """Choose the side streams by trial.  `body(g, engine)` enqueues one slice of the caller's loop for group g (e.g. a Stepper
+        replay); for every side stream, `candidates` fresh streams are tried with `warm + timed` rounds of all groups and the
+        fastest is kept.  Returns the trial times [s] of the last group's candidates."""
+        import time
+        times = []
+        for g in range(1, self.groups):
+            times = []
+            pool = [torch.cuda.Stream(device=self.device) for _ in range(candidates)]
+            for cand in pool:
+                self.streams[g] = cand
+                for _ in range(warm):
+                    self.each(body)
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                for _ in range(timed):
+                    self.each(body)
+                torch.cuda.synchronize(self.device)
+                times.append(time.perf_counter() - t0)
+            self.streams[g] = pool[times.index(min(times))]
+        return times
+
+    def idle_steps(self):
+        return sum(eng.idle_steps() for eng in self.engines)
+
+    def close(self):
+        for eng in self.engines:
+            eng.close()
