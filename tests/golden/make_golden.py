@@ -894,7 +894,7 @@ def chain_fixture(name, config, seed, learner_steps, frame_skip=5, levels=5, coe
                 push(per_step, 'chain_cam_obs', np.asarray(observations, dtype=np.float64))
                 push(per_step, 'chain_reward_cam', np.asarray(rewards, dtype=np.float64))
                 push(per_step, 'reward_cam', infos[0]['raw_reward'])
-                push(per_step, 'coverage_rate', infos[0]['coverage_rate'])
+                push(per_step, 'info_coverage_rate', infos[0]['coverage_rate'])
                 push(per_step, 'done', bool(dones[0]))
                 push(per_step, 'learner_step', ls)
                 for k, v in snapshot_dynamic(base).items():

@@ -269,3 +269,68 @@ def test_soft_coverage_score(name):
         if reduction != 'none':
             shaped = np.full_like(shaped, {'mean': np.mean, 'sum': np.sum, 'max': np.max, 'min': np.min}[reduction](shaped))
         np.testing.assert_allclose(shaped, fx['step/aux_reward_cam'][s], rtol=1e-9, atol=1e-9)
+
+
+def _chain_camera_rows(rows, Nc, Nt, No):
+    """RelativeCoordinates then RescaledObservation of camera rows (mate/agents/utils.py:40-137), restated in NumPy for this test:
+    coordinates of the warehouses and of VISIBLE entities minus the row owner's location; then (v - low) on every column bounded
+    below and 2 (v - low) / (high - low) - 1 on every column bounded on both sides."""
+    from mate_amd import constants as consts
+    rows = np.array(rows, dtype=np.float64)
+    space = consts.camera_observation_space_of(Nc, Nt, No)
+    cmask = np.array(consts.camera_coordinate_mask_of(Nc, Nt, No), dtype=bool)
+    low, high = np.asarray(space.low, dtype=np.float64), np.asarray(space.high, dtype=np.float64)
+    out = rows.copy()
+    for i in range(rows.shape[0]):
+        visible = np.ones(rows.shape[1], dtype=bool)
+        col = 13 + 9
+        for count, width in ((Nt, 5), (No, 4), (Nc, 7)):
+            for _ in range(count):
+                visible[col:col + width] = rows[i, col + width - 1] != 0.0
+                col += width
+        sel = cmask & visible
+        origin = rows[i, 13:15]
+        out[i, sel] -= np.tile(origin, sel.sum() // 2)
+    below = np.isfinite(low)
+    both = below & np.isfinite(high) & (high > low)
+    out[:, below] -= low[below]
+    out[:, both] = 2.0 * out[:, both] / (high - low)[both] - 1.0
+    return out
+
+
+def test_training_chain_fixture_through_the_oracle():
+    """The example trainers' wrapper chain (examples/ippo/camera/config.py:19-51; fixture chain_4v8-9_s15.npz recorded from the
+    reference's own wrappers) on the CPU oracle: DiscreteCamera's decode, the greedy target opponents on their recorded draws, the
+    environment, RelativeCoordinates + RescaledObservation of the camera rows, AuxiliaryCameraRewards' coverage term and FrameSkip's
+    sums -- joint actions 1e-9, masks / goals / episode reward exact, chain observations 1e-9, shaped rewards 1e-12."""
+    from mate_amd.spaces import camera_action_grid
+    fx = G.load('chain_4v8-9_s15.npz')
+    Nc, Nt, No = (int(fx[k]) for k in ('num_cameras', 'num_targets', 'num_obstacles'))
+    assert np.array_equal(camera_action_grid(int(fx['discrete_levels'])), fx['camera_action_grid'])
+    env = G.oracle_from_fixture(fx)
+    env.set('camera_target_view_mask', fx['reset/camera_target_view_mask'].astype(np.float64))
+    co, _ = env.observe()
+    np.testing.assert_allclose(_chain_camera_rows(co, Nc, Nt, No), fx['reset/chain_cam_obs'], rtol=0, atol=1e-9)
+    agents = O.GreedyPolicies()
+    T = len(fx['step/done'])
+    shaped = np.zeros((T, Nc))
+    for s in range(T):
+        ca, _ = env.decode_discrete(fx['step/cam_idx'][s], fx['camera_action_grid'], None, None)
+        assert np.array_equal(ca, fx['step/cam_act'][s]), s
+        _, ta = agents.act(env, np.zeros(Nc), np.zeros((Nc, 2)), np.full((Nc, Nc), -1), fx['step/agent_tgt_choice_u'][s],
+                           fx['step/agent_tgt_binom_u'][s], fx['step/agent_tgt_sample_u'][s], fx['agent/tgt_reset_sample_u'])
+        assert np.abs(ta - fx['step/tgt_act'][s]).max() < 1e-9, ('the opponents joint action', s)
+        env.step(ca, ta, fx['step/tape_ct'][s], fx['step/goal_u'][s])
+        for m in G.MASK_FIELDS:
+            assert np.array_equal(np.asarray(env.get(m)) != 0, fx['step/' + m][s].astype(bool)), (m, s)
+        assert np.array_equal(np.asarray(env.get('tgt_goals'), dtype=np.float64), np.asarray(fx['step/tgt_goals'][s], dtype=np.float64)), s
+        assert env.get('episode_reward') == fx['step/episode_reward'][s]
+        co, _ = env.observe()
+        np.testing.assert_allclose(_chain_camera_rows(co, Nc, Nt, No), fx['step/chain_cam_obs'][s], rtol=0, atol=1e-9, err_msg=str(s))
+        coverage = float(np.mean(np.asarray(env.get('tracked_bits')) != 0))      # environment.py:966
+        assert abs(coverage - float(fx['step/info_coverage_rate'][s])) < 1e-12 and abs(coverage - float(fx['step/coverage_rate'][s])) < 1e-12
+        shaped[s] = coverage                                   # {'coverage_rate': 1.0}, reduction 'mean' of equal values
+        np.testing.assert_allclose(shaped[s], fx['step/chain_reward_cam'][s], rtol=0, atol=1e-12)
+    for ls in range(len(fx['skip/done'])):                      # FrameSkip: rewards summed over the action's frames
+        frames = np.nonzero(fx['step/learner_step'] == ls)[0]
+        np.testing.assert_allclose(shaped[frames].sum(axis=0), fx['skip/reward_cam'][ls], rtol=0, atol=1e-12)
