@@ -255,8 +255,14 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     // four for the 16 the engine takes (the pair's message delay: the lane's own Philox word in the first round, one more block
     // keyed by the pair's index beyond)
     const bool one_round = Nc * Nc <= 64;
+    // Serial loops of the agents turned into loops over BALLOT bits (round 5; the fused Greedy rollouts are VALU-bound and a latency-bound
+    // per-step launch waits for every LDS round trip): a pair lane ORs the messages of the senders that DID send to its camera (bits
+    // s Nc + c of `sent`: a message goes out every ~28 steps per pair) instead of reading all Nc staging words; a camera lane scans the
+    // targets that ARE candidates (bits c Nt + t of `candidates`) instead of all Nt distances; the targets AND the warehouse sets of the
+    // targets that DO broadcast (`needers`: a target that has just seen an empty warehouse) instead of testing all Nt.  Same order, same values.
+    unsigned long long sent = ~0ull, candidates = ~0ull;
     if (cams) {
-    auto send_pair = [&](int k) {
+    auto send_pair = [&](int k) -> int {
         const int s = (int)(((float)k + 0.5f) * p.inv_Nc), c = k - s * Nc;
         int bits = 0;
         int d = a.delay(s, c) - 1;
@@ -283,8 +289,11 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         // receive_responses: the recipient learns its neighbour (greedy.py:192-226).  One round of pairs: every lane has read
         // neighbor(s, c) above before any lane writes here (one wave, one instruction stream, LDS operations in order)
         if (one_round && bits < 0) a.neighbor(c, s) = 1;
+        return bits;
     };
-    if (lane < Nc * Nc) send_pair(lane);
+    int my_bits = 0;
+    if (lane < Nc * Nc) my_bits = send_pair(lane);
+    if (one_round) sent = __ballot(my_bits != 0);
     if (!one_round)
         for (int k = lane + 64; k < Nc * Nc; k += 64) send_pair(k);
     if (!one_round) {                                       // several rounds: behind EVERY round's reads
@@ -297,9 +306,18 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     wave_sync();
     // ... and the positions of the targets it was told about; then the tracking candidates: distance camera -> remembered
     // position, +inf when forgotten or out of reach (greedy.py:115-127)
+    unsigned long long col_mask = 0ull;                                  // bit s Nc for every sender s (one round of pairs)
+    if (one_round) for (int s = 0; s < Nc; ++s) col_mask |= 1ull << (s * Nc);
+    double dn_lane = INFINITY;
     for (int k = lane; k < Nc * Nt; k += 64) {
         const int c = (int)(((float)k + 0.5f) * p.inv_Nt), t = k - c * Nt;
         int told = 0;
+        if (one_round) {
+            for (unsigned long long m = (sent >> c) & col_mask; m != 0ull; m &= m - 1ull) {
+                const int sb = __ffsll((long long)m) - 1;                // = s Nc
+                told |= a.si[sb + c];                                    // send_bits(s, c)
+            }
+        } else
         for (int s = 0; s < Nc; ++s) told |= a.send_bits(s, c);
         double mx = a.mem(c, t, 0), my = a.mem(c, t, 1);
         int left = a.t2f(c, t);
@@ -310,14 +328,18 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
             if (dnorm < threshold) dn = dnorm;
         }
         a.pair_dist(c, t) = dn;
+        if (k == lane) dn_lane = dn;
     }
+    if (Nc * Nt <= 64) candidates = __ballot(dn_lane < INFINITY);
     if (lane < Nc && (a.has_state(lane) || seen_mask(lane))) a.has_state(lane) = 0;   // message2send.clear()
     }
     // targets: broadcast non-empty warehouse sets (greedy.py:334-358).  Every lane's reads precede every lane's writes: one wave,
     // one instruction stream, LDS operations in order.
-    if (tgts && tl >= 0 && tl < Nt) {
+    const bool broadcasts = tgts && tl >= 0 && tl < Nt && a.tgt_need(tl) != 0;
+    const uint32_t needers = (uint32_t)(__ballot(broadcasts) >> 32);      // (target t on lane 32 + t; nobody: the sets stay as they are)
+    if (needers != 0u && tgts && tl >= 0 && tl < Nt) {
         int set = a.tgt_nonempty(tl);
-        for (int s = 0; s < Nt; ++s) if (a.tgt_need(s)) set &= a.tgt_nonempty(s);
+        for (uint32_t m = needers; m != 0u; m &= m - 1u) set &= a.tgt_nonempty(__ffs((int)m) - 1);
         a.tgt_nonempty(tl) = set;
         a.tgt_need(tl) = 0;
     }
@@ -341,7 +363,14 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         const double q2 = div_nz(sight, p.rmax);
         min_va = theta * (q2 * q2);
         double best_d = INFINITY;
-        for (int t = 0; t < Nt; ++t) {                               // ascending t, first minimum wins, like the reference's loop
+        if (Nc * Nt <= 64) {                                         // ascending t over the candidates, first minimum wins, like the reference's loop
+            for (uint32_t m = (uint32_t)(candidates >> (c * Nt)) & ((1u << Nt) - 1u); m != 0u; m &= m - 1u) {
+                const int t = __ffs((int)m) - 1;
+                const double dnorm = a.pair_dist(c, t);
+                if (dnorm < best_d) { best = t; best_d = dnorm; }
+            }
+        } else
+        for (int t = 0; t < Nt; ++t) {
             const double dnorm = a.pair_dist(c, t);
             if (dnorm < best_d) { best = t; best_d = dnorm; }
         }
