@@ -258,7 +258,10 @@ int mate_engine_step_greedy(mate_engine *engine, const mate_step_io *io, const m
                             int32_t auto_reset, void *stream);
 /* MultiCamera / MultiTarget (mate/wrappers/single_team.py:180-306, SingleTeamMultiAgent.step :245-264): the caller -- the
  * learner of examples/ippo|mappo|qmix|... -- plays ONE team, the on-device greedy agents play the other:
- * `group_step(env, opponent_agents, ...)` + `env.step((action, opponent_joint_action))` in two launches.  `team` is the
+ * `group_step(env, opponent_agents, ...)` + `env.step((action, opponent_joint_action))` -- ONE launch (step_greedy_kernel: the opponents'
+ * agents, then the step) unless a policy tape, a step tape, a fused observation transform / team mode, f64 observations or a missing output
+ * asks for the two-launch form.  Only the OPPONENTS' agents act, as in the reference's wrapper (which holds no agents for the learner's team):
+ * the caller's team's agent memory is left as it is, and a team's agent.reset(observation) runs at its own first acting call of an episode.  `team` is the
  * CALLER's team; io->camera_actions_dev (MATE_TEAM_CAMERA) or io->target_actions_dev (MATE_TEAM_TARGET) holds its joint
  * action in the encoding io->act_dtype names (f32 / f64 pairs, or grid indices with that team's *_DISCRETE bit); the other
  * action pointer is ignored.  The opponents observe, exchange messages and act exactly as in mate_engine_step_greedy

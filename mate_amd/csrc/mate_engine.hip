@@ -241,7 +241,7 @@ static void setup_two_tier(mate_engine *e) {
     e->rl_small = ResetLds{};
     if (e->rl.sort_in_hbm || e->rl.sort_cap < 1024) return;
     int cap = e->rl.sort_cap / 2;
-    if (e->sw.lut_small_cap > 0) cap = std::max(512, next_pow2(e->sw.lut_small_cap));
+    if (e->sw.lut_small_cap > 0) cap = std::max(512, round_up(e->sw.lut_small_cap, 64));      // (any multiple of 64 rays: build_lut needs no power of two)
     if (cap >= e->rl.sort_cap) return;
     layout_reset_lds(e->p, e->rl_small, cap);
 }
