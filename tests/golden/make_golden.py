@@ -806,26 +806,36 @@ def xform_fixture(trace_name, steps):
     print(f'xform_{trace_name[6:]}: {steps} steps, {os.path.getsize(path) / 1024:.0f} KiB')
 
 
-def chain_fixture(name, config, seed, learner_steps, frame_skip=5, levels=5, coefficients=None, reduction='mean'):
+def chain_fixture(name, config, seed, learner_steps, frame_skip=5, levels=5, coefficients=None, reduction='mean', team='camera'):
     """The wrapper chain every example trainer's make_env builds for a camera learner (examples/ippo/camera/config.py:19-51, and its
     qmix / mappo / ... siblings): base -> DiscreteCamera(levels) -> MultiCamera(GreedyTargetAgent(seed=0)) -> RelativeCoordinates ->
-    RescaledObservation -> RepeatedRewardIndividualDone -> AuxiliaryCameraRewards(coverage_rate, 'mean') -> FrameSkip(5), all of them
-    the REFERENCE's own classes from mate.wrappers -- except FrameSkip, which lives in examples/utils/wrappers.py:254-323 behind
-    `ray` imports: it is restated here as what it does (the same action for `frame_skip` env.step calls, rewards summed, stop when
-    all(dones)).  Recorded per FRAME: the learner's grid indices, the opponents' joint action and every random draw (environment
-    and agents), the chain's camera observations (relative + rescaled), the shaped and raw rewards, dones, masks, state; per
-    LEARNER STEP: the FrameSkip sums and the observation it returns."""
+    RescaledObservation -> RepeatedRewardIndividualDone -> AuxiliaryCameraRewards(coverage_rate, 'mean') -> FrameSkip(5) -- or, with
+    team='target', for a target learner (examples/ippo/target/config.py:20-51: DiscreteTarget, MultiTarget(GreedyCameraAgent(seed=0)),
+    AuxiliaryTargetRewards, FrameSkip(10) on MATE-2v4-0) -- all of them the REFERENCE's own classes from mate.wrappers, except
+    FrameSkip, which lives in examples/utils/wrappers.py:254-323 behind `ray` imports: it is restated here as what it does (the same
+    action for `frame_skip` env.step calls, rewards summed, stop when all(dones)).  Recorded per FRAME: the learner's grid indices, the
+    opponents' joint action and every random draw (environment and agents), the chain's observations of the learner's team (relative
+    + rescaled), the shaped and raw rewards, dones, masks, state; per LEARNER STEP: the FrameSkip sums and the observation it
+    returns.  Keys carry the learner's team: cam_idx / chain_cam_obs / chain_reward_cam, or tgt_idx / chain_tgt_obs / chain_reward_tgt."""
     import mate.wrappers.single_team as single_team
-    coefficients = coefficients or {'coverage_rate': 1.0}
+    me, opp = ('cam', 'tgt') if team == 'camera' else ('tgt', 'cam')
     base = mate.make('MultiAgentTracking-v0', config=config, reward_type='dense')
-    disc = mate.DiscreteCamera(base, levels=levels)
-    multi = mate.MultiCamera(disc, target_agent=GreedyTargetAgent(seed=0))
-    chain = mate.AuxiliaryCameraRewards(mate.RepeatedRewardIndividualDone(mate.RescaledObservation(mate.RelativeCoordinates(multi))),
-                                        coefficients=coefficients, reduction=reduction)
+    if team == 'camera':
+        coefficients = coefficients or {'coverage_rate': 1.0}
+        disc = mate.DiscreteCamera(base, levels=levels)
+        multi = mate.MultiCamera(disc, target_agent=GreedyTargetAgent(seed=0))
+        shaper = mate.AuxiliaryCameraRewards
+    else:
+        disc = mate.DiscreteTarget(base, levels=levels)
+        multi = mate.MultiTarget(disc, camera_agent=GreedyCameraAgent(seed=0))
+        shaper = mate.AuxiliaryTargetRewards
+    chain = shaper(mate.RepeatedRewardIndividualDone(mate.RescaledObservation(mate.RelativeCoordinates(multi))),
+                   coefficients=coefficients, reduction=reduction)
     chain.seed(seed)
-    tgt_agents = multi.opponent_agents_ordered
+    opp_agents = multi.opponent_agents_ordered
+    cam_agents, tgt_agents = ([], opp_agents) if team == 'camera' else (opp_agents, [])
     gym.spaces.Box.sample = _recording_box_sample
-    for agent in tgt_agents:
+    for agent in opp_agents:
         agent._np_random = AgentRNG(agent.np_random, AGENT_LOG, None)
     AGENT_LOG.clear()
     opponent_actions = []
@@ -838,15 +848,16 @@ def chain_fixture(name, config, seed, learner_steps, frame_skip=5, levels=5, coe
 
     single_team.group_step = recording_group_step
     try:
-        cam_obs = chain.reset()
-        for agent in tgt_agents:
-            agent._np_random._who = ('tgt', agent.index)
-        reset_draws = drain_agent_log([], tgt_agents)
+        my_obs = chain.reset()
+        for agent in opp_agents:
+            agent._np_random._who = (opp, agent.index)
+        reset_draws = drain_agent_log(cam_agents, tgt_agents)
         log = []
         install_proxies(base, log)
         Nc, Nt, No = base.num_cameras, base.num_targets, base.num_obstacles
+        n_me, n_opp = (Nc, Nt) if team == 'camera' else (Nt, Nc)
         out = {
-            'config_file': np.str_(config), 'seed': np.int64(seed), 'policy': np.str_('chain'),
+            'config_file': np.str_(config), 'seed': np.int64(seed), 'policy': np.str_('chain'), 'learner_team': np.str_(team),
             'num_cameras': np.int64(Nc), 'num_targets': np.int64(Nt), 'num_obstacles': np.int64(No),
             'transmittance': np.float64(base.obstacle_transmittance), 'max_episode_steps': np.int64(base.max_episode_steps),
             'sparse_reward': np.bool_(base._sparse_reward), 'freight_scale': np.float64(base.freight_scale),
@@ -854,7 +865,7 @@ def chain_fixture(name, config, seed, learner_steps, frame_skip=5, levels=5, coe
             'max_target_team_episode_reward': np.float64(base.max_target_team_episode_reward),
             'target_step_size': np.float64(base.target_step_size),
             'frame_skip': np.int64(frame_skip), 'discrete_levels': np.int64(levels),
-            'camera_action_grid': disc.normalized_action_grid,
+            ('camera' if team == 'camera' else 'target') + '_action_grid': disc.normalized_action_grid,
             'aux_keys': np.asarray(list(coefficients.keys())), 'aux_coefficients': np.asarray(list(coefficients.values()), dtype=np.float64),
             'aux_reduction': np.str_(reduction),
             'agent/tgt_reset_sample_u': reset_draws['tgt_sample_u'],
@@ -863,7 +874,7 @@ def chain_fixture(name, config, seed, learner_steps, frame_skip=5, levels=5, coe
             out['static/' + k] = v
         for k, v in snapshot_dynamic(base).items():
             out['reset/' + k] = v
-        out['reset/chain_cam_obs'] = np.asarray(cam_obs, dtype=np.float64)
+        out[f'reset/chain_{me}_obs'] = np.asarray(my_obs, dtype=np.float64)
         per_step, per_skip = {}, {}
 
         def push(store, key, value):
@@ -872,29 +883,41 @@ def chain_fixture(name, config, seed, learner_steps, frame_skip=5, levels=5, coe
         rng = np.random.RandomState(seed + 1000)
         finished = False
         for ls in range(learner_steps):
-            cam_idx = rng.randint(0, levels ** 2, size=Nc)
+            my_idx = rng.randint(0, levels ** 2, size=n_me)
+            if team == 'target':                             # a learner that mostly heads for its goal: the chain's deliveries get exercised
+                import mate.constants as consts
+                grid = np.asarray(disc.normalized_action_grid, dtype=np.float64)
+                for i, target in enumerate(base.targets):
+                    if target.goal_bits.any() and rng.random_sample() < 0.8:
+                        heading = consts.WAREHOUSES[int(np.argmax(target.goal_bits))] - np.asarray(target.location, dtype=np.float64)
+                        heading /= max(np.abs(heading).max(), 1e-9)
+                        my_idx[i] = int(np.argmin(((grid - heading) ** 2).sum(axis=1)))
             fragment_rewards, frames = [], 0
             for f in range(frame_skip):                      # FrameSkip.step (examples/utils/wrappers.py:301-323)
                 log.clear()
-                observations, rewards, dones, infos = chain.step(cam_idx)
+                observations, rewards, dones, infos = chain.step(my_idx)
                 fragment_rewards.append(rewards)
                 frames += 1
                 tape_ct, _, goal_u, goal_k, goal_j = drain_log(base, log)
-                for k, v in drain_agent_log([], tgt_agents).items():
-                    if k.startswith('tgt_'):
+                for k, v in drain_agent_log(cam_agents, tgt_agents).items():
+                    if k.startswith(opp + '_'):
                         push(per_step, 'agent_' + k, v)
-                push(per_step, 'cam_idx', cam_idx)
-                push(per_step, 'cam_act', np.asarray(disc.action((cam_idx, None))[0], dtype=np.float64).reshape(Nc, 2))
-                push(per_step, 'tgt_act', opponent_actions.pop().reshape(Nt, 2))
+                push(per_step, me + '_idx', my_idx)
+                decoded = disc.action((my_idx, None))[0] if team == 'camera' else disc.action((None, my_idx))[1]
+                push(per_step, me + '_act', np.asarray(decoded, dtype=np.float64).reshape(n_me, 2))
+                push(per_step, opp + '_act', opponent_actions.pop().reshape(n_opp, 2))
                 assert not opponent_actions
                 push(per_step, 'tape_ct', tape_ct)
                 push(per_step, 'goal_u', goal_u)
                 push(per_step, 'goal_k', goal_k)
                 push(per_step, 'goal_j', goal_j)
-                push(per_step, 'chain_cam_obs', np.asarray(observations, dtype=np.float64))
-                push(per_step, 'chain_reward_cam', np.asarray(rewards, dtype=np.float64))
-                push(per_step, 'reward_cam', infos[0]['raw_reward'])
+                push(per_step, f'chain_{me}_obs', np.asarray(observations, dtype=np.float64))
+                push(per_step, f'chain_reward_{me}', np.asarray(rewards, dtype=np.float64))
+                push(per_step, 'reward_' + me, infos[0]['raw_reward'])
                 push(per_step, 'info_coverage_rate', infos[0]['coverage_rate'])
+                if team == 'target':                         # AuxiliaryTargetRewards' per-target terms (auxiliary_target_rewards.py:118-216)
+                    for key in coefficients:
+                        push(per_step, 'aux_' + key, np.asarray([info['auxiliary_reward_' + key] for info in infos], dtype=np.float64))
                 push(per_step, 'done', bool(dones[0]))
                 push(per_step, 'learner_step', ls)
                 for k, v in snapshot_dynamic(base).items():
@@ -902,10 +925,10 @@ def chain_fixture(name, config, seed, learner_steps, frame_skip=5, levels=5, coe
                 if all(dones):
                     finished = True
                     break
-            push(per_skip, 'cam_idx', cam_idx)
+            push(per_skip, me + '_idx', my_idx)
             push(per_skip, 'frames', frames)
-            push(per_skip, 'reward_cam', np.sum(fragment_rewards, axis=0))
-            push(per_skip, 'chain_cam_obs', np.asarray(observations, dtype=np.float64))
+            push(per_skip, 'reward_' + me, np.sum(fragment_rewards, axis=0))
+            push(per_skip, f'chain_{me}_obs', np.asarray(observations, dtype=np.float64))
             push(per_skip, 'done', bool(dones[0]))
             if finished:
                 break
@@ -921,7 +944,7 @@ def chain_fixture(name, config, seed, learner_steps, frame_skip=5, levels=5, coe
     np.savez_compressed(path, **out)
     nsteps = len(per_step['done'])
     print(f'{name}: {len(per_skip["done"])} learner steps = {nsteps} frames, delivered={int(out["step/num_delivered_cargoes"][-1])}, '
-          f'in-sector draws={int(np.isfinite(out["step/tape_ct"]).sum())}, mean shaped reward={float(out["step/chain_reward_cam"].mean()):.3f}, '
+          f'in-sector draws={int(np.isfinite(out["step/tape_ct"]).sum())}, mean shaped reward={float(out[f"step/chain_reward_{me}"].mean()):.3f}, '
           f'{os.path.getsize(path) / 1024:.0f} KiB')
 
 
@@ -929,6 +952,9 @@ def main():
     check_binomial_model()
     if sys.argv[1:] == ['chain']:
         chain_fixture('chain_4v8-9_s15', 'MATE-4v8-9.yaml', 15, learner_steps=13)
+        chain_fixture('chain_target_2v4-0_s16', 'MATE-2v4-0.yaml', 16, learner_steps=24, frame_skip=10, team='target', reduction='none',
+                      coefficients={'raw_reward': 1.0, 'normalized_goal_distance': -0.5, 'is_tracked': -0.25, 'is_colliding': -1.0,
+                                    'sparse_delivery': 5.0})
         return
     if sys.argv[1:] == ['agents']:
         make_trace('greedy_4v8-9_s5', 'MATE-4v8-9.yaml', 5, 'greedy', 300, record_agents=True)

@@ -271,25 +271,31 @@ def test_soft_coverage_score(name):
         np.testing.assert_allclose(shaped, fx['step/aux_reward_cam'][s], rtol=1e-9, atol=1e-9)
 
 
-def _chain_camera_rows(rows, Nc, Nt, No):
-    """RelativeCoordinates then RescaledObservation of camera rows (mate/agents/utils.py:40-137), restated in NumPy for this test:
+def _chain_rows(team, rows, Nc, Nt, No):
+    """RelativeCoordinates then RescaledObservation of one team's rows (mate/agents/utils.py:40-137), restated in NumPy for this test:
     coordinates of the warehouses and of VISIBLE entities minus the row owner's location; then (v - low) on every column bounded
     below and 2 (v - low) / (high - low) - 1 on every column bounded on both sides."""
     from mate_amd import constants as consts
     rows = np.array(rows, dtype=np.float64)
-    space = consts.camera_observation_space_of(Nc, Nt, No)
-    cmask = np.array(consts.camera_coordinate_mask_of(Nc, Nt, No), dtype=bool)
+    if team == 'camera':
+        space, cmask = consts.camera_observation_space_of(Nc, Nt, No), consts.camera_coordinate_mask_of(Nc, Nt, No)
+        first, blocks = consts.PRESERVED_DIM + consts.CAMERA_STATE_DIM_PRIVATE, ((Nt, 5), (No, 4), (Nc, 7))
+    else:
+        space, cmask = consts.target_observation_space_of(Nc, Nt, No), consts.target_coordinate_mask_of(Nc, Nt, No)
+        first, blocks = consts.PRESERVED_DIM + consts.TARGET_STATE_DIM_PRIVATE, ((Nc, 7), (No, 4), (Nt, 5))
+    cmask = np.array(cmask, dtype=bool)
     low, high = np.asarray(space.low, dtype=np.float64), np.asarray(space.high, dtype=np.float64)
     out = rows.copy()
     for i in range(rows.shape[0]):
         visible = np.ones(rows.shape[1], dtype=bool)
-        col = 13 + 9
-        for count, width in ((Nt, 5), (No, 4), (Nc, 7)):
+        col = first
+        for count, width in blocks:
             for _ in range(count):
                 visible[col:col + width] = rows[i, col + width - 1] != 0.0
                 col += width
+        assert col == rows.shape[1]
         sel = cmask & visible
-        origin = rows[i, 13:15]
+        origin = rows[i, consts.PRESERVED_DIM:consts.PRESERVED_DIM + 2]
         out[i, sel] -= np.tile(origin, sel.sum() // 2)
     below = np.isfinite(low)
     both = below & np.isfinite(high) & (high > low)
@@ -298,39 +304,67 @@ def _chain_camera_rows(rows, Nc, Nt, No):
     return out
 
 
-def test_training_chain_fixture_through_the_oracle():
-    """The example trainers' wrapper chain (examples/ippo/camera/config.py:19-51; fixture chain_4v8-9_s15.npz recorded from the
-    reference's own wrappers) on the CPU oracle: DiscreteCamera's decode, the greedy target opponents on their recorded draws, the
-    environment, RelativeCoordinates + RescaledObservation of the camera rows, AuxiliaryCameraRewards' coverage term and FrameSkip's
-    sums -- joint actions 1e-9, masks / goals / episode reward exact, chain observations 1e-9, shaped rewards 1e-12."""
-    from mate_amd.spaces import camera_action_grid
-    fx = G.load('chain_4v8-9_s15.npz')
+@pytest.mark.parametrize('name', ['chain_4v8-9_s15', 'chain_target_2v4-0_s16'])
+def test_training_chain_fixture_through_the_oracle(name):
+    """The example trainers' wrapper chains (examples/ippo/camera/config.py:19-51 and examples/ippo/target/config.py:20-51; fixtures
+    recorded from the reference's own wrappers) on the CPU oracle: DiscreteCamera's / DiscreteTarget's decode, the greedy opponents on
+    their recorded draws, the environment, RelativeCoordinates + RescaledObservation of the learner's rows, the auxiliary reward terms
+    and FrameSkip's sums -- joint actions 1e-9, masks / goals / episode reward exact, chain observations 1e-9, shaped rewards 1e-12."""
+    from mate_amd.spaces import camera_action_grid, target_action_grid
+    fx = G.load(name + '.npz')
+    team = str(fx['learner_team'])
+    me, opp = ('cam', 'tgt') if team == 'camera' else ('tgt', 'cam')
     Nc, Nt, No = (int(fx[k]) for k in ('num_cameras', 'num_targets', 'num_obstacles'))
-    assert np.array_equal(camera_action_grid(int(fx['discrete_levels'])), fx['camera_action_grid'])
+    grid = fx[team + '_action_grid']
+    assert np.array_equal((camera_action_grid if team == 'camera' else target_action_grid)(int(fx['discrete_levels'])), grid)
     env = G.oracle_from_fixture(fx)
     env.set('camera_target_view_mask', fx['reset/camera_target_view_mask'].astype(np.float64))
-    co, _ = env.observe()
-    np.testing.assert_allclose(_chain_camera_rows(co, Nc, Nt, No), fx['reset/chain_cam_obs'], rtol=0, atol=1e-9)
+    mine = lambda pair: pair[0] if team == 'camera' else pair[1]  # noqa: E731
+    np.testing.assert_allclose(_chain_rows(team, mine(env.observe()), Nc, Nt, No), fx[f'reset/chain_{me}_obs'], rtol=0, atol=1e-9)
     agents = O.GreedyPolicies()
     T = len(fx['step/done'])
-    shaped = np.zeros((T, Nc))
+    n_me = Nc if team == 'camera' else Nt
+    shaped = np.zeros((T, n_me))
+    keys, coef = [str(k) for k in fx['aux_keys']], fx['aux_coefficients']
+    zeros_cam = (np.zeros(Nc), np.zeros((Nc, 2)), np.full((Nc, Nc), -1))
+    zeros_tgt = (np.zeros(Nt), np.zeros(Nt), np.zeros((Nt, 2)))
     for s in range(T):
-        ca, _ = env.decode_discrete(fx['step/cam_idx'][s], fx['camera_action_grid'], None, None)
-        assert np.array_equal(ca, fx['step/cam_act'][s]), s
-        _, ta = agents.act(env, np.zeros(Nc), np.zeros((Nc, 2)), np.full((Nc, Nc), -1), fx['step/agent_tgt_choice_u'][s],
-                           fx['step/agent_tgt_binom_u'][s], fx['step/agent_tgt_sample_u'][s], fx['agent/tgt_reset_sample_u'])
-        assert np.abs(ta - fx['step/tgt_act'][s]).max() < 1e-9, ('the opponents joint action', s)
-        env.step(ca, ta, fx['step/tape_ct'][s], fx['step/goal_u'][s])
+        idx = fx[f'step/{me}_idx'][s]
+        decoded = mine(env.decode_discrete(idx, grid, None, None) if team == 'camera' else env.decode_discrete(None, None, idx, grid))
+        assert np.array_equal(decoded, fx[f'step/{me}_act'][s]), s
+        if team == 'camera':
+            _, theirs = agents.act(env, *zeros_cam, fx['step/agent_tgt_choice_u'][s], fx['step/agent_tgt_binom_u'][s],
+                                   fx['step/agent_tgt_sample_u'][s], fx['agent/tgt_reset_sample_u'])
+            joint = (decoded, theirs)
+        else:
+            theirs, _ = agents.act(env, fx['step/agent_cam_binom_u'][s], fx['step/agent_cam_sample_u'][s], fx['step/agent_cam_delay'][s],
+                                   *zeros_tgt, fx['agent/tgt_reset_sample_u'])
+            joint = (theirs, decoded)
+        assert np.abs(theirs - fx[f'step/{opp}_act'][s]).max() < 1e-9, ('the opponents joint action', s)
+        before = env.get('episode_reward')
+        env.step(joint[0], joint[1], fx['step/tape_ct'][s], fx['step/goal_u'][s])
         for m in G.MASK_FIELDS:
             assert np.array_equal(np.asarray(env.get(m)) != 0, fx['step/' + m][s].astype(bool)), (m, s)
         assert np.array_equal(np.asarray(env.get('tgt_goals'), dtype=np.float64), np.asarray(fx['step/tgt_goals'][s], dtype=np.float64)), s
         assert env.get('episode_reward') == fx['step/episode_reward'][s]
-        co, _ = env.observe()
-        np.testing.assert_allclose(_chain_camera_rows(co, Nc, Nt, No), fx['step/chain_cam_obs'][s], rtol=0, atol=1e-9, err_msg=str(s))
+        np.testing.assert_allclose(_chain_rows(team, mine(env.observe()), Nc, Nt, No), fx[f'step/chain_{me}_obs'][s], rtol=0, atol=1e-9,
+                                   err_msg=str(s))
         coverage = float(np.mean(np.asarray(env.get('tracked_bits')) != 0))      # environment.py:966
         assert abs(coverage - float(fx['step/info_coverage_rate'][s])) < 1e-12 and abs(coverage - float(fx['step/coverage_rate'][s])) < 1e-12
-        shaped[s] = coverage                                   # {'coverage_rate': 1.0}, reduction 'mean' of equal values
-        np.testing.assert_allclose(shaped[s], fx['step/chain_reward_cam'][s], rtol=0, atol=1e-12)
+        if team == 'camera':
+            shaped[s] = coverage                               # {'coverage_rate': 1.0}, reduction 'mean' of equal values
+        else:                                                  # reduction 'none': the sum of the terms (auxiliary_target_rewards.py:118-216)
+            raw = env.get('episode_reward') - before           # the target team's reward is the step's change of the episode sum
+            assert abs(raw - float(fx['step/reward_tgt'][s])) < 1e-9, s
+            terms = {
+                'raw_reward': np.full(Nt, float(fx['step/reward_tgt'][s])),
+                'is_tracked': (np.asarray(env.get('tracked_bits')) != 0).astype(np.float64),
+                'is_colliding': (np.asarray(env.get('tgt_colliding')) != 0).astype(np.float64),
+            }
+            for key in terms:
+                assert np.array_equal(terms[key], fx['step/aux_' + key][s]), (key, s)
+            shaped[s] = sum(c * (terms[k] if k in terms else fx['step/aux_' + k][s]) for k, c in zip(keys, coef))
+        np.testing.assert_allclose(shaped[s], fx[f'step/chain_reward_{me}'][s], rtol=0, atol=1e-12 if team == 'camera' else 1e-9)
     for ls in range(len(fx['skip/done'])):                      # FrameSkip: rewards summed over the action's frames
         frames = np.nonzero(fx['step/learner_step'] == ls)[0]
-        np.testing.assert_allclose(shaped[frames].sum(axis=0), fx['skip/reward_cam'][ls], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(shaped[frames].sum(axis=0), fx[f'skip/reward_{me}'][ls], rtol=0, atol=1e-9)
