@@ -541,29 +541,28 @@ def measure_learner_flows(torch, device_index, workload, batch, graph_steps, res
             out['versus_greedy']['reset_interval'] = versus_reset_interval
             del st
             # ---- ... and with FrameSkip(5) on top, what every example trainer's make_env ends with (examples/ippo/camera/config.py:
-            # frame_skip = 5; examples/utils/wrappers.py:301-323): ONE launch per learner action (rollout_versus_greedy), direct launches
+            # frame_skip = 5; examples/utils/wrappers.py:301-323): ONE launch per learner action (rollout_versus_greedy), replayed from
+            # a HIP graph like the per-step flows (Stepper(frame_skip=K): the device-resident step counter advances by K per launch)
             K = 5
-            per = max(1, versus_reset_interval // K)
-            eng.reserve_rollout(K, search='none')
-            launches = max(2 * per, steps // K // per * per)
-
-            def run_skip(n):
-                for _ in range(n):
-                    mine.mul_(-1.0)
-                    eng.rollout_versus_greedy('camera', mine, K, auto_reset=per)
-
-            run_skip(2 * per)
+            per = max(1, versus_reset_interval // K)               # launches per reset interval
+            Gs = max(per, (G // K) // per * per)                   # launches per graph
+            launches = max(Gs, steps // K // Gs * Gs)
+            st = eng.make_stepper(mine, None, auto_reset=per, graph_steps=Gs, between=lambda: mine.mul_(-1.0), versus='camera', frame_skip=K)
+            st.run(2 * Gs)
             torch.cuda.synchronize()
             times = []
             for _ in range(3):
                 i0, t0 = eng.idle_steps(), time.perf_counter()
-                run_skip(launches)
+                st.run(launches)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 times.append((dt, batch * launches * K - (eng.idle_steps() - i0)))
             dt, ex = sorted(times)[1]
+            st.close()
+            del st
             eng.kernel_time(enable=1)
-            run_skip(per)
+            for _ in range(4 * per):
+                eng.rollout_versus_greedy('camera', mine, K, auto_reset=per)
             torch.cuda.synchronize()
             km, _ = eng.kernel_time(enable=False)
             b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
@@ -573,7 +572,8 @@ def measure_learner_flows(torch, device_index, workload, batch, graph_steps, res
                 'end_to_end_frac': b_alg * ex / dt / 1e9 / HBM_PEAK_GBS, 'kernel': 'rollout_greedy_kernel', 'kernel_avg_us': km * 1e3,
                 'roofline_frac': b_alg * batch * K / (km * 1e-3) / 1e9 / HBM_PEAK_GBS if km > 0 else 0.0,
                 'flow': f'FrameSkip({K}) over MultiCamera(GreedyTargetAgent): one policy kernel and ONE fused launch per learner action ({K} frames, the greedy targets '
-                        f'act anew on every frame), direct launches, one restart of the finished environments per {per} launches; executed env-steps'}
+                        f'act anew on every frame), {Gs} (policy kernel, launch) pairs per HIP graph replay, one restart of the finished environments per {per} launches; '
+                        'executed env-steps'}
             del mine
         eng.close()
         del eng

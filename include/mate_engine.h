@@ -209,8 +209,10 @@ int mate_engine_set_episode_stats(mate_engine *engine, double *stats_dev);
  * and the auto-reset launch that closes every interval of k steps advances them, so a whole interval (k step launches +
  * one auto-reset launch; k = 1: a (step, auto-reset) pair) has identical arguments every time and any number of
  * intervals may be captured (hipStreamBeginCapture on `stream`, or torch.cuda.graph) and replayed.  Results are
- * bit-identical to the host-counted flow with the same auto_reset.  While enabled only step() / step_random() with
- * auto_reset = k, observe() and reset() are accepted (MATE_ESTATE otherwise).  enable == 0 (at an interval boundary)
+ * bit-identical to the host-counted flow with the same auto_reset.  While enabled only step() / step_random() /
+ * step_greedy() / step_versus_greedy() with auto_reset = k, observe() and reset() are accepted (MATE_ESTATE otherwise) -- and
+ * mate_engine_rollout_versus_greedy (FrameSkip in a graph): there k counts LAUNCHES, every launch of an interval has the same
+ * number of frames K, and the auto-reset launch behind the k-th advances the counter by k * K.  enable == 0 (at an interval boundary)
  * drains `stream` and takes the counter back to the host.  The reference has no counterpart (environment.py:590 runs one
  * Python call per step); this is how its `for t in range(T): env.step(policy(obs))` loop is enqueued on a GPU. */
 int mate_engine_device_tick(mate_engine *engine, int32_t enable, void *stream);
@@ -285,7 +287,12 @@ int mate_engine_step_versus_greedy(mate_engine *engine, int32_t team, const mate
  * so results do not depend on timing -- the same calls with MATE_PIPELINED_SERIAL=1, which runs the resets on the caller's
  * stream, give the same bytes).  A finished environment idles through the rest of its launch and all of the next one (scalar
  * rows done = 2, counted by mate_engine_idle_steps).  Any other entry point of the handle first waits for the resets in flight
- * and turns the tags back into plain live environments. */
+ * and turns the tags back into plain live environments.
+ * auto_reset = -m (m > 1): ONE such restart launch behind every m-th rollout launch (short launches -- a learner's FrameSkip actions --
+ * whose restart group is longer than a launch): what finishes in interval i of m launches idles through i + 1 and is live again in
+ * the first launch of i + 2; leaving the mode inside an interval restarts what it had listed.  (Measured on FrameSkip(5) launches of
+ * MATE-4v8-9 x 4096 / 16 384: 65.5 against 66.3 us per launch and 1.3 % more idle slots -- no gain: the launch fills its registers'
+ * worth of every SIMD and the restart's workgroups wait for its tail either way.  tools/frameskip_pipelined_probe.py) */
 #define MATE_RESET_PIPELINED (-1)
 int mate_engine_rollout_greedy(mate_engine *engine, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream);
 /* FrameSkip(frame_skip = steps) over MultiCamera / MultiTarget (examples/utils/wrappers.py:301-323: the same action for
@@ -293,7 +300,7 @@ int mate_engine_rollout_greedy(mate_engine *engine, const mate_step_io *io, int3
  * the joint action of io (as in mate_engine_step_versus_greedy) for `steps` frames, the greedy opponents act anew on every
  * frame.  Outputs are rollout-shaped; the wrapper's summed reward is the column sum of the scalar rows (rows with
  * done = 2 are zero), its observation the last row with done != 2.  Bit-identical to `steps` calls of
- * mate_engine_step_versus_greedy with the same action. */
+ * mate_engine_step_versus_greedy with the same action.  Graph-replayable under mate_engine_device_tick (see there). */
 int mate_engine_rollout_versus_greedy(mate_engine *engine, int32_t team, const mate_step_io *io, int32_t steps,
                                       int32_t auto_reset, void *stream);
 

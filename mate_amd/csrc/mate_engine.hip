@@ -148,11 +148,13 @@ struct mate_engine {
     int64_t steps_since_reset = 0;   // batched auto-reset bookkeeping
     bool was_reset = false;
     bool dev_tick = false;     // mate_engine_device_tick: the step counter lives on the device (graph-replayable launches)
+    int dev_frames = 1;        // ... frames per launch of the reset interval in progress (1: the per-step flows; K: FrameSkip launches, rollout_versus_greedy)
     int dev_interval = 1;      // ... and the auto-reset interval every step() must then use
     int pending_interval = 0;  // auto_reset value of the batched-reset interval in progress (steps_since_reset > 0)
     // pipelined restarts (mate_engine_rollout_greedy with auto_reset = MATE_RESET_PIPELINED): the side stream the resets run on, the
     // event behind the last rollout launch, one event per list parity behind the reset that consumed that list
     bool pipelined = false;          // records may carry "restarted" tags (Ptrs::pipelined): leave_pipelined() before anything else runs
+    int pipe_every = 1, pipe_count = 0;   // ... one restart launch behind every pipe_every-th rollout launch (auto_reset = -pipe_every); launches into the interval
     bool pipelined_serial = false;   // MATE_PIPELINED_SERIAL=1: the same protocol with the resets on the CALLER's stream (the tests' reference)
     hipStream_t side = nullptr;
     hipEvent_t ev_launch = nullptr, ev_reset[2] = {nullptr, nullptr};
@@ -776,6 +778,16 @@ static int leave_pipelined(mate_engine *e, hipStream_t stream) {
     HIP_TRY(hipSetDevice(e->device));
     for (int q = 0; q < 2; ++q)
         if (e->reset_in_flight[q]) { HIP_TRY(hipStreamWaitEvent(stream, e->ev_reset[q], 0)); e->reset_in_flight[q] = false; }
+    if (e->pipe_count > 0) {         // an interval left open (restarts behind every pipe_every-th launch): what it has listed restarts now
+        Ptrs r = e->g;
+        apply_io(r, nullptr);
+        r.pipelined = 1;
+        int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream, true);
+        if (rc != MATE_OK) return rc;
+        HIP_TRY(hipMemsetAsync(e->g.done_count + e->parity, 0, sizeof(int32_t), stream));
+        e->parity ^= 1;
+        e->pipe_count = 0;
+    }
     hipLaunchKernelGGL(untag_kernel, dim3((unsigned)((e->N + 255) / 256)), dim3(256), 0, stream, (const Params *)e->d_params, (const Ptrs)e->g);
     HIP_TRY(hipGetLastError());
     e->pipelined = false;
@@ -802,7 +814,7 @@ extern "C" int mate_engine_device_tick(mate_engine *e, int32_t enable, void *str
         // (flush_pending, once the host counts again) -- the same thing a change of auto_reset inside an interval does.
         uint32_t words[2] = {0, 0};
         HIP_TRY(hipMemcpy(words, reinterpret_cast<const char *>(e->d_params) + offsetof(Params, dev_tick), sizeof(words), hipMemcpyDeviceToHost));
-        e->tick = words[0] + (uint32_t)e->steps_since_reset; e->parity = (int)(words[1] & 1u);
+        e->tick = words[0] + (uint32_t)e->steps_since_reset * (uint32_t)e->dev_frames; e->parity = (int)(words[1] & 1u);
         e->p.dev_tick = 0; e->p.dev_group = 0; e->p.dev_tick_on = 0;      // zero while the host counts (the kernels ADD them to the launch arguments)
     }
     HIP_TRY(hipMemcpy(e->d_params, &e->p, sizeof(Params), hipMemcpyHostToDevice));
@@ -817,6 +829,10 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     if (!e->was_reset) return fail(MATE_ESTATE, "step()/observe() called before reset() (or import_state)");
     if (e->dev_tick && mode != MODE_OBSERVE && auto_reset != e->dev_interval)
         return fail(MATE_ESTATE, "with a device-resident step counter (mate_engine_device_tick) step() needs auto_reset = %d: the auto-reset launch advances it", e->dev_interval);
+    if (e->dev_tick && mode != MODE_OBSERVE) {      // (one frame per launch: see rollout_with_policies)
+        if (e->steps_since_reset == 0) e->dev_frames = 1;
+        else if (e->dev_frames != 1) return fail(MATE_ESTATE, "device-resident step counter: a one-frame step inside a reset interval of %d-frame launches", e->dev_frames);
+    }
     HIP_TRY(hipSetDevice(e->device));
     note_stream(e, stream);
     if (mode != MODE_OBSERVE) { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | kStepFlow) : auto_reset, stream); if (rc != MATE_OK) return rc; }
@@ -1074,17 +1090,23 @@ extern "C" int mate_engine_step_versus_greedy(mate_engine *e, int32_t team, cons
 static int rollout_with_policies(mate_engine *e, int team_caller, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_, bool per_step) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     if (!e->was_reset) return fail(MATE_ESTATE, "rollout_greedy called before reset() (or import_state)");
-    if (e->dev_tick && !per_step) return fail(MATE_ESTATE, "not available while the step counter is device-resident (mate_engine_device_tick)");
+    // (device-resident counter: the per-step flows, and the K-frame launches of a learner against the greedy opponents -- FrameSkip in a
+    // HIP graph; the auto-reset launch behind every auto_reset-th launch advances the counter by auto_reset * K)
+    if (e->dev_tick && !per_step && team_caller < 0) return fail(MATE_ESTATE, "not available while the step counter is device-resident (mate_engine_device_tick)");
     if (e->dev_tick && auto_reset != e->dev_interval)
         return fail(MATE_ESTATE, "with a device-resident step counter (mate_engine_device_tick) step() needs auto_reset = %d: the auto-reset launch advances it", e->dev_interval);
+    if (e->dev_tick) {
+        if (e->steps_since_reset == 0) e->dev_frames = steps;
+        else if (e->dev_frames != steps) return fail(MATE_ESTATE, "device-resident step counter: %d frames per launch inside a reset interval that began with %d", steps, e->dev_frames);
+    }
     if (!e->policy_ready) return fail(MATE_ESTATE, "call mate_engine_policy_enable() before the reset whose observations the policies act on");
     if (steps < 1) return fail(MATE_EINVAL, "rollout needs at least one step");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
-    const bool pipelined = auto_reset == MATE_RESET_PIPELINED;
+    const bool pipelined = auto_reset < 0;          // MATE_RESET_PIPELINED (-1), or -m: one restart launch behind every m-th rollout launch
+    const int pipe_every = pipelined ? -auto_reset : 1;
     if (pipelined && (per_step || e->dev_tick)) return fail(MATE_EINVAL, "pipelined restarts (auto_reset = MATE_RESET_PIPELINED) belong to the fused rollouts");
-    if (auto_reset < 0 && !pipelined) return fail(MATE_EINVAL, "auto_reset = %d", auto_reset);
-    if (!pipelined) { const int rc_ = leave_pipelined(e, stream); if (rc_ != MATE_OK) return rc_; }
+    if (!pipelined || (e->pipelined && e->pipe_every != pipe_every)) { const int rc_ = leave_pipelined(e, stream); if (rc_ != MATE_OK) return rc_; }
     note_stream(e, stream);
     { int rc = flush_pending(e, auto_reset > 1 ? (auto_reset | (per_step ? kStepFlow : kRolloutFlow)) : auto_reset, stream); if (rc != MATE_OK) return rc; }
     if (pipelined && !e->side) {
@@ -1105,6 +1127,7 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
         HIP_TRY(hipMemsetAsync(e->g.done_count, 0, 2 * sizeof(int32_t), stream));
         e->reset_in_flight[0] = e->reset_in_flight[1] = false;
         e->pipelined = true;
+        e->pipe_every = pipe_every; e->pipe_count = 0;
     }
     Ptrs g = e->g;
     apply_io(g, io);
@@ -1125,7 +1148,7 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     if (lds > 160 * 1024) return fail(MATE_EINVAL, "rollout_greedy: %zu bytes of LDS per workgroup do not fit", lds);
     g.mode = MODE_STEP; g.reset_kind = -1; g.rollout_steps = steps;
     g.parity = e->dev_tick ? 0 : e->parity;
-    g.tick = e->dev_tick ? (uint32_t)e->steps_since_reset : e->tick;     // device-resident counter: the offset inside the reset interval
+    g.tick = e->dev_tick ? (uint32_t)e->steps_since_reset * (uint32_t)steps : e->tick;     // device-resident counter: the offset inside the reset interval
     g.tape_ct = nullptr; g.tape_goal = nullptr; g.freeze_done = 0;
     g.rotate_prio = e->sw.rollout_rotate;
     // the finished-episode list: the rollout flows keep it for the immediate restart only (a batched restart finds the finished
@@ -1168,8 +1191,11 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
         }
         return MATE_OK;
     }
-    if (pipelined) {
-        // the reset of what THIS launch finishes (list `parity`): on the side stream, behind this launch, under the next one
+    if (pipelined && ++e->pipe_count < e->pipe_every) {
+        // inside a restart interval: the following launches append to the same list; what has finished idles (listed) until the interval's restart
+    } else if (pipelined) {
+        e->pipe_count = 0;
+        // the reset of what THIS launch (this interval of launches) finishes (list `parity`): on the side stream, behind this launch, under the next ones
         hipStream_t rs = e->pipelined_serial ? stream : e->side;
         if (!e->pipelined_serial) { HIP_TRY(hipEventRecord(e->ev_launch, stream)); HIP_TRY(hipStreamWaitEvent(rs, e->ev_launch, 0)); }
         Ptrs r = e->g;
@@ -1187,13 +1213,15 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     } else if (auto_reset == 1) {
         Ptrs r = e->g;
         apply_io(r, nullptr);     // state and the engine's own masks: the agents of the next rollout act on the fresh view
+        r.tick_advance = (uint32_t)steps;
         int rc = launch_reset(e, r, RESET_DONE, PH_PLACE | PH_LUT | PH_VIEW, stream, true);
         if (rc != MATE_OK) return rc;
-        e->parity ^= 1;
+        if (!e->dev_tick) e->parity ^= 1;
     } else if (auto_reset > 1 && (e->pending_interval = auto_reset | kRolloutFlow, ++e->steps_since_reset >= auto_reset)) {
         e->steps_since_reset = 0; e->pending_interval = 0;
         Ptrs r = e->g;
         apply_io(r, nullptr);
+        r.tick_advance = (uint32_t)auto_reset * (uint32_t)steps;
         int rc = launch_reset(e, r, RESET_FLAGGED, PH_PLACE | PH_LUT | PH_VIEW, stream);
         if (rc != MATE_OK) return rc;
     }

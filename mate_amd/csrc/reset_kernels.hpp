@@ -493,8 +493,9 @@ __global__ __launch_bounds__(256) void reset_kernel(const Params *__restrict__ p
     // device-resident step counter (Params::dev_tick): the immediate auto-reset launch behind a step takes the list
     // parity that step used and advances the counter for the next one (this kernel touches the counter only here)
     const int32_t parity = (p.dev_tick_on && g.reset_kind == RESET_DONE) ? g.ctrl[0] : g.parity;
-    // (a reset split into several launches advances it in the last one: tick_advance = 0 in the others)
-    if (p.dev_tick_on && g.reset_kind == RESET_DONE && g.tick_advance != 0u && blockIdx.x == 0 && threadIdx.x == 0) { g.dev_tick_ptr[0] += g.tick_advance; g.dev_tick_ptr[1] += 1u; }
+    // (a reset split into several launches advances it in the last one: tick_advance = 0 in the others; only the auto-reset launches of
+    // the flows that run with the counter on the device carry one: list-driven behind the per-step flows, by flag behind K-frame launches)
+    if (p.dev_tick_on && g.tick_advance != 0u && blockIdx.x == 0 && threadIdx.x == 0) { g.dev_tick_ptr[0] += g.tick_advance; g.dev_tick_ptr[1] += 1u; }
     if (g.reset_kind == RESET_DONE && (int64_t)blockIdx.x >= (int64_t)g.done_count[parity] * ((phases & PH_PER_CAMERA) ? p.Nc : 1)) return;   // idle: nothing finished
     if (g.reset_kind == RESET_LIST && (int64_t)blockIdx.x >= (int64_t)g.flag_count[0] * ((phases & PH_PER_CAMERA) ? p.Nc : 1)) return;
     const bool pairs = g.reset_kind == RESET_PAIRS;

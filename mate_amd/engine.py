@@ -252,12 +252,22 @@ class Engine:
 
     RESET_PIPELINED = -1     # MATE_RESET_PIPELINED (include/mate_engine.h)
 
+    @classmethod
+    def _auto_reset_code(cls, auto_reset):
+        """'pipelined' -> MATE_RESET_PIPELINED; ('pipelined', m) -> -m: one restart launch (on the engine's side stream) behind every
+        m-th rollout launch; everything else as it is."""
+        if auto_reset == 'pipelined':
+            return cls.RESET_PIPELINED
+        if isinstance(auto_reset, tuple) and len(auto_reset) == 2 and auto_reset[0] == 'pipelined':
+            assert int(auto_reset[1]) >= 1
+            return -int(auto_reset[1])
+        return int(auto_reset)
+
     def rollout_greedy(self, steps, auto_reset=True, want_masks=False):
         """`steps` fused (agents act, environment steps) iterations of the on-device Greedy policies (enable_policies()
         first).  Same rollout-shaped tensors as rollout_random.  auto_reset = 'pipelined' (Engine.RESET_PIPELINED): the reset of
         what a launch finishes runs on the engine's side stream under the next launch, restarted environments join the one after."""
-        if auto_reset == 'pipelined':
-            auto_reset = self.RESET_PIPELINED
+        auto_reset = self._auto_reset_code(auto_reset)
         return self._run_rollout(self.lib.mate_engine_rollout_greedy, steps, auto_reset, want_masks)
 
     def rollout_versus_greedy(self, team, joint_action, steps, auto_reset=True, want_masks=False):
@@ -266,8 +276,7 @@ class Engine:
         the on-device greedy opponents act anew on every frame.  Rollout-shaped tensors; the caller sums the reward rows."""
         team = {'camera': 0, 'target': 1}.get(team, team)
         assert team in (0, 1)
-        if auto_reset == 'pipelined':
-            auto_reset = self.RESET_PIPELINED
+        auto_reset = self._auto_reset_code(auto_reset)
         steps = int(steps)
         buf = self.reserve_rollout(steps, want_masks)
         io, keep = self._io(cam_act=joint_action if team == 0 else None, tgt_act=joint_action if team == 1 else None)
@@ -439,11 +448,12 @@ class Engine:
         arguments in every reset interval and can be captured in a HIP graph.  False / 0 gives the counter back."""
         check(self.lib.mate_engine_device_tick(self._h, int(enable), self._stream()))
 
-    def make_stepper(self, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None, versus=None):
+    def make_stepper(self, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None, versus=None, frame_skip=1):
         """A replayable `for _ in range(n): between(); step((cam_act, tgt_act))` loop over caller-owned action tensors
-        (see Stepper); versus = 'camera' / 'target': the caller plays that team only, the greedy agents the other.
+        (see Stepper); versus = 'camera' / 'target': the caller plays that team only, the greedy agents the other;
+        frame_skip = K > 1 on top of `versus`: every step is one K-frame launch (FrameSkip, the example trainers' flow).
         With graph_steps > 0 the constructor runs `auto_reset` REAL steps before it captures (Stepper.warmup_steps)."""
-        return Stepper(self, cam_act, tgt_act, auto_reset, graph_steps, between, versus)
+        return Stepper(self, cam_act, tgt_act, auto_reset, graph_steps, between, versus, frame_skip)
 
     def enable_policies(self):
         """Allocate the on-device policy state (call before the reset whose observations the agents act on)."""
@@ -661,8 +671,14 @@ class Stepper:
     real (outputs in the engine's tensors, episode statistics counted) and a learner that must see every transition
     reads them like any other step; "bit-identical to Engine.step in a loop" means a loop that includes them."""
 
-    def __init__(self, eng, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None, versus=None):
+    def __init__(self, eng, cam_act, tgt_act, auto_reset=True, graph_steps=0, between=None, versus=None, frame_skip=1):
         self.eng, self.between, self.graph_steps = eng, between, int(graph_steps)
+        # frame_skip = K > 1 (with `versus`): FrameSkip(K) over MultiCamera / MultiTarget, the example trainers' flow -- every "step" of
+        # this stepper is ONE K-frame launch (Engine.rollout_versus_greedy: the caller's action repeated, the greedy opponents acting
+        # anew on every frame), `auto_reset` and `graph_steps` count launches, and run() returns the rollout-shaped tensors
+        # ([K, N, ...]: the caller sums the reward rows, reads the last frame's observation) instead of the engine's per-step ones
+        self.frame_skip = int(frame_skip)
+        assert self.frame_skip >= 1 and (self.frame_skip == 1 or versus is not None), 'frame_skip belongs to the learner-versus-greedy flow'
         self.auto_reset = int(auto_reset)        # True / 1: immediate; k > 1: batched (finished environments idle up to k - 1 steps)
         # versus = 'camera' / 'target': the caller's team (MultiCamera / MultiTarget); the other team is played by the on-device
         # greedy agents (Engine.step_versus_greedy) and its tensor argument is ignored
@@ -677,6 +693,15 @@ class Stepper:
         assert (tgt_act is None or self.io.target_actions_dev == tgt_act.data_ptr()) and \
             (cam_act is None or eng.num_cameras == 0 or self.io.camera_actions_dev == cam_act.data_ptr()), \
             'action tensors must be contiguous f32/f64 (or int32 grid indices) on the engine device'
+        self.outputs = None
+        if self.frame_skip > 1:
+            buf = eng.reserve_rollout(self.frame_skip)
+            self.io.camera_obs_dev = buf['camera_obs'].data_ptr() if eng.num_cameras else None
+            self.io.target_obs_dev = buf['target_obs'].data_ptr()
+            self.io.scalars_dev = buf['scalars'].data_ptr()
+            self.io.masks_dev = None
+            self.outputs = (buf['camera_obs'][:self.frame_skip], buf['target_obs'][:self.frame_skip], buf['scalars'][:self.frame_skip])
+            self.keep = (self.keep, buf)
         self.ref = ctypes.byref(self.io)
         self.graph = None
         self._phase = 0                                   # steps into the current reset interval (graphs hold whole intervals)
@@ -699,6 +724,8 @@ class Stepper:
         eng = self.eng
         if self.versus is None:
             status = eng.lib.mate_engine_step(eng._h, self.ref, self.auto_reset, eng._stream())
+        elif self.frame_skip > 1:
+            status = eng.lib.mate_engine_rollout_versus_greedy(eng._h, self.versus, self.ref, self.frame_skip, self.auto_reset, eng._stream())
         else:
             status = eng.lib.mate_engine_step_versus_greedy(eng._h, self.versus, self.ref, None, self.auto_reset, eng._stream())
         if status != 0:
@@ -717,6 +744,8 @@ class Stepper:
             self._phase = steps % self.auto_reset
         for _ in range(steps):
             self._one()
+        if self.outputs is not None:
+            return self.outputs
         eng = self.eng
         return eng.camera_obs, eng.target_obs, eng.scalars
 

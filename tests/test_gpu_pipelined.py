@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(cfg, n, K, launches, serial, seed=9):
+def _run(cfg, n, K, launches, serial, seed=9, mode='pipelined'):
     from mate_amd.engine import Engine
     os.environ['MATE_PIPELINED_SERIAL'] = '1' if serial else '0'
     try:
@@ -18,7 +18,7 @@ def _run(cfg, n, K, launches, serial, seed=9):
         eng.reset()
         rec = []
         for _ in range(launches):
-            cam, tgt, sc = eng.rollout_greedy(K, auto_reset='pipelined', want_masks=True)
+            cam, tgt, sc = eng.rollout_greedy(K, auto_reset=mode, want_masks=True)
             rec.append((cam.clone(), tgt.clone(), sc.clone(), eng._rollout['masks'][:K].clone()))
         idle = eng.idle_steps()
         state = eng.export_state().clone()           # (any other entry point: waits for the resets in flight, clears the hand-over tags)
@@ -60,6 +60,43 @@ def test_pipelined_restarts_equal_their_serial_form_and_join_two_launches_later(
     cam, tgt, sc = eng.rollout_greedy(K, auto_reset=True)
     torch.cuda.synchronize()
     assert torch.isfinite(tgt).all() and (sc[0, :, 2] != 2).sum() >= n // 2
+
+
+@pytest.mark.parametrize('every', [3, 4])
+def test_pipelined_restarts_behind_every_mth_launch(every):
+    """auto_reset = ('pipelined', m) (the C ABI's -m): ONE restart launch, on the side stream, behind every m-th rollout launch --
+    short launches (a learner's FrameSkip(5) actions) whose restart group, four latency-bound launches, is longer than a launch.
+    The concurrent form equals the serial one bit for bit; an environment whose episode ends in interval i (launches i m ... i m + m - 1)
+    idles through the rest of i and all of i + 1 and is live again in the first launch of interval i + 2; leaving the mode inside an
+    interval (any other entry point) restarts what that interval had listed."""
+    from mate_amd.config import read_config
+    cfg = read_config('MATE-4v8-9.yaml', max_episode_steps=29)
+    n, K, launches = 130, 5, 8 * every + 2                  # (stops inside an interval)
+    mode = ('pipelined', every)
+    _, conc, state_c, idle_c = _run(cfg, n, K, launches, serial=False, mode=mode)
+    eng, ser, state_s, idle_s = _run(cfg, n, K, launches, serial=True, mode=mode)
+    for a, b in zip(conc, ser):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+    assert torch.equal(state_c.view(torch.uint8), state_s.view(torch.uint8)) and idle_c == idle_s
+    done = torch.stack([r[2][:, :, 2] for r in conc]).cpu().numpy()          # [launch][frame][env]
+    intervals = launches // every
+    per = done[:intervals * every].reshape(intervals, every * K, n)           # [interval][frame of the interval][env]
+    finished = 0
+    for i in range(intervals - 2):
+        ended = (per[i] == 1).any(axis=0)
+        finished += int(ended.sum())
+        assert (per[i + 1][:, ended] == 2).all()                             # the restart owns them for the whole next interval
+        assert (per[i + 2][0, ended] != 2).all()                             # ... and they are live again in the one after
+        for env in np.nonzero(ended)[0][:8]:
+            r = int(np.argmax(per[i][:, env] == 1))
+            assert (per[i][r + 1:, env] == 2).all()
+    assert finished >= n
+    sd = {k: state_s[:, off:off + (int(np.prod(shape)) if shape else 1)].cpu().numpy() for k, (off, shape) in eng.export_fields.items()}
+    assert set(np.unique(sd['done'])) <= {0.0}                               # the open interval's finished environments restarted on the way out
+    cam, tgt, sc = eng.rollout_greedy(K, auto_reset=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tgt).all() and (sc[0, :, 2] != 2).all()
 
 
 def test_pipelined_mode_changes_nothing_while_no_episode_ends():

@@ -209,6 +209,56 @@ def test_graph_replayed_learner_versus_greedy(team, interval):
     assert float(outs[0][-1][0][:, -2].min()) >= 2          # (export column `episode`) every environment restarted at least once
 
 
+@pytest.mark.parametrize('team,config,skip,interval', [('camera', 'MATE-4v8-9.yaml', 5, 2), ('target', 'MATE-2v4-0.yaml', 10, 1),
+                                                       ('camera', 'MATE-4v8-9.yaml', 3, 4)])
+def test_graph_replayed_frame_skip_versus_greedy(team, config, skip, interval):
+    """FrameSkip(K) over MultiCamera / MultiTarget, the example trainers' loop, in ONE HIP graph: every learner action is one K-frame
+    launch (rollout_versus_greedy), the step counter on the device advances by interval * K at the restart launch behind every
+    `interval`-th launch == the same launches made one by one with the host counting: the rollout-shaped outputs, the state and the
+    agents' memory bit for bit, across episode ends (time limit 23 frames), through a call that stops inside an interval, and on
+    into the host-counted flow after close()."""
+    from mate_amd._native import EngineError
+    from mate_amd.config import read_config
+    from mate_amd.engine import Engine
+    cfg = read_config(config, max_episode_steps=23)
+    n = 70
+    outs = []
+    for graph_steps in (0, 2 * interval):
+        eng = Engine(cfg, n, seed=5)
+        eng.enable_policies()
+        eng.reset()
+        eng.step_greedy(auto_reset=True)      # an odd host tick before the counter moves to the device
+        agents = eng.num_cameras if team == 'camera' else eng.num_targets
+        gen = torch.Generator(device='cuda').manual_seed(9)
+        mine = (torch.rand((n, agents, 2), device='cuda', generator=gen) * 2 - 1) * (6 if team == 'camera' else 25)
+
+        def policy():
+            mine.mul_(-1.0).add_(0.125)
+
+        stepper = eng.make_stepper(mine if team == 'camera' else None, mine if team == 'target' else None, auto_reset=interval,
+                                   graph_steps=graph_steps, between=policy, versus=team, frame_skip=skip)
+        rec = []
+        if not graph_steps:
+            stepper.run(interval)             # what the constructor's warm-up (one reset interval) did on the graph side
+        for chunk in (4 * interval, interval + 1, 2 * interval + 1):
+            co, to, sc = stepper.run(chunk)
+            torch.cuda.synchronize()
+            assert sc.shape[0] == skip and to.shape[0] == skip
+            rec.append([t.clone() for t in (co, to, sc) if t.numel()])
+        if graph_steps and (7 * interval + 2) % interval:      # the last call stopped inside a reset interval
+            with pytest.raises(EngineError):
+                eng.step_versus_greedy(team, mine, auto_reset=interval)      # a one-frame step inside an interval of K-frame launches
+        stepper.close()
+        eng.step_greedy(auto_reset=True)      # the host-counted flow continues seamlessly afterwards
+        rec.append([eng.export_state().clone(), eng.scalars.clone(), eng.camera_obs.clone(), eng.target_obs.clone()])
+        outs.append(rec)
+        del stepper, eng
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))
+    assert float(outs[0][-1][0][:, -2].min()) >= 2          # (export column `episode`) every environment restarted at least once
+
+
 @pytest.mark.parametrize('policy', ['random', 'greedy'])
 def test_rollouts_with_batched_resets(policy):
     """auto_reset = k > 1 on the fused rollouts: finished environments idle through the following launches and all
