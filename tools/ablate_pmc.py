@@ -22,13 +22,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mate_amd.config import read_config
 from mate_amd.engine import Engine
+# ABLATE_FLOW=actions: step(actions) with f32 joint actions (the learner's flow) instead of step_random
+flow = os.environ.get('ABLATE_FLOW', 'random')
 eng = Engine(read_config('MATE-4v8-9.yaml'), 4096, seed=0)
 eng.lib.mate_engine_debug_skip.argtypes = [ctypes.c_void_p, ctypes.c_int32]
 eng.reset()
+cam = (torch.rand((4096, 4, 2), device='cuda') * 2 - 1) * torch.tensor([5.0, 2.5], device='cuda')
+tgt = (torch.rand((4096, 8, 2), device='cuda') * 2 - 1) * 20.0
+one = (lambda: eng.step_random(auto_reset=False)) if flow == 'random' else (lambda: eng.step(cam, tgt, auto_reset=False))
 for _ in range(50):
-    eng.step_random(auto_reset=False)
+    one()
 for mask, name in MASKS:
     eng.lib.mate_engine_debug_skip(eng._h, mask)
     for _ in range(REPS):
-        eng.step_random(auto_reset=False)
+        one()
 torch.cuda.synchronize()
