@@ -457,6 +457,9 @@ def measure_learner_flows(torch, device_index, workload, batch, graph_steps, res
       versus_greedy     MultiCamera(GreedyTargetAgent) (mate/wrappers/single_team.py:245-264; every examples/*/camera/config.py): the
                         learner's stand-in policy kernel writes the camera team's joint action, the on-device greedy targets act and
                         the environment steps in ONE launch (step_greedy_kernel)
+      versus_greedy_frameskip5     ... with FrameSkip(5) on top (one fused launch per learner action): the camera trainers' whole flow
+      target_learner_frameskip10   the TARGET trainers' flow (examples/*/target/config.py): MATE-2v4-0, MultiTarget(GreedyCameraAgent),
+                        FrameSkip(10) -- a small scenario (rows a fifth of MATE-4v8-9's: a wave's lanes are mostly idle)
       external_actions_two_groups   the same batch as two half-batch engines on two streams, graphs replayed alternately -- a learner
                         that alternates between two groups of environments (double-buffered sampling): one group's step runs under
                         the other group's policy and launch ramp
@@ -578,6 +581,50 @@ def measure_learner_flows(torch, device_index, workload, batch, graph_steps, res
         eng.close()
         del eng
         torch.cuda.empty_cache()
+        # ---- the TARGET learner's flow of the example trainers (examples/ippo/target/config.py:20-67 and its siblings): MATE-2v4-0,
+        # MultiTarget(GreedyCameraAgent), FrameSkip(10) -- one policy kernel and one ten-frame launch per learner action, from a HIP graph
+        if workload == 'MATE-4v8-9.yaml':
+            cfg_t = read_config('MATE-2v4-0.yaml')
+            eng = Engine(cfg_t, batch, device=device_index, seed=0)
+            eng.enable_policies()
+            eng.reset()
+            K = 10
+            per = max(1, versus_reset_interval // K)
+            Gs = max(per, (G // K) // per * per)
+            launches = max(Gs, steps // K // Gs * Gs)
+            eng.reserve_rollout(K, search='none')
+            mine = (torch.rand((batch, eng.num_targets, 2), device=eng.device) * 2 - 1) * 10.0
+            st = eng.make_stepper(None, mine, auto_reset=per, graph_steps=Gs, between=lambda: mine.mul_(-1.0), versus='target', frame_skip=K)
+            st.run(2 * Gs)
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(3):
+                i0, t0 = eng.idle_steps(), time.perf_counter()
+                st.run(launches)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                times.append((dt, batch * launches * K - (eng.idle_steps() - i0)))
+            dt, ex = sorted(times)[1]
+            st.close()
+            del st
+            eng.kernel_time(enable=1)
+            for _ in range(4 * per):
+                eng.rollout_versus_greedy('target', mine, K, auto_reset=per)
+            torch.cuda.synchronize()
+            km, _ = eng.kernel_time(enable=False)
+            b_alg = algorithmic_bytes(eng.num_cameras, eng.num_targets, eng.num_obstacles)
+            out['target_learner_frameskip10'] = {
+                'workload': 'MATE-2v4-0.yaml', 'value': ex * world / dt, 'unit': 'env-steps/s', 'us_per_step': dt / (launches * K) * 1e6, 'us_per_launch': dt / launches * 1e6,
+                'passes_us_per_step': [round(t[0] / (launches * K) * 1e6, 3) for t in times], 'algorithmic_bytes_per_env_step': b_alg,
+                'end_to_end_frac': b_alg * ex / dt / 1e9 / HBM_PEAK_GBS, 'kernel': 'rollout_greedy_kernel', 'kernel_avg_us': km * 1e3,
+                'roofline_frac': b_alg * batch * K / (km * 1e-3) / 1e9 / HBM_PEAK_GBS if km > 0 else 0.0,
+                'flow': f'FrameSkip({K}) over MultiTarget(GreedyCameraAgent) on MATE-2v4-0 (the target trainers\' scenario): one policy kernel and ONE fused launch per learner '
+                        f'action ({K} frames, the greedy cameras act anew on every frame), {Gs} (policy kernel, launch) pairs per HIP graph replay, one restart of the finished '
+                        f'environments per {per} launches; executed env-steps; rows of this scenario are a fifth of MATE-4v8-9\'s'}
+            del mine
+            eng.close()
+            del eng
+            torch.cuda.empty_cache()
         # ---- two half-batch groups on two streams (mate_amd.engine.EngineGroups): step(actions), and the learner versus the greedy opponents
         if batch % 2 == 0 and batch >= 2048:
             from mate_amd.engine import EngineGroups
