@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of two builds of the library on the per-step kernels, interleaved in one process: python tools/step_ab.py libA.so libB.so [batch]
+"""A/B of two builds of the library on the per-step kernels, interleaved in one process: python tools/step_ab.py libA.so libB.so [batch] [workload]
 (step_random and the learner-versus-greedy step; kernel time from the dispatch events, 400 launches per round, 3 rounds each)."""
 import ctypes, os, sys
 import torch
@@ -10,7 +10,7 @@ from mate_amd.engine import Engine  # noqa: E402
 
 libs = sys.argv[1:3]
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
-cfg = read_config('MATE-4v8-9.yaml')
+cfg = read_config(sys.argv[4] if len(sys.argv) > 4 else 'MATE-4v8-9.yaml')
 engines = []
 for path in libs:
     _native.lib, _native.LIB_PATH = None, os.path.abspath(path)      # every Engine keeps the handle it was created with
