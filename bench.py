@@ -995,6 +995,12 @@ def main():
             batches = [args.batch] + ([b for b in LEARNER_BATCHES if b != args.batch] if default_case else [])
             flows = [measure_learner_flows(torch, local_rank, args.workload, b, args.graph_steps, args.step_reset_interval, args.versus_reset_interval) for b in batches]
             line['learner_flows'] = flows
+            # next to the fractions of the vendor peak: of the copy rate measured on this box in this run (what a kernel that reads
+            # and writes HBM can reach here: 4.6-5.3 TB/s on this pool) -- the per-step flows at 65 536 environments run at it
+            for fl in flows:
+                for entry in fl.values():
+                    if isinstance(entry, dict) and 'end_to_end_frac' in entry:
+                        entry['end_to_end_frac_of_measured_copy_peak'] = entry['end_to_end_frac'] * HBM_PEAK_GBS / copy_peak
             for key in ('per_step_launch', 'external_actions', 'versus_greedy'):
                 if key in flows[0]:
                     line[key] = dict({'reset_interval': args.step_reset_interval}, **flows[0][key], batch=args.batch)

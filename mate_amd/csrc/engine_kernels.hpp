@@ -468,11 +468,7 @@ struct DrawCarry { uint32_t z, w, block; };      // second half of the lane's Ph
 // What a lane draws is the same at every step of a launch: its stream and index, whether it draws at all, and -- an agent -- the
 // bounds of its two action components.  The fused rollout derives it once and holds it (22 vector instructions per step).
 struct DrawRole { uint32_t stream, sub; int32_t kind; double m0, m1; };      // kind: 0 none, 1 agent (action sample), 2 pair (transmittance draw)
-// A lane with nothing to draw in the step's Philox call may draw a block of ANOTHER stream in the same call (step_greedy_kernel: the
-// greedy agents' draws of this tick -- one Philox per step instead of two); the four words go to LDS, into the tail of the predrawn
-// uniforms' array that the scenario's pairs do not reach (udraw slots [Nc Nt, 64): two slots per block).
-struct ExtraDraws { uint32_t stream, tick; int32_t sub, slot; };      // sub < 0: nothing
-template <typename ObsT> __device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry = nullptr, const DrawRole *held = nullptr, const ExtraDraws *extra = nullptr);
+template <typename ObsT> __device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry = nullptr, const DrawRole *held = nullptr);
 
 // The caller's joint action of this lane's agent (lanes [0, Nc): cameras, [Nc, Nc + Nt): targets), f32 or f64 per team, as issued loads
 template <typename ObsT>
@@ -491,7 +487,7 @@ __device__ __forceinline__ StepDraws prefetch_action(const Ctx<ObsT> &c) {
 }
 
 template <typename ObsT>
-__device__ __forceinline__ StepDraws load_records_with_draws(Ctx<ObsT> &c, uint32_t tick, bool draw, const ExtraDraws *extra = nullptr) {
+__device__ __forceinline__ StepDraws load_records_with_draws(Ctx<ObsT> &c, uint32_t tick, bool draw) {
     const Params &p = c.p;
     const int lane = c.lane;
     const double *s = c.g.stat + c.env * p.SW;
@@ -513,7 +509,7 @@ __device__ __forceinline__ StepDraws load_records_with_draws(Ctx<ObsT> &c, uint3
         if (draw) (void)step_draws(c, tick);
         draws = act;
     } else
-    if (draw) draws = step_draws(c, tick, nullptr, nullptr, extra);
+    if (draw) draws = step_draws(c, tick);
     if (lane < p.SW) c.st[lane] = s0;
     if (lane < p.DW) c.dy[lane] = d0;
     if (lane + 64 < p.SW) c.st[lane + 64] = s1;
@@ -574,7 +570,7 @@ __device__ __forceinline__ void pin_draw_role(DrawRole &r) {
     asm volatile("" : "+v"(r.stream)); asm volatile("" : "+v"(r.sub)); asm volatile("" : "+v"(r.kind)); asm volatile("" : "+v"(r.m0)); asm volatile("" : "+v"(r.m1));
 }
 template <typename ObsT>
-__device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry, const DrawRole *held, const ExtraDraws *extra) {
+__device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry, const DrawRole *held) {
     const Params &p = c.p;
     const int lane = c.lane;
     StepDraws d{0.0, 0.0};
@@ -585,15 +581,10 @@ __device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, Dra
     // (a lane's role -- stream, sub -- is the same at every step of a launch, so the words it carries are its own)
     const uint32_t block = tick >> 1;
     uint32_t w0 = 0, w1 = 0;
-    const bool other = extra != nullptr && !active && extra->sub >= 0;      // (an idle lane of the step stream serving another one)
     if (carry && (tick & 1u) && carry->block == block) { w0 = carry->z; w1 = carry->w; }        // wave-uniform: no Philox at all on this step
-    else if (active || other) {
-        const U4 r = philox(p.seed_lo, p.seed_hi, c.env_global(), other ? extra->tick : block, other ? extra->stream : stream, other ? (uint32_t)extra->sub : sub);
-        if (other) {
-            uint64_t *slot = reinterpret_cast<uint64_t *>(&c.udraw(p.Nc * p.Nt)) + 2 * extra->slot;
-            slot[0] = (uint64_t)r.x | ((uint64_t)r.y << 32); slot[1] = (uint64_t)r.z | ((uint64_t)r.w << 32);
-        }
-        else if (tick & 1u) { w0 = r.z; w1 = r.w; }
+    else if (active) {
+        const U4 r = philox(p.seed_lo, p.seed_hi, c.env_global(), block, stream, sub);
+        if (tick & 1u) { w0 = r.z; w1 = r.w; }
         else { w0 = r.x; w1 = r.y; if (carry) { carry->z = r.z; carry->w = r.w; } }
     }
     if (carry && !(tick & 1u)) carry->block = block;

@@ -1039,8 +1039,8 @@ static int step_with_policies(mate_engine *e, int team_caller, const mate_step_i
         (team_caller < 0 || (team_caller == 0 ? io->camera_actions_dev : io->target_actions_dev)))
         return rollout_with_policies(e, team_caller, io, 1, auto_reset, (void *)stream, true);
     if (!e->was_reset) return fail(MATE_ESTATE, "step_greedy called before reset() (or import_state)");
-    // (works with a device-resident step counter too, so the learner-versus-greedy loop can be captured in a HIP graph like step();
-    // launch_step checks the reset interval)
+    // (works with a device-resident step counter too -- the agents take their tick from the environment record -- so the
+    // learner-versus-greedy loop can be captured in a HIP graph like step(); launch_step checks the reset interval)
     if (!e->policy_ready) return fail(MATE_ESTATE, "call mate_engine_policy_enable() before the reset whose observations the policies act on");
     if (team_caller == 0 && e->p.Nc == 0) return fail(MATE_EINVAL, "the scenario has no cameras to act for");
     if (team_caller >= 0 && (!io || !(team_caller == 0 ? io->camera_actions_dev : io->target_actions_dev)))
@@ -1059,7 +1059,6 @@ static int step_with_policies(mate_engine *e, int team_caller, const mate_step_i
     const unsigned blocks = (unsigned)((e->N + 3) / 4);
     Ptrs gp = e->g;
     gp.freeze_done = auto_reset > 1;
-    gp.tick = e->dev_tick ? (uint32_t)e->steps_since_reset : e->tick;      // the agents' draws are keyed by the step's tick, like the environment's (launch_step behind this sets the same)
     hipLaunchKernelGGL(e->policy_fn, dim3(blocks), dim3(256), 4 * q.lds_bytes + 1024, stream,   // + the shared zoom-solve exchange
                        (const Params *)e->d_params, (const Ptrs)gp, (const PolicyPtrs)q);
     HIP_TRY(hipGetLastError());

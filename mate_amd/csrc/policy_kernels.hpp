@@ -20,9 +20,7 @@ namespace mate {
 //   word 1            -> the agent's Bernoulli uniform                          (greedy.py:93, 315)
 //   words 2, 3        -> the two uniforms of the agent's action / noise sample (greedy.py:95, 319)
 // (camera c is lane c, target t is lane 32 + t).  32-bit uniforms: the thresholds are 0.05 .. 0.75 and the
-// samples feed a clipped action.  Keyed (seed, global environment index, the STEP's tick, stream, lane) like the environment's own
-// draws; S_POL_TGT_RESET is keyed by the episode counter.  (Where the step's own Philox call has idle lanes, step_greedy_kernel
-// draws these blocks there: same keys, same words, one call instead of two.)
+// samples feed a clipped action.  S_POL_TGT_RESET is keyed by the episode counter.
 enum PolicyStream : uint32_t { S_POL_STEP = 16, S_POL_TGT_RESET = 19 };
 
 struct PolicyTape {          // all optional (NULL = Philox); device pointers
@@ -162,9 +160,8 @@ __device__ __forceinline__ double zoom_lookup(const PolicyPtrs &q, double K) {
 template <typename ObsT>
 __device__ __forceinline__ void greedy_policy_body(const Params &p, const PolicyPtrs &q, PolCtx<ObsT> &a, const double *st, const double *dy,
                                                    const int32_t *di, const uint32_t *mk,
-                                                   int wave, int lane, int64_t env, uint32_t tick, bool active, double *lds_cam_act, double *lds_tgt_act,
-                                                   long long *acc = nullptr, long long *t_prev = nullptr, bool publish = true,
-                                                   const uint64_t *drawn = nullptr, int drawn_slot = 0) {
+                                                   int wave, int lane, int64_t env, bool active, double *lds_cam_act, double *lds_tgt_act,
+                                                   long long *acc = nullptr, long long *t_prev = nullptr, bool publish = true) {
     // Which teams' agents act (wave-uniform, `cams` / `tgts` below): both under step_greedy / rollout_greedy; under MultiCamera /
     // MultiTarget (q.caller_team = the learner's team, single_team.py:245-264) ONLY THE OPPONENTS -- the reference's wrapper holds no
     // agents for the learner's team, and its joint action is the caller's.  A team that does not act keeps its memory as it is and
@@ -185,8 +182,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     auto ty = [&](int t) { return dy[2 * Nc + Nt + t]; };
     auto sees = [&](int c, int t) { const int b = c * Nt + t; return (mk[b >> 5] >> (b & 31)) & 1u; };
     const int32_t *env_i = di + Nt * TI_STRIDE;
-    // `tick`: the step's own (the launch's tick, like the environment's draws; through round 5's first half the agents keyed theirs by
-    // the record's EI_TICK, which lags behind after idle steps -- the first action of an episode that began with a batched restart)
+    const uint32_t tick = (uint32_t)env_i[EI_TICK];
     const uint32_t env_global = p.first_env + (uint32_t)env;
     const bool cams = q.caller_team != 0, tgts = q.caller_team != 1;      // (which teams act: see below)
     // a team's first call of a new episode: agent.reset(observation)
@@ -195,11 +191,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     double u_bern = 0.0, u_s0 = 0.0, u_s1 = 0.0;
     uint32_t w_delay = 0, w_choice = 0;
     if (!(q.tape.cam_binom_u && q.tape.cam_sample_u && q.tape.cam_delay && q.tape.tgt_choice_u && q.tape.tgt_binom_u && q.tape.tgt_sample_u)) {
-        // `drawn`: this lane's block of the stream was drawn by a lane that had nothing to draw in the STEP's Philox call
-        // (step_greedy_kernel: one call instead of two) and waits in LDS; same key, same words
-        U4 r;
-        if (drawn) { const uint64_t lo = drawn[2 * drawn_slot], hi = drawn[2 * drawn_slot + 1]; r.x = (uint32_t)lo; r.y = (uint32_t)(lo >> 32); r.z = (uint32_t)hi; r.w = (uint32_t)(hi >> 32); }
-        else r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_STEP, (uint32_t)lane);
+        const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_STEP, (uint32_t)lane);
         w_delay = r.x & 0xffffu; w_choice = r.x >> 16;
         u_bern = (double)r.y * 2.3283064365386963e-10;
         u_s0 = (double)r.z * 2.3283064365386963e-10; u_s1 = (double)r.w * 2.3283064365386963e-10;
@@ -497,7 +489,7 @@ __global__ __launch_bounds__(256) void greedy_policy_kernel(const Params *__rest
     }
     wave_sync();
     if (g.freeze_done && (di + p.Nt * TI_STRIDE)[EI_DONE] != 0) return;          // finished, waiting for the batched reset
-    greedy_policy_body<ObsT>(p, q, a, st, dy, di, mk, wave, lane, env, p.dev_tick + g.tick, true, nullptr, nullptr);
+    greedy_policy_body<ObsT>(p, q, a, st, dy, di, mk, wave, lane, env, true, nullptr, nullptr);
     wave_sync();
     double *dst = q.pol + env * q.PW;
     for (int k = lane; k < q.PW; k += 64) dst[k] = a.f[k];
@@ -696,14 +688,14 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
             continue;
         }
         // (the joint actions stay in LDS; the last executed step's are published once, at the end of the launch)
-        const uint32_t tick = p.dev_tick + g.tick + (uint32_t)r;
-        MATE_PHASE(128, greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, c.mask, wave_r, lane_r, env_r, tick, true, act_cam, act_tgt, GREEDY_ACC, false));
+        MATE_PHASE(128, greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, c.mask, wave_r, lane_r, env_r, true, act_cam, act_tgt, GREEDY_ACC, false));
         wave_sync();
         GREEDY_STAMP(10);
         if (q.caller_team >= 0) {
             load_caller_actions(c, q.caller_team, act_cam, act_tgt);
             wave_sync();
         }
+        const uint32_t tick = p.dev_tick + g.tick + (uint32_t)r;
         StepDraws draws{0.0, 0.0};
         MATE_PHASE(1, draws = step_draws(c, tick, &carry));       // see-through uniforms only (mode() is MODE_STEP)
         GREEDY_STAMP(0);
@@ -764,10 +756,10 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
 // the registers allow -- with greedy_policy_body between the entity table and the kinematics and the joint actions handed over in
 // LDS (FLOW_STEP_GREEDY).  Same phase functions, same bytes as the two-launch form and as the fused rollout with one step (tested).
 // LDS per workgroup: 4 step slices, then 4 x (agents' memory + staging + joint actions + the previous step's mask words).
-// (compiled for every shipped shape but MATE-1v2-* and MATE-1v1-0: there the register allocator leaves 36-48 bytes of private
-// scratch, which costs ~5 us per launch -- mate_amd/build.py refuses such a kernel; those three scenarios keep the one-step
+// (compiled for every shipped shape but MATE-1v2-*: with one camera and two targets the register allocator leaves 36-48 bytes of
+// private scratch, which costs ~5 us per launch -- mate_amd/build.py refuses such a kernel; those two scenarios keep the one-step
 // rollout_greedy_kernel form)
-constexpr bool step_greedy_compiled(int Nc, int Nt, int No) { return !(Nc == 1 && Nt == 2) && !(Nc == 1 && Nt == 1 && No == 0); }
+constexpr bool step_greedy_compiled(int Nc, int Nt, int /*No*/) { return !(Nc == 1 && Nt == 2); }
 // (`cameras` false: the caller plays the cameras -- MultiCamera, the flow of every examples/*/camera/config.py --, so only the target
 // agents act: their section of the memory record, the joint actions and the mask words: 0.7 KB per environment instead of 1.8, and seven
 // workgroups per CU instead of six at MATE-4v8-9)
@@ -820,29 +812,7 @@ void step_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const Polic
 #define SG_ACC nullptr, nullptr
 #endif
     SG_STAMP(0);
-    // The acting team's draws of this tick (greedy_policy_body: the lane's block of S_POL_STEP) ride in the STEP's Philox call, on lanes
-    // that draw nothing there -- the agents' own lanes [0, Nc + Nt) (their actions come from the agents / the caller) and the tail behind
-    // the pair lanes -- when one team acts, its policy lanes are [0, Nc Nc) (cameras: own draws on lane c, a message's delay on the
-    // (sender, recipient) lane) or 32 + t (targets), and everything fits: the blocks' slots in the free tail of the predrawn uniforms,
-    // the busy policy lanes' helpers in the idle tail.  Same keys, same words as a call of its own (the two-launch form, the fused
-    // rollouts): ~95 vector instructions per step less on a kernel that is issue-bound from 16 384 environments on.
-    ExtraDraws extra{(uint32_t)S_POL_STEP, tick, -1, 0};
-    bool shared_call = false;
-    {
-        const int nact = p.Nc + p.Nt, npair = p.Nc * p.Nt, tail = nact + npair;
-        const int n_pol = cams ? p.Nc * p.Nc : p.Nt, first = cams ? 0 : 32;
-        const int lo_busy = first > nact ? first : nact, hi_busy = (first + n_pol < tail ? first + n_pol : tail);      // policy lanes in [nact, tail) are pair lanes
-        const int n_busy = hi_busy > lo_busy ? hi_busy - lo_busy : 0;
-        // (this kernel never runs with recorded agent draws; the last clause: no policy lane of its own sits in the idle tail where the helpers are)
-        shared_call = (cams != tgts) && p.Nc > 0 && npair <= 64 - nact && 2 * n_pol <= 64 - npair && first + n_pol <= 64 &&
-                      tail + n_busy <= 64 && (n_busy == 0 || first + n_pol <= tail);
-        if (shared_call) {
-            const int L = lane - first;                             // this lane as a policy lane
-            if (L >= 0 && L < n_pol && (lane < nact || lane >= tail)) { extra.sub = lane; extra.slot = L; }                       // idle in the step stream: in place
-            else if (lane >= tail && lane - tail < n_busy) { const int served = lo_busy + (lane - tail); extra.sub = served; extra.slot = served - first; }   // a helper
-        }
-    }
-    const StepDraws draws = load_records_with_draws(c, tick, true, &extra);      // (extra.sub stays -1 on every lane unless the call is shared)
+    const StepDraws draws = load_records_with_draws(c, tick, true);
     double *pol_lds = a.f + w_lo;
     if (lane < w_n) pol_lds[lane] = pw0;
     if (lane + 64 < w_n) pol_lds[lane + 64] = pw1;
@@ -870,11 +840,7 @@ void step_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const Polic
 #ifdef MATE_PHASE_CLOCKS
     pol_prev = (long long)__builtin_amdgcn_s_memtime();
 #endif
-    {
-        const int slot = lane - (cams ? 0 : 32), n_pol = cams ? p.Nc * p.Nc : p.Nt;
-        greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, mk, wave, lane, env, tick, true, act_cam, act_tgt, SG_ACC, false,
-                                 shared_call ? reinterpret_cast<const uint64_t *>(&c.udraw(p.Nc * p.Nt)) : nullptr, slot >= 0 && slot < n_pol ? slot : 0);
-    }
+    greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, mk, wave, lane, env, true, act_cam, act_tgt, SG_ACC, false);
     wave_sync();
     if (q.caller_team >= 0) {
         load_caller_actions(c, q.caller_team, act_cam, act_tgt);
