@@ -299,3 +299,14 @@ def test_every_environment_switch_is_documented_in_the_header():
     assert len(names) >= 15, names
     missing = sorted(n for n in names if n not in header)
     assert not missing, missing
+
+
+def test_auto_reset_spellings_of_the_python_mirror():
+    """Engine._auto_reset_code: what the rollout entry points hand to the C ABI -- 'pipelined' is MATE_RESET_PIPELINED (-1),
+    ('pipelined', m) is -m (one restart launch on the side stream behind every m-th rollout launch), everything else an int."""
+    from mate_amd.engine import Engine
+    assert Engine._auto_reset_code('pipelined') == Engine.RESET_PIPELINED == -1
+    assert Engine._auto_reset_code(('pipelined', 12)) == -12 and Engine._auto_reset_code(('pipelined', 1)) == -1
+    assert Engine._auto_reset_code(True) == 1 and Engine._auto_reset_code(False) == 0 and Engine._auto_reset_code(7) == 7
+    with pytest.raises(AssertionError):
+        Engine._auto_reset_code(('pipelined', 0))
