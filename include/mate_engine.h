@@ -413,6 +413,11 @@ int mate_engine_block_free(void *ptr);
  * a few candidates, keeps the fastest and frees the rest -- Engine.reserve_rollout does.  The block is left filled with zeros. */
 int mate_engine_block_probe(int32_t device, void *block, int64_t bytes, int32_t rows_per_step, int32_t row_bytes, void *stream,
                             double *gbytes_per_s);
+/* The HBM rates of THIS GPU as this library's own streaming kernels see them (the yardsticks beside the vendor peak in bench.py's
+ * roofline object): `mode` 0 = read `src` and write `dst` (read + write bytes counted), 1 = write `dst` only, 2 = read `src` only;
+ * 16 bytes per lane, grid-stride over `bytes` (use >= 1 GiB), non-temporal, median of five launches timed with HIP events on `stream`.
+ * No reference counterpart: measurement support (SURVEY.md section 8d "confirm on the box"). */
+int mate_engine_hbm_probe(int32_t device, const void *src, void *dst, int64_t bytes, int32_t mode, void *stream, double *gbytes_per_s);
 /* Physical device memory taken and held without being mapped (hipMemCreate in 256 MiB pieces), and given back: what a search
  * for a fast block puts between two candidates so that the next one comes from further into the device's memory -- the blocks'
  * chunks come out of the same pool, in order; memory from hipMalloc does not move that pool's cursor. */

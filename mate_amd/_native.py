@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = (
     'mate_engine_rollout_random', 'mate_engine_policy_enable', 'mate_engine_step_greedy', 'mate_engine_step_versus_greedy', 'mate_engine_rollout_greedy', 'mate_engine_rollout_versus_greedy', 'mate_engine_policy_actions',
     'mate_engine_observe', 'mate_engine_export_state', 'mate_engine_import_state', 'mate_engine_lut_read',
     'mate_engine_block_alloc', 'mate_engine_block_free', 'mate_engine_block_probe', 'mate_engine_set_store_form',
-    'mate_engine_memory_hold', 'mate_engine_memory_release',
+    'mate_engine_memory_hold', 'mate_engine_memory_release', 'mate_engine_hbm_probe',
     'mate_engine_lut_write', 'mate_engine_enable_outer_boundary', 'mate_engine_lut_read_outer', 'mate_engine_lut_write_outer', 'mate_engine_soft_coverage', 'mate_engine_rebuild_luts', 'mate_engine_idle_steps', 'mate_engine_kernel_time', 'mate_engine_last_flow',
 )
 
@@ -130,6 +130,7 @@ def load():
     handle.mate_engine_memory_hold.argtypes = [I32, I64, ctypes.POINTER(P)]
     handle.mate_engine_memory_release.argtypes = [P]
     handle.mate_engine_block_probe.argtypes = [I32, P, I64, I32, I32, P, ctypes.POINTER(ctypes.c_double)]
+    handle.mate_engine_hbm_probe.argtypes = [I32, P, P, I64, I32, P, ctypes.POINTER(ctypes.c_double)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(handle, name)
         if name not in ('mate_engine_last_error',):
@@ -190,6 +191,26 @@ class ScatteredBlock:
             if status != 0:         # (a finaliser cannot raise: say that device memory may not have come back)
                 import warnings
                 warnings.warn(f'mate_engine_block_free failed ({status}): {self._lib.mate_engine_last_error().decode()}', RuntimeWarning)
+
+
+def hbm_rates(device_index, gib=1.0):
+    """GB/s of this GPU under the library's own streaming kernels (``mate_engine_hbm_probe``): ``{'copy': read + write bytes of a
+    copy, 'fill': write-only, 'read': read-only}`` over two ``gib``-sized buffers, each the median of five launches."""
+    import torch
+    n = int(gib * (1 << 30)) // 16 * 16
+    out = {}
+    with torch.cuda.device(device_index):
+        a = torch.zeros(n, dtype=torch.uint8, device='cuda')
+        b = torch.zeros(n, dtype=torch.uint8, device='cuda')
+        torch.cuda.synchronize()
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for name, mode in (('copy', 0), ('fill', 1), ('read', 2)):
+            rate = ctypes.c_double()
+            check(load().mate_engine_hbm_probe(int(device_index), ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n, mode, stream, ctypes.byref(rate)))
+            out[name] = rate.value
+        del a, b
+        torch.cuda.empty_cache()
+    return out
 
 
 def check(status):

@@ -1045,6 +1045,11 @@ static int step_with_policies(mate_engine *e, int team_caller, const mate_step_i
     if (team_caller == 0 && e->p.Nc == 0) return fail(MATE_EINVAL, "the scenario has no cameras to act for");
     if (team_caller >= 0 && (!io || !(team_caller == 0 ? io->camera_actions_dev : io->target_actions_dev)))
         return fail(MATE_EINVAL, "step_versus_greedy needs the %s team's joint action", team_caller == 0 ? "camera" : "target");
+    // the checks launch_step would make only after the policy launch below has advanced the agents' memory: a rejected call must leave it alone
+    if (e->dev_tick && auto_reset != e->dev_interval)
+        return fail(MATE_ESTATE, "with a device-resident step counter (mate_engine_device_tick) step() needs auto_reset = %d: the auto-reset launch advances it", e->dev_interval);
+    if (e->dev_tick && e->steps_since_reset != 0 && e->dev_frames != 1)
+        return fail(MATE_ESTATE, "device-resident step counter: a one-frame step inside a reset interval of %d-frame launches", e->dev_frames);
     HIP_TRY(hipSetDevice(e->device));
     note_stream(e, stream);
     PolicyPtrs q = e->q;
@@ -1104,6 +1109,7 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(e->device));
     const bool pipelined = auto_reset < 0;          // MATE_RESET_PIPELINED (-1), or -m: one restart launch behind every m-th rollout launch
+    if (auto_reset < -(1 << 16)) return fail(MATE_EINVAL, "auto_reset = %d: pipelined restarts every -auto_reset launches take 1 .. 65536", auto_reset);
     const int pipe_every = pipelined ? -auto_reset : 1;
     if (pipelined && (per_step || e->dev_tick)) return fail(MATE_EINVAL, "pipelined restarts (auto_reset = MATE_RESET_PIPELINED) belong to the fused rollouts");
     if (!pipelined || (e->pipelined && e->pipe_every != pipe_every)) { const int rc_ = leave_pipelined(e, stream); if (rc_ != MATE_OK) return rc_; }
@@ -1595,6 +1601,62 @@ extern "C" int mate_engine_block_probe(int32_t device, void *block, int64_t byte
     const int64_t tail = bytes - steps * rows_per_step * row_bytes;
     if (tail > 0) HIP_TRY(hipMemsetAsync((char *)block + (bytes - tail), 0, (size_t)tail, (hipStream_t)stream));
     *gbytes_per_s = (double)(steps * rows_per_step) * row_bytes / ((double)best * 1e6);
+    return MATE_OK;
+}
+
+namespace {
+// the three rates a streaming kernel of this library can be priced against on THIS GPU: 16 bytes per lane, grid-stride, the
+// non-temporal stores the row writers use.  mode 0: read src + write dst; 1: write dst only; 2: read src only (folded into one word
+// per lane that is stored only if it equals a value it cannot have)
+__global__ __launch_bounds__(256) void hbm_probe_kernel(const char *src, char *dst, int64_t chunks, int32_t mode) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 *in = reinterpret_cast<const f32x4 *>(src);
+    f32x4 *out = reinterpret_cast<f32x4 *>(dst);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 fill = {1.f, 2.f, 3.f, 4.f};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += stride) {
+        if (mode == 0) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+        else if (mode == 1) __builtin_nontemporal_store(fill, out + i);
+        else acc += __builtin_nontemporal_load(in + i);
+    }
+    if (mode == 2 && acc.x + acc.y + acc.z + acc.w == -1.2345e30f) out[0] = acc;
+}
+}  // namespace
+
+extern "C" int mate_engine_hbm_probe(int32_t device, const void *src, void *dst, int64_t bytes, int32_t mode, void *stream, double *gbytes_per_s) {
+    if (!gbytes_per_s || bytes < 16 || mode < 0 || mode > 2 || !dst || (mode != 1 && !src))
+        return fail(MATE_EINVAL, "hbm_probe: null rate / buffer, fewer than 16 bytes or a mode other than 0 (copy), 1 (fill), 2 (read)");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int64_t chunks = bytes / 16;
+    const unsigned grid = (unsigned)std::min<int64_t>((chunks + 255) / 256, (int64_t)prop.multiProcessorCount * 8);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<float> ms_all;
+    auto measure = [&]() -> hipError_t {
+        hipError_t err;
+        if ((err = hipEventCreate(&e0)) != hipSuccess) return err;
+        if ((err = hipEventCreate(&e1)) != hipSuccess) return err;
+        for (int rep = 0; rep < 6; ++rep) {      // (the first launch also pages the kernel in)
+            if ((err = hipEventRecord(e0, (hipStream_t)stream)) != hipSuccess) return err;
+            hipLaunchKernelGGL(hbm_probe_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char *)src, (char *)dst, chunks, mode);
+            if ((err = hipGetLastError()) != hipSuccess) return err;
+            if ((err = hipEventRecord(e1, (hipStream_t)stream)) != hipSuccess) return err;
+            if ((err = hipEventSynchronize(e1)) != hipSuccess) return err;
+            float ms = 0.f;
+            if ((err = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) return err;
+            if (rep > 0) ms_all.push_back(ms);
+        }
+        return hipSuccess;
+    };
+    const hipError_t probe_err = measure();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (probe_err != hipSuccess) { (void)hipGetLastError(); return fail(MATE_EHIP, "hbm_probe: %s", hipGetErrorString(probe_err)); }
+    std::sort(ms_all.begin(), ms_all.end());
+    const double ms = ms_all[ms_all.size() / 2];          // the median of five
+    *gbytes_per_s = (double)(chunks * 16) * (mode == 0 ? 2.0 : 1.0) / (ms * 1e6);
     return MATE_OK;
 }
 

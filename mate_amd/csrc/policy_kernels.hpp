@@ -595,8 +595,9 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         bool mine = false;
         const int32_t parity = (int32_t)((p.dev_group + (uint32_t)g.parity) & 1u);
         if (g.pipelined) {
-            const volatile int32_t *done_word = reinterpret_cast<const volatile int32_t *>(g.dyn + env * p.DW + p.DF) + p.Nt * TI_STRIDE + EI_DONE;
-            d_entry = __builtin_amdgcn_readfirstlane(*done_word);
+            // (read while a reset on another stream may be writing it: an agent-scope atomic load, not a plain one the compiler may keep or split)
+            const int32_t *done_word = reinterpret_cast<const int32_t *>(g.dyn + env * p.DW + p.DF) + p.Nt * TI_STRIDE + EI_DONE;
+            d_entry = __builtin_amdgcn_readfirstlane(__hip_atomic_load(done_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             mine = (d_entry & kDoneTag) && ((d_entry >> 3) & 1) == parity;
             untouched = d_entry != 0 && !mine;      // (a wave past the end of the batch mirrors environment N - 1: the same rule)
         }
@@ -608,7 +609,15 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
             const double *src = q.pol + env * q.PW;
             for (int k = lane; k < q.PW; k += 64) a.f[k] = src[k];
             build_entities(c);
-        } else if (lane == 0) c.ei(EI_DONE) = d_entry;               // (all the step loop reads of it: "not live")
+        } else {
+            // nothing of this environment is loaded: the launch prologue below (image statics, lane roles, collision seeds) still runs
+            // over the wave's record slice, so the slice is zeros, not whatever the LDS held -- its results are discarded, but no
+            // address may ever be formed from an unwritten field
+            uint32_t *slice = reinterpret_cast<uint32_t *>(smem + wave * p.lds_wave_bytes);
+            for (int i = lane; i < (p.lds_wave_bytes >> 2); i += 64) slice[i] = 0u;
+            wave_sync();
+            if (lane == 0) c.ei(EI_DONE) = d_entry;                  // (all the step loop reads of it: "not live")
+        }
         if (g.pipelined) {
             if (d_entry == 1 && in_batch && lane == 0 && g.done_count) {      // finished under auto_reset = 0 earlier, never listed: list it, and say so in the record itself
                 const int slot = atomicAdd(g.done_count + parity, 1);

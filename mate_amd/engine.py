@@ -258,9 +258,12 @@ class Engine:
         m-th rollout launch; everything else as it is."""
         if auto_reset == 'pipelined':
             return cls.RESET_PIPELINED
-        if isinstance(auto_reset, tuple) and len(auto_reset) == 2 and auto_reset[0] == 'pipelined':
-            assert int(auto_reset[1]) >= 1
+        if isinstance(auto_reset, tuple):
+            if len(auto_reset) != 2 or auto_reset[0] != 'pipelined' or not 1 <= int(auto_reset[1]) <= 1 << 16:
+                raise ValueError(f"auto_reset = {auto_reset!r}: ('pipelined', m) takes 1 <= m <= 65536")
             return -int(auto_reset[1])
+        if int(auto_reset) < 0 and int(auto_reset) != cls.RESET_PIPELINED:      # (a typo such as -5 would silently defer restarts five launches)
+            raise ValueError(f"auto_reset = {auto_reset!r}: negative values other than Engine.RESET_PIPELINED are spelt ('pipelined', m)")
         return int(auto_reset)
 
     def rollout_greedy(self, steps, auto_reset=True, want_masks=False):
@@ -392,9 +395,16 @@ class Engine:
         block, unprobed).  Every candidate that loses keeps its address range reserved (mate_engine_block_free), bounded per
         process by MATE_BLOCK_DEAD_GIB."""
         steps = int(steps)
-        assert search in (None, 'shallow', 'deep', 'none')
-        self._block_search = search
+        if search not in (None, 'shallow', 'deep', 'none'):
+            raise ValueError(f"reserve_rollout(search={search!r}): 'shallow', 'deep', 'none' or None (= the last explicit choice)")
+        if search is not None:                       # an explicit choice stays for the (re)allocations that follow, the internal ones included
+            self._block_search = search
         buf = getattr(self, '_rollout', None)
+        depth = {'none': 0, 'shallow': 1, 'deep': 2}
+        if buf is not None and search is not None and depth[search] > depth.get(buf.get('search'), 0) and buf['steps'] >= steps:
+            import warnings                          # (buffers that exist are kept: say that the deeper search was not run)
+            warnings.warn(f"reserve_rollout(search={search!r}): the rollout buffers exist (searched {buf.get('search')!r}); release them "
+                          '(Engine.close() or a longer reservation) to search again', RuntimeWarning, stacklevel=2)
         if buf is None or buf['steps'] < steps or (want_masks and buf['masks'] is None):     # a shorter rollout fills a prefix
             import time
             t0 = self._reserve_t0 = time.perf_counter()
@@ -404,7 +414,7 @@ class Engine:
                 target_block, target_rates = self._observation_block((steps, N, Nt, L.target_obs_dim), deep=True)      # (first: its search holds the most memory)
                 camera_block, camera_rates = self._observation_block((steps, N, Nc, L.camera_obs_dim))
                 buf = {
-                    'steps': steps,
+                    'steps': steps, 'search': getattr(self, '_block_search', None) or ('deep' if self._block_switches['deep'] else 'shallow'),
                     'camera_obs': camera_block,
                     'target_obs': target_block,
                     'scalars': torch.zeros((steps, N, 8), dtype=torch.float32, device=self.device),
@@ -811,13 +821,20 @@ class EngineGroups:
     def pick_streams(self, body, candidates=3, warm=2, timed=4):
         """Choose the side streams by trial.  `body(g, engine)` enqueues one slice of the caller's loop for group g (e.g. a Stepper
         replay); for every side stream, `candidates` fresh streams are tried with `warm + timed` rounds of all groups and the
-        fastest is kept.  Returns the trial times [s] of the last group's candidates."""
+        fastest is kept.  Returns the trial times [s] of the last group's candidates.
+
+        The trial STEPS the environments (`candidates * (warm + timed)` slices per group): call it before the episodes that matter,
+        or reset afterwards.  A group's engine moves to a stream that knows nothing of the work queued on its previous one (a
+        reset, an import), so the device is synchronised before the first trial and at every change of stream; the engine's buffers
+        were allocated on the first stream and live as long as the engine, so the caching allocator never hands them out again."""
         import time
         times = []
+        torch.cuda.synchronize(self.device)           # everything queued on the groups' present streams is complete before one of them changes
         for g in range(1, self.groups):
             times = []
             pool = [torch.cuda.Stream(device=self.device) for _ in range(candidates)]
             for cand in pool:
+                torch.cuda.synchronize(self.device)
                 self.streams[g] = cand
                 for _ in range(warm):
                     self.each(body)
@@ -827,6 +844,7 @@ class EngineGroups:
                     self.each(body)
                 torch.cuda.synchronize(self.device)
                 times.append(time.perf_counter() - t0)
+            torch.cuda.synchronize(self.device)
             self.streams[g] = pool[times.index(min(times))]
         return times
 

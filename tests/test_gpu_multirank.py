@@ -70,15 +70,24 @@ def test_device_episode_statistics_equal_sums_over_the_step_records(flow):
 
 
 def _bench(args, timeout=900):
+    """One bench.py run as a child process; returns its FULL record (the details file), after checking that the last stdout line is the
+    compact headline the driver parses and agrees with it."""
+    import tempfile
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    details = os.path.join(tempfile.mkdtemp(), 'details.json')
     # a CHILD process per run: this pytest process has initialised the GPU and must not be replaced by another program
-    done = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+    done = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args + ['--details', details], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                           universal_newlines=True, timeout=timeout)
     assert done.returncode == 0, done.stderr[-3000:]
-    lines = [json.loads(l) for l in done.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, done.stdout[-2000:]
-    return lines[0]
+    last = done.stdout.rstrip().splitlines()[-1]
+    assert last.startswith('{') and len(last) <= 3000, done.stdout[-2000:]
+    line = json.loads(last)
+    with open(details) as fh:
+        full = json.load(fh)
+    assert line['value'] == full['value'] and line['ms_per_step'] == full['ms_per_step'] and line['details_file'] == details
+    assert line['roofline']['kernel_avg_us'] == pytest.approx(full['roofline']['kernel_avg_us'], rel=1e-4)
+    return full
 
 
 def test_two_ranks_on_one_gpu_run_the_real_engine_and_shard_bit_for_bit(tmp_path):

@@ -308,5 +308,7 @@ def test_auto_reset_spellings_of_the_python_mirror():
     assert Engine._auto_reset_code('pipelined') == Engine.RESET_PIPELINED == -1
     assert Engine._auto_reset_code(('pipelined', 12)) == -12 and Engine._auto_reset_code(('pipelined', 1)) == -1
     assert Engine._auto_reset_code(True) == 1 and Engine._auto_reset_code(False) == 0 and Engine._auto_reset_code(7) == 7
-    with pytest.raises(AssertionError):
-        Engine._auto_reset_code(('pipelined', 0))
+    # what is not one of those spellings is refused, not passed on: a typo such as -5 would silently defer restarts five launches
+    for bad in (('pipelined', 0), ('pipelined', (1 << 16) + 1), ('piplined', 2), ('pipelined',), -5, -(1 << 31)):
+        with pytest.raises(ValueError):
+            Engine._auto_reset_code(bad)
