@@ -312,11 +312,25 @@ def dry_run(args, world, rank):
         dist.destroy_process_group()
 
 
+OUT = sys.stdout       # where emit() prints; main() points it at the process's REAL stdout and sends everything else to stderr
+
+
+def own_stdout():
+    """The driver parses the LAST stdout line.  Libraries write to file descriptor 1 behind Python's back -- RCCL prints `Librccl path : ...`
+    through C stdio, flushed when the process ends, i.e. AFTER the headline (and from every rank of an N-rank run) --, so descriptor 1 is
+    pointed at stderr for the whole process, and the lines of emit() go to a private duplicate of the original stdout."""
+    global OUT
+    sys.stdout.flush()
+    OUT = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
+
 def main():
     t_main = time.perf_counter()
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(launch_ranks(args))
+    own_stdout()
     if args.force_collectives and 'WORLD_SIZE' not in os.environ:      # a one-rank rendezvous of our own
         os.environ.update({'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(free_port())})
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -653,7 +667,7 @@ def emit(full, details_file):
         text = json.dumps(side, separators=(',', ':'))
         if len(text) > SIDE_LIMIT:       # (never at the cost of the headline's place in the driver's tail)
             text = json.dumps({'side': 'see details_file'})
-        print(text, flush=True)
+        print(text, file=OUT, flush=True)
     shown = details_file and (os.path.relpath(details_file, ROOT) if os.path.abspath(details_file).startswith(ROOT + os.sep) else os.path.abspath(details_file))
     line = headline_line(full, shown)
     text = json.dumps(line)
@@ -664,7 +678,7 @@ def emit(full, details_file):
                 line[group][item] = str(line[group][item])[:60]
         text = json.dumps(line)
     assert len(text) <= LINE_LIMIT, len(text)
-    print(text, flush=True)
+    print(text, file=OUT, flush=True)
 
 
 if __name__ == '__main__':

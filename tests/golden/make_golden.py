@@ -278,13 +278,18 @@ def drain_agent_log(cam_agents, tgt_agents):
 
 
 def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f64_obs_steps=None, record_agents=False,
-               extra_factory=None, discrete_levels=None, aux_rewards=None, aux_target_rewards=None):
-    env = mate.make('MultiAgentTracking-v0', config=config, **(overrides or {}))
-    env.seed(seed)
-    cam_obs, tgt_obs = env.reset()
-    if tweak is not None:
-        tweak(env)
-        cam_obs, tgt_obs = env.joint_observation()
+               extra_factory=None, discrete_levels=None, aux_rewards=None, aux_target_rewards=None, env=None, first_obs=None):
+    """`env` / `first_obs`: continue on an environment object that already exists, from the observations its last reset() returned (the
+    second episode of two_episode_fixture); otherwise the environment is made, seeded and reset here.  Returns the environment."""
+    if env is None:
+        env = mate.make('MultiAgentTracking-v0', config=config, **(overrides or {}))
+        env.seed(seed)
+        cam_obs, tgt_obs = env.reset()
+        if tweak is not None:
+            tweak(env)
+            cam_obs, tgt_obs = env.joint_observation()
+    else:
+        cam_obs, tgt_obs = first_obs
     log = []
     install_proxies(env, log)
 
@@ -442,6 +447,7 @@ def make_trace(name, config, seed, policy, steps, overrides=None, tweak=None, f6
     nsee = int(np.isfinite(out['step/tape_ct']).sum()) if Nc else 0
     print(f'{name}: {nsteps} steps, delivered={ndel}, collisions={ncol}, in-sector draws={nsee}, '
           f'done={bool(out["step/done"][-1])}, {os.path.getsize(path) / 1024:.0f} KiB')
+    return env
 
 
 def Nc_of(env):
@@ -732,15 +738,25 @@ def _tape_box_sample(self):
     return (self.low + (self.high - self.low) * u).astype(self.dtype)
 
 
-def reset_fixture(name, config, seed, overrides=None):
-    """reset() of the reference with every RandomState replaced by a TapeDrivenRNG: the tape + the state it produced."""
-    env = mate.make('MultiAgentTracking-v0', config=config, **(overrides or {}))
-    env.seed(seed)
+def _underlying(rng):
+    """The numpy RandomState behind any stack of this script's proxies."""
+    while isinstance(rng, (RecordingRNG, TapeDrivenRNG)):
+        rng = rng._real
+    return rng
+
+
+def reset_fixture(name, config, seed, overrides=None, env=None):
+    """reset() of the reference with every RandomState replaced by a TapeDrivenRNG: the tape + the state it produced.
+    `env`: an environment object that has already run an episode (two_episode_fixture) -- its generators go on where that episode
+    left them; returns (environment, observations of the reset)."""
+    if env is None:
+        env = mate.make('MultiAgentTracking-v0', config=config, **(overrides or {}))
+        env.seed(seed)
     pair_log = []
     for entity in list(env.cameras_ordered) + list(env.targets_ordered) + list(env.obstacles_ordered):
         box = entity.location_random_range
-        box._np_random = TapeDrivenRNG(box.np_random, pair_log, entity)
-    env._np_random = TapeDrivenRNG(env.np_random, pair_log, 'env')
+        box._np_random = TapeDrivenRNG(_underlying(box.np_random), pair_log, entity)
+    env._np_random = TapeDrivenRNG(_underlying(env.np_random), pair_log, 'env')
     RESET_TAPE.clear()
     gym.spaces.Box.sample = _tape_box_sample
     try:
@@ -780,6 +796,24 @@ def reset_fixture(name, config, seed, overrides=None):
     print(f'{name}: {len(tape)} draws ({len(tape) - minimal} beyond the retry-free minimum without goal draws), '
           f'{int(np.isfinite(tape_ct).sum())} in-sector pairs, zero-radius obstacles={int((out["static/obs_xyr"][:, 2] == 0).sum()) if No else 0}, '
           f'{os.path.getsize(path) / 1024:.0f} KiB')
+    # the plain generators back in place: whoever steps this environment next installs its own proxies
+    for entity in list(env.cameras_ordered) + list(env.targets_ordered) + list(env.obstacles_ordered):
+        entity.location_random_range._np_random = _underlying(entity.location_random_range.np_random)
+    env._np_random = _underlying(env.np_random)
+    return env, (cam_obs, tgt_obs)
+
+
+def two_episode_fixture(tag, config, seed, steps1, steps2, policy='greedy'):
+    """ONE reference environment through an episode end (environment.py:629-632) and the reset() behind it (shuffle_entities on: the
+    shipped scenarios' default), as three fixtures in the standard formats:
+      trace_<tag>_<policy>_ep1_s<seed>   an episode that ends inside the trace (only the cargoes in transit are left: tweak_few_cargoes)
+      reset_<tag>_ep2_s<seed>            the reset() of that SAME object behind it, on a tape (its generators go on where episode 1 left them)
+      trace_<tag>_<policy>_ep2_s<seed>   the steps of the second episode
+    tests/test_gpu_parity.py::test_two_episodes_through_a_recorded_reset replays all three on one engine, in order."""
+    env = make_trace(f'trace_{tag}_{policy}_ep1_s{seed}', config, seed, policy, steps1, None, tweak_few_cargoes)
+    assert env.episode_step > 0
+    env, first_obs = reset_fixture(f'reset_{tag}_ep2_s{seed}', config, seed, env=env)
+    make_trace(f'trace_{tag}_{policy}_ep2_s{seed}', config, seed + 100, policy, steps2, env=env, first_obs=first_obs)
 
 
 def xform_fixture(trace_name, steps):
@@ -1011,9 +1045,14 @@ def main():
         xform_fixture('trace_4v8-9_greedy_s2', 48)
         xform_fixture('trace_nav_greedy_s1', 32)
         return
-    kat_obstruct()
-    kat_scalar()
-    kat_perceive()
+    if sys.argv[1:] == ['episodes']:
+        two_episode_fixture('8v8-9', 'MATE-8v8-9.yaml', 21, 500, 96)
+        two_episode_fixture('4v2-9', 'MATE-4v2-9.yaml', 22, 500, 64)
+        return
+    if not sys.argv[1:]:
+        kat_obstruct()
+        kat_scalar()
+        kat_perceive()
     plan = [
         # name,                      config,                 seed, policy,  steps, overrides, tweak
         ('trace_4v2-9_random_s0',    'MATE-4v2-9.yaml',        0, 'random',   96, None, None),
@@ -1029,6 +1068,11 @@ def main():
         ('trace_4v8-0_greedy_s1',    'MATE-4v8-0.yaml',        1, 'greedy',  192, None, None),
         ('trace_nav_random_s0',      'MATE-Navigation.yaml',   0, 'random',   96, None, None),
         ('trace_nav_greedy_s1',      'MATE-Navigation.yaml',   1, 'greedy',  256, None, None),
+        # third seeds of configurations 1, 3, 4, 5 (>= 3 F2 traces per configuration; configuration 2 has five)
+        ('trace_4v2-9_random_s3',    'MATE-4v2-9.yaml',        3, 'random',   96, None, None),
+        ('trace_8v8-9_greedy_s3',    'MATE-8v8-9.yaml',        3, 'greedy',  160, None, None),
+        ('trace_4v8-0_greedy_s3',    'MATE-4v8-0.yaml',        3, 'greedy',  160, None, None),
+        ('trace_nav_random_s3',      'MATE-Navigation.yaml',   3, 'random',  128, None, None),
     ]
     only = sys.argv[1:]
     for name, config, seed, policy, steps, overrides, tweak in plan:

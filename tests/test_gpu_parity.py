@@ -86,6 +86,67 @@ def test_trace_parity(path, dtype):
         check_obs(co, to, fx['step/cam_obs'][s], fx['step/tgt_obs'][s], ('step', s))
 
 
+def _check_step_against_trace(eng, fx, s, N, co, to, sc, dtype):
+    """One replayed step of a reference trace: masks and integer state exact, rewards exact, positions 1e-9, observations 1e-9 (f64) / 1e-5 rel (f32)."""
+    Nc = eng.num_cameras
+    masks = eng.unpack_masks()
+    for m in MASKS:
+        for e in range(N):
+            assert np.array_equal(masks[m][e], fx['step/' + m][s].astype(bool)), (m, s, e)
+    sd = eng.state_dict()
+    for k in INT_KEYS:
+        for e in range(N):
+            assert np.array_equal(sd[k][e], np.asarray(fx['step/' + k][s], dtype=np.float64)), (k, s, e)
+    sc = sc.cpu().numpy()
+    for e in range(N):
+        assert sc[e, 0] == np.float32(fx['step/reward_cam'][s]) and sc[e, 1] == np.float32(fx['step/reward_tgt'][s]), (s, sc[e])
+        assert bool(sc[e, 2]) == bool(fx['step/done'][s]), s
+        assert sd['episode_reward'][e] == fx['step/episode_reward'][s]
+    xy = fx['step/tgt_xy'][s]
+    assert np.abs(sd['tgt_x'] - xy[:, 0]).max() < 1e-9 and np.abs(sd['tgt_y'] - xy[:, 1]).max() < 1e-9, s
+    for e in range(N):
+        for got, ref in (((co[e], fx['step/cam_obs'][s]),) if Nc else ()) + ((to[e], fx['step/tgt_obs'][s]),):
+            got = got.double().cpu().numpy()
+            assert np.allclose(got, ref, rtol=0, atol=1e-9) if dtype == torch.float64 else rel_close(got, ref, 1e-5), (s, e, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize('tag,seed', [('8v8-9', 21), ('4v2-9', 22)])
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32], ids=['f64obs', 'f32obs'])
+def test_two_episodes_through_a_recorded_reset(tag, seed, dtype):
+    """ONE reference environment object through an episode end and the reset() behind it (shuffle_entities on), replayed on ONE engine:
+    the first episode's steps until `done` (environment.py:629-632), then -- on the same engine, mid-run -- the reset the reference made
+    next, consuming its recorded draws (mate_engine_reset_tape; environment.py:679-834: placements, shuffles, cargo matrix, goals, the
+    occlusion tables BUILT ON THE DEVICE from that placement), then the second episode's steps on that state.  Nothing is injected
+    between the two episodes: what the second episode's masks, rewards and observations are checked against is the reference's own
+    continuation (tests/golden/make_golden.py two_episode_fixture)."""
+    ep1, rs, ep2 = (G.load(f'trace_{tag}_greedy_ep1_s{seed}.npz'), G.load(f'reset_{tag}_ep2_s{seed}.npz'), G.load(f'trace_{tag}_greedy_ep2_s{seed}.npz'))
+    N = 3
+    eng = U.engine_from_fixture(ep1, N, obs_dtype=dtype)
+    Nc, Nt = eng.num_cameras, eng.num_targets
+    T1 = len(ep1['step/done'])
+    assert bool(ep1['step/done'][T1 - 2]) and not bool(ep1['step/done'][T1 - 3])      # the episode ends inside the trace (one more step is recorded behind it)
+    for s in range(T1 - 1):                                                            # up to and including the step that reports done
+        co, to, sc = _replay(eng, ep1, s, N)
+        _check_step_against_trace(eng, ep1, s, N, co, to, sc, dtype)
+    tape = torch.from_numpy(np.broadcast_to(rs['tape'], (N, len(rs['tape']))).copy())
+    tape_ct = torch.from_numpy(np.broadcast_to(np.nan_to_num(rs['tape_ct'], nan=0.0), (N, Nc, Nt)).copy()).cuda()
+    co, to, used = eng.reset_tape(tape, tape_ct)
+    assert used.cpu().tolist() == [len(rs['tape'])] * N
+    sd = eng.state_dict()
+    for key, ref in G.reset_expectation(rs).items():
+        for e in range(N):
+            assert np.array_equal(sd[key][e].reshape(ref.shape), ref), (key, e)
+    # the reset fixture and the second trace describe the same moment of the same object
+    assert np.array_equal(rs['reset/tgt_xy'], ep2['reset/tgt_xy']) and np.array_equal(rs['static/obs_xyr'], ep2['static/obs_xyr'])
+    for e in range(N):
+        got = to[e].double().cpu().numpy()
+        assert np.allclose(got, ep2['reset/tgt_obs'], rtol=0, atol=1e-9) if dtype == torch.float64 else rel_close(got, ep2['reset/tgt_obs'], 1e-5)
+    for s in range(len(ep2['step/done'])):
+        co, to, sc = _replay(eng, ep2, s, N)
+        _check_step_against_trace(eng, ep2, s, N, co, to, sc, dtype)
+    assert int(ep2['step/num_delivered_cargoes'][-1]) > 0 or tag == '4v2-9'
+
+
 @pytest.mark.parametrize('name', ['auxtgt_4v8-9_s11', 'auxtgt_8v8-9_s12', 'auxtgt_4v2-9_s13', 'auxtgt_nav_s14'])
 def test_auxiliary_target_rewards_fixtures(name):
     """mate_amd.auxiliary_rewards.AuxiliaryTargetRewards on traces the reference's AuxiliaryTargetRewards wrapper shaped
