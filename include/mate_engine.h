@@ -413,6 +413,16 @@ int mate_engine_block_free(void *ptr);
  * a few candidates, keeps the fastest and frees the rest -- Engine.reserve_rollout does.  The block is left filled with zeros. */
 int mate_engine_block_probe(int32_t device, void *block, int64_t bytes, int32_t rows_per_step, int32_t row_bytes, void *stream,
                             double *gbytes_per_s);
+/* Environments per wave of the fused rollouts (mate_engine_rollout_random / _rollout_greedy / _rollout_versus_greedy).  The engine maps ONE
+ * environment onto one 64-lane wave; the small scenarios (at most four cameras and four targets: MATE-{1v1,1v2,2v2,2v4,4v2,4v4}-{0,9}, e.g. the
+ * MATE-2v4-0 of the reference's target trainers, examples/ippo/target/config.py:63-66) fill a quarter of one, so their fused rollouts
+ * can step FOUR environments per wave, sixteen lanes each -- same results, bit for bit.  `enable`: 0 = one per wave; 1 = the shape's
+ * own number in every fused launch; 2 (the default; MATE_SUBWAVE=0 in the environment makes 0 the default) = where it measured faster:
+ * batches of at least 32 environments per compute unit, and under the random policy every such shape but MATE-4v4-* (whose
+ * one-per-wave rollout, carried by the register-resident row image, is as fast); negative = leave it as it is.  `*in_use` (may be NULL) receives
+ * the number the Greedy rollouts of this engine now run with (1 for a shape without such kernels).  Takes effect from the next launch
+ * on; no state changes. */
+int mate_engine_set_sub_wave(mate_engine *engine, int32_t enable, int32_t *in_use);
 /* The HBM rates of THIS GPU as this library's own streaming kernels see them (the yardsticks beside the vendor peak in bench.py's
  * roofline object): `mode` 0 = read `src` and write `dst` (read + write bytes counted), 1 = write `dst` only, 2 = read `src` only;
  * 16 bytes per lane, grid-stride over `bytes` (use >= 1 GiB), non-temporal, median of five launches timed with HIP events on `stream`.

@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = (
     'mate_engine_rollout_random', 'mate_engine_policy_enable', 'mate_engine_step_greedy', 'mate_engine_step_versus_greedy', 'mate_engine_rollout_greedy', 'mate_engine_rollout_versus_greedy', 'mate_engine_policy_actions',
     'mate_engine_observe', 'mate_engine_export_state', 'mate_engine_import_state', 'mate_engine_lut_read',
     'mate_engine_block_alloc', 'mate_engine_block_free', 'mate_engine_block_probe', 'mate_engine_set_store_form',
-    'mate_engine_memory_hold', 'mate_engine_memory_release', 'mate_engine_hbm_probe',
+    'mate_engine_memory_hold', 'mate_engine_memory_release', 'mate_engine_hbm_probe', 'mate_engine_set_sub_wave',
     'mate_engine_lut_write', 'mate_engine_enable_outer_boundary', 'mate_engine_lut_read_outer', 'mate_engine_lut_write_outer', 'mate_engine_soft_coverage', 'mate_engine_rebuild_luts', 'mate_engine_idle_steps', 'mate_engine_kernel_time', 'mate_engine_last_flow',
 )
 
@@ -130,6 +130,7 @@ def load():
     handle.mate_engine_memory_hold.argtypes = [I32, I64, ctypes.POINTER(P)]
     handle.mate_engine_memory_release.argtypes = [P]
     handle.mate_engine_block_probe.argtypes = [I32, P, I64, I32, I32, P, ctypes.POINTER(ctypes.c_double)]
+    handle.mate_engine_set_sub_wave.argtypes = [P, I32, ctypes.POINTER(I32)]
     handle.mate_engine_hbm_probe.argtypes = [I32, P, P, I64, I32, P, ctypes.POINTER(ctypes.c_double)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(handle, name)

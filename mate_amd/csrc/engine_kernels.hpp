@@ -104,7 +104,8 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
     int off = 0;
     p.off_st = off; off += shape_round_up(p.SW * 8, 16);
     p.off_dy = off; off += shape_round_up(p.DW * 8, 16);
-    p.off_tmp = off; off += shape_round_up((Nc + 3 * Nt + (Nc > 0 ? 64 : 0)) * 8, 16);      // (sight^2 | step vectors | the 64 predrawn transmittance uniforms: cameras only)
+    // (sight^2 | step vectors | the predrawn transmittance uniforms, one per camera->target pair up to 64: only where there are obstacles to see through)
+    p.off_tmp = off; off += shape_round_up((Nc + 3 * Nt + ((Nc > 0 && No > 0) ? (Nc * Nt < 64 ? Nc * Nt : 64) : 0)) * 8, 16);
     p.off_scratch = off; off += image ? 0 : shape_round_up(p.nscratch * obs_size, 16);
     p.off_mask = off; off += shape_round_up(p.MW * 4, 16);
     p.off_misc = off; off += shape_round_up((4 * Nt + 8) * 4, 16);
@@ -131,10 +132,20 @@ constexpr bool image_fits(int Nc, int Nt, int No) {
            p.sector_rounds <= 1 && p.range_rounds <= 5 && p.lds_wave_bytes <= 10 * 1024;
 }
 
+// Environments per wave the fused rollouts of a compiled shape run with (Ctx, `L` = 64 / E lanes per environment): 4 where the
+// agents fit eight lanes per team (the greedy agents' lane roles: cameras from lane 0, targets from lane L / 2), the pairs of a
+// visibility test fit a few rounds of 16 lanes, and the whole-wave row image is not what carries the shape (every shape with at
+// most four cameras and four targets; MATE-4v8-* and MATE-8v8-* fill half a wave and keep their register-resident kernels).
+__host__ __device__ constexpr int sub_wave_of(int Nc, int Nt, int No) {
+    return (Nc <= 4 && Nt <= 4 && Nc + Nt <= 8 && Nt * (Nc + No + Nt) <= 16 * 8 && Nc * (Nt + Nc) <= 16 * 4) ? 4 : 1;
+}
+
 // Kernel shape policies: AnyShape reads every constant from the device-resident Params on demand;
 // FixedShape<Nc, Nt, No> is compiled for one scenario shape (the host picks it when the counts match).
 struct AnyShape {
     static constexpr int kHeldGC = 2, kHeldGT = 6;
+    static constexpr int kChunksC = 0, kChunksT = 0;      // 16-byte chunks of the shape's f32 row blocks (unknown here)
+    static constexpr int kSubWave = 1;
     static constexpr bool kImage = false;
     static constexpr bool kHoldRoles = false;      // rollout kernel: lane roles in registers (needs compile-time round counts)
     static constexpr bool kGreedyRoles = false;
@@ -164,6 +175,9 @@ struct FixedShape {
     // observation descriptors the fused rollouts hold per lane: all chunks of the shape's rows (up to twelve uint4)
     static constexpr int kRowsC = (NC * (13 + 9 + 5 * NT + 4 * NO + 7 * NC) / 4 + 63) / 64, kRowsT = (NT * (13 + 14 + 7 * NC + 4 * NO + 5 * NT) / 4 + 63) / 64;
     static constexpr int kHeldGC = (kRowsC + kRowsT <= 12) ? kRowsC : 2, kHeldGT = (kRowsC + kRowsT <= 12) ? kRowsT : 6;
+    static constexpr int kChunksC = NC * (13 + 9 + 5 * NT + 4 * NO + 7 * NC) / 4, kChunksT = NT * (13 + 14 + 7 * NC + 4 * NO + 5 * NT) / 4;
+    // Environments per wave of the fused rollouts (sub_wave_of below): the scenarios whose agents and visibility pairs fill a quarter of a wave
+    static constexpr int kSubWave = sub_wave_of(NC, NT, NO);
     static constexpr int kGreedyBlocks = 4;
     static constexpr bool kGreedyHeld = true;
     // (MATE-8v8-9 sits at 63 of the 64 registers of full occupancy: with the state's stores ahead of the packer it needs 65)
@@ -318,12 +332,24 @@ enum Flow : int {
     FLOW_STEP_GREEDY = 4,   // step_greedy_kernel (policy_kernels.hpp): ONE (agents act, environment steps) iteration per launch with the per-step flows' semantics
 };
 
-template <typename ObsT>
+// `L`: LANES PER ENVIRONMENT.  64 = one wave per environment, the mapping of everything above; 32 / 16 = two / four environments
+// per wave (round 6, the small scenarios: MATE-2v4-0 has 6 agents and 12 + 24 visibility pairs, so a whole wave spent its
+// life on a handful of live lanes while every vector instruction cost its four cycles).  A sub-wave group of L lanes owns one
+// environment: `lane` is the lane INSIDE the group, `shift` the group's first hardware lane, every pointer of the context is the
+// group's own LDS slice (a per-lane value: the compiler keeps one base VGPR and folds the field offsets into the DS
+// instructions), `ballot()` returns the group's own L bits, and whatever was wave-uniform per environment (episode over, a
+// target in a warehouse) is merely group-uniform: a branch on it diverges between the groups of a wave and the compiler's
+// EXEC masking does the rest.  The phase functions that take `Ctx<ObsT, L>` are written for any L; the register-resident
+// variants (held roles, the row image, the held state, the compacted sector list) exist for L = 64 only.
+template <typename ObsT, int L = 64>
 struct Ctx {
+    static_assert(L == 64 || L == 32 || L == 16, "lanes per environment: a wave, half a wave, a quarter");
+    static constexpr int W = L;
     const Params &p;
     const Ptrs &g;
     const int flow;               // a compile-time constant of the kernel instantiation (folds once Ctx is scalarised)
-    int lane;
+    int lane;                     // lane inside the environment's group, [0, L)
+    int shift = 0;                // the group's first hardware lane (0 when L == 64)
     int64_t env;
     int64_t out;                  // row of this environment in the output buffers (env, or step*N + env in rollouts)
     double *st, *dy, *tmp;
@@ -361,7 +387,22 @@ struct Ctx {
         pub = reinterpret_cast<float *>(wave_base + p.off_pub); img = reinterpret_cast<float *>(wave_base + p.off_img);
     }
     // row-image mode (a compile-time constant of the shape-specialised fused rollouts; zero in the device record otherwise)
-    __device__ __forceinline__ bool image() const { return p.image != 0; }
+    __device__ __forceinline__ bool image() const { return L == 64 && p.image != 0; }
+    // the verdicts of THIS environment's lanes: bit i = lane i of the group
+    __device__ __forceinline__ unsigned long long ballot(bool x) const {
+        if constexpr (L == 64) return __ballot(x);
+        else return (__ballot(x) >> shift) & ((1ull << L) - 1ull);
+    }
+    // L verdicts into the packed mask words at bit `bit` (a multiple of L) -- by the group's lane 0
+    __device__ __forceinline__ void put_bits(int bit, unsigned long long b) const {
+        if constexpr (L == 64) { if (lane == 0) { mask[bit >> 5] = (uint32_t)b; mask[(bit >> 5) + 1] = (uint32_t)(b >> 32); } }
+        else if (lane == 0) {
+            if constexpr (L == 32) mask[bit >> 5] = (uint32_t)b;
+            else reinterpret_cast<uint16_t *>(mask)[bit >> 4] = (uint16_t)b;
+        }
+    }
+    // rounds of L pairs that cover n pairs (Params::sector_rounds / range_rounds count rounds of 64: they lay out the mask BITS)
+    __device__ __forceinline__ static constexpr int rounds_of(int n) { return (n + L - 1) / L; }
     __device__ __forceinline__ float *pub_cam(int c) const { return pub + 8 * c; }
     __device__ __forceinline__ float *pub_tgt(int t) const { return pub + 8 * p.Nc + 8 * t; }
     __device__ __forceinline__ float *pub_obs(int o) const { return pub + 8 * (p.Nc + p.Nt) + 4 * o; }
@@ -381,7 +422,7 @@ struct Ctx {
     __device__ __forceinline__ bool act_prefetched() const { return flow == FLOW_ACT_F32; }
     // camera->target pairs whose transmittance draw step_draws makes ahead of the visibility phase: one lane each -- the lanes
     // behind the agents', and the agents' own wherever those draw no actions (every flow but the on-device random policy)
-    __device__ __forceinline__ int predrawn_pairs() const { return mode() == MODE_STEP_RANDOM ? 64 - p.Nc - p.Nt : 64; }
+    __device__ __forceinline__ int predrawn_pairs() const { return mode() == MODE_STEP_RANDOM ? L - p.Nc - p.Nt : L; }
     __device__ __forceinline__ int act_f64() const { return g.act_f64; }     // (a launch argument in every flow: f32 and f64 joint actions, per team, run the specialised kernel)
     __device__ __forceinline__ int act_discrete() const { return flow != FLOW_ANY ? 0 : g.act_discrete; }
     __device__ __forceinline__ const double *tape_ct() const { return flow != FLOW_ANY ? nullptr : g.tape_ct; }
@@ -438,25 +479,25 @@ struct Ctx {
 template <typename ObsT> struct Bits;
 template <> struct Bits<float> { using type = uint32_t; };
 template <> struct Bits<double> { using type = uint64_t; };
-template <typename ObsT>
-__device__ __forceinline__ void set_flag(const Ctx<ObsT> &c, int bit, bool on) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void set_flag(const Ctx<ObsT, L> &c, int bit, bool on) {
     using U = typename Bits<ObsT>::type;
     reinterpret_cast<U *>(c.base + c.p.off_flags)[bit] = on ? ~(U)0 : (U)0;
 }
 
 // ---------------------------------------------------------------------------------------------
 // record <-> LDS
-template <typename ObsT>
-__device__ __forceinline__ void load_records(Ctx<ObsT> &c) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void load_records(Ctx<ObsT, L> &c) {
     const double *s = c.g.stat + c.env * c.p.SW;
     const double *d = c.g.dyn + c.env * c.p.DW;
-    for (int i = c.lane; i < c.p.SW; i += 64) c.st[i] = s[i];
-    for (int i = c.lane; i < c.p.DW; i += 64) c.dy[i] = d[i];
+    for (int i = c.lane; i < c.p.SW; i += L) c.st[i] = s[i];
+    for (int i = c.lane; i < c.p.DW; i += L) c.dy[i] = d[i];
     if (c.has_scratch_init() && !c.image()) {
         const ObsT *si = reinterpret_cast<const ObsT *>(c.g.scratch_init);
-        for (int i = c.lane; i < c.p.nscratch; i += 64) c.scratch[i] = si[i];
+        for (int i = c.lane; i < c.p.nscratch; i += L) c.scratch[i] = si[i];
     }
-    for (int i = c.lane; i < c.p.MW; i += 64) c.mask[i] = 0u;
+    for (int i = c.lane; i < c.p.MW; i += L) c.mask[i] = 0u;
 }
 
 // The step kernel's version: the record loads are issued into registers first, the step's Philox draws run
@@ -468,11 +509,11 @@ struct DrawCarry { uint32_t z, w, block; };      // second half of the lane's Ph
 // What a lane draws is the same at every step of a launch: its stream and index, whether it draws at all, and -- an agent -- the
 // bounds of its two action components.  The fused rollout derives it once and holds it (22 vector instructions per step).
 struct DrawRole { uint32_t stream, sub; int32_t kind; double m0, m1; };      // kind: 0 none, 1 agent (action sample), 2 pair (transmittance draw)
-template <typename ObsT> __device__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry = nullptr, const DrawRole *held = nullptr);
+template <typename ObsT, int L> __device__ StepDraws step_draws(Ctx<ObsT, L> &c, uint32_t tick, DrawCarry *carry = nullptr, const DrawRole *held = nullptr);
 
 // The caller's joint action of this lane's agent (lanes [0, Nc): cameras, [Nc, Nc + Nt): targets), f32 or f64 per team, as issued loads
-template <typename ObsT>
-__device__ __forceinline__ StepDraws prefetch_action(const Ctx<ObsT> &c) {
+template <typename ObsT, int L>
+__device__ __forceinline__ StepDraws prefetch_action(const Ctx<ObsT, L> &c) {
     const Params &p = c.p;
     const int lane = c.lane, t = lane - p.Nc;
     StepDraws a{0.0, 0.0};
@@ -527,10 +568,10 @@ __device__ __forceinline__ StepDraws load_records_with_draws(Ctx<ObsT> &c, uint3
 }
 
 // unified entity table (after the records are visible in LDS)
-template <typename ObsT>
-__device__ __forceinline__ void build_entities(Ctx<ObsT> &c) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void build_entities(Ctx<ObsT, L> &c) {
     const Params &p = c.p;
-    for (int j = c.lane; j < p.NJ; j += 64) {
+    for (int j = c.lane; j < p.NJ; j += L) {
         double x, y, r;
         if (j < p.Nc) { x = c.cam_x(j); y = c.cam_y(j); r = p.cam_radius; }
         else if (j < p.Nc + p.No) { const int o = j - p.Nc; x = c.obs_x(o); y = c.obs_y(o); r = c.obs_r(o); }
@@ -540,25 +581,25 @@ __device__ __forceinline__ void build_entities(Ctx<ObsT> &c) {
     }
 }
 
-template <typename ObsT>
-__device__ __forceinline__ void store_dynamic(Ctx<ObsT> &c) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void store_dynamic(Ctx<ObsT, L> &c) {
     double *d = c.g.dyn + c.env * c.p.DW;
-    for (int i = c.lane; i < c.p.DW; i += 64) d[i] = c.dy[i];
+    for (int i = c.lane; i < c.p.DW; i += L) d[i] = c.dy[i];
 }
 
 // ---------------------------------------------------------------------------------------------
 // Random numbers of one step, one Philox call per lane, all lanes at once: lanes [0, Nc) camera
 // actions, [Nc, Nc+Nt) target actions, the remaining lanes pre-draw the see-through uniforms of the
 // first camera->target pairs (cheaper than a second divergent Philox in the visibility phase).
-template <typename ObsT>
-__device__ __forceinline__ DrawRole draw_role(const Ctx<ObsT> &c) {
+template <typename ObsT, int L>
+__device__ __forceinline__ DrawRole draw_role(const Ctx<ObsT, L> &c) {
     const Params &p = c.p;
     const int lane = c.lane, nact = p.Nc + p.Nt;
     const bool random_policy = c.mode() == MODE_STEP_RANDOM;
     const bool need_draws = !c.tape_ct() && p.Nc > 0 && p.No > 0;      // (without obstacles nothing is ever seen THROUGH one)
     DrawRole r{0u, 0u, 0, 0.0, 0.0};
     if (lane < nact && !random_policy) {       // an agent's lane with no action to draw: the pair behind the last pair lane's (predrawn_pairs)
-        const int pair = 64 - nact + lane;
+        const int pair = L - nact + lane;
         if (pair < p.Nc * p.Nt) { r.stream = S_TRANSMIT; r.sub = (uint32_t)pair; r.kind = need_draws ? 2 : 0; }
     }
     else if (lane < p.Nc) { r.stream = S_ACT_CAM; r.sub = (uint32_t)lane; r.kind = 1; r.m0 = p.rot; r.m1 = p.zoom; }
@@ -569,8 +610,8 @@ __device__ __forceinline__ DrawRole draw_role(const Ctx<ObsT> &c) {
 __device__ __forceinline__ void pin_draw_role(DrawRole &r) {
     asm volatile("" : "+v"(r.stream)); asm volatile("" : "+v"(r.sub)); asm volatile("" : "+v"(r.kind)); asm volatile("" : "+v"(r.m0)); asm volatile("" : "+v"(r.m1));
 }
-template <typename ObsT>
-__device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, DrawCarry *carry, const DrawRole *held) {
+template <typename ObsT, int L>
+__device__ __forceinline__ StepDraws step_draws(Ctx<ObsT, L> &c, uint32_t tick, DrawCarry *carry, const DrawRole *held) {
     const Params &p = c.p;
     const int lane = c.lane;
     StepDraws d{0.0, 0.0};
@@ -596,8 +637,8 @@ __device__ __forceinline__ StepDraws step_draws(Ctx<ObsT> &c, uint32_t tick, Dra
 }
 
 // Phase A: kinematics.  Camera.simulate (entities.py:347-360), Target.simulate (entities.py:645-668).
-template <typename ObsT>
-__device__ __forceinline__ void simulate_cameras(Ctx<ObsT> &c, const StepDraws &draws, bool advance) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void simulate_cameras(Ctx<ObsT, L> &c, const StepDraws &draws, bool advance) {
     const Params &p = c.p;
     const int lane = c.lane;
     if (lane < p.Nc) {
@@ -680,13 +721,14 @@ __device__ __forceinline__ uint64_t near_field(const Params &p, const NearCarry 
 }
 // `collide_word` (the two-wave step, whose target wave does not own the targets' integer words): the colliding bits of all
 // targets as one word, bit t, instead of bit 24 of each TI_GW.
-template <typename ObsT>
-__device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &draws, const NearCarry *carried = nullptr, int32_t *collide_word = nullptr) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void simulate_targets(Ctx<ObsT, L> &c, const StepDraws &draws, const NearCarry *carried = nullptr, int32_t *collide_word = nullptr) {
     const Params &p = c.p;
     const int lane = c.lane;
     const int t = lane - p.Nc;
     const bool is_target = t >= 0 && t < p.Nt;
-    const bool ballot_screen = !carried && p.Nt * p.NK <= 64 * kNearWords && p.NK <= 64;
+    // (sub-wave groups, L < 64: the LDS form of the screen below -- its verdicts land in the target's own words whatever the lane count)
+    const bool ballot_screen = L == 64 && !carried && p.Nt * p.NK <= 64 * kNearWords && p.NK <= 64;
     double ox = 0.0, oy = 0.0, vx = 0.0, vy = 0.0, n = 0.0, desx = 0.0, desy = 0.0;
     if (is_target) {
         double ax, ay;
@@ -730,7 +772,7 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
             // order the circles are walked in (obstacles, cameras: Target.add_obstacles, environment.py:743)
             todo_carried = near_field(p, *carried, t);
         }
-    } else if (p.Nt * p.NK <= 64 * kNearWords && p.NK <= 64) {
+    } else if (ballot_screen) {
         // every shipped scenario: the screen's verdicts as ballots (one 64-bit word per round of pairs, in scalar registers), a
         // target's lane cuts its NK bits out of them -- no LDS atomics, no second hand-off
         wave_sync();
@@ -764,7 +806,7 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
     wave_sync();
     SUB_STAMP(c, 10);
     const int npairs = p.Nt * p.NK;
-    for (int base = 0; base < npairs; base += 64) {
+    for (int base = 0; base < npairs; base += L) {
         const int q = base + lane;
         if (q < npairs) {
             const int tt = (int)(((float)q + 0.5f) * p.inv_NK);
@@ -806,7 +848,7 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT> &c, const StepDraws &
         c.ex[c.tgt_slot(t)] = nx; c.ey[c.tgt_slot(t)] = ny;
         c.exf[c.tgt_slot(t)] = (float)nx; c.eyf[c.tgt_slot(t)] = (float)ny;
         if (collide_word) {
-            const unsigned long long b = __ballot(colliding);
+            const unsigned long long b = c.ballot(colliding);
             if (t == 0) *collide_word = (int32_t)(b >> p.Nc);
         } else {
         int gw = c.ti(t, TI_GW) & ~(1 << 24);
@@ -919,8 +961,8 @@ constexpr int kRoleRounds = 5;       // (five: MATE-Navigation's row-image rollo
 // 2 * lim * 1.3e-4 + 3e-7 * lim^2 near the limit; outside a band of 2e-3 * lim + 2e-5 * lim^2 (eight times that) the f32
 // comparison IS the verdict, inside it the f64 test below decides (a pair in 10^5).
 __device__ __forceinline__ float range_rim(float lim) { return lim * (lim * 2e-5f + 2e-3f); }
-template <typename ObsT>
-__device__ __forceinline__ bool range_exact(const Ctx<ObsT> &c, int tj, int j) {
+template <typename ObsT, int L>
+__device__ __forceinline__ bool range_exact(const Ctx<ObsT, L> &c, int tj, int j) {
     const double dx = c.ex[tj] - c.ex[j], dy = c.ey[tj] - c.ey[j];
     const double d2 = fma(dy, dy, dx * dx);
     const double lim = c.p.tgt_sight + c.er[j], lim2 = lim * lim;
@@ -1075,8 +1117,8 @@ __device__ __forceinline__ bool sector_out_of_range(double d2, double s2) {
     if (d2 > s2 * (1.0 + 1e-14)) return true;
     return !(d2 < s2 * (1.0 - 1e-14)) && sqrt_pos(d2) > sqrt_pos(s2);
 }
-template <bool RANGED = false, typename ObsT>
-__device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT> &c, int q, uint32_t tick, uint32_t stream, bool predrawn, int role = kNoRole) {
+template <bool RANGED = false, typename ObsT, int L>
+__device__ __forceinline__ SectorEval sector_eval(Ctx<ObsT, L> &c, int q, uint32_t tick, uint32_t stream, bool predrawn, int role = kNoRole) {
     const Params &p = c.p;
     SectorEval e;                    // rn, x, lc: meaningful under `need` only -- left undefined on the early exits (zeroing them on
     e.seen = false; e.need = false;  // every exit path was 18 vector moves per step)
@@ -1142,8 +1184,8 @@ __device__ __forceinline__ SectorEval sector_eval_held(Ctx<ObsT> &c, const Range
     return e;
 }
 
-template <typename ObsT>
-__device__ __forceinline__ void sector_fetch(const Ctx<ObsT> &c, const SectorEval &e, double2 (&w)[kDegWords]) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void sector_fetch(const Ctx<ObsT, L> &c, const SectorEval &e, double2 (&w)[kDegWords]) {
     if (e.need) {
         const double2 *rec = c.g.lut_deg + (MATE_LUT_TABLE_OF(e.lc) * kLutCells + degree_of(e.x)) * kDegWords;
 #pragma unroll
@@ -1151,8 +1193,8 @@ __device__ __forceinline__ void sector_fetch(const Ctx<ObsT> &c, const SectorEva
     }
 }
 
-template <typename ObsT>
-__device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorEval &e, double2 (&w)[kDegWords]) {
+template <typename ObsT, int L>
+__device__ __forceinline__ bool sector_resolve(const Ctx<ObsT, L> &c, const SectorEval &e, double2 (&w)[kDegWords]) {
     if (!e.need) return e.seen;
     bool overflow;
     double limit = segment_interp(w, e.x, overflow);
@@ -1219,8 +1261,8 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT> &c, const SectorE
 // `sector_ballot` (the register-resident step of the fused rollout, HeldState): the packed camera->target / camera->camera
 // word as the ballot that made it, and NO tail here -- tracked bits and warehouse membership are derived from it and from the
 // positions in registers (view_tail_held), without the two LDS hand-offs of the tail below.
-template <bool HELD, bool COMPACT = false, typename ObsT>
-__device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn, const RangeRoles &held, uint32_t &seen_out,
+template <bool HELD, bool COMPACT = false, typename ObsT, int L>
+__device__ __forceinline__ void update_view(Ctx<ObsT, L> &c, uint32_t tick, uint32_t stream, bool predrawn, const RangeRoles &held, uint32_t &seen_out,
                                             NearCarry *near_next = nullptr, unsigned long long *sector_ballot = nullptr) {
     const Params &p = c.p;
     const int lane = c.lane;
@@ -1228,7 +1270,12 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     double2 w[kDegWords];
     int n_cand = 0;
     uint8_t *cand = c.base + p.off_list;
-    const bool compact = COMPACT && p.sector_rounds >= 2 && p.n_sector <= 256;
+    static_assert(L == 64 || !HELD, "held lane roles: one wave per environment");
+    const bool compact = L == 64 && COMPACT && p.sector_rounds >= 2 && p.n_sector <= 256;
+    // rounds of L pairs (the Params' round counts are rounds of 64: they lay out the mask bits, which stay where they are) -- expressions, not
+    // locals: a local that the range_tests lambda captures cost the MATE-8v8-9 step kernel its 64-register budget (65: seven waves per SIMD)
+#define MATE_N_SR (L == 64 ? p.sector_rounds : c.rounds_of(p.n_sector))
+#define MATE_N_RR (L == 64 ? p.range_rounds : c.rounds_of(p.n_range))
     if (compact) {
         // ---- two or more rounds of sector pairs (8 cameras: 128): most are out of sight range, and only the others need the
         // long part of Camera.perceive (atan2, the transmittance draw, the occlusion lookup).  Pass 1 makes the range test
@@ -1305,8 +1352,8 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         }
     } else {
 #pragma unroll 4
-    for (int round = 0; round < p.range_rounds; ++round) {
-        const int q = round * 64 + lane;
+    for (int round = 0; round < MATE_N_RR; ++round) {
+        const int q = round * L + lane;
         const int qq = q < p.n_range ? q : 0;
         const int t = (int)(((float)qq + 0.5f) * p.inv_NJ);
         const int j = qq - t * p.NJ;
@@ -1320,13 +1367,14 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         seen_bits |= (uint32_t)((seen || diag) && q < p.n_range) << round;
     }
     }
-    for (int round = 0; round < p.range_rounds; ++round) {
-        const int q = round * 64 + lane;
+    for (int round = 0; round < MATE_N_RR; ++round) {
+        const int q = round * L + lane;
         const bool seen = (seen_bits >> round) & 1u;
         if (!c.image() && q < p.n_range) set_flag(c, p.fs_range + q, seen);
-        const unsigned long long b = __ballot(seen);
+        const unsigned long long b = c.ballot(seen);
         if (HELD && round < kRoleRounds) range_ballot[round] = b;      // (written with the sector word, below)
-        else if (lane == 0) { c.mask[rbase + 2 * round] = (uint32_t)b; c.mask[rbase + 2 * round + 1] = (uint32_t)(b >> 32); }
+        else if constexpr (L == 64) { if (lane == 0) { c.mask[rbase + 2 * round] = (uint32_t)b; c.mask[rbase + 2 * round + 1] = (uint32_t)(b >> 32); } }
+        else c.put_bits(p.bit_range + round * L, b);
     }
     seen_out |= seen_bits << 1;
     };
@@ -1366,22 +1414,23 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
     } else {
         // ---- sector tests for camera->target and camera->camera; all rounds but the last resolve at once, the last round's
         // occlusion records travel while the range tests run
-        for (int round = 0; round + 1 < p.sector_rounds; ++round) {
-            const SectorEval e = sector_eval(c, round * 64 + lane, tick, stream, predrawn);
+        for (int round = 0; round + 1 < MATE_N_SR; ++round) {
+            const SectorEval e = sector_eval(c, round * L + lane, tick, stream, predrawn);
             sector_fetch(c, e, w);
             const bool seen = sector_resolve(c, e, w);
-            if (round * 64 + lane < p.n_sector) set_flag(c, round * 64 + lane, seen);
-            const unsigned long long b = __ballot(seen);
-            if (lane == 0) { c.mask[2 * round] = (uint32_t)b; c.mask[2 * round + 1] = (uint32_t)(b >> 32); }
+            if (round * L + lane < p.n_sector) set_flag(c, round * L + lane, seen);
+            const unsigned long long b = c.ballot(seen);
+            if constexpr (L == 64) { if (lane == 0) { c.mask[2 * round] = (uint32_t)b; c.mask[2 * round + 1] = (uint32_t)(b >> 32); } }
+            else c.put_bits(round * L, b);
         }
-        const int last = p.sector_rounds - 1;
+        const int last = MATE_N_SR - 1;
         SectorEval pending;
         pending.seen = false; pending.need = false;
         if (last >= 0) {
             // (a branch-free form of this test -- every lane computing everything, verdicts combined at the end -- measured
             // no faster: the early exits cost scalar instructions, which issue beside the other waves' vector work)
             if constexpr (HELD) pending = sector_eval_held(c, held, tick, stream, predrawn);
-            else pending = sector_eval(c, last * 64 + lane, tick, stream, predrawn);
+            else pending = sector_eval(c, last * L + lane, tick, stream, predrawn);
             sector_fetch(c, pending, w);
         }
         SUB_STAMP(c, 13);
@@ -1392,10 +1441,11 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         if (last >= 0) {
             const bool seen = sector_resolve(c, pending, w);
             SUB_ACC(c, 2);                               // wait for the record + interpolation (+ overflow trips)
-            if (!c.image() && last * 64 + lane < p.n_sector) set_flag(c, last * 64 + lane, seen);
+            if (!c.image() && last * L + lane < p.n_sector) set_flag(c, last * L + lane, seen);
             seen_out |= (uint32_t)seen;
-            const unsigned long long b = __ballot(seen);
-            if (lane == 0) { c.mask[2 * last] = (uint32_t)b; c.mask[2 * last + 1] = (uint32_t)(b >> 32); }
+            const unsigned long long b = c.ballot(seen);
+            if constexpr (L == 64) { if (lane == 0) { c.mask[2 * last] = (uint32_t)b; c.mask[2 * last + 1] = (uint32_t)(b >> 32); } }
+            else c.put_bits(last * L, b);
             if (sector_ballot) *sector_ballot = b;
         }
         write_range_ballots();
@@ -1410,7 +1460,7 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         }
         if (lane == 0) { c.mask[p.bit_always >> 5] = 1u; if (!c.image()) set_flag(c, p.fs_always, true); }
         if (!c.image())
-        for (int q = lane; q < p.Nc * p.No; q += 64) {
+        for (int q = lane; q < p.Nc * p.No; q += L) {
             const int cam = (int)(((float)q + 0.5f) * p.inv_No);
             const int o = q - cam * p.No;
             set_flag(c, p.fs_camobs + cam * p.No + o, (c.camobs(cam) >> o) & 1ull);
@@ -1433,23 +1483,25 @@ __device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_
         c.inside(lane) = sup <= kWarehouseRadius ? (px ? (py ? 0 : 3) : (py ? 1 : 2)) : -1;
     }
     wave_sync();
+#undef MATE_N_SR
+#undef MATE_N_RR
 }
 
-template <bool HELD, bool COMPACT = false, typename ObsT>
-__device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn, const RangeRoles &held) {
+template <bool HELD, bool COMPACT = false, typename ObsT, int L>
+__device__ __forceinline__ void update_view(Ctx<ObsT, L> &c, uint32_t tick, uint32_t stream, bool predrawn, const RangeRoles &held) {
     uint32_t seen;
     update_view<HELD, COMPACT>(c, tick, stream, predrawn, held, seen);
 }
-template <typename ObsT>
-__device__ __forceinline__ void update_view(Ctx<ObsT> &c, uint32_t tick, uint32_t stream, bool predrawn) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void update_view(Ctx<ObsT, L> &c, uint32_t tick, uint32_t stream, bool predrawn) {
     RangeRoles none;
     update_view<false>(c, tick, stream, predrawn, none);
 }
 
 // The order-dependent part of _assign_goals (environment.py:1278-1318: the warehouses' remaining cargo is shared), on ONE lane,
 // for the targets standing in a warehouse (c.inside); dense and delayed rewards of the deliveries are added to `reward` / `delayed`.
-template <typename ObsT>
-__device__ __forceinline__ void goal_logistics(Ctx<ObsT> &c, uint32_t tick, double &reward, double &delayed, uint32_t inside_mask) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void goal_logistics(Ctx<ObsT, L> &c, uint32_t tick, double &reward, double &delayed, uint32_t inside_mask) {
     const Params &p = c.p;
     // `inside_mask`: bit t = target t stands in a warehouse (the callers' ballot, wave-uniform): the loop visits those targets only, in
     // ascending order as the reference's does -- one LDS round trip per target in a warehouse (usually one) instead of one per target
@@ -1525,8 +1577,8 @@ __device__ __forceinline__ void view_tail_regs(Ctx<ObsT> &c, unsigned long long 
 // Phase C: _assign_goals + the bookkeeping of step() (environment.py:1271-1324, 613-632).
 // `tracked_reg` / `inside_reg` (the single-step kernel, shapes with one sector round): the lane's tracked bit and warehouse straight
 // from the sector ballot and the position (view_tail_regs) instead of through update_view's tail and its two LDS hand-offs.
-template <typename ObsT>
-__device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, float *scalars_out, const int *tracked_reg = nullptr, const int *inside_reg = nullptr) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void assign_and_score(Ctx<ObsT, L> &c, uint32_t tick, float *scalars_out, const int *tracked_reg = nullptr, const int *inside_reg = nullptr) {
     const Params &p = c.p;
     const int lane = c.lane;
     bool penal = false;
@@ -1540,8 +1592,8 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
         const int nb = b - tr;
         c.ti(lane, TI_BOUNTY) = nb > 0 ? nb : 0;               // environment.py:1276
     }
-    const int n_penal = __popcll(__ballot(penal));
-    const uint32_t inside_mask = (uint32_t)__ballot(lane < p.Nt && inside_lane >= 0);      // (target t on lane t; at most 16 targets)
+    const int n_penal = __popcll(c.ballot(penal));
+    const uint32_t inside_mask = (uint32_t)c.ballot(lane < p.Nt && inside_lane >= 0);      // (target t on lane t; at most 16 targets)
     const bool any_inside = inside_mask != 0u;
     wave_sync();
     double reward = -(double)n_penal, delayed = 0.0;
@@ -1563,9 +1615,9 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
         c.ti(lane, TI_TSTEPS) += 1;
         c.ti(lane, TI_TRSTEPS) += (int)tr;
     }
-    const int n_tracked = __popcll(__ballot(tr));
-    const int n_bounty = __popcll(__ballot(with_bounty));
-    const int n_both = __popcll(__ballot(tr && with_bounty));
+    const int n_tracked = __popcll(c.ballot(tr));
+    const int n_bounty = __popcll(c.ballot(with_bounty));
+    const int n_both = __popcll(c.ballot(tr && with_bounty));
     if (lane == 0) {
         const double epr = c.ep_reward() + reward;
         const double epd = c.ep_delayed() + delayed;
@@ -1602,14 +1654,14 @@ __device__ __forceinline__ void assign_and_score(Ctx<ObsT> &c, uint32_t tick, fl
 }
 
 // metrics only (after reset / observe): no counters advance
-template <typename ObsT>
-__device__ __forceinline__ void score_only(Ctx<ObsT> &c, float *scalars_out) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void score_only(Ctx<ObsT, L> &c, float *scalars_out) {
     const Params &p = c.p;
     bool with_bounty = false, tr = false;
     if (c.lane < p.Nt) { with_bounty = c.ti(c.lane, TI_BOUNTY) > 0; tr = c.tracked(c.lane) != 0; }
-    const int n_tracked = __popcll(__ballot(tr));
-    const int n_bounty = __popcll(__ballot(with_bounty));
-    const int n_both = __popcll(__ballot(tr && with_bounty));
+    const int n_tracked = __popcll(c.ballot(tr));
+    const int n_bounty = __popcll(c.ballot(with_bounty));
+    const int n_both = __popcll(c.ballot(tr && with_bounty));
     if (c.lane == 0 && scalars_out) {
         float *o = scalars_out + c.out * 8;
         const int delivered = c.ei(EI_DELIVERED);
@@ -1625,8 +1677,8 @@ __device__ __forceinline__ void score_only(Ctx<ObsT> &c, float *scalars_out) {
 // `last_gw`: the packed goal word (goal, cargo weight, known-empty warehouses) this lane's target had when its slots were
 // last written -- the fused rollout carries it from step to step and rewrites the ten slots it determines only when
 // it changes (a pick-up, a delivery, a newly seen empty warehouse); -1 = write.
-template <typename ObsT>
-__device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c, int &last_gw) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void fill_scratch(Ctx<ObsT, L> &c, int &last_gw) {
     const Params &p = c.p;
     const int lane = c.lane;
     const int tgt_mode = (c.obs_mode() >> 2) & 3;
@@ -1660,7 +1712,7 @@ __device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c, int &last_gw) {
       }
     }
     if (!c.statics_done)
-        for (int o = lane; o < p.No; o += 64) {   // Obstacle.state, entities.py:147-148
+        for (int o = lane; o < p.No; o += L) {   // Obstacle.state, entities.py:147-148
             ObsT *sc = c.scratch + p.sc_obs + o * 3;
             sc[0] = (ObsT)c.obs_x(o); sc[1] = (ObsT)c.obs_y(o); sc[2] = (ObsT)c.obs_r(o);
         }
@@ -1668,14 +1720,14 @@ __device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c, int &last_gw) {
     // (shared_field_of_view.py:97-100, 117-120); flags live behind the mask flags, see build_descriptors
     if ((c.obs_mode() & 3) == 2) {
         if (lane < p.Nt) set_flag(c, p.fs_shared + lane, c.tracked(lane) != 0);
-        for (int o = lane; o < p.No; o += 64) {
+        for (int o = lane; o < p.No; o += L) {
             bool any = false;
             for (int cam = 0; cam < p.Nc; ++cam) any = any || ((c.camobs(cam) >> o) & 1ull);
             set_flag(c, p.fs_shared + p.Nt + o, any);
         }
     }
     if (tgt_mode == 2) {
-        for (int j = lane; j < p.Nc + p.No; j += 64) {
+        for (int j = lane; j < p.Nc + p.No; j += L) {
             bool any = false;
             for (int t = 0; t < p.Nt; ++t) any = any || c.mask_bit(p.bit_range + t * p.NJ + j);
             set_flag(c, p.fs_shared + p.Nt + p.No + j, any);
@@ -1684,8 +1736,8 @@ __device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c, int &last_gw) {
     wave_sync();
 }
 
-template <typename ObsT>
-__device__ __forceinline__ void fill_scratch(Ctx<ObsT> &c) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void fill_scratch(Ctx<ObsT, L> &c) {
     int always = -1;
     fill_scratch(c, always);
 }
@@ -1701,8 +1753,8 @@ template <> struct Vec<double> { using type = double2; static constexpr int W = 
 
 // descriptor = byte offset of the source slot | byte offset of the visibility word << 16 (both inside the
 // wave's LDS slice); the word is all-ones or zero, so a bitwise AND is the masked copy (exact +0.0 when hidden)
-template <typename ObsT>
-__device__ __forceinline__ ObsT gather_one(const Ctx<ObsT> &c, uint32_t d) {
+template <typename ObsT, int L>
+__device__ __forceinline__ ObsT gather_one(const Ctx<ObsT, L> &c, uint32_t d) {
     using U = typename Bits<ObsT>::type;
     const U v = *reinterpret_cast<const U *>(c.base + (d & 0xffffu));
     const U m = *reinterpret_cast<const U *>(c.base + (d >> 16));
@@ -1712,14 +1764,14 @@ __device__ __forceinline__ ObsT gather_one(const Ctx<ObsT> &c, uint32_t d) {
     return out;
 }
 
-template <typename ObsT>
-__device__ __forceinline__ void pack_block(const Ctx<ObsT> &c, ObsT *dst, const uint32_t *table, int elems) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void pack_block(const Ctx<ObsT, L> &c, ObsT *dst, const uint32_t *table, int elems) {
     constexpr int W = Vec<ObsT>::W;
     using V = typename Vec<ObsT>::type;
     if ((elems % W) == 0) {                       // row block is 16-byte aligned for every environment
         V *out = reinterpret_cast<V *>(dst);
         const int nvec = elems / W;
-        for (int i = c.lane; i < nvec; i += 64) {
+        for (int i = c.lane; i < nvec; i += L) {
             if constexpr (W == 4) {
                 const uint4 d = reinterpret_cast<const uint4 *>(table)[i];
                 float4 v;
@@ -1741,29 +1793,29 @@ __device__ __forceinline__ void pack_block(const Ctx<ObsT> &c, ObsT *dst, const 
         f32x2 *out = reinterpret_cast<f32x2 *>(dst);
         const uint2 *tab = reinterpret_cast<const uint2 *>(table);
         const int nvec = elems / 2;
-        for (int base = c.lane; base < nvec; base += 256) {
+        for (int base = c.lane; base < nvec; base += 4 * L) {
             uint2 d[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int i = base + 64 * k; d[k] = tab[i < nvec ? i : 0]; }
+            for (int k = 0; k < 4; ++k) { const int i = base + L * k; d[k] = tab[i < nvec ? i : 0]; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(d[k].x), "+v"(d[k].y));   // descriptors before the first store
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int i = base + 64 * k;
+                const int i = base + L * k;
                 if (i < nvec) { const f32x2 v = {(float)gather_one(c, d[k].x), (float)gather_one(c, d[k].y)}; stream_store(v, &out[i]); }
             }
         }
     } else {
-        for (int i = c.lane; i < elems; i += 64) dst[i] = gather_one(c, table[i]);
+        for (int i = c.lane; i < elems; i += L) dst[i] = gather_one(c, table[i]);
     }
 }
 
 // Fused observation post-processing (RelativeCoordinates = agents/utils.py:40-94, RescaledObservation =
 // agents/utils.py:97-137 of the reference): out = ((value - own coordinate) if visible else 0) * scale + bias.
-template <typename ObsT>
-__device__ __forceinline__ void pack_block_xf(const Ctx<ObsT> &c, ObsT *dst, const uint2 *xdesc, const ObsT *xab, int elems) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void pack_block_xf(const Ctx<ObsT, L> &c, ObsT *dst, const uint2 *xdesc, const ObsT *xab, int elems) {
     using U = typename Bits<ObsT>::type;
-    for (int i = c.lane; i < elems; i += 64) {
+    for (int i = c.lane; i < elems; i += L) {
         const uint2 d = xdesc[i];
         const ObsT v = *reinterpret_cast<const ObsT *>(c.base + (d.x & 0xffffu));
         const ObsT o = *reinterpret_cast<const ObsT *>(c.base + d.y);
@@ -1790,17 +1842,17 @@ template <int GC_, int GT_> struct PackDescriptorsT { static constexpr int GC = 
 using PackDescriptors = PackDescriptorsT<kPackGC, kPackGT>;
 constexpr int pack_chunks_per_lane(int elems) { return (elems / 4 + 63) / 64; }
 
-template <typename ObsT, typename D>
-__device__ __forceinline__ void load_pack_descriptors(const Ctx<ObsT> &c, D &d) {
+template <typename ObsT, int L, typename D>
+__device__ __forceinline__ void load_pack_descriptors(const Ctx<ObsT, L> &c, D &d) {
     constexpr int kPackGC = D::GC, kPackGT = D::GT;
     const Params &p = c.p;
     const int nvc = p.cam_elems / 4, nvt = p.tgt_elems / 4;
     const uint4 *tabc = reinterpret_cast<const uint4 *>(c.table);
     const uint4 *tabt = reinterpret_cast<const uint4 *>(c.table + p.tgt_table_off);
 #pragma unroll
-    for (int k = 0; k < kPackGC; ++k) { const int s = c.lane + 64 * k; d.dc[k] = tabc[s < nvc ? s : 0]; }
+    for (int k = 0; k < kPackGC; ++k) { const int s = c.lane + L * k; d.dc[k] = tabc[s < nvc ? s : 0]; }
 #pragma unroll
-    for (int k = 0; k < kPackGT; ++k) { const int s = c.lane + 64 * k; d.dt[k] = tabt[s < nvt ? s : 0]; }
+    for (int k = 0; k < kPackGT; ++k) { const int s = c.lane + L * k; d.dt[k] = tabt[s < nvt ? s : 0]; }
 #pragma unroll
     for (int k = 0; k < kPackGC; ++k) asm volatile("" : "+v"(d.dc[k].x), "+v"(d.dc[k].y), "+v"(d.dc[k].z), "+v"(d.dc[k].w));
 #pragma unroll
@@ -1808,8 +1860,8 @@ __device__ __forceinline__ void load_pack_descriptors(const Ctx<ObsT> &c, D &d) 
 }
 
 // `PART`: 3 both teams' rows (default), 1 the camera rows only, 2 the target rows only
-template <int PART = 3, typename ObsT, typename D>
-__device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT> &c, const D &d) {
+template <int PART = 3, typename ObsT, int L, typename D>
+__device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT, L> &c, const D &d) {
     if constexpr (sizeof(ObsT) == 4) {
         const Params &p = c.p;
         typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1822,44 +1874,44 @@ __device__ __forceinline__ void pack_rows_f32(const Ctx<ObsT> &c, const D &d) {
         auto chunk = [&](const uint4 &d) { return f32x4{gather_one(c, d.x), gather_one(c, d.y), gather_one(c, d.z), gather_one(c, d.w)}; };
         if constexpr ((PART & 1) != 0) {
 #pragma unroll
-        for (int k = 0; k < GC; ++k) { const int s = c.lane + 64 * k; if (s < nvc) stream_store(chunk(d.dc[k]), &cam[s]); }
-        for (int s = c.lane + 64 * GC; s < nvc; s += 64) stream_store(chunk(tabc[s]), &cam[s]);   // larger scenarios
+        for (int k = 0; k < GC; ++k) { const int s = c.lane + L * k; if (s < nvc) stream_store(chunk(d.dc[k]), &cam[s]); }
+        for (int s = c.lane + L * GC; s < nvc; s += L) stream_store(chunk(tabc[s]), &cam[s]);   // larger scenarios
         }
         if constexpr ((PART & 2) != 0) {
 #pragma unroll
-        for (int k = 0; k < GT; ++k) { const int s = c.lane + 64 * k; if (s < nvt) stream_store(chunk(d.dt[k]), &tgt[s]); }
-        for (int s = c.lane + 64 * GT; s < nvt; s += 64) stream_store(chunk(tabt[s]), &tgt[s]);
+        for (int k = 0; k < GT; ++k) { const int s = c.lane + L * k; if (s < nvt) stream_store(chunk(d.dt[k]), &tgt[s]); }
+        for (int s = c.lane + L * GT; s < nvt; s += L) stream_store(chunk(tabt[s]), &tgt[s]);
         }
     }
 }
 
-template <typename ObsT>
-__device__ __forceinline__ bool packs_rows_f32(const Ctx<ObsT> &c) {
+template <typename ObsT, int L>
+__device__ __forceinline__ bool packs_rows_f32(const Ctx<ObsT, L> &c) {
     const Params &p = c.p;
     return !c.xdesc() && sizeof(ObsT) == 4 && (p.cam_elems % 4) == 0 && (p.tgt_elems % 4) == 0 && c.has_tgt_obs() && (c.has_cam_obs() || p.cam_elems == 0);
 }
 
-template <typename ObsT>
-__device__ __forceinline__ void store_masks(const Ctx<ObsT> &c) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void store_masks(const Ctx<ObsT, L> &c) {
     const Params &p = c.p;
     // (one round when the words fit a wave -- every shipped scenario: the general loop's trip-count arithmetic is a dozen
     // vector instructions per step)
     if (c.g.masks) {
         uint32_t *m = c.g.masks + c.out * p.MW;
-        if (p.MW <= 64) { if (c.lane < p.MW) m[c.lane] = c.mask[c.lane]; }
-        else for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
+        if (p.MW <= L) { if (c.lane < p.MW) m[c.lane] = c.mask[c.lane]; }
+        else for (int i = c.lane; i < p.MW; i += L) m[i] = c.mask[i];
     }
     if (c.g.own_masks) {
         uint32_t *m = c.g.own_masks + c.env * p.MW;
-        if (p.MW <= 64) { if (c.lane < p.MW) m[c.lane] = c.mask[c.lane]; }
-        else for (int i = c.lane; i < p.MW; i += 64) m[i] = c.mask[i];
+        if (p.MW <= L) { if (c.lane < p.MW) m[c.lane] = c.mask[c.lane]; }
+        else for (int i = c.lane; i < p.MW; i += L) m[i] = c.mask[i];
     }
 }
 
 // HELD: the caller loaded this lane's descriptors before (the rollout kernel, once per launch); otherwise they are
 // loaded here.  A template switch, not a pointer: a nullable pointer to the register array would force it into memory.
-template <bool HELD, typename ObsT, typename D>
-__device__ __forceinline__ void pack_observations(Ctx<ObsT> &c, D &held) {
+template <bool HELD, typename ObsT, int L, typename D>
+__device__ __forceinline__ void pack_observations(Ctx<ObsT, L> &c, D &held) {
     const Params &p = c.p;
     if (c.xdesc()) {
         const ObsT *xab = reinterpret_cast<const ObsT *>(c.g.xab);
@@ -2752,8 +2804,8 @@ void step_split_kernel(const Params *__restrict__ pp, const Ptrs g) {
 // An environment whose episode had ended BEFORE a fused rollout began (a step or rollout with auto_reset = 0, or an
 // imported done flag) is skipped by every step of the launch, so the step that would have listed it for the reset
 // launch never runs: list it here, or it would idle forever.
-template <typename ObsT>
-__device__ __forceinline__ void list_finished_at_entry(Ctx<ObsT> &c) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void list_finished_at_entry(Ctx<ObsT, L> &c) {
     if (c.lane == 0 && c.g.done_count && c.ei(EI_DONE) == 1) {     // (3: a batched-reset step listed it already)
         const int parity = c.list_parity();
         const int slot = atomicAdd(c.g.done_count + parity, 1);
@@ -2769,16 +2821,22 @@ __device__ __forceinline__ void list_finished_at_entry(Ctx<ObsT> &c) {
 // wave time per step instead of the slowest wave's, and there is no kernel boundary between steps.
 // An environment whose episode ends stops stepping (rows of the remaining steps carry done = 2 in the
 // scalar record) and is reset by the host-launched reset kernel after the rollout.
-template <typename ObsT, typename Shape, int FLOW = FLOW_ANY>
+// `E` environments per wave (Ctx: L = 64 / E lanes each; policy_kernels.hpp, rollout_greedy_kernel says what that means): E > 1 runs
+// the phase functions written for any L -- the descriptor packer, no held roles, no row image, no register-resident state.
+template <typename ObsT, typename Shape, int FLOW = FLOW_ANY, int E = 1>
 __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restrict__ pp, const Ptrs g) {
+    constexpr int L = 64 / E;
+    static_assert(E == 1 || E == 2 || E == 4, "environments per wave");
     const Shape shape(pp, true);
     const Params &p = shape.get();
     extern __shared__ __align__(16) unsigned char smem[];
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;
     // wave-uniform by construction; readfirstlane lets the compiler keep everything derived from it in SGPRs
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int64_t env = (int64_t)blockIdx.x * 4 + wave;
-    if (env >= g.N) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int hw_lane = threadIdx.x & 63, lane = hw_lane & (L - 1), shift = hw_lane & ~(L - 1);      // lane inside the environment's group; the group's first lane
+    const int slot = E == 1 ? wave : wave * E + (hw_lane >> (E == 4 ? 4 : 5));                       // the environment's slice of the workgroup's LDS
+    const int64_t env = (int64_t)blockIdx.x * (4 * E) + slot;
+    if (env >= g.N) return;               // (E > 1: the groups past the end of the batch leave; the others go on under their EXEC mask)
     const Ptrs &gk = kernarg_ptrs(g);     // launch arguments read where they are used (see step_kernel)
 #ifdef MATE_PHASE_CLOCKS      // the launch's prologue, in s_memtime ticks since the wave began: slots 8..11 (tools/rollout_prologue.py), 12 the epilogue
     const long long t_wave = (long long)__builtin_amdgcn_s_memtime();
@@ -2787,7 +2845,8 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
 #define PROLOGUE_STAMP(i) do { } while (0)
 #endif
     {
-        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env);
+        Ctx<ObsT, L> c(p, gk, smem + slot * p.lds_wave_bytes, lane, env);
+        c.shift = shift;
         load_records(c);
         wave_sync();
         build_entities(c);
@@ -2798,16 +2857,21 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     // The observation descriptors of this lane are the same for every step: loaded once and held in 32 VGPRs (the
     // headline batch runs 4 waves per SIMD, the register file has room), which takes the table's two global-load
     // round trips out of every step's pack phase.
-    constexpr bool IMAGE = Shape::kImage;   // row-image mode: the observation rows live in LDS (see image_statics)
+    constexpr bool IMAGE = E == 1 && Shape::kImage;   // row-image mode: the observation rows live in LDS (see image_statics)
+    constexpr bool HOLD_ROLES = E == 1 && Shape::kHoldRoles;
+    static_assert(E == 1 || !Shape::kImage, "the row image is a whole-wave mode");
     static_assert(kNearWords == kRoleRounds, "one ballot per range round");
     static_assert(!IMAGE || (Shape::kHoldRoles && sizeof(ObsT) == 4 && FLOW != FLOW_ANY), "row-image mode: f32 rows, held lane roles, a folded flow");
-    PackDescriptorsT<Shape::kHeldGC, Shape::kHeldGT> held;
+    // the row chunks a lane holds descriptors of (E > 1: a group of L lanes takes L chunks per round -- all of them where that is at most twelve per lane)
+    constexpr int kSubC = (Shape::kChunksC + L - 1) / L, kSubT = (Shape::kChunksT + L - 1) / L;
+    constexpr int kGC = E == 1 ? Shape::kHeldGC : (kSubC + kSubT <= 12 ? kSubC : 2), kGT = E == 1 ? Shape::kHeldGT : (kSubC + kSubT <= 12 ? kSubT : 6);
+    PackDescriptorsT<kGC, kGT> held;
     if constexpr (!IMAGE) {
-        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
+        Ctx<ObsT, L> c(p, gk, smem + slot * p.lds_wave_bytes, lane, env, FLOW);
         load_pack_descriptors(c, held);      // (indices clamped: harmless when another pack path runs)
     }
     RangeRoles roles;                        // the lane's range-test pairs and limits, static inside an episode
-    if constexpr (Shape::kHoldRoles) {
+    if constexpr (HOLD_ROLES) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
         range_roles(c, roles);
         pin_roles(roles);
@@ -2816,7 +2880,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     }
     PROLOGUE_STAMP(10);
     NearCarry near{};                       // the collision screen of the step to come, made by the range tests of the step before
-    if constexpr (Shape::kHoldRoles) {
+    if constexpr (HOLD_ROLES) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
         near_seed(c, roles, near);
     }
@@ -2843,7 +2907,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     DrawCarry carry{0u, 0u, 0xffffffffu};
     DrawRole draws_of_lane;
     {
-        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW);
+        Ctx<ObsT, L> c(p, gk, smem + slot * p.lds_wave_bytes, lane, env, FLOW);
         draws_of_lane = draw_role(c);
     }
     // The register-resident step (HeldState): the row-image shapes under the random-policy flow
@@ -2868,18 +2932,20 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     for (int r = 0; r < n_steps; ++r) {
         // an opaque copy of the lane id per iteration keeps the compiler from hoisting every lane-role
         // computation of the body out of the loop (which costs >100 VGPRs of spills)
-        int lane_r = lane, wave_r = wave;
+        int lane_r = lane, wave_r = wave, slot_r = slot;
         asm volatile("" : "+v"(lane_r));
         asm volatile("" : "+s"(wave_r));
+        if constexpr (E == 1) slot_r = wave_r; else asm volatile("" : "+v"(slot_r));
         const Params *pr = pp;
         asm volatile("" : "+s"(pr));
         const Shape shape_r(pr, true);
         const Params &p = shape_r.get();
-        const int64_t env_r = (int64_t)blockIdx.x * 4 + wave_r;
+        const int64_t env_r = (int64_t)blockIdx.x * (4 * E) + slot_r;
         // (... and the held roles: predicates derived from them would otherwise be hoisted out of the loop as SGPR masks, which
         // the kernel has no scalar registers left for -- each came back as two v_readlane per step)
-        if constexpr (Shape::kHoldRoles) pin_roles(roles, p.range_rounds, IMAGE, p.sector_rounds == 1);
-        Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW);
+        if constexpr (HOLD_ROLES) pin_roles(roles, p.range_rounds, IMAGE, p.sector_rounds == 1);
+        Ctx<ObsT, L> c(p, gk, smem + slot_r * p.lds_wave_bytes, lane_r, env_r, FLOW);
+        c.shift = shift;
         c.out = (int64_t)r * g.N + env_r;
         c.statics_done = stepped;
         c.pivots = Shape::kGreedyHeld;      // (the compiled shapes; the generic kernel has no registers to spare)
@@ -2945,11 +3011,11 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         MATE_PHASE(2, simulate_cameras(c, draws, true));
         MATE_PHASE_AGAIN(2, wave_sync(); simulate_cameras(c, StepDraws{0.0, 0.0}, true));      // (a zero action: the same instructions, the same state)
         ROLL_STAMP(1);
-        MATE_PHASE(4, simulate_targets(c, draws, Shape::kHoldRoles ? &near : nullptr));
+        MATE_PHASE(4, simulate_targets(c, draws, HOLD_ROLES ? &near : nullptr));
         ROLL_STAMP(2);
         uint32_t seen = 0u;
-        MATE_PHASE(8, update_view<Shape::kHoldRoles, true>(c, tick, S_TRANSMIT, true, roles, seen, Shape::kHoldRoles ? &near : nullptr));
-        MATE_PHASE_AGAIN(8, uint32_t again; update_view<Shape::kHoldRoles, true>(c, tick, S_TRANSMIT, true, roles, again, Shape::kHoldRoles ? &near : nullptr); seen |= again);
+        MATE_PHASE(8, update_view<HOLD_ROLES, true>(c, tick, S_TRANSMIT, true, roles, seen, HOLD_ROLES ? &near : nullptr));
+        MATE_PHASE_AGAIN(8, uint32_t again; update_view<HOLD_ROLES, true>(c, tick, S_TRANSMIT, true, roles, again, HOLD_ROLES ? &near : nullptr); seen |= again);
         ROLL_STAMP(3);
         MATE_PHASE(16, assign_and_score(c, tick, g.scalars));
         ROLL_STAMP(4);
@@ -2988,7 +3054,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
 #endif
 #endif
     {
-        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env);
+        Ctx<ObsT, L> c(p, gk, smem + slot * p.lds_wave_bytes, lane, env);
         if constexpr (HELDSTATE) held_store(c, h);
         store_dynamic(c);
     }

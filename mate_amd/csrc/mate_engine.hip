@@ -74,8 +74,9 @@ static int fail(int code, const char *fmt, ...) {
 // workgroups fit a CU -- 3072 of the 4096 environments of a MATE-4v8-9 batch resident -- and a second pass costs more than
 // the packer's instructions.)
 static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no_image, StepFn *step, StepFn *rollout, PolicyFn *policy, PolicyFn *rollout_greedy,
-                         int *specialised, int *image, StepFn *split, PolicyFn *step_greedy) {
+                         int *specialised, int *image, StepFn *split, PolicyFn *step_greedy, KernelSet *sub) {
     *specialised = 0; *image = 0;
+    sub->rollout_sub[0] = sub->rollout_sub[1] = nullptr; sub->rollout_greedy_sub = nullptr; sub->sub_wave = 1;
     *step_greedy = f64 ? nullptr : (PolicyFn)step_greedy_kernel<float, AnyShape>;
     for (int i = 0; i < 3; ++i) split[i] = nullptr;      // the two-wave step (step_split_kernel): f32 observations, the folded flows
     if (!generic) {
@@ -87,6 +88,7 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no
             rollout[0] = k.rollout[0]; rollout[1] = k.rollout[1];
             *policy = k.policy; *rollout_greedy = k.rollout_greedy; *step_greedy = k.step_greedy;
             *specialised = 1; *image = k.image;
+            sub->rollout_sub[0] = k.rollout_sub[0]; sub->rollout_sub[1] = k.rollout_sub[1]; sub->rollout_greedy_sub = k.rollout_greedy_sub; sub->sub_wave = k.sub_wave;
             return;
         }
     }
@@ -112,6 +114,7 @@ struct Switches {
     bool policy_split = false;     // MATE_POLICY_SPLIT=1: step_greedy / step_versus_greedy as two launches (agents' kernel, step kernel) even when the fused one-launch form applies
     int step_split = -1;           // MATE_STEP_SPLIT=0 / 1: the one-wave / two-wave form of the per-step kernel in the folded flows (-1: by batch size)
     bool zoom_iterate = false;     // MATE_ZOOM_ITERATE=1: the greedy camera agents iterate the zoom solve (greedy.py:139-145) instead of reading its table
+    bool no_sub_wave = false;      // MATE_SUBWAVE=0: one environment per wave in the fused rollouts of the small scenarios too (mate_engine_set_sub_wave switches at run time)
     bool step_greedy_rollout = false;   // MATE_STEP_GREEDY_ROLLOUT=1: the one-launch form of step_greedy / step_versus_greedy on rollout_greedy_kernel with one step (round 3) instead of step_greedy_kernel
 };
 static Switches read_switches() {
@@ -127,6 +130,7 @@ static Switches read_switches() {
     w.policy_split = flag("MATE_POLICY_SPLIT");
     w.step_greedy_rollout = flag("MATE_STEP_GREEDY_ROLLOUT");
     w.no_image = flag("MATE_NO_IMAGE");
+    if (const char *v = getenv("MATE_SUBWAVE")) w.no_sub_wave = atoi(v) == 0;
     if (const char *v = getenv("MATE_STEP_SPLIT")) w.step_split = atoi(v) != 0;
     return w;
 }
@@ -163,6 +167,10 @@ struct mate_engine {
     int image = 0;                         // the fused rollouts (random-policy flow, greedy) run their row-image compilation ...
     size_t image_wave_bytes = 0;           // ... whose per-environment LDS slice is this
     PolicyFn policy_fn = nullptr, rollout_greedy_fn = nullptr;
+    // E environments per wave (engine_kernels.hpp, Ctx): the fused rollouts of the small scenarios; sub_wave = the E in use (1: one wave per environment)
+    KernelSet sub{};
+    int sub_mode = 2;              // 0: one environment per wave; 1: the shape's E wherever it is compiled; 2 (default): where it measured faster (sub_wave_of_launch)
+    int64_t cus = 256;             // compute units of the device
     PolicyFn step_greedy_fn = nullptr;     // step_greedy_kernel: the per-step flows with the on-device agents as ONE launch (f32 observations), or null
     StepFn split_fn[3] = {nullptr, nullptr, nullptr};      // step_split_kernel per flow (two waves per environment), or null
     int split_on = 0;                                      // ... and whether launch_step uses it (MATE_STEP_SPLIT, or the batch is one resident generation)
@@ -378,7 +386,8 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.first_env = (uint32_t)first_env_index;
     e->step_lds = 4 * (size_t)p.lds_wave_bytes;
     e->sw = read_switches();
-    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->sw.generic, e->sw.no_image, e->step_fn, e->rollout_fn, &e->policy_fn, &e->rollout_greedy_fn, &e->specialised, &e->image, e->split_fn, &e->step_greedy_fn);
+    pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->sw.generic, e->sw.no_image, e->step_fn, e->rollout_fn, &e->policy_fn, &e->rollout_greedy_fn, &e->specialised, &e->image, e->split_fn, &e->step_greedy_fn, &e->sub);
+    e->sub_mode = e->sw.no_sub_wave ? 0 : 2;
     { Params pi = p; fill_shape(pi, Nc, Nt, No, false, true); e->image_wave_bytes = e->image ? (size_t)pi.lds_wave_bytes : (size_t)p.lds_wave_bytes; }
     e->flow_generic = e->sw.flow_generic;
     if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }
@@ -402,6 +411,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         // environments run 15-30 % faster without)
         hipDeviceProp_t prop;
         const int64_t cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+        e->cus = cus;
         // (round 4: with the rows leaving early the priorities cost 3 % at the headline batch on the boxes measured -- off unless asked for)
         const int digits = e->sw.stagger >= 0 ? e->sw.stagger : 0;
 
@@ -470,6 +480,8 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         for (int f = 0; f < 2 && err == hipSuccess; ++f)
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rollout_fn[f]), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(f == 1 && e->image ? 4 * e->image_wave_bytes : e->step_lds));
+        for (int f = 0; f < 2 && err == hipSuccess && e->sub.rollout_sub[f]; ++f)
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->sub.rollout_sub[f]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(e->sub.sub_wave * e->step_lds));
         if (err != hipSuccess) {
         } else if (p.obs_f64) {
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(&reset_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->reset_lds);
@@ -907,6 +919,20 @@ extern "C" int mate_engine_step(mate_engine *e, const mate_step_io *io, int32_t 
 extern "C" int mate_engine_step_random(mate_engine *e, const mate_step_io *io, int32_t auto_reset, void *stream) {
     return launch_step(e, io, MODE_STEP_RANDOM, auto_reset, (hipStream_t)stream);
 }
+// Environments per wave of a fused launch (engine_kernels.hpp, Ctx<ObsT, L>): the shape's E = 4 where the sub-wave kernels exist and
+//   mode 1: always;
+//   mode 2: where they measured faster (profiles/r06_subwave_probe.txt) -- batches of at least 32 environments per CU (8192 on an MI355X:
+//           below that a launch has one wave per SIMD or less and is latency-bound whatever the lane use: x0.6 .. 1.1 at 4096), and,
+//           under the random policy, every shape but MATE-4v4-*, whose one-per-wave rollout (the register-resident row image) is as fast.
+//           Greedy flows x1.2 .. 3.3, random-policy flows x1.1 .. 2.9 there.
+static int sub_wave_of_launch(const mate_engine *e, bool greedy) {
+    if (e->sub_mode == 0 || e->sub.sub_wave <= 1 || !(greedy ? (const void *)e->sub.rollout_greedy_sub : (const void *)e->sub.rollout_sub[0])) return 1;
+    if (e->sub_mode == 1) return e->sub.sub_wave;
+    if (e->N < 32 * e->cus) return 1;
+    if (!greedy && e->p.Nc * e->p.Nt >= 16) return 1;      // MATE-4v4-*: the row-image kernel is as fast or faster (x0.72 .. 1.14)
+    return e->sub.sub_wave;
+}
+
 extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream_) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     { const int rc_ = leave_pipelined(e, (hipStream_t)stream_); if (rc_ != MATE_OK) return rc_; }
@@ -923,7 +949,8 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
     g.tape_ct = nullptr; g.tape_goal = nullptr;
     g.rotate_prio = e->sw.rollout_rotate;
     if (auto_reset != 1) g.done_count = nullptr;     // no list: nothing restarts (0), or a batched reset finds the finished ones by their flag (k > 1)
-    const unsigned blocks = (unsigned)((e->N + 3) / 4);
+    const int E = sub_wave_of_launch(e, false);      // environments per wave (1, or the small scenarios' 4)
+    const unsigned blocks = (unsigned)((e->N + 4 * E - 1) / (4 * E));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e->timing > 0 && (e->timing_tick++ % e->timing) == 0) {
         if (e->events_used == e->events.size()) {
@@ -936,6 +963,8 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
     const int flow = (!e->flow_generic && !g.act_discrete && g.obs_mode == 0 && !g.xdesc && !g.xab && g.scratch_init &&
                       (g.cam_obs || e->p.Nc == 0) && g.tgt_obs && g.scalars) ? FLOW_RANDOM : FLOW_ANY;
     e->last_flow = flow;
+    if (E > 1) hipExtLaunchKernelGGL(e->sub.rollout_sub[flow], dim3(blocks), dim3(256), E * e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
+    else
     hipExtLaunchKernelGGL(e->rollout_fn[flow], dim3(blocks), dim3(256), (flow == FLOW_RANDOM && e->image) ? 4 * e->image_wave_bytes : e->step_lds, stream, ev0, ev1, 0,
                           (const Params *)e->d_params, (const Ptrs)g);
     HIP_TRY(hipGetLastError());
@@ -957,7 +986,9 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
 }
 
 // LDS per workgroup of the two one-launch forms of a step with the on-device agents
-static size_t fused_rollout_lds(const mate_engine *e) { return 4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt) + 1024; }
+// (the 1024 bytes behind the slices: the exchange area of the zoom solve the agents once shared -- nothing reads it since the solve became a table lookup; the
+// one-per-wave launches keep their size, the sub-wave launches, whose occupancy the LDS bounds, do without)
+static size_t fused_rollout_lds(const mate_engine *e, int E = 1) { return (size_t)E * (4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt)) + (E == 1 ? 1024 : 0); }
 static size_t step_greedy_lds(const mate_engine *e, bool cameras = true) {
     return 4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)step_greedy_slice_bytes(e->q.PW, e->q.TW, e->p.Nc, e->p.Nt, e->p.MW, cameras);
 }
@@ -1007,6 +1038,8 @@ static int policy_enable(mate_engine *e) {
         const size_t fused = 4 * (size_t)p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(q.PW, p.Nc, p.Nt) + 1024;
         if (fused <= 160 * 1024)
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rollout_greedy_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused);
+        if (err == hipSuccess && e->sub.rollout_greedy_sub && fused_rollout_lds(e, e->sub.sub_wave) <= 160 * 1024)
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->sub.rollout_greedy_sub), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_rollout_lds(e, e->sub.sub_wave));
     }
     if (err == hipSuccess && e->step_greedy_fn && step_greedy_lds(e) <= 160 * 1024)
         err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->step_greedy_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_greedy_lds(e));
@@ -1148,9 +1181,11 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     // the per-step flows run step_greedy_kernel (step_kernel's sequence with the agents in front) where it exists; the fused
     // rollouts -- and MATE_STEP_GREEDY_ROLLOUT=1 -- rollout_greedy_kernel
     const bool light = per_step && use_step_greedy(e);
-    const PolicyFn fn = light ? e->step_greedy_fn : e->rollout_greedy_fn;
+    // E environments per wave: the fused launches of the small scenarios (not the per-step flows' one-step form)
+    const int E = (!per_step && fused_rollout_lds(e, e->sub.sub_wave) <= 160 * 1024) ? sub_wave_of_launch(e, true) : 1;
+    const PolicyFn fn = light ? e->step_greedy_fn : E > 1 ? e->sub.rollout_greedy_sub : e->rollout_greedy_fn;
     // (the caller plays the cameras: step_greedy_kernel holds the target agents' section only -- a smaller slice, one more workgroup per CU)
-    const size_t lds = light ? step_greedy_lds(e, team_caller != 0) : fused_rollout_lds(e);
+    const size_t lds = light ? step_greedy_lds(e, team_caller != 0) : fused_rollout_lds(e, E);
     if (lds > 160 * 1024) return fail(MATE_EINVAL, "rollout_greedy: %zu bytes of LDS per workgroup do not fit", lds);
     g.mode = MODE_STEP; g.reset_kind = -1; g.rollout_steps = steps;
     g.parity = e->dev_tick ? 0 : e->parity;
@@ -1166,7 +1201,7 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     PolicyPtrs q = e->q;
     std::memset(&q.tape, 0, sizeof(q.tape));
     q.caller_team = team_caller;
-    const unsigned blocks = (unsigned)((e->N + 3) / 4);
+    const unsigned blocks = (unsigned)((e->N + 4 * E - 1) / (4 * E));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e->timing > 0 && !e->dev_tick && (e->timing_tick++ % e->timing) == 0) {
         if (e->events_used == e->events.size()) {
@@ -1657,6 +1692,14 @@ extern "C" int mate_engine_hbm_probe(int32_t device, const void *src, void *dst,
     std::sort(ms_all.begin(), ms_all.end());
     const double ms = ms_all[ms_all.size() / 2];          // the median of five
     *gbytes_per_s = (double)(chunks * 16) * (mode == 0 ? 2.0 : 1.0) / (ms * 1e6);
+    return MATE_OK;
+}
+
+extern "C" int mate_engine_set_sub_wave(mate_engine *e, int32_t enable, int32_t *in_use) {
+    if (!e) return fail(MATE_EINVAL, "null engine");
+    if (enable > 2) return fail(MATE_EINVAL, "set_sub_wave: 0 (one per wave), 1 (the shape's number), 2 (where it measured faster) or negative (query)");
+    if (enable >= 0) e->sub_mode = enable;      // (negative: a query)
+    if (in_use) { in_use[0] = sub_wave_of_launch(e, true); }
     return MATE_OK;
 }
 

@@ -157,11 +157,19 @@ __device__ __forceinline__ double zoom_lookup(const PolicyPtrs &q, double K) {
 // `di` the static and dynamic records, `mk` the packed view masks of the previous step.  One wave, one environment.  Joint
 // actions go to q.cam_act / q.tgt_act when `active` and `publish`, and to lds_cam_act / lds_tgt_act when those are given (the
 // fused rollout steps from them and publishes the last executed step's once per launch).
-template <typename ObsT>
+// `L` lanes per environment (Ctx): camera c is lane c of the environment's group, target t lane L / 2 + t (32 + t in a whole wave);
+// `shift` the group's first hardware lane.  The draws are keyed by the lane a role has in a WHOLE wave (camera c: c, target t: 32 + t,
+// pair k: k), so every L draws the same numbers.
+template <typename ObsT, int L = 64>
 __device__ __forceinline__ void greedy_policy_body(const Params &p, const PolicyPtrs &q, PolCtx<ObsT> &a, const double *st, const double *dy,
                                                    const int32_t *di, const uint32_t *mk,
                                                    int wave, int lane, int64_t env, bool active, double *lds_cam_act, double *lds_tgt_act,
-                                                   long long *acc = nullptr, long long *t_prev = nullptr, bool publish = true) {
+                                                   long long *acc = nullptr, long long *t_prev = nullptr, bool publish = true, int shift = 0) {
+    constexpr int TB = L / 2;                       // the target agents' first lane
+    auto group_ballot = [&](bool x) -> unsigned long long {
+        if constexpr (L == 64) return __ballot(x);
+        else return (__ballot(x) >> shift) & ((1ull << L) - 1ull);
+    };
     // Which teams' agents act (wave-uniform, `cams` / `tgts` below): both under step_greedy / rollout_greedy; under MultiCamera /
     // MultiTarget (q.caller_team = the learner's team, single_team.py:245-264) ONLY THE OPPONENTS -- the reference's wrapper holds no
     // agents for the learner's team, and its joint action is the caller's.  A team that does not act keeps its memory as it is and
@@ -191,7 +199,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     double u_bern = 0.0, u_s0 = 0.0, u_s1 = 0.0;
     uint32_t w_delay = 0, w_choice = 0;
     if (!(q.tape.cam_binom_u && q.tape.cam_sample_u && q.tape.cam_delay && q.tape.tgt_choice_u && q.tape.tgt_binom_u && q.tape.tgt_sample_u)) {
-        const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_STEP, (uint32_t)lane);
+        const U4 r = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_STEP, (uint32_t)(lane < TB ? lane : 32 + (lane - TB)));
         w_delay = r.x & 0xffffu; w_choice = r.x >> 16;
         u_bern = (double)r.y * 2.3283064365386963e-10;
         u_s0 = (double)r.z * 2.3283064365386963e-10; u_s1 = (double)r.w * 2.3283064365386963e-10;
@@ -210,11 +218,11 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     if (cams && lane < Nc) a.near_bits(lane) = 0;
     if (fresh_c) {                                          // GreedyCameraAgent.reset (greedy.py:43-61)
         if (lane < Nc) { a.prev_action(lane, 0) = 0.0; a.prev_action(lane, 1) = 0.0; a.has_state(lane) = 1; }
-        for (int k = lane; k < Nc * Nc; k += 64) { a.ci[Nc * Nt + k] = 0; a.ci[Nc * Nt + Nc * Nc + k] = 0; }   // delay, neighbor
+        for (int k = lane; k < Nc * Nc; k += L) { a.ci[Nc * Nt + k] = 0; a.ci[Nc * Nt + Nc * Nc + k] = 0; }   // delay, neighbor
     }
     wave_sync();
     if (cams)
-    for (int k = lane; k < Nc * Nt; k += 64) {              // process_messages of the observation (greedy.py:100-113)
+    for (int k = lane; k < Nc * Nt; k += L) {              // process_messages of the observation (greedy.py:100-113)
         const int c = (int)(((float)k + 0.5f) * p.inv_Nt), t = k - c * Nt;
         const bool s = sees(c, t);
         int left = 0;
@@ -225,7 +233,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         a.t2f(c, t) = left;
         if (norm2(x - cam_x(c), y - cam_y(c)) < threshold) atomicOr(&a.near_bits(c), 1 << t);
     }
-    const int tl = lane - 32;
+    const int tl = lane - TB;
     if (tgts && tl >= 0 && tl < Nt) {                       // GreedyTargetAgent.reset / process_messages (greedy.py:262-283,326-332)
         const int t = tl;
         const int gw = di[t * TI_STRIDE + TI_GW];
@@ -254,7 +262,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     // cameras: send_responses (greedy.py:158-190), one lane per (sender, recipient) -- one round of pairs up to 8 cameras, up to
     // four for the 16 the engine takes (the pair's message delay: the lane's own Philox word in the first round, one more block
     // keyed by the pair's index beyond)
-    const bool one_round = Nc * Nc <= 64;
+    const bool one_round = Nc * Nc <= L;
     // Serial loops of the agents turned into loops over BALLOT bits (round 5; the fused Greedy rollouts are VALU-bound and a latency-bound
     // per-step launch waits for every LDS round trip): a pair lane ORs the messages of the senders that DID send to its camera (bits
     // s Nc + c of `sent`: a message goes out every ~28 steps per pair) instead of reading all Nc staging words; a camera lane scans the
@@ -279,7 +287,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
                 if (q.tape.cam_delay) v = q.tape.cam_delay[(env * Nc + s) * Nc + c];
                 else { const int lo = q.memory_period / 4, hi = 2 * q.memory_period;        // randint(6, 50)
                        uint32_t w = w_delay;
-                       if (k >= 64) w = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_STEP, (uint32_t)k).x & 0xffffu;
+                       if (k >= (L == 64 ? 64 : TB)) w = philox(p.seed_lo, p.seed_hi, env_global, tick, S_POL_STEP, (uint32_t)k).x & 0xffffu;      // (pair k's word is lane k's of a whole wave; this lane drew it itself only below L / 2)
                        v = lo + (int)((w * (uint32_t)(hi - lo)) >> 16); }
                 d = v;
             }
@@ -293,12 +301,12 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     };
     int my_bits = 0;
     if (lane < Nc * Nc) my_bits = send_pair(lane);
-    if (one_round) sent = __ballot(my_bits != 0);
+    if (one_round) sent = group_ballot(my_bits != 0);
     if (!one_round)
-        for (int k = lane + 64; k < Nc * Nc; k += 64) send_pair(k);
+        for (int k = lane + L; k < Nc * Nc; k += L) send_pair(k);
     if (!one_round) {                                       // several rounds: behind EVERY round's reads
         wave_sync();
-        for (int k = lane; k < Nc * Nc; k += 64) {
+        for (int k = lane; k < Nc * Nc; k += L) {
             const int s = (int)(((float)k + 0.5f) * p.inv_Nc), c = k - s * Nc;
             if (a.send_bits(s, c) < 0) a.neighbor(c, s) = 1;
         }
@@ -309,7 +317,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
     unsigned long long col_mask = 0ull;                                  // bit s Nc for every sender s (one round of pairs)
     if (one_round) for (int s = 0; s < Nc; ++s) col_mask |= 1ull << (s * Nc);
     double dn_lane = INFINITY;
-    for (int k = lane; k < Nc * Nt; k += 64) {
+    for (int k = lane; k < Nc * Nt; k += L) {
         const int c = (int)(((float)k + 0.5f) * p.inv_Nt), t = k - c * Nt;
         int told = 0;
         if (one_round) {
@@ -330,13 +338,13 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         a.pair_dist(c, t) = dn;
         if (k == lane) dn_lane = dn;
     }
-    if (Nc * Nt <= 64) candidates = __ballot(dn_lane < INFINITY);
+    if (Nc * Nt <= L) candidates = group_ballot(dn_lane < INFINITY);
     if (lane < Nc && (a.has_state(lane) || seen_mask(lane))) a.has_state(lane) = 0;   // message2send.clear()
     }
     // targets: broadcast non-empty warehouse sets (greedy.py:334-358).  Every lane's reads precede every lane's writes: one wave,
     // one instruction stream, LDS operations in order.
     const bool broadcasts = tgts && tl >= 0 && tl < Nt && a.tgt_need(tl) != 0;
-    const uint32_t needers = (uint32_t)(__ballot(broadcasts) >> 32);      // (target t on lane 32 + t; nobody: the sets stay as they are)
+    const uint32_t needers = (uint32_t)(group_ballot(broadcasts) >> TB);      // (target t on lane L / 2 + t; nobody: the sets stay as they are)
     if (needers != 0u && tgts && tl >= 0 && tl < Nt) {
         int set = a.tgt_nonempty(tl);
         for (uint32_t m = needers; m != 0u; m &= m - 1u) set &= a.tgt_nonempty(__ffs((int)m) - 1);
@@ -363,7 +371,7 @@ __device__ __forceinline__ void greedy_policy_body(const Params &p, const Policy
         const double q2 = div_nz(sight, p.rmax);
         min_va = theta * (q2 * q2);
         double best_d = INFINITY;
-        if (Nc * Nt <= 64) {                                         // ascending t over the candidates, first minimum wins, like the reference's loop
+        if (Nc * Nt <= L) {                                         // ascending t over the candidates, first minimum wins, like the reference's loop
             for (uint32_t m = (uint32_t)(candidates >> (c * Nt)) & ((1u << Nt) - 1u); m != 0u; m &= m - 1u) {
                 const int t = __ffs((int)m) - 1;
                 const double dnorm = a.pair_dist(c, t);
@@ -506,8 +514,8 @@ __host__ __device__ constexpr int policy_slice_bytes(int PW, int Nc, int Nt) { r
 
 // The caller's team of a fused rollout: its joint action, decoded as step() would (f32 / f64 pairs, or grid indices:
 // DiscreteCamera.action / DiscreteTarget.action, discrete_action_spaces.py:71-73, 177-179), over the agents' in LDS.
-template <typename ObsT>
-__device__ __forceinline__ void load_caller_actions(Ctx<ObsT> &c, int team, double *act_cam, double *act_tgt) {
+template <typename ObsT, int L>
+__device__ __forceinline__ void load_caller_actions(Ctx<ObsT, L> &c, int team, double *act_cam, double *act_tgt) {
     const Params &p = c.p;
     const Ptrs &g = c.g;
     const int k = c.lane;
@@ -560,8 +568,25 @@ __device__ __forceinline__ const PolicyPtrs &kernarg_policy_ptrs(const PolicyPtr
 #endif
 }
 
-template <typename ObsT, typename Shape>
-__global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q_arg) {
+// 16-byte row chunks per lane when a group of L lanes packs the shape's f32 row blocks (camera block / target block)
+template <typename Shape, int L>
+constexpr int sub_held_chunks(bool camera) { return ((camera ? Shape::kChunksC : Shape::kChunksT) + L - 1) / L; }
+
+// `E` ENVIRONMENTS PER WAVE (round 6; engine_kernels.hpp, Ctx): 1 = the mapping above; 2 / 4 = sub-wave groups of L = 64 / E lanes, one
+// environment each -- the small scenarios, whose agents and visibility pairs fill a quarter of a wave: every vector instruction then
+// advances E environments.  A workgroup holds 4 E environments (wave w, group s: environment (4 block + w) E + s); the groups of a wave
+// share nothing but the instruction stream.  E > 1 runs the phase functions written for any L (no held roles, no carried collision
+// screen); same results as E = 1, bit for bit (tests/test_gpu_subwave.py).
+#ifndef MATE_SUB_HOLD
+#define MATE_SUB_HOLD 1        // (experiments: 0 = the sub-wave groups fetch their row descriptors at every step)
+#endif
+#ifndef MATE_SUB_BLOCKS
+#define MATE_SUB_BLOCKS 4      // (experiments: workgroups per CU the sub-wave kernels' register budget is set for)
+#endif
+template <typename ObsT, typename Shape, int E = 1>
+__global__ __launch_bounds__(256, E == 1 ? Shape::kGreedyBlocks : MATE_SUB_BLOCKS) void rollout_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q_arg) {
+    constexpr int L = 64 / E;
+    static_assert(E == 1 || E == 2 || E == 4, "environments per wave");
     const PolicyPtrs &q = kernarg_policy_ptrs(q_arg);
     const Shape shape(pp, true);
     const Params &p = shape.get();
@@ -573,18 +598,21 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         if (!g.pipelined) g.done_count[parity ^ 1] = 0;      // (pipelined restarts: the other list is being consumed right now; its reset clears it)
         g.ctrl[0] = parity;
     }
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int64_t env_raw = (int64_t)blockIdx.x * 4 + wave;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int hw_lane = threadIdx.x & 63, lane = hw_lane & (L - 1), shift = hw_lane & ~(L - 1);      // lane inside the environment's group; the group's first lane
+    const int slot = E == 1 ? wave : wave * E + (hw_lane >> (E == 4 ? 4 : 5));                       // the environment's slice of the workgroup's LDS
+    const int64_t env_raw = (int64_t)blockIdx.x * (4 * E) + slot;
     const bool in_batch = env_raw < g.N;
     const int64_t env = in_batch ? env_raw : g.N - 1;
-    bool untouched = false;          // pipelined restarts: not live at entry, see below (wave-uniform)
+    bool untouched = false;          // pipelined restarts: not live at entry, see below (uniform per environment)
     const Ptrs &gk = kernarg_ptrs(g);
     const int pol_bytes = policy_slice_bytes(q.PW, p.Nc, p.Nt);
-    unsigned char *pol_base = smem + 4 * p.lds_wave_bytes + wave * pol_bytes;
+    unsigned char *pol_base = smem + 4 * E * p.lds_wave_bytes + slot * pol_bytes;
     PolCtx<ObsT> a(p, q, pol_base);
     double *act_cam = a.f + (q.PW + policy_staging_words(p.Nc, p.Nt)), *act_tgt = act_cam + 2 * p.Nc;
     {
-        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
+        Ctx<ObsT, L> c(p, gk, smem + slot * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
+        c.shift = shift;
         // pipelined restarts (Ptrs::pipelined): an environment tagged for this launch's list parity goes live; one that is not
         // live at entry -- tagged for the other parity, or finished and in the hands of the reset running under this launch --
         // is left alone: no step and, at the end, no store (the reset may be rewriting its records right now).  Whether it is
@@ -597,7 +625,8 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         if (g.pipelined) {
             // (read while a reset on another stream may be writing it: an agent-scope atomic load, not a plain one the compiler may keep or split)
             const int32_t *done_word = reinterpret_cast<const int32_t *>(g.dyn + env * p.DW + p.DF) + p.Nt * TI_STRIDE + EI_DONE;
-            d_entry = __builtin_amdgcn_readfirstlane(__hip_atomic_load(done_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            d_entry = __hip_atomic_load(done_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (E == 1) d_entry = __builtin_amdgcn_readfirstlane(d_entry);
             mine = (d_entry & kDoneTag) && ((d_entry >> 3) & 1) == parity;
             untouched = d_entry != 0 && !mine;      // (a wave past the end of the batch mirrors environment N - 1: the same rule)
         }
@@ -605,16 +634,16 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
             load_records(c);
             wave_sync();
             const uint32_t *m = q.masks + env * p.MW;                 // the view the previous step / reset left
-            for (int i = lane; i < p.MW; i += 64) c.mask[i] = m[i];
+            for (int i = lane; i < p.MW; i += L) c.mask[i] = m[i];
             const double *src = q.pol + env * q.PW;
-            for (int k = lane; k < q.PW; k += 64) a.f[k] = src[k];
+            for (int k = lane; k < q.PW; k += L) a.f[k] = src[k];
             build_entities(c);
         } else {
             // nothing of this environment is loaded: the launch prologue below (image statics, lane roles, collision seeds) still runs
             // over the wave's record slice, so the slice is zeros, not whatever the LDS held -- its results are discarded, but no
             // address may ever be formed from an unwritten field
-            uint32_t *slice = reinterpret_cast<uint32_t *>(smem + wave * p.lds_wave_bytes);
-            for (int i = lane; i < (p.lds_wave_bytes >> 2); i += 64) slice[i] = 0u;
+            uint32_t *slice = reinterpret_cast<uint32_t *>(smem + slot * p.lds_wave_bytes);
+            for (int i = lane; i < (p.lds_wave_bytes >> 2); i += L) slice[i] = 0u;
             wave_sync();
             if (lane == 0) c.ei(EI_DONE) = d_entry;                  // (all the step loop reads of it: "not live")
         }
@@ -630,16 +659,20 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         else if (in_batch) list_finished_at_entry(c);
         wave_sync();
     }
-    constexpr bool IMAGE = Shape::kImage;   // row-image mode (engine_kernels.hpp: image_statics)
-    PackDescriptorsT<Shape::kHeldGC, Shape::kHeldGT> held;
+    constexpr bool IMAGE = E == 1 && Shape::kImage;   // row-image mode (engine_kernels.hpp: image_statics)
+    // the row chunks a lane holds descriptors of: all of them where they are few (E = 1: Shape::kHeldGC / GT; a group of L lanes: L per round)
+    constexpr int kGC = E == 1 ? Shape::kHeldGC : sub_held_chunks<Shape, L>(true), kGT = E == 1 ? Shape::kHeldGT : sub_held_chunks<Shape, L>(false);
+    constexpr bool HOLD = Shape::kGreedyHeld && (E == 1 || (MATE_SUB_HOLD && kGC + kGT <= 12));
+    PackDescriptorsT<HOLD ? kGC : kPackGC, HOLD ? kGT : kPackGT> held;
     RangeRoles roles;
     {
-        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
+        Ctx<ObsT, L> c(p, gk, smem + slot * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
+        c.shift = shift;
         if constexpr (IMAGE) { range_roles(c, roles); pin_roles(roles); image_statics(c); }
-        else if constexpr (Shape::kGreedyHeld) load_pack_descriptors(c, held);
+        else if constexpr (HOLD) { if (packs_rows_f32(c)) load_pack_descriptors(c, held); }
     }
     // the lane's range-test roles held in registers, and with them the collision screen carried from step to step (NearCarry)
-    constexpr bool ROLES = Shape::kGreedyRoles;
+    constexpr bool ROLES = E == 1 && Shape::kGreedyRoles;
     NearCarry near{};
     if constexpr (ROLES) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
@@ -667,17 +700,19 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
 #endif
 #pragma clang loop unroll(disable)
     for (int r = 0; r < g.rollout_steps; ++r) {
-        int lane_r = lane, wave_r = wave;                          // opaque per iteration, see rollout_kernel
+        int lane_r = lane, wave_r = wave, slot_r = slot;          // opaque per iteration, see rollout_kernel
         asm volatile("" : "+v"(lane_r));
         asm volatile("" : "+s"(wave_r));
+        if constexpr (E == 1) slot_r = wave_r; else asm volatile("" : "+v"(slot_r));
         const Params *pr = pp;
         asm volatile("" : "+s"(pr));
         const Shape shape_r(pr, true);
         const Params &p = shape_r.get();
-        const int64_t env_w = (int64_t)blockIdx.x * 4 + wave_r;
+        const int64_t env_w = (int64_t)blockIdx.x * (4 * E) + slot_r;
         const int64_t env_r = env_w < g.N ? env_w : g.N - 1;
         if constexpr (ROLES) pin_roles(roles, p.range_rounds, IMAGE, p.sector_rounds == 1);
-        Ctx<ObsT> c(p, gk, smem + wave_r * p.lds_wave_bytes, lane_r, env_r, FLOW_GREEDY);
+        Ctx<ObsT, L> c(p, gk, smem + slot_r * p.lds_wave_bytes, lane_r, env_r, FLOW_GREEDY);
+        c.shift = shift;
         c.out = (int64_t)r * g.N + env_r;
         c.act_cam = act_cam; c.act_tgt = act_tgt;
         c.statics_done = stepped;
@@ -697,7 +732,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
             continue;
         }
         // (the joint actions stay in LDS; the last executed step's are published once, at the end of the launch)
-        MATE_PHASE(128, greedy_policy_body<ObsT>(p, q, a, c.st, c.dy, c.di, c.mask, wave_r, lane_r, env_r, true, act_cam, act_tgt, GREEDY_ACC, false));
+        MATE_PHASE(128, greedy_policy_body<ObsT, L>(p, q, a, c.st, c.dy, c.di, c.mask, wave_r, lane_r, env_r, true, act_cam, act_tgt, GREEDY_ACC, false, shift));
         wave_sync();
         GREEDY_STAMP(10);
         if (q.caller_team >= 0) {
@@ -727,7 +762,7 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
         MATE_PHASE(32, fill_scratch(c));
         GREEDY_STAMP(5);
         MATE_PHASE(64,
-            if constexpr (Shape::kGreedyHeld) pack_observations<true>(c, held);
+            if constexpr (HOLD) pack_observations<true>(c, held);
             else { PackDescriptors now; pack_observations<false>(c, now); });
         }
         wave_sync();
@@ -742,13 +777,13 @@ __global__ __launch_bounds__(256, Shape::kGreedyBlocks) void rollout_greedy_kern
     }
 #endif
     if (in_batch && !untouched) {
-        Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
+        Ctx<ObsT, L> c(p, gk, smem + slot * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
         store_dynamic(c);
         double *dst = q.pol + env * q.PW;
-        for (int k = lane; k < q.PW; k += 64) dst[k] = a.f[k];
+        for (int k = lane; k < q.PW; k += L) dst[k] = a.f[k];
         if (stepped) {                                             // what mate_engine_policy_actions reads: the last executed step's joint actions
-            for (int k = lane; k < 2 * p.Nc; k += 64) q.cam_act[env * 2 * p.Nc + k] = act_cam[k];
-            for (int k = lane; k < 2 * p.Nt; k += 64) q.tgt_act[env * 2 * p.Nt + k] = act_tgt[k];
+            for (int k = lane; k < 2 * p.Nc; k += L) q.cam_act[env * 2 * p.Nc + k] = act_cam[k];
+            for (int k = lane; k < 2 * p.Nt; k += L) q.tgt_act[env * 2 * p.Nt + k] = act_tgt[k];
         }
     }
 }

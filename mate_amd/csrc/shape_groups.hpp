@@ -27,6 +27,10 @@ struct KernelSet {
     PolicyFn policy, rollout_greedy;
     PolicyFn step_greedy;      // step_greedy_kernel (f32 observations), or null
     int image;
+    // E environments per wave (FixedShape::kSubWave, f32 observations): the fused rollouts of the small scenarios, or null / 1
+    StepFn rollout_sub[2];     // [0] generic flow, [1] FLOW_RANDOM
+    PolicyFn rollout_greedy_sub;
+    int sub_wave;
 };
 
 // true = the group holds the shape and `out` is filled (false for an f64-observation engine of a Y shape)

@@ -630,6 +630,22 @@ class Engine:
         check(self.lib.mate_engine_idle_steps(self._h, ctypes.byref(total)))
         return total.value
 
+    def set_sub_wave(self, enable='auto'):
+        """Environments per wave of the fused rollouts (mate_engine_set_sub_wave): the small scenarios (at most four cameras and four
+        targets) can step four environments per wave.  'auto' (the default of a new engine) = where that measured faster (batches of at
+        least 32 environments per compute unit; under the random policy every such shape but MATE-4v4-*), True = in every fused
+        launch of such a shape, False = one per wave.  Returns the number the Greedy rollouts now run with."""
+        in_use = ctypes.c_int32()
+        check(self.lib.mate_engine_set_sub_wave(self._h, 2 if enable == 'auto' else int(bool(enable)), ctypes.byref(in_use)))
+        return in_use.value
+
+    @property
+    def sub_wave(self):
+        """Environments per wave the fused Greedy rollouts run with (1, or 4 for the small scenarios)."""
+        in_use = ctypes.c_int32()
+        check(self.lib.mate_engine_set_sub_wave(self._h, -1, ctypes.byref(in_use)))
+        return in_use.value
+
     def kernel_time(self, enable=1):
         """(avg ms, launches) of the step kernel since the last call; `enable` = k arms the HIP-event timer
         for every k-th launch (0 disarms)."""

@@ -1,0 +1,117 @@
+"""GPU (-m gpu): FOUR ENVIRONMENTS PER WAVE (engine_kernels.hpp, Ctx<ObsT, L>; include/mate_engine.h, mate_engine_set_sub_wave).
+
+The engine maps one environment onto one 64-lane wave.  The scenarios of the reference's target trainers and its other small scenarios
+(at most four cameras and four targets: MATE-2v4-0 of examples/*/target/config.py, MATE-4v2-9 of BASELINE config 1, ...) fill a quarter
+of a wave, so their fused rollouts run sub-wave groups of sixteen lanes, one environment each.  Everything here holds the two mappings
+to the same bits: rows, scalars, masks, the records, the agents' memory, across episode ends and restarts, at batch sizes that are no
+multiple of sixteen, in every fused flow (random policy, Greedy vs Greedy, a learner's team against the greedy opponents with frame skip,
+pipelined restarts, the fused observation transforms of the generic flow)."""
+import numpy as np
+import pytest
+import torch
+
+from mate_amd.config import read_config
+from mate_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ['MATE-1v1-0', 'MATE-1v1-9', 'MATE-1v2-0', 'MATE-1v2-9', 'MATE-2v2-0', 'MATE-2v2-9', 'MATE-2v4-0', 'MATE-2v4-9', 'MATE-4v2-0', 'MATE-4v2-9',
+         'MATE-4v4-0', 'MATE-4v4-9']
+
+
+def same(a, b):
+    return torch.equal(a.contiguous().view(torch.uint8), b.contiguous().view(torch.uint8))
+
+
+def _pair(name, n, **kw):
+    cfg = read_config(name + '.yaml', **kw)
+    engines = []
+    for on in (True, False):
+        eng = Engine(cfg, n, seed=41, first_env_index=3)
+        assert eng.set_sub_wave(on) == (4 if on else 1) and eng.sub_wave == (4 if on else 1)
+        eng.enable_policies()
+        eng.reset()
+        engines.append(eng)
+    return engines
+
+
+@pytest.mark.parametrize('name', SMALL)
+def test_four_environments_per_wave_equal_one_per_wave(name):
+    n = 53                                                   # (no multiple of 16: the last wave's groups past the batch idle)
+    sub, one = _pair(name, n, max_episode_steps=11)
+    assert same(sub.export_state(), one.export_state())
+    for steps, auto_reset in ((5, True), (9, True), (4, 2), (4, 2), (7, False)):
+        out = []
+        for eng in (sub, one):
+            cam, tgt, sc = eng.rollout_random(steps, auto_reset=auto_reset, want_masks=True)
+            out.append((cam.clone(), tgt.clone(), sc.clone(), eng._rollout['masks'][:steps].clone(), eng.export_state().clone()))
+        for x, y in zip(*out):
+            assert same(x, y), (name, 'random', steps, auto_reset)
+    for eng in (sub, one):
+        eng.reset()
+    for steps, auto_reset in ((6, True), (8, True), (3, 2), (3, 2), (5, 'pipelined'), (5, 'pipelined'), (5, 'pipelined'), (4, True)):
+        out = []
+        for eng in (sub, one):
+            cam, tgt, sc = eng.rollout_greedy(steps, auto_reset=auto_reset, want_masks=True)
+            torch.cuda.synchronize()
+            out.append((cam.clone(), tgt.clone(), sc.clone(), eng._rollout['masks'][:steps].clone()))
+        for x, y in zip(*out):
+            assert same(x, y), (name, 'greedy', steps, auto_reset)
+    for eng in (sub, one):
+        eng.rollout_greedy(1, auto_reset=True)               # (leaves the pipelined mode: restarts what it finished)
+    assert same(sub.export_state(), one.export_state()) and same(sub.policy_actions()[1], one.policy_actions()[1])
+    assert sub.idle_steps() == one.idle_steps() and same(sub.episode_stats, one.episode_stats)
+    assert float(sub.episode_stats[0]) >= n                  # episodes ended (time limit 11) and restarted inside all this
+
+
+@pytest.mark.parametrize('name,team,frames', [('MATE-2v4-0', 'target', 10), ('MATE-2v4-0', 'camera', 5), ('MATE-4v2-9', 'target', 10), ('MATE-4v4-9', 'camera', 5),
+                                              ('MATE-1v1-9', 'target', 3), ('MATE-2v2-0', 'camera', 4)])
+def test_frame_skip_against_the_greedy_opponents(name, team, frames):
+    """FrameSkip(K) over MultiTarget(GreedyCameraAgent) / MultiCamera(GreedyTargetAgent) (examples/utils/wrappers.py:301-323 over
+    mate/wrappers/single_team.py:245-306; the target trainers run MATE-2v4-0 with K = 10): one launch per learner action, f32 / f64 /
+    discrete joint actions of the learner's team, restarts every other launch."""
+    n = 40
+    sub, one = _pair(name, n, max_episode_steps=23)
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    k = sub.num_targets if team == 'target' else sub.num_cameras
+    scale = torch.tensor([20.0, 20.0] if team == 'target' else [5.0, 2.5], device='cuda')
+    for it in range(9):
+        act = (torch.rand((n, k, 2), device='cuda', generator=gen) * 2 - 1) * scale * 1.2
+        if it % 3 == 1:
+            act = act.double()
+        out = []
+        for eng in (sub, one):
+            cam, tgt, sc = eng.rollout_versus_greedy(team, act, frames, auto_reset=2, want_masks=True)
+            out.append((cam.clone(), tgt.clone(), sc.clone(), eng._rollout['masks'][:frames].clone(), eng.export_state().clone(),
+                        eng.policy_actions()[0 if team == 'target' else 1].clone()))
+        for x, y in zip(*out):
+            assert same(x, y), (name, team, it)
+    assert float(sub.episode_stats[0]) > 0 and same(sub.episode_stats, one.episode_stats)
+
+
+def test_generic_flow_with_fused_transforms():
+    """rollout_random under the FLOW_ANY compilation (a fused RelativeCoordinates + RescaledObservation transform and the
+    EnhancedObservation team mode switch the folded flow off): the element-wise packer and the team-wide flags in sixteen-lane groups."""
+    name, n = 'MATE-4v2-9', 37
+    sub, one = _pair(name, n, max_episode_steps=9)
+    out = []
+    for eng in (sub, one):
+        eng.set_obs_transform(relative_coordinates=True, rescaled_observation=True)
+        eng.set_obs_mode(camera='enhanced', target='shared')
+        rec = []
+        for steps in (6, 7):
+            cam, tgt, sc = eng.rollout_random(steps, auto_reset=True, want_masks=True)
+            rec += [cam.clone(), tgt.clone(), sc.clone(), eng._rollout['masks'][:steps].clone()]
+        assert eng.last_flow == 0
+        out.append(rec)
+    for x, y in zip(*out):
+        assert same(x, y)
+
+
+def test_sub_wave_is_the_default_only_where_it_is_compiled_and_measured_faster():
+    for name, want in (('MATE-2v4-0', 4), ('MATE-4v2-9', 4), ('MATE-4v8-9', 1), ('MATE-8v8-9', 1), ('MATE-Navigation', 1)):
+        eng = Engine(read_config(name + '.yaml'), 8, seed=1)
+        assert eng.sub_wave == 1                                  # 'auto' at a batch of 8: one per wave everywhere
+        assert eng.set_sub_wave(True) == want and eng.set_sub_wave(False) == 1 and eng.set_sub_wave('auto') == 1
+    big = Engine(read_config('MATE-2v4-0.yaml'), 16384, seed=1)
+    assert big.sub_wave == 4 and big.set_sub_wave(False) == 1 and big.set_sub_wave('auto') == 4
