@@ -26,16 +26,17 @@ def same(a, b):
 def _pair(name, n, **kw):
     cfg = read_config(name + '.yaml', **kw)
     engines = []
+    per_wave = 2 if name.startswith('MATE-4v8') else 4
     for on in (True, False):
         eng = Engine(cfg, n, seed=41, first_env_index=3)
-        assert eng.set_sub_wave(on) == (4 if on else 1) and eng.sub_wave == (4 if on else 1)
+        assert eng.set_sub_wave(on) == (per_wave if on else 1) and eng.sub_wave == (per_wave if on else 1)
         eng.enable_policies()
         eng.reset()
         engines.append(eng)
     return engines
 
 
-@pytest.mark.parametrize('name', SMALL)
+@pytest.mark.parametrize('name', SMALL + ['MATE-4v8-0'])      # (MATE-4v8-0: two per wave, thirty-two lanes each)
 def test_four_environments_per_wave_equal_one_per_wave(name):
     n = 53                                                   # (no multiple of 16: the last wave's groups past the batch idle)
     sub, one = _pair(name, n, max_episode_steps=11)
@@ -65,7 +66,7 @@ def test_four_environments_per_wave_equal_one_per_wave(name):
 
 
 @pytest.mark.parametrize('name,team,frames', [('MATE-2v4-0', 'target', 10), ('MATE-2v4-0', 'camera', 5), ('MATE-4v2-9', 'target', 10), ('MATE-4v4-9', 'camera', 5),
-                                              ('MATE-1v1-9', 'target', 3), ('MATE-2v2-0', 'camera', 4)])
+                                              ('MATE-1v1-9', 'target', 3), ('MATE-2v2-0', 'camera', 4), ('MATE-4v8-0', 'camera', 5)])
 def test_frame_skip_against_the_greedy_opponents(name, team, frames):
     """FrameSkip(K) over MultiTarget(GreedyCameraAgent) / MultiCamera(GreedyTargetAgent) (examples/utils/wrappers.py:301-323 over
     mate/wrappers/single_team.py:245-306; the target trainers run MATE-2v4-0 with K = 10): one launch per learner action, f32 / f64 /
@@ -109,7 +110,7 @@ def test_generic_flow_with_fused_transforms():
 
 
 def test_sub_wave_is_the_default_only_where_it_is_compiled_and_measured_faster():
-    for name, want in (('MATE-2v4-0', 4), ('MATE-4v2-9', 4), ('MATE-4v8-9', 1), ('MATE-8v8-9', 1), ('MATE-Navigation', 1)):
+    for name, want in (('MATE-2v4-0', 4), ('MATE-4v2-9', 4), ('MATE-4v8-0', 2), ('MATE-4v8-9', 1), ('MATE-8v8-9', 1), ('MATE-Navigation', 1)):
         eng = Engine(read_config(name + '.yaml'), 8, seed=1)
         assert eng.sub_wave == 1                                  # 'auto' at a batch of 8: one per wave everywhere
         assert eng.set_sub_wave(True) == want and eng.set_sub_wave(False) == 1 and eng.set_sub_wave('auto') == 1

@@ -42,6 +42,11 @@ CASES = {
     # the learner-versus-greedy step (step_greedy_kernel): a target script of its own, not a bench.py command
     'versus': ('step_greedy_kernel', 1, 4096, ['4096', '300'], 'tools/versus_target.py'),
     'versus16k': ('step_greedy_kernel', 1, 16384, ['16384', '200'], 'tools/versus_target.py'),
+    # round 6: four environments per wave against one (tools/subwave_target.py): the target trainers' MATE-2v4-0 FrameSkip(10) flow, BASELINE config 1's scenario fused
+    'sub_target10_one': ('rollout_greedy_kernel', 10, 16384, ['target10', 'MATE-2v4-0.yaml', '16384', '40', '0'], 'tools/subwave_target.py'),
+    'sub_target10_four': ('rollout_greedy_kernel', 10, 16384, ['target10', 'MATE-2v4-0.yaml', '16384', '40', '1'], 'tools/subwave_target.py'),
+    'sub_4v2_one': ('rollout_kernel', 64, 16384, ['random64', 'MATE-4v2-9.yaml', '16384', '12', '0'], 'tools/subwave_target.py'),
+    'sub_4v2_four': ('rollout_kernel', 64, 16384, ['random64', 'MATE-4v2-9.yaml', '16384', '12', '1'], 'tools/subwave_target.py'),
     'c4full': ('rollout_kernel', 64, 65536, ['--workload', 'MATE-4v8-0.yaml', '--batch', '65536', '--rollout', '64', '--steps', '256', '--warmup', '64']),
     'c5full': ('rollout_kernel', 64, 32768, ['--workload', 'MATE-Navigation.yaml', '--batch', '32768', '--rollout', '64', '--steps', '256', '--warmup', '64']),
 }

@@ -21,6 +21,9 @@ CASES = {
     # name: (scenario, flow, steps per launch)
     'target10': ('MATE-2v4-0.yaml', 'versus_target', 10),      # the target trainers: MultiTarget(GreedyCameraAgent) + FrameSkip(10)
     'camera5_2v4': ('MATE-2v4-0.yaml', 'versus_camera', 5),
+    'camera5_4v8-9': ('MATE-4v8-9.yaml', 'versus_camera', 5),
+    'greedy_4v8-9': ('MATE-4v8-9.yaml', 'greedy', 32),
+    'greedy_4v8-0': ('MATE-4v8-0.yaml', 'greedy', 32),
 }
 for _s in ('1v1-0', '1v1-9', '1v2-0', '1v2-9', '2v2-0', '2v2-9', '2v4-0', '2v4-9', '4v2-0', '4v2-9', '4v4-0', '4v4-9'):
     CASES['random_' + _s] = (f'MATE-{_s}.yaml', 'random', 64)
