@@ -398,7 +398,7 @@ def main():
     else:
         step = lambda: eng.step_random(auto_reset=args.step_reset_interval)     # noqa: E731
     rollout_fn = eng.rollout_greedy if args.policy == 'greedy' else eng.rollout_random
-    # default restart cadence of the fused flows: Greedy vs Greedy every 2 launches (k = 2..4 are within 1.5 %); random policy about every 128
+    # default restart cadence of the fused flows: Greedy vs Greedy every 2 launches (profiles/HISTORY.md 3.1c: k = 2..4 are within 1.5 %); random policy about every 128
     # steps whatever the launch length (after each 128-step launch; after every 6th 20-step launch): a finished environment then idles
     # ~64 of its 10^4 steps (idle slots are not counted in `value`) and short launches do not each drag an idle reset launch behind them
     rollout_resets = args.rollout_reset_interval if args.rollout_reset_interval > 0 else (2 if args.policy == 'greedy' else max(1, 128 // max(R, 1)))
@@ -580,7 +580,7 @@ def main():
                 # the other BASELINE configurations that fit one GPU, about a second each
                 full['other_configs'] = [X.measure_other_config(torch, local_rank, spec, args.other_seconds, args.buffer_gib) for spec in X.OTHER_CONFIGS]
             if not args.no_extras and R > 0:
-                # the learner-facing per-step flows, at this run's batch and -- the default run -- at the two larger batches
+                # the learner-facing per-step flows (profiles/HISTORY.md 3.1e), at this run's batch and -- the default run -- at the two larger batches
                 batches = [args.batch] + ([b for b in X.LEARNER_BATCHES if b != args.batch] if default_case else [])
                 full['learner_flows'] = [X.measure_learner_flows(torch, local_rank, args.workload, b, args.graph_steps, args.step_reset_interval, args.versus_reset_interval)
                                          for b in batches]

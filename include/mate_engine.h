@@ -44,7 +44,7 @@
  *   MATE_STEP_SPLIT=0|1      the per-step kernel of the folded flows (step_random / step with real-valued actions, f32 observations)
  *                            as one wave per environment (0) or two (1: cameras, sector tests and goals on one wave, targets
  *                            and range tests on the other; engine_kernels.hpp: step_split_kernel); default: by what measured
- *                            faster at the batch size; the same bytes either way (tests compare the two)
+ *                            faster at the batch size (profiles/HISTORY.md 3.1d); the same bytes either way (tests compare the two)
  *   MATE_ZOOM_ITERATE=1      the on-device GreedyCameraAgent runs the reference's 20-iteration zoom solve
  *                            (mate/agents/greedy.py:139-145) instead of reading its tabulation; the two differ by
  *                            <= 1.5e-13 degrees in the viewing angle (parity runs that want the iteration itself)
@@ -424,7 +424,8 @@ int mate_engine_block_probe(int32_t device, void *block, int64_t bytes, int32_t 
  * on; no state changes. */
 int mate_engine_set_sub_wave(mate_engine *engine, int32_t enable, int32_t *in_use);
 /* The HBM rates of THIS GPU as this library's own streaming kernels see them (the yardsticks beside the vendor peak in bench.py's
- * roofline object): `mode` 0 = read `src` and write `dst` (read + write bytes counted), 1 = write `dst` only, 2 = read `src` only;
+ * roofline object): `mode` 0 = read `src` and write `dst` (read + write bytes counted), 1 = write `dst` only (non-temporal stores, as the row
+ * writers), 2 = read `src` only, 3 = write `dst` only with plain stores (a memset);
  * 16 bytes per lane, grid-stride over `bytes` (use >= 1 GiB), non-temporal, median of five launches timed with HIP events on `stream`.
  * No reference counterpart: measurement support (SURVEY.md section 8d "confirm on the box"). */
 int mate_engine_hbm_probe(int32_t device, const void *src, void *dst, int64_t bytes, int32_t mode, void *stream, double *gbytes_per_s);

@@ -196,7 +196,8 @@ class ScatteredBlock:
 
 def hbm_rates(device_index, gib=1.0):
     """GB/s of this GPU under the library's own streaming kernels (``mate_engine_hbm_probe``): ``{'copy': read + write bytes of a
-    copy, 'fill': write-only, 'read': read-only}`` over two ``gib``-sized buffers, each the median of five launches."""
+    copy, 'fill': write-only (the faster of non-temporal and plain stores), 'read': read-only}`` over two ``gib``-sized buffers, each the
+    median of five launches."""
     import torch
     n = int(gib * (1 << 30)) // 16 * 16
     out = {}
@@ -205,10 +206,10 @@ def hbm_rates(device_index, gib=1.0):
         b = torch.zeros(n, dtype=torch.uint8, device='cuda')
         torch.cuda.synchronize()
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for name, mode in (('copy', 0), ('fill', 1), ('read', 2)):
+        for name, mode in (('copy', 0), ('fill', 1), ('read', 2), ('fill', 3)):
             rate = ctypes.c_double()
             check(load().mate_engine_hbm_probe(int(device_index), ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n, mode, stream, ctypes.byref(rate)))
-            out[name] = rate.value
+            out[name] = max(out.get(name, 0.0), rate.value)
         del a, b
         torch.cuda.empty_cache()
     return out

@@ -241,7 +241,7 @@ __device__ __forceinline__ void sincos_deg_f32(double deg, float &sn, float &cs)
 // `Vector2D.norm = value` (utils.py:223-229) the reference's way: the vector is re-made from its polar form, value * (cos, sin) of
 // atan2_deg(v) (utils.py:144-152).  The kernels rescale the vector instead (below); -DMATE_POLAR_CLAMP (python -m mate_amd.build
 // --variant polar -DMATE_POLAR_CLAMP) builds them with THIS on the two places the hot path sets a norm -- the over-long step and the
-// ray truncated by an obstacle -- for the census that weighs the departure (DESIGN.md section 4, profiles/r05_polar_census.txt).
+// ray truncated by an obstacle -- for the census that weighs the departure (DESIGN.md section 5, profiles/r05_polar_census.txt).
 __device__ __forceinline__ void set_norm_polar(double &vx, double &vy, double value) {
     double sn, cs;
     sincos_deg(atan2_deg(vy, vx), sn, cs);

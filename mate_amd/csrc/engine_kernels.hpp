@@ -1,6 +1,6 @@
 // engine_kernels.hpp -- gfx950 kernels of the batched MultiAgentTracking step engine.
 //
-// Mapping: ONE WAVE (64 lanes) PER ENVIRONMENT, four environments per 256-thread
+// Mapping: a group of L lanes per environment (Ctx<ObsT, L>) -- ONE WAVE (64 lanes), four environments per 256-thread
 // workgroup.  An environment's state is two small contiguous records (static geometry,
 // dynamic state) that the wave loads with one coalesced 8-byte-per-lane read, stages in LDS,
 // and then works on with lanes mapped to (entity, entity) pairs; wave ballots produce the
@@ -472,7 +472,7 @@ struct Ctx {
     __device__ __forceinline__ bool mask_bit(int b) const { return (mask[b >> 5] >> (b & 31)) & 1u; }
     __device__ __forceinline__ uint32_t env_global() const { return p.first_env + (uint32_t)env; }
     // A tick-keyed draw.  One Philox-4x32 block holds two 64-bit draws: ticks 2k and 2k + 1 share the block with counter k and
-    // take its first / second half (DESIGN.md 3.3) -- the fused rollouts compute a block once per TWO steps (DrawCarry).
+    // take its first / second half (DESIGN.md 3.5) -- the fused rollouts compute a block once per TWO steps (DrawCarry).
     __device__ __forceinline__ double draw(uint32_t tick, uint32_t stream, uint32_t sub) const {
         const U4 r = philox(p.seed_lo, p.seed_hi, env_global(), tick >> 1, stream, sub);
         return (tick & 1u) ? u53(r.z, r.w) : u53(r.x, r.y);
@@ -1209,7 +1209,7 @@ __device__ __forceinline__ bool sector_resolve(const Ctx<ObsT, L> &c, const Sect
         // selection first narrows it -- one round trip per level, 65 knots in one, 257 in two -- instead of the general path's
         // dependent binary search (ten round trips).  A launch of 4096 one-step waves lasts as long as its slowest wave, and with
         // one such lookup in a thousand there is one in (almost) every launch: it WAS the slowest wave, 14 k cycles in this phase
-        // against 5.4 k.
+        // against 5.4 k (profiles/HISTORY.md 3.1d).
         // Eight PIVOT ANGLES ride in the overflow record itself (kPivotKnots; the builders write the angles of knots q, 2q, ... 8q of
         // the degree, q = ceil((count - 1) / 9), +inf beyond the last): up to 37 knots -- every degree but the rarest -- the
         // bracketing five are fetched at once, ONE round trip behind the record's instead of two (pivots, then knots).  A step in
@@ -1745,7 +1745,7 @@ __device__ __forceinline__ void fill_scratch(Ctx<ObsT, L> &c) {
     fill_scratch(c, always);
 }
 
-// The observation rows leave through this store: non-temporal (a write-once stream; -9 % kernel time against plain stores)
+// The observation rows leave through this store: non-temporal (a write-once stream; -9 % kernel time against plain stores, profiles/HISTORY.md 3.1)
 template <typename V>
 __device__ __forceinline__ void stream_store(V v, V *dst) { MATE_ROW_STORE(v, dst); }
 template <typename V>
@@ -1911,9 +1911,65 @@ __device__ __forceinline__ void store_masks(const Ctx<ObsT, L> &c) {
     }
 }
 
+// Both f32 row blocks of a shape whose rows are NOT whole 16-byte chunks everywhere (MATE-4v2-*: two target rows of 101 floats; the
+// 1vN shapes), with EVERY descriptor of the lane fetched before the lane's first store.  pack_block fetches its descriptors inside
+// its loop: on gfx9 loads and stores retire through one in-order counter, so a descriptor load issued behind a row store is waited
+// for together with that store's HBM acknowledgement -- the PMC passes of the four-per-wave MATE-4v2-9 rollout showed waves waiting
+// 62 % of their cycles with 231 vector instructions per environment-step (profiles/r06_pmc_subwave_first.json).  Compiled shapes only
+// (the counts are literals, the arrays registers); a block takes 16-byte chunks when its element count is a multiple of 4, 8-byte
+// chunks when it is even.  False = not applicable: the caller runs the loops.
+template <typename ObsT, int L>
+__device__ __forceinline__ bool pack_blocks_prefetched(const Ctx<ObsT, L> &c) {
+    if constexpr (sizeof(ObsT) != 4) return false;
+    else {
+        const Params &p = c.p;
+        constexpr int CAP = 8;                                   // descriptors of a block per lane
+        const int wc = p.cam_elems == 0 ? 4 : (p.cam_elems % 4 == 0 ? 4 : (p.cam_elems % 2 == 0 ? 2 : 0));
+        const int wt = p.tgt_elems % 4 == 0 ? 4 : (p.tgt_elems % 2 == 0 ? 2 : 0);
+        if (wc == 0 || wt == 0) return false;
+        const int nc = p.cam_elems / wc, nt = p.tgt_elems / wt;
+        if (nc > CAP * L || nt > CAP * L || !c.has_tgt_obs() || (p.cam_elems > 0 && !c.has_cam_obs())) return false;
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const uint32_t *tabc = c.table, *tabt = c.table + p.tgt_table_off;
+        uint4 dc[CAP], dt[CAP];
+#pragma unroll
+        for (int k = 0; k < CAP; ++k) {
+            const int i = c.lane + L * k, ic = i < nc ? i : 0, it = i < nt ? i : 0;
+            dc[k] = make_uint4(0u, 0u, 0u, 0u); dt[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (L * k < nc) { if (wc == 4) dc[k] = reinterpret_cast<const uint4 *>(tabc)[ic]; else { const uint2 d = reinterpret_cast<const uint2 *>(tabc)[ic]; dc[k].x = d.x; dc[k].y = d.y; } }
+            if (L * k < nt) { if (wt == 4) dt[k] = reinterpret_cast<const uint4 *>(tabt)[it]; else { const uint2 d = reinterpret_cast<const uint2 *>(tabt)[it]; dt[k].x = d.x; dt[k].y = d.y; } }
+        }
+#pragma unroll
+        for (int k = 0; k < CAP; ++k) {                          // every descriptor before the first store
+            if (L * k < nc) asm volatile("" : "+v"(dc[k].x), "+v"(dc[k].y), "+v"(dc[k].z), "+v"(dc[k].w));
+            if (L * k < nt) asm volatile("" : "+v"(dt[k].x), "+v"(dt[k].y), "+v"(dt[k].z), "+v"(dt[k].w));
+        }
+        float *cam = reinterpret_cast<float *>(c.g.cam_obs) + c.out * p.cam_elems, *tgt = reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems;
+#pragma unroll
+        for (int k = 0; k < CAP; ++k) {
+            const int i = c.lane + L * k;
+            if (L * k < nc && i < nc) {
+                if (wc == 4) stream_store(f32x4{gather_one(c, dc[k].x), gather_one(c, dc[k].y), gather_one(c, dc[k].z), gather_one(c, dc[k].w)}, reinterpret_cast<f32x4 *>(cam) + i);
+                else stream_store(f32x2{gather_one(c, dc[k].x), gather_one(c, dc[k].y)}, reinterpret_cast<f32x2 *>(cam) + i);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CAP; ++k) {
+            const int i = c.lane + L * k;
+            if (L * k < nt && i < nt) {
+                if (wt == 4) stream_store(f32x4{gather_one(c, dt[k].x), gather_one(c, dt[k].y), gather_one(c, dt[k].z), gather_one(c, dt[k].w)}, reinterpret_cast<f32x4 *>(tgt) + i);
+                else stream_store(f32x2{gather_one(c, dt[k].x), gather_one(c, dt[k].y)}, reinterpret_cast<f32x2 *>(tgt) + i);
+            }
+        }
+        return true;
+    }
+}
+
 // HELD: the caller loaded this lane's descriptors before (the rollout kernel, once per launch); otherwise they are
 // loaded here.  A template switch, not a pointer: a nullable pointer to the register array would force it into memory.
-template <bool HELD, typename ObsT, int L, typename D>
+// PREFETCH (the fused rollouts of the compiled shapes): rows that are not whole 16-byte chunks go through pack_blocks_prefetched.
+template <bool HELD, bool PREFETCH = false, typename ObsT, int L, typename D>
 __device__ __forceinline__ void pack_observations(Ctx<ObsT, L> &c, D &held) {
     const Params &p = c.p;
     if (c.xdesc()) {
@@ -1927,10 +1983,14 @@ __device__ __forceinline__ void pack_observations(Ctx<ObsT, L> &c, D &held) {
         if constexpr (!HELD) load_pack_descriptors(c, held);
         pack_rows_f32(c, held);
     } else {
+    bool packed = false;
+    if constexpr (PREFETCH) packed = pack_blocks_prefetched(c);
+    if (!packed) {
     if (c.has_cam_obs() && p.cam_elems > 0)
         pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.cam_obs) + c.out * p.cam_elems, c.table, p.cam_elems);
     if (c.has_tgt_obs())
         pack_block<ObsT>(c, reinterpret_cast<ObsT *>(c.g.tgt_obs) + c.out * p.tgt_elems, c.table + p.tgt_table_off, p.tgt_elems);
+    }
     }
     store_masks(c);
 }
@@ -3031,7 +3091,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         } else {
         MATE_PHASE(32, fill_scratch(c, last_gw));
         ROLL_STAMP(5);
-        MATE_PHASE(64, pack_observations<true>(c, held));
+        MATE_PHASE(64, pack_observations<true, Shape::kGreedyHeld>(c, held));
         }
         wave_sync();
         stepped = true;

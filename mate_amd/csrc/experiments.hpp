@@ -4,7 +4,7 @@
 // at the top of engine_kernels.hpp, and its kernels are instruction for instruction what they were with the hooks spelled out in
 // the step loops (lib/kernel_resources.json unchanged).
 //
-//   -DMATE_ABLATE=bits   a phase of the fused step loop COMPILED OUT, to weigh it (a build without a phase is
+//   -DMATE_ABLATE=bits   a phase of the fused step loop COMPILED OUT, to weigh it (profiles/HISTORY.md section 5, round 2; a build without a phase is
 //                        not a simulation -- the deltas over-attribute what the missing phase feeds): 1 draws, 2 cameras, 4 targets,
 //                        8 visibility, 16 goals / rewards, 32 scratch or row-image blocks, 64 pack + stores, 128 the greedy agents,
 //                        256 the zoom solve iterates once instead of twenty times

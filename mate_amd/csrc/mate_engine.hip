@@ -416,7 +416,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         const int digits = e->sw.stagger >= 0 ? e->sw.stagger : 0;
 
         // the two-wave step: where it measured faster -- batches of at most 8 environments per CU (half a generation of the one-wave
-        // kernel: 2048 environments on 256 CUs, -3 % random policy, -8 % caller's actions; at 4096 it is 17 % slower)
+        // kernel: 2048 environments on 256 CUs, -3 % random policy, -8 % caller's actions; at 4096 it is 17 % slower, profiles/HISTORY.md 3.1d)
         if (e->sw.step_split < 0) e->sw.step_split = (Nc > 0 && num_envs <= 8 * cus) ? 1 : 0;
         g.stagger = 0;
         if (digits > 0) {
@@ -1653,6 +1653,7 @@ __global__ __launch_bounds__(256) void hbm_probe_kernel(const char *src, char *d
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += stride) {
         if (mode == 0) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
         else if (mode == 1) __builtin_nontemporal_store(fill, out + i);
+        else if (mode == 3) out[i] = fill;                       // (plain stores: what a memset does)
         else acc += __builtin_nontemporal_load(in + i);
     }
     if (mode == 2 && acc.x + acc.y + acc.z + acc.w == -1.2345e30f) out[0] = acc;
@@ -1660,13 +1661,14 @@ __global__ __launch_bounds__(256) void hbm_probe_kernel(const char *src, char *d
 }  // namespace
 
 extern "C" int mate_engine_hbm_probe(int32_t device, const void *src, void *dst, int64_t bytes, int32_t mode, void *stream, double *gbytes_per_s) {
-    if (!gbytes_per_s || bytes < 16 || mode < 0 || mode > 2 || !dst || (mode != 1 && !src))
-        return fail(MATE_EINVAL, "hbm_probe: null rate / buffer, fewer than 16 bytes or a mode other than 0 (copy), 1 (fill), 2 (read)");
+    if (!gbytes_per_s || bytes < 16 || mode < 0 || mode > 3 || !dst || ((mode == 0 || mode == 2) && !src))
+        return fail(MATE_EINVAL, "hbm_probe: null rate / buffer, fewer than 16 bytes or a mode other than 0 (copy), 1 (fill, non-temporal), 2 (read), 3 (fill, plain stores)");
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     const int64_t chunks = bytes / 16;
-    const unsigned grid = (unsigned)std::min<int64_t>((chunks + 255) / 256, (int64_t)prop.multiProcessorCount * 8);
+    // (a copy / read runs best with a few resident workgroups per CU striding over the buffer; a fill with one thread per few chunks)
+    const unsigned grid = (unsigned)std::min<int64_t>((chunks + 255) / 256, (int64_t)prop.multiProcessorCount * ((mode == 1 || mode == 3) ? 64 : 8));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<float> ms_all;
     auto measure = [&]() -> hipError_t {

@@ -762,8 +762,8 @@ __global__ __launch_bounds__(256, E == 1 ? Shape::kGreedyBlocks : MATE_SUB_BLOCK
         MATE_PHASE(32, fill_scratch(c));
         GREEDY_STAMP(5);
         MATE_PHASE(64,
-            if constexpr (HOLD) pack_observations<true>(c, held);
-            else { PackDescriptors now; pack_observations<false>(c, now); });
+            if constexpr (HOLD) pack_observations<true, Shape::kGreedyHeld>(c, held);
+            else { PackDescriptors now; pack_observations<false, Shape::kGreedyHeld>(c, now); });
         }
         wave_sync();
         stepped = true;

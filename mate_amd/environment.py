@@ -634,7 +634,7 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
         (cam_obs, tgt_obs), (r_cam, r_tgt), done, info = env.step((cam_act, tgt_act))
 
     `first_env_index` makes the RNG streams of a shard equal to those of the same environments in a
-    larger single-GPU batch (sharding invariance, DESIGN.md section "multi-GPU")."""
+    larger single-GPU batch (sharding invariance)."""
 
     def __init__(self, config=None, num_envs=1, device=0, seed=0, first_env_index=0, obs_dtype=torch.float32, auto_reset=True,
                  relative_coordinates=False, rescaled_observation=False, enhanced_observation=None, shared_field_of_view=None,
@@ -695,13 +695,13 @@ class BatchedMultiAgentTracking(_ScenarioMixin):
         return (cam, tgt), (s[..., 0], s[..., 1]), s[..., 2] == 1, info
 
     def rollout_random(self, steps):
-        """`steps` env.step(random action) iterations in ONE launch (the fastest flow): every tensor of
+        """`steps` env.step(random action) iterations in ONE launch (the fastest flow, profiles/HISTORY.md 3.1b): every tensor of
         step()'s result with a leading [steps] axis.  Finished episodes restart after the launch."""
         return self._rollout_result(self.engine.rollout_random(steps, auto_reset=int(self.auto_reset)))
 
     def rollout_greedy(self, steps):
         """`steps` iterations of mate.group_step with the reference's Greedy camera / target agents + env.step in ONE
-        launch (agents on the device)."""
+        launch (agents on the device, profiles/HISTORY.md 3.1c)."""
         if not getattr(self, '_policies_on', False):
             raise RuntimeError('enable_greedy_policies() must precede the reset() the agents first act on')
         return self._rollout_result(self.engine.rollout_greedy(steps, auto_reset=int(self.auto_reset)))

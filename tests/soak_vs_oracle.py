@@ -4,7 +4,7 @@
 
 Native reset + Philox random-policy rollout of N environments for S steps, the CPU oracle stepping the same
 streams beside the GPU.  Counts environments whose masks / integer state ever differ from the oracle's and the
-largest position error; a tangent-ray coin flip of the reference (DESIGN.md section 4) would show up here as a
+largest position error; a tangent-ray coin flip of the reference (DESIGN.md section 5) would show up here as a
 diverging environment, which is why this is a census and not an assertion."""
 import os
 import sys

@@ -160,7 +160,7 @@ def test_step_masks_with_independently_built_tables(workload, n, oracle_lib):
     """The same census with the oracle keeping the occlusion tables IT built (nothing copied from the device), so that a
     table divergence would surface as a mask disagreement.  The two builders differ only where the reference itself is
     a coin flip -- rays exactly tangent to an obstacle, clipped or not by the last bit of asin / atan2 (DESIGN.md
-    section 4), at most two knots per obstacle and table -- and a target has to stand within a hundredth of a degree
+    section 5), at most two knots per obstacle and table -- and a target has to stand within a hundredth of a degree
     of such a ray, behind the obstacle, inside the sector, to notice: at most 1 environment in 256 may diverge, and all
     the others must agree with the oracle exactly."""
     diverged, worst, obs_ok, rew_ok = _census(workload, n, 40, 1, True, oracle_lib)

@@ -118,7 +118,7 @@ def test_reset_tape_parity(path):
         p2, r2 = env.get_lut(c)
         assert len(p2) == len(phis), (c, len(p2), len(phis))
         np.testing.assert_allclose(p2, phis, rtol=0, atol=1e-10)
-        # tangent-ray coin flips of the reference itself (DESIGN.md section 4): at a tangent direction or nowhere
+        # tangent-ray coin flips of the reference itself (DESIGN.md section 5): at a tangent direction or nowhere
         flips += G.assert_only_tangent_flips(phis, r2, rhos, fx['static/cam_xy'][c], float(fx['static/cam_max_sight_range'][c]), fx['static/obs_xyr'], 1e-8, c)
     for m in G.MASK_FIELDS:
         assert np.array_equal(np.asarray(env.get(m)) != 0, fx['reset/' + m].astype(bool)), m

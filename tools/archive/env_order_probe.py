@@ -25,7 +25,7 @@ eng.reset()
 lib = eng.lib
 if not hasattr(lib, 'mate_engine_env_order'):
     raise SystemExit('tools/archive/env_order_probe.py: this tree does not export mate_engine_env_order -- the kernel side of the experiment was removed '
-                     'when it measured no gain (DESIGN.md section 5, profiles/r04_env_order_probe.txt); the script is kept as the record of how it was run')
+                     'when it measured no gain (profiles/HISTORY.md section 5, profiles/r04_env_order_probe.txt); the script is kept as the record of how it was run')
 lib.mate_engine_debug_phase_clocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.mate_engine_env_order.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 buf = torch.zeros((batch, 16), dtype=torch.int64, device='cuda')

@@ -1,4 +1,4 @@
-// Which PHYSICAL chunks may be written side by side?  ("the stores": the same block allocated twice takes the fused
+// Which PHYSICAL chunks may be written side by side?  (profiles/HISTORY.md 3.1b, "the stores": the same block allocated twice takes the fused
 // rollout's row stores at 4.3 or 5.5 TB/s; physically contiguous memory is the slowest, shuffled 2 MiB chunks mostly fast.)
 //
 // A pool of 2 MiB physical chunks is created in allocation order (a proxy for physical order: the driver hands chunks out in

@@ -1,4 +1,4 @@
-// Minimal repro of "a reused virtual range loses stores" (mate_engine_block_free): a block of 2 MiB chunks is mapped,
+// Minimal repro of "a reused virtual range loses stores" (profiles/HISTORY.md 3.1b, mate_engine_block_free): a block of 2 MiB chunks is mapped,
 // written, unmapped CHUNK BY CHUNK, its chunks released, hipDeviceSynchronize; then NEW chunks are mapped at the SAME virtual
 // address -- (a) the range kept reserved, (b) the range freed (hipMemAddressFree) and reserved again -- a kernel writes a new pattern
 // and the block is read back three ways: by a kernel, by hipMemcpy to the host, by a device-to-device copy into hipMalloc memory.
