@@ -233,11 +233,11 @@ def launch_ranks(args):
 
 class StatsGather:
     """Episode statistics all-gathered OFF the critical path.  The engine accumulates the record of
-    every finished episode on the device (Engine.episode_stats: count, return, length, coverage, delivered); a gather is
-    an event on the launch stream, and behind it on a SIDE stream a 40-byte copy of the accumulators and the RCCL
-    all-gather of the copy.  Nothing is enqueued on the launch stream but the event.  With the gloo backend (ranks
-    sharing a GPU in the one-box test) the side stream copies into pinned host memory and the collective of the LAST
-    submitted copy runs on the host in result()."""
+    every finished episode on the device (Engine.episode_stats: count, return, length, coverage, delivered); a gather is a
+    40-byte snapshot of the accumulators on the launch stream (one 64-thread launch, Engine.snapshot_episode_stats) and an event
+    behind it, and on a SIDE stream, behind that event, the RCCL all-gather of the snapshot -- with one rank the all-gather is
+    the identity and the side stream has nothing to do.  With the gloo backend (ranks sharing a GPU in the one-box test) the side
+    stream copies the snapshot into pinned host memory and the collective of the LAST submitted copy runs on the host in result()."""
 
     def __init__(self, torch, dist, distributed, eng, host_staged=False):
         self.torch, self.dist, self.distributed, self.eng, self.host_staged = torch, dist, distributed, eng, host_staged
@@ -247,30 +247,29 @@ class StatsGather:
         self.gathered = [[torch.zeros(5, dtype=torch.float64, device=eng.device) for _ in range(world)] for _ in range(2)]
         self.host = [torch.zeros(5, dtype=torch.float64).pin_memory() for _ in range(2)] if host_staged else None
         self.events = [torch.cuda.Event() for _ in range(2)]
+        self.consumed = [None, None]      # per slot: the side stream's event behind its last reader
         self.turn = self.last = 0
         self.count = 0
-        self.marked = False
-
-    def mark(self):
-        """The point of the launch stream the next submit() gathers at (default: where submit() itself is called)."""
-        self.events[self.turn].record()
-        self.marked = True
 
     def submit(self):
         torch = self.torch
-        ready = self.events[self.turn]
-        if not self.marked:
+        if self.consumed[self.turn] is not None:                     # (the collective of two gathers ago has read this slot: long done, no stall)
+            torch.cuda.current_stream(self.eng.device).wait_event(self.consumed[self.turn])
+        self.eng.snapshot_episode_stats(self.slots[self.turn])      # on the launch stream: what has finished up to here
+        if self.host_staged or self.distributed:
+            ready = self.events[self.turn]
             ready.record()
-        self.marked = False
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
-            self.slots[self.turn].copy_(self.eng.episode_stats, non_blocking=True)
-            if self.host_staged:
-                self.host[self.turn].copy_(self.slots[self.turn], non_blocking=True)
-            elif self.distributed:
-                self.dist.all_gather(self.gathered[self.turn], self.slots[self.turn])
-            else:
-                self.gathered[self.turn][0] = self.slots[self.turn]      # one rank: the all-gather is the identity (no second copy)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                if self.host_staged:
+                    self.host[self.turn].copy_(self.slots[self.turn], non_blocking=True)
+                else:
+                    self.dist.all_gather(self.gathered[self.turn], self.slots[self.turn])
+                if self.consumed[self.turn] is None:
+                    self.consumed[self.turn] = torch.cuda.Event()
+                self.consumed[self.turn].record(self.side)
+        else:
+            self.gathered[self.turn][0] = self.slots[self.turn]      # one rank: the all-gather is the identity
         self.last = self.turn
         self.turn ^= 1
         self.count += 1

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get('MATE_ENGINE_LIB') or os.path.join(os.path.dirname(os.
 
 EXPORTED_SYMBOLS = (
     'mate_engine_last_error', 'mate_engine_abi_version', 'mate_engine_create', 'mate_engine_destroy',
-    'mate_engine_get_layout', 'mate_engine_set_obs_transform', 'mate_engine_set_obs_mode', 'mate_engine_set_action_grids', 'mate_engine_seed', 'mate_engine_reset', 'mate_engine_reset_tape', 'mate_engine_step', 'mate_engine_device_tick', 'mate_engine_set_episode_stats', 'mate_engine_step_random',
+    'mate_engine_get_layout', 'mate_engine_set_obs_transform', 'mate_engine_set_obs_mode', 'mate_engine_set_action_grids', 'mate_engine_seed', 'mate_engine_reset', 'mate_engine_reset_tape', 'mate_engine_step', 'mate_engine_device_tick', 'mate_engine_set_episode_stats', 'mate_engine_snapshot_episode_stats', 'mate_engine_step_random',
     'mate_engine_rollout_random', 'mate_engine_policy_enable', 'mate_engine_step_greedy', 'mate_engine_step_versus_greedy', 'mate_engine_rollout_greedy', 'mate_engine_rollout_versus_greedy', 'mate_engine_policy_actions',
     'mate_engine_observe', 'mate_engine_export_state', 'mate_engine_import_state', 'mate_engine_lut_read',
     'mate_engine_block_alloc', 'mate_engine_block_free', 'mate_engine_block_probe', 'mate_engine_set_store_form',
@@ -130,6 +130,7 @@ def load():
     handle.mate_engine_memory_hold.argtypes = [I32, I64, ctypes.POINTER(P)]
     handle.mate_engine_memory_release.argtypes = [P]
     handle.mate_engine_block_probe.argtypes = [I32, P, I64, I32, I32, P, ctypes.POINTER(ctypes.c_double)]
+    handle.mate_engine_snapshot_episode_stats.argtypes = [P, P, P]
     handle.mate_engine_set_sub_wave.argtypes = [P, I32, ctypes.POINTER(I32)]
     handle.mate_engine_hbm_probe.argtypes = [I32, P, P, I64, I32, P, ctypes.POINTER(ctypes.c_double)]
     for name in EXPORTED_SYMBOLS:

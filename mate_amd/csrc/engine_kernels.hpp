@@ -142,6 +142,14 @@ __host__ __device__ constexpr int sub_wave_of(int Nc, int Nt, int No) {
          : (Nc == 4 && Nt == 8 && No == 0) ? 2
          : 1;
 }
+// (experiment, -DMATE_SUB_EIGHT: eight per wave where the agents fit eight lanes and the agents' (sender, recipient) pairs one round)
+__host__ __device__ constexpr int sub_wave_eight(int Nc, int Nt, int No) {
+#ifdef MATE_SUB_EIGHT
+    return (Nc <= 2 && Nt <= 4 && Nc * Nt <= 8) ? 8 : sub_wave_of(Nc, Nt, No);
+#else
+    return sub_wave_of(Nc, Nt, No);
+#endif
+}
 
 // Kernel shape policies: AnyShape reads every constant from the device-resident Params on demand;
 // FixedShape<Nc, Nt, No> is compiled for one scenario shape (the host picks it when the counts match).
@@ -180,7 +188,7 @@ struct FixedShape {
     static constexpr int kHeldGC = (kRowsC + kRowsT <= 12) ? kRowsC : 2, kHeldGT = (kRowsC + kRowsT <= 12) ? kRowsT : 6;
     static constexpr int kChunksC = NC * (13 + 9 + 5 * NT + 4 * NO + 7 * NC) / 4, kChunksT = NT * (13 + 14 + 7 * NC + 4 * NO + 5 * NT) / 4;
     // Environments per wave of the fused rollouts (sub_wave_of below): the scenarios whose agents and visibility pairs fill a quarter of a wave
-    static constexpr int kSubWave = sub_wave_of(NC, NT, NO);
+    static constexpr int kSubWave = sub_wave_eight(NC, NT, NO);
     static constexpr int kGreedyBlocks = 4;
     static constexpr bool kGreedyHeld = true;
     // (MATE-8v8-9 sits at 63 of the 64 registers of full occupancy: with the state's stores ahead of the packer it needs 65)
@@ -346,7 +354,7 @@ enum Flow : int {
 // variants (held roles, the row image, the held state, the compacted sector list) exist for L = 64 only.
 template <typename ObsT, int L = 64>
 struct Ctx {
-    static_assert(L == 64 || L == 32 || L == 16, "lanes per environment: a wave, half a wave, a quarter");
+    static_assert(L == 64 || L == 32 || L == 16 || L == 8, "lanes per environment: a wave, a half, a quarter, an eighth");
     static constexpr int W = L;
     const Params &p;
     const Ptrs &g;
@@ -401,7 +409,8 @@ struct Ctx {
         if constexpr (L == 64) { if (lane == 0) { mask[bit >> 5] = (uint32_t)b; mask[(bit >> 5) + 1] = (uint32_t)(b >> 32); } }
         else if (lane == 0) {
             if constexpr (L == 32) mask[bit >> 5] = (uint32_t)b;
-            else reinterpret_cast<uint16_t *>(mask)[bit >> 4] = (uint16_t)b;
+            else if constexpr (L == 16) reinterpret_cast<uint16_t *>(mask)[bit >> 4] = (uint16_t)b;
+            else reinterpret_cast<uint8_t *>(mask)[bit >> 3] = (uint8_t)b;
         }
     }
     // rounds of L pairs that cover n pairs (Params::sector_rounds / range_rounds count rounds of 64: they lay out the mask BITS)
@@ -2889,7 +2898,7 @@ __device__ __forceinline__ void list_finished_at_entry(Ctx<ObsT, L> &c) {
 template <typename ObsT, typename Shape, int FLOW = FLOW_ANY, int E = 1>
 __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restrict__ pp, const Ptrs g) {
     constexpr int L = 64 / E;
-    static_assert(E == 1 || E == 2 || E == 4, "environments per wave");
+    static_assert(E == 1 || E == 2 || E == 4 || E == 8, "environments per wave");
     const Shape shape(pp, true);
     const Params &p = shape.get();
     extern __shared__ __align__(16) unsigned char smem[];
@@ -2897,7 +2906,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     // wave-uniform by construction; readfirstlane lets the compiler keep everything derived from it in SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int hw_lane = threadIdx.x & 63, lane = hw_lane & (L - 1), shift = hw_lane & ~(L - 1);      // lane inside the environment's group; the group's first lane
-    const int slot = E == 1 ? wave : wave * E + (hw_lane >> (E == 4 ? 4 : 5));                       // the environment's slice of the workgroup's LDS
+    const int slot = E == 1 ? wave : wave * E + (hw_lane >> (E == 8 ? 3 : E == 4 ? 4 : 5));                       // the environment's slice of the workgroup's LDS
     const int64_t env = (int64_t)blockIdx.x * (4 * E) + slot;
     if (env >= g.N) return;               // (E > 1: the groups past the end of the batch leave; the others go on under their EXEC mask)
     const Ptrs &gk = kernarg_ptrs(g);     // launch arguments read where they are used (see step_kernel)

@@ -586,7 +586,7 @@ constexpr int sub_held_chunks(bool camera) { return ((camera ? Shape::kChunksC :
 template <typename ObsT, typename Shape, int E = 1>
 __global__ __launch_bounds__(256, E == 1 ? Shape::kGreedyBlocks : MATE_SUB_BLOCKS) void rollout_greedy_kernel(const Params *__restrict__ pp, const Ptrs g, const PolicyPtrs q_arg) {
     constexpr int L = 64 / E;
-    static_assert(E == 1 || E == 2 || E == 4, "environments per wave");
+    static_assert(E == 1 || E == 2 || E == 4 || E == 8, "environments per wave");
     const PolicyPtrs &q = kernarg_policy_ptrs(q_arg);
     const Shape shape(pp, true);
     const Params &p = shape.get();
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256, E == 1 ? Shape::kGreedyBlocks : MATE_SUB_BLOCK
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int hw_lane = threadIdx.x & 63, lane = hw_lane & (L - 1), shift = hw_lane & ~(L - 1);      // lane inside the environment's group; the group's first lane
-    const int slot = E == 1 ? wave : wave * E + (hw_lane >> (E == 4 ? 4 : 5));                       // the environment's slice of the workgroup's LDS
+    const int slot = E == 1 ? wave : wave * E + (hw_lane >> (E == 8 ? 3 : E == 4 ? 4 : 5));                       // the environment's slice of the workgroup's LDS
     const int64_t env_raw = (int64_t)blockIdx.x * (4 * E) + slot;
     const bool in_batch = env_raw < g.N;
     const int64_t env = in_batch ? env_raw : g.N - 1;

@@ -630,6 +630,12 @@ class Engine:
         check(self.lib.mate_engine_idle_steps(self._h, ctypes.byref(total)))
         return total.value
 
+    def snapshot_episode_stats(self, out):
+        """`out` (5 f64 on the device) <- the episode-statistics accumulators, ordered on the current stream behind the launches enqueued
+        so far (mate_engine_snapshot_episode_stats: one tiny launch)."""
+        check(self.lib.mate_engine_snapshot_episode_stats(self._h, ctypes.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
     def set_sub_wave(self, enable='auto'):
         """Environments per wave of the fused rollouts (mate_engine_set_sub_wave): the small scenarios (at most four cameras and four
         targets) can step four environments per wave.  'auto' (the default of a new engine) = where that measured faster (batches of at
