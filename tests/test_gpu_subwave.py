@@ -116,3 +116,38 @@ def test_sub_wave_is_the_default_only_where_it_is_compiled_and_measured_faster()
         assert eng.set_sub_wave(True) == want and eng.set_sub_wave(False) == 1 and eng.set_sub_wave('auto') == 1
     big = Engine(read_config('MATE-2v4-0.yaml'), 16384, seed=1)
     assert big.sub_wave == 4 and big.set_sub_wave(False) == 1 and big.set_sub_wave('auto') == 4
+
+
+@pytest.mark.parametrize('team,name,skip,interval', [('target', 'MATE-2v4-0', 10, 2), ('camera', 'MATE-2v4-0', 5, 3)])
+def test_graph_replayed_frame_skip_with_four_environments_per_wave(team, name, skip, interval):
+    """The target trainers' loop as bench.py and a learner run it -- FrameSkip(K) over MultiTarget(GreedyCameraAgent), one K-frame launch
+    per learner action, `graph_steps` of them replayed from ONE HIP graph with the step counter on the device -- on the four-per-wave
+    kernels: bit for bit the same launches made one by one with one environment per wave and the host counting, across episode ends."""
+    cfg = read_config(name + '.yaml', max_episode_steps=23)
+    n = 70
+    outs = []
+    for sub, graph_steps in ((False, 0), (True, 2 * interval)):
+        eng = Engine(cfg, n, seed=5)
+        assert eng.set_sub_wave(sub) == (4 if sub else 1)
+        eng.enable_policies()
+        eng.reset()
+        agents = eng.num_cameras if team == 'camera' else eng.num_targets
+        gen = torch.Generator(device='cuda').manual_seed(9)
+        mine = (torch.rand((n, agents, 2), device='cuda', generator=gen) * 2 - 1) * (6 if team == 'camera' else 25)
+        stepper = eng.make_stepper(mine if team == 'camera' else None, mine if team == 'target' else None, auto_reset=interval,
+                                   graph_steps=graph_steps, between=lambda m=mine: m.mul_(-1.0).add_(0.125), versus=team, frame_skip=skip)
+        rec = []
+        if not graph_steps:
+            stepper.run(interval)             # what the constructor's warm-up (one reset interval) did on the graph side
+        for chunk in (4 * interval, interval + 1, 2 * interval - 1):
+            co, to, sc = stepper.run(chunk)
+            torch.cuda.synchronize()
+            rec.append([t.clone() for t in (co, to, sc) if t.numel()])
+        stepper.close()
+        rec.append([eng.export_state().clone(), eng.policy_actions()[0 if team == 'target' else 1].clone()])
+        outs.append(rec)
+        del stepper, eng
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert same(x, y)
+    assert float(outs[0][-1][0][:, -2].min()) >= 2          # (export column `episode`) every environment restarted at least once
