@@ -1426,7 +1426,19 @@ __device__ __forceinline__ void update_view(Ctx<ObsT, L> &c, uint32_t tick, uint
     } else {
         // ---- sector tests for camera->target and camera->camera; all rounds but the last resolve at once, the last round's
         // occlusion records travel while the range tests run
-        for (int round = 0; round + 1 < MATE_N_SR; ++round) {
+        // Sub-wave groups with TWO rounds of sector pairs (MATE-4v2-*: 24 pairs, MATE-4v4-*: 32, in rounds of 16): both rounds' occlusion
+        // records travel while the range tests run -- resolved one after the other, the first round's record was a bare round trip to
+        // L2 / HBM on every step (the view phase of the four-per-wave MATE-4v2-9 rollout: 9.5 k of a step's 24 k cycles).
+        // (MATE-4v2-* only: the MATE-4v4-9 kernels have no 24 registers left for a second record)
+        const bool both_in_flight = L < 64 && MATE_N_SR == 2 && p.Nc * p.Nt < 16;
+        SectorEval early;
+        early.seen = false; early.need = false;
+        double2 w_early[kDegWords];
+        if (both_in_flight) {
+            early = sector_eval(c, lane, tick, stream, predrawn);
+            sector_fetch(c, early, w_early);
+        }
+        for (int round = 0; round + 1 < MATE_N_SR && !both_in_flight; ++round) {
             const SectorEval e = sector_eval(c, round * L + lane, tick, stream, predrawn);
             sector_fetch(c, e, w);
             const bool seen = sector_resolve(c, e, w);
@@ -1450,6 +1462,11 @@ __device__ __forceinline__ void update_view(Ctx<ObsT, L> &c, uint32_t tick, uint
         SUB_COUNT(c, 0, pending.need);                   // steps with an occlusion lookup
         range_tests();
         SUB_ACC(c, 1);                                   // range tests
+        if (both_in_flight) {
+            const bool seen = sector_resolve(c, early, w_early);
+            if (lane < p.n_sector) set_flag(c, lane, seen);
+            c.put_bits(0, c.ballot(seen));
+        }
         if (last >= 0) {
             const bool seen = sector_resolve(c, pending, w);
             SUB_ACC(c, 2);                               // wait for the record + interpolation (+ overflow trips)
@@ -1921,58 +1938,81 @@ __device__ __forceinline__ void store_masks(const Ctx<ObsT, L> &c) {
 }
 
 // Both f32 row blocks of a shape whose rows are NOT whole 16-byte chunks everywhere (MATE-4v2-*: two target rows of 101 floats; the
-// 1vN shapes), with EVERY descriptor of the lane fetched before the lane's first store.  pack_block fetches its descriptors inside
+// 1vN shapes), with EVERY descriptor of the lane in registers before the lane's first store.  pack_block fetches its descriptors inside
 // its loop: on gfx9 loads and stores retire through one in-order counter, so a descriptor load issued behind a row store is waited
 // for together with that store's HBM acknowledgement -- the PMC passes of the four-per-wave MATE-4v2-9 rollout showed waves waiting
 // 62 % of their cycles with 231 vector instructions per environment-step (profiles/r06_pmc_subwave_first.json).  Compiled shapes only
 // (the counts are literals, the arrays registers); a block takes 16-byte chunks when its element count is a multiple of 4, 8-byte
-// chunks when it is even.  False = not applicable: the caller runs the loops.
+// chunks when it is even.  load_odd_descriptors fetches them at the top of every step's pack, ahead of the step's stores
+// (pack_blocks_prefetched); holding them for the whole launch instead -- 38 registers on MATE-4v2-9 in sixteen-lane groups -- measured
+// no faster (0.493 against 0.496 of the roofline at 16 384 environments) and was dropped.  False = not applicable, the caller runs
+// pack_block's loops.
+constexpr int kOddCap = 8;                                       // descriptors of a block per lane
+struct OddDescriptors { uint4 dc[kOddCap], dt[kOddCap]; };
 template <typename ObsT, int L>
-__device__ __forceinline__ bool pack_blocks_prefetched(const Ctx<ObsT, L> &c) {
-    if constexpr (sizeof(ObsT) != 4) return false;
-    else {
+__device__ __forceinline__ bool odd_rows_apply(const Ctx<ObsT, L> &c, int &wc, int &wt, int &nc, int &nt) {
+    const Params &p = c.p;
+    wc = p.cam_elems == 0 ? 4 : (p.cam_elems % 4 == 0 ? 4 : (p.cam_elems % 2 == 0 ? 2 : 0));
+    wt = p.tgt_elems % 4 == 0 ? 4 : (p.tgt_elems % 2 == 0 ? 2 : 0);
+    if (sizeof(ObsT) != 4 || wc == 0 || wt == 0) return false;
+    nc = p.cam_elems / wc; nt = p.tgt_elems / wt;
+    return nc <= kOddCap * L && nt <= kOddCap * L && c.has_tgt_obs() && (p.cam_elems == 0 || c.has_cam_obs()) && !c.xdesc();
+}
+__device__ __forceinline__ void pin_odd_descriptors(OddDescriptors &d, int nc, int nt, int L) {
+#pragma unroll
+    for (int k = 0; k < kOddCap; ++k) {
+        if (L * k < nc) asm volatile("" : "+v"(d.dc[k].x), "+v"(d.dc[k].y), "+v"(d.dc[k].z), "+v"(d.dc[k].w));
+        if (L * k < nt) asm volatile("" : "+v"(d.dt[k].x), "+v"(d.dt[k].y), "+v"(d.dt[k].z), "+v"(d.dt[k].w));
+    }
+}
+template <typename ObsT, int L>
+__device__ __forceinline__ bool load_odd_descriptors(const Ctx<ObsT, L> &c, OddDescriptors &d) {
+    int wc, wt, nc, nt;
+    if (!odd_rows_apply(c, wc, wt, nc, nt)) return false;
+    const uint32_t *tabc = c.table, *tabt = c.table + c.p.tgt_table_off;
+#pragma unroll
+    for (int k = 0; k < kOddCap; ++k) {
+        const int i = c.lane + L * k, ic = i < nc ? i : 0, it = i < nt ? i : 0;
+        d.dc[k] = make_uint4(0u, 0u, 0u, 0u); d.dt[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (L * k < nc) { if (wc == 4) d.dc[k] = reinterpret_cast<const uint4 *>(tabc)[ic]; else { const uint2 q = reinterpret_cast<const uint2 *>(tabc)[ic]; d.dc[k].x = q.x; d.dc[k].y = q.y; } }
+        if (L * k < nt) { if (wt == 4) d.dt[k] = reinterpret_cast<const uint4 *>(tabt)[it]; else { const uint2 q = reinterpret_cast<const uint2 *>(tabt)[it]; d.dt[k].x = q.x; d.dt[k].y = q.y; } }
+    }
+    pin_odd_descriptors(d, nc, nt, L);                           // every descriptor before the first store
+    return true;
+}
+template <typename ObsT, int L>
+__device__ __forceinline__ void pack_blocks_odd(const Ctx<ObsT, L> &c, const OddDescriptors &d) {
+    if constexpr (sizeof(ObsT) == 4) {
         const Params &p = c.p;
-        constexpr int CAP = 8;                                   // descriptors of a block per lane
-        const int wc = p.cam_elems == 0 ? 4 : (p.cam_elems % 4 == 0 ? 4 : (p.cam_elems % 2 == 0 ? 2 : 0));
-        const int wt = p.tgt_elems % 4 == 0 ? 4 : (p.tgt_elems % 2 == 0 ? 2 : 0);
-        if (wc == 0 || wt == 0) return false;
-        const int nc = p.cam_elems / wc, nt = p.tgt_elems / wt;
-        if (nc > CAP * L || nt > CAP * L || !c.has_tgt_obs() || (p.cam_elems > 0 && !c.has_cam_obs())) return false;
+        int wc, wt, nc, nt;
+        (void)odd_rows_apply(c, wc, wt, nc, nt);
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const uint32_t *tabc = c.table, *tabt = c.table + p.tgt_table_off;
-        uint4 dc[CAP], dt[CAP];
-#pragma unroll
-        for (int k = 0; k < CAP; ++k) {
-            const int i = c.lane + L * k, ic = i < nc ? i : 0, it = i < nt ? i : 0;
-            dc[k] = make_uint4(0u, 0u, 0u, 0u); dt[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (L * k < nc) { if (wc == 4) dc[k] = reinterpret_cast<const uint4 *>(tabc)[ic]; else { const uint2 d = reinterpret_cast<const uint2 *>(tabc)[ic]; dc[k].x = d.x; dc[k].y = d.y; } }
-            if (L * k < nt) { if (wt == 4) dt[k] = reinterpret_cast<const uint4 *>(tabt)[it]; else { const uint2 d = reinterpret_cast<const uint2 *>(tabt)[it]; dt[k].x = d.x; dt[k].y = d.y; } }
-        }
-#pragma unroll
-        for (int k = 0; k < CAP; ++k) {                          // every descriptor before the first store
-            if (L * k < nc) asm volatile("" : "+v"(dc[k].x), "+v"(dc[k].y), "+v"(dc[k].z), "+v"(dc[k].w));
-            if (L * k < nt) asm volatile("" : "+v"(dt[k].x), "+v"(dt[k].y), "+v"(dt[k].z), "+v"(dt[k].w));
-        }
         float *cam = reinterpret_cast<float *>(c.g.cam_obs) + c.out * p.cam_elems, *tgt = reinterpret_cast<float *>(c.g.tgt_obs) + c.out * p.tgt_elems;
 #pragma unroll
-        for (int k = 0; k < CAP; ++k) {
+        for (int k = 0; k < kOddCap; ++k) {
             const int i = c.lane + L * k;
             if (L * k < nc && i < nc) {
-                if (wc == 4) stream_store(f32x4{gather_one(c, dc[k].x), gather_one(c, dc[k].y), gather_one(c, dc[k].z), gather_one(c, dc[k].w)}, reinterpret_cast<f32x4 *>(cam) + i);
-                else stream_store(f32x2{gather_one(c, dc[k].x), gather_one(c, dc[k].y)}, reinterpret_cast<f32x2 *>(cam) + i);
+                if (wc == 4) stream_store(f32x4{gather_one(c, d.dc[k].x), gather_one(c, d.dc[k].y), gather_one(c, d.dc[k].z), gather_one(c, d.dc[k].w)}, reinterpret_cast<f32x4 *>(cam) + i);
+                else stream_store(f32x2{gather_one(c, d.dc[k].x), gather_one(c, d.dc[k].y)}, reinterpret_cast<f32x2 *>(cam) + i);
             }
         }
 #pragma unroll
-        for (int k = 0; k < CAP; ++k) {
+        for (int k = 0; k < kOddCap; ++k) {
             const int i = c.lane + L * k;
             if (L * k < nt && i < nt) {
-                if (wt == 4) stream_store(f32x4{gather_one(c, dt[k].x), gather_one(c, dt[k].y), gather_one(c, dt[k].z), gather_one(c, dt[k].w)}, reinterpret_cast<f32x4 *>(tgt) + i);
-                else stream_store(f32x2{gather_one(c, dt[k].x), gather_one(c, dt[k].y)}, reinterpret_cast<f32x2 *>(tgt) + i);
+                if (wt == 4) stream_store(f32x4{gather_one(c, d.dt[k].x), gather_one(c, d.dt[k].y), gather_one(c, d.dt[k].z), gather_one(c, d.dt[k].w)}, reinterpret_cast<f32x4 *>(tgt) + i);
+                else stream_store(f32x2{gather_one(c, d.dt[k].x), gather_one(c, d.dt[k].y)}, reinterpret_cast<f32x2 *>(tgt) + i);
             }
         }
-        return true;
     }
+}
+template <typename ObsT, int L>
+__device__ __forceinline__ bool pack_blocks_prefetched(const Ctx<ObsT, L> &c) {
+    OddDescriptors d;
+    if (!load_odd_descriptors(c, d)) return false;
+    pack_blocks_odd(c, d);
+    return true;
 }
 
 // HELD: the caller loaded this lane's descriptors before (the rollout kernel, once per launch); otherwise they are
