@@ -739,8 +739,9 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT, L> &c, const StepDraw
     const int lane = c.lane;
     const int t = lane - p.Nc;
     const bool is_target = t >= 0 && t < p.Nt;
-    // (sub-wave groups, L < 64: the LDS form of the screen below -- its verdicts land in the target's own words whatever the lane count)
+    // (sub-wave groups, L < 64: the verdicts of all rounds in ONE 64-bit word -- every such shape has at most 64 (target, circle) pairs)
     const bool ballot_screen = L == 64 && !carried && p.Nt * p.NK <= 64 * kNearWords && p.NK <= 64;
+    const bool group_screen = L < 64 && !carried && p.Nt * p.NK <= 64;
     double ox = 0.0, oy = 0.0, vx = 0.0, vy = 0.0, n = 0.0, desx = 0.0, desy = 0.0;
     if (is_target) {
         double ax, ay;
@@ -775,7 +776,7 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT, L> &c, const StepDraw
 #endif
         }
         desx = ox + vx; desy = oy + vy;
-        if (!carried) { c.snorm(t) = n; if (!ballot_screen) { c.near(t) = 0; c.near(p.Nt + t) = 0; } }
+        if (!carried) { c.snorm(t) = n; if (!ballot_screen && !group_screen) { c.near(t) = 0; c.near(p.Nt + t) = 0; } }
     }
     uint64_t todo_carried = 0;
     if (carried) {
@@ -814,6 +815,22 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT, L> &c, const StepDraw
                 if (word == k) { lo = hit[k]; hi = k + 1 < kNearWords ? hit[k + 1] : 0ull; }
             todo_carried = ((lo >> sh) | (sh ? hi << (64 - sh) : 0ull)) & (p.NK >= 64 ? ~0ull : ((1ull << p.NK) - 1ull));
         }
+    } else if (group_screen) {
+        wave_sync();
+        const int npairs = p.Nt * p.NK;
+        unsigned long long bits = 0ull;
+        for (int base = 0; base < npairs; base += L) {
+            const int q = base + lane, qq = q < npairs ? q : 0;
+            const int tt = (int)(((float)qq + 0.5f) * p.inv_NK);
+            const int k = qq - tt * p.NK;
+            const int j = k < p.No ? p.Nc + k : k - p.No, tj = c.tgt_slot(tt);
+            const float dx = c.exf[j] - c.exf[tj], dy = c.eyf[j] - c.eyf[tj];
+            const float d2 = fmaf(dy, dy, dx * dx);
+            const float nn = (float)c.snorm(tt);
+            const float reach = nn + c.erf[j] + 1e-3f;             // (the same conservative f32 test as the other two forms)
+            bits |= c.ballot(q < npairs && nn != 0.0f && !(d2 > reach * reach)) << base;
+        }
+        if (is_target) todo_carried = (bits >> (t * p.NK)) & ((1ull << p.NK) - 1ull);
     } else {
     wave_sync();
     SUB_STAMP(c, 10);
@@ -839,7 +856,7 @@ __device__ __forceinline__ void simulate_targets(Ctx<ObsT, L> &c, const StepDraw
     }
     SUB_STAMP(c, 11);
     if (is_target) {
-        uint64_t todo = (carried || ballot_screen) ? todo_carried : ((uint64_t)(uint32_t)c.near(t) | ((uint64_t)(uint32_t)c.near(p.Nt + t) << 32));
+        uint64_t todo = (carried || ballot_screen || group_screen) ? todo_carried : ((uint64_t)(uint32_t)c.near(t) | ((uint64_t)(uint32_t)c.near(p.Nt + t) << 32));
         bool n_known = true;
         while (todo) {
             const int k = __ffsll((long long)todo) - 1;
