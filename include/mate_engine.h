@@ -420,7 +420,7 @@ int mate_engine_block_probe(int32_t device, void *block, int64_t bytes, int32_t 
  * environment onto one 64-lane wave; the small scenarios (at most four cameras and four targets: MATE-{1v1,1v2,2v2,2v4,4v2,4v4}-{0,9}, e.g. the
  * MATE-2v4-0 of the reference's target trainers, examples/ippo/target/config.py:63-66) fill a quarter of one, so their fused rollouts
  * can step FOUR environments per wave, sixteen lanes each -- same results, bit for bit.  `enable`: 0 = one per wave; 1 = the shape's
- * own number in every fused launch; 2 (the default; MATE_SUBWAVE=0 in the environment makes 0 the default) = where it measured faster:
+ * own number in every fused launch; 2 (the default; MATE_SUBWAVE=0 / MATE_SUBWAVE=1 in the environment make 0 / 1 the default) = where it measured faster:
  * batches of at least 32 environments per compute unit, and under the random policy every such shape but MATE-4v4-* (whose
  * one-per-wave rollout, carried by the register-resident row image, is as fast); negative = leave it as it is.  `*in_use` (may be NULL) receives
  * the number the Greedy rollouts of this engine now run with (1 for a shape without such kernels).  Takes effect from the next launch

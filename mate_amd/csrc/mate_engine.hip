@@ -114,7 +114,7 @@ struct Switches {
     bool policy_split = false;     // MATE_POLICY_SPLIT=1: step_greedy / step_versus_greedy as two launches (agents' kernel, step kernel) even when the fused one-launch form applies
     int step_split = -1;           // MATE_STEP_SPLIT=0 / 1: the one-wave / two-wave form of the per-step kernel in the folded flows (-1: by batch size)
     bool zoom_iterate = false;     // MATE_ZOOM_ITERATE=1: the greedy camera agents iterate the zoom solve (greedy.py:139-145) instead of reading its table
-    bool no_sub_wave = false;      // MATE_SUBWAVE=0: one environment per wave in the fused rollouts of the small scenarios too (mate_engine_set_sub_wave switches at run time)
+    int sub_wave_mode = 2;         // MATE_SUBWAVE=0 / 1: one environment per wave in the fused rollouts of the small scenarios too / the shape's number in EVERY fused launch (default 2: where it measured faster; mate_engine_set_sub_wave switches at run time)
     bool step_greedy_rollout = false;   // MATE_STEP_GREEDY_ROLLOUT=1: the one-launch form of step_greedy / step_versus_greedy on rollout_greedy_kernel with one step (round 3) instead of step_greedy_kernel
 };
 static Switches read_switches() {
@@ -130,7 +130,7 @@ static Switches read_switches() {
     w.policy_split = flag("MATE_POLICY_SPLIT");
     w.step_greedy_rollout = flag("MATE_STEP_GREEDY_ROLLOUT");
     w.no_image = flag("MATE_NO_IMAGE");
-    if (const char *v = getenv("MATE_SUBWAVE")) w.no_sub_wave = atoi(v) == 0;
+    if (const char *v = getenv("MATE_SUBWAVE")) w.sub_wave_mode = atoi(v) == 0 ? 0 : 1;
     if (const char *v = getenv("MATE_STEP_SPLIT")) w.step_split = atoi(v) != 0;
     return w;
 }
@@ -387,7 +387,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
     e->step_lds = 4 * (size_t)p.lds_wave_bytes;
     e->sw = read_switches();
     pick_kernels(Nc, Nt, No, p.obs_f64 != 0, e->sw.generic, e->sw.no_image, e->step_fn, e->rollout_fn, &e->policy_fn, &e->rollout_greedy_fn, &e->specialised, &e->image, e->split_fn, &e->step_greedy_fn, &e->sub);
-    e->sub_mode = e->sw.no_sub_wave ? 0 : 2;
+    e->sub_mode = e->sw.sub_wave_mode;
     { Params pi = p; fill_shape(pi, Nc, Nt, No, false, true); e->image_wave_bytes = e->image ? (size_t)pi.lds_wave_bytes : (size_t)p.lds_wave_bytes; }
     e->flow_generic = e->sw.flow_generic;
     if (p.lds_wave_bytes > 0xffff) { delete e; return fail(MATE_EINVAL, "scenario too large for 16-bit LDS descriptors"); }

@@ -151,3 +151,16 @@ def test_graph_replayed_frame_skip_with_four_environments_per_wave(team, name, s
         for x, y in zip(a, b):
             assert same(x, y)
     assert float(outs[0][-1][0][:, -2].min()) >= 2          # (export column `episode`) every environment restarted at least once
+
+
+@pytest.mark.parametrize('workload', ['MATE-2v4-0.yaml', 'MATE-4v2-9.yaml', 'MATE-1v2-9.yaml', 'MATE-4v4-9.yaml'])
+def test_four_per_wave_census_against_the_oracle(workload, oracle_lib, monkeypatch):
+    """... and directly against the CPU oracle on the same Philox streams (not only through the one-per-wave kernels): native reset +
+    fused random-policy rollouts with four environments per wave forced (MATE_SUBWAVE=1) -- no environment may differ in a mask bit or
+    an integer at any step, positions 1e-9, both teams' f32 rows 1e-5 relative and the reward at EVERY step."""
+    from test_gpu_stepper import _census
+    monkeypatch.setenv('MATE_SUBWAVE', '1')
+    diverged, worst, obs_ok, rew_ok = _census(workload, 176, 24, 8, False, oracle_lib, seed=7, first=300)
+    assert diverged == 0 and worst < 1e-9 and obs_ok and rew_ok, (diverged, worst, obs_ok, rew_ok)
+    eng = Engine(read_config(workload), 8, seed=1)
+    assert eng.sub_wave == 4                                   # the switch was in force (engines read it when they are created)
