@@ -335,6 +335,9 @@ __device__ __forceinline__ bool build_lut(Ctx<ObsT> &c, int cam, double *keys, d
                 a = normalize_angle(a);
             }
             double sn, cs;
+#ifdef MATE_ABLATE_DEGREE_SINCOS      // (experiment: what a sin / cos TABLE for the 360 integer-degree rays could save at most -- their evaluation made free, wrong values)
+            if (i < 360) { sn = 0.0; cs = 1.0; } else
+#endif
             sincos_deg(a, sn, cs);
             for (int q = 0; q < No; ++q) {                                        // entities.py:450-455
                 if (m_num[q] <= 0) continue;
