@@ -146,6 +146,8 @@ __host__ __device__ constexpr int sub_wave_of(int Nc, int Nt, int No) {
 __host__ __device__ constexpr int sub_wave_eight(int Nc, int Nt, int No) {
 #ifdef MATE_SUB_EIGHT
     return (Nc <= 2 && Nt <= 4 && Nc * Nt <= 8) ? 8 : sub_wave_of(Nc, Nt, No);
+#elif defined(MATE_SUB_TWO)      // (experiment: two per wave where four are the rule)
+    return sub_wave_of(Nc, Nt, No) == 4 ? 2 : sub_wave_of(Nc, Nt, No);
 #else
     return sub_wave_of(Nc, Nt, No);
 #endif
