@@ -202,7 +202,8 @@ int mate_engine_step(mate_engine *engine, const mate_step_io *io, int32_t auto_r
  * handful of atomics per finished episode.  The caller zeroes / reads the buffer on its own streams. */
 int mate_engine_set_episode_stats(mate_engine *engine, double *stats_dev);
 /* ... and a snapshot of those 5 doubles into `dst_dev`, ordered on `stream` behind everything enqueued on it so far (one tiny launch):
- * the buffer a sharded job all-gathers while later launches go on accumulating (bench.py, StatsGather). */
+ * the buffer a sharded job all-gathers while later launches go on accumulating (bench.py, StatsGather).  No reference counterpart:
+ * the reference's trainers log episode returns on the host (SURVEY.md section 8e defines the record). */
 int mate_engine_snapshot_episode_stats(mate_engine *engine, double *dst_dev, void *stream);
 
 /* Graph-replayable stepping (the learner-in-the-loop flow: policy kernels write the joint actions into caller
