@@ -1960,7 +1960,7 @@ __device__ __forceinline__ void store_masks(const Ctx<ObsT, L> &c) {
 // 1vN shapes), with EVERY descriptor of the lane in registers before the lane's first store.  pack_block fetches its descriptors inside
 // its loop: on gfx9 loads and stores retire through one in-order counter, so a descriptor load issued behind a row store is waited
 // for together with that store's HBM acknowledgement -- the PMC passes of the four-per-wave MATE-4v2-9 rollout showed waves waiting
-// 62 % of their cycles with 231 vector instructions per environment-step (profiles/r06_pmc_subwave_first.json).  Compiled shapes only
+// 62 % of their cycles with 231 vector instructions per environment-step (profiles/r06_pmc_summary.json).  Compiled shapes only
 // (the counts are literals, the arrays registers); a block takes 16-byte chunks when its element count is a multiple of 4, 8-byte
 // chunks when it is even.  load_odd_descriptors fetches them at the top of every step's pack, ahead of the step's stores
 // (pack_blocks_prefetched); holding them for the whole launch instead -- 38 registers on MATE-4v2-9 in sixteen-lane groups -- measured
