@@ -76,7 +76,7 @@ static int fail(int code, const char *fmt, ...) {
 static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no_image, StepFn *step, StepFn *rollout, PolicyFn *policy, PolicyFn *rollout_greedy,
                          int *specialised, int *image, StepFn *split, PolicyFn *step_greedy, KernelSet *sub) {
     *specialised = 0; *image = 0;
-    sub->rollout_sub[0] = sub->rollout_sub[1] = nullptr; sub->rollout_greedy_sub = nullptr; sub->sub_wave = 1; sub->rollout_greedy_image = nullptr;
+    sub->rollout_sub[0] = sub->rollout_sub[1] = nullptr; sub->rollout_greedy_sub = nullptr; sub->sub_wave = 1;
     *step_greedy = f64 ? nullptr : (PolicyFn)step_greedy_kernel<float, AnyShape>;
     for (int i = 0; i < 3; ++i) split[i] = nullptr;      // the two-wave step (step_split_kernel): f32 observations, the folded flows
     if (!generic) {
@@ -89,7 +89,6 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no
             *policy = k.policy; *rollout_greedy = k.rollout_greedy; *step_greedy = k.step_greedy;
             *specialised = 1; *image = k.image;
             sub->rollout_sub[0] = k.rollout_sub[0]; sub->rollout_sub[1] = k.rollout_sub[1]; sub->rollout_greedy_sub = k.rollout_greedy_sub; sub->sub_wave = k.sub_wave;
-            sub->rollout_greedy_image = no_image ? nullptr : k.rollout_greedy_image;
             return;
         }
     }
@@ -115,7 +114,6 @@ struct Switches {
     bool policy_split = false;     // MATE_POLICY_SPLIT=1: step_greedy / step_versus_greedy as two launches (agents' kernel, step kernel) even when the fused one-launch form applies
     int step_split = -1;           // MATE_STEP_SPLIT=0 / 1: the one-wave / two-wave form of the per-step kernel in the folded flows (-1: by batch size)
     bool zoom_iterate = false;     // MATE_ZOOM_ITERATE=1: the greedy camera agents iterate the zoom solve (greedy.py:139-145) instead of reading its table
-    int greedy_image = -1;         // MATE_GREEDY_IMAGE=0 / 1: the fused Greedy rollouts never / always on the row image where that kernel exists (-1: by batch size)
     int sub_wave_mode = 2;         // MATE_SUBWAVE=0 / 1: one environment per wave in the fused rollouts of the small scenarios too / the shape's number in EVERY fused launch (default 2: where it measured faster; mate_engine_set_sub_wave switches at run time)
     bool step_greedy_rollout = false;   // MATE_STEP_GREEDY_ROLLOUT=1: the one-launch form of step_greedy / step_versus_greedy on rollout_greedy_kernel with one step (round 3) instead of step_greedy_kernel
 };
@@ -132,7 +130,6 @@ static Switches read_switches() {
     w.policy_split = flag("MATE_POLICY_SPLIT");
     w.step_greedy_rollout = flag("MATE_STEP_GREEDY_ROLLOUT");
     w.no_image = flag("MATE_NO_IMAGE");
-    if (const char *v = getenv("MATE_GREEDY_IMAGE")) w.greedy_image = atoi(v) != 0;
     if (const char *v = getenv("MATE_SUBWAVE")) w.sub_wave_mode = atoi(v) == 0 ? 0 : 1;
     if (const char *v = getenv("MATE_STEP_SPLIT")) w.step_split = atoi(v) != 0;
     return w;
@@ -1004,7 +1001,6 @@ extern "C" int mate_engine_rollout_random(mate_engine *e, const mate_step_io *io
 }
 
 // LDS per workgroup of the two one-launch forms of a step with the on-device agents
-static size_t fused_rollout_lds_image(const mate_engine *e) { return 4 * e->image_wave_bytes + 4 * (size_t)policy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt) + 1024; }
 // (the 1024 bytes behind the slices: the exchange area of the zoom solve the agents once shared -- nothing reads it since the solve became a table lookup; the
 // one-per-wave launches keep their size, the sub-wave launches, whose occupancy the LDS bounds, do without)
 static size_t fused_rollout_lds(const mate_engine *e, int E = 1) { return (size_t)E * (4 * (size_t)e->p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(e->q.PW, e->p.Nc, e->p.Nt)) + (E == 1 ? 1024 : 0); }
@@ -1057,8 +1053,6 @@ static int policy_enable(mate_engine *e) {
         const size_t fused = 4 * (size_t)p.lds_wave_bytes + 4 * (size_t)policy_slice_bytes(q.PW, p.Nc, p.Nt) + 1024;
         if (fused <= 160 * 1024)
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rollout_greedy_fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused);
-        if (err == hipSuccess && e->sub.rollout_greedy_image && fused_rollout_lds_image(e) <= 160 * 1024)
-            err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->sub.rollout_greedy_image), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_rollout_lds_image(e));
         if (err == hipSuccess && e->sub.rollout_greedy_sub && fused_rollout_lds(e, e->sub.sub_wave) <= 160 * 1024)
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->sub.rollout_greedy_sub), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_rollout_lds(e, e->sub.sub_wave));
     }
@@ -1204,13 +1198,9 @@ static int rollout_with_policies(mate_engine *e, int team_caller, const mate_ste
     const bool light = per_step && use_step_greedy(e);
     // E environments per wave: the fused launches of the small scenarios (not the per-step flows' one-step form)
     const int E = (!per_step && fused_rollout_lds(e, e->sub.sub_wave) <= 160 * 1024) ? sub_wave_of_launch(e, true) : 1;
-    // the row-image compilation of the fused Greedy rollout (MATE-4v8-9): three workgroups per CU instead of four, so only where a launch
-    // holds several generations of them anyway (MATE_GREEDY_IMAGE forces either)
-    const bool image = !per_step && E == 1 && e->sub.rollout_greedy_image && fused_rollout_lds_image(e) <= 160 * 1024 &&
-                       (e->sw.greedy_image >= 0 ? e->sw.greedy_image != 0 : e->N >= 64 * e->cus);
-    const PolicyFn fn = light ? e->step_greedy_fn : E > 1 ? e->sub.rollout_greedy_sub : image ? e->sub.rollout_greedy_image : e->rollout_greedy_fn;
+    const PolicyFn fn = light ? e->step_greedy_fn : E > 1 ? e->sub.rollout_greedy_sub : e->rollout_greedy_fn;
     // (the caller plays the cameras: step_greedy_kernel holds the target agents' section only -- a smaller slice, one more workgroup per CU)
-    const size_t lds = light ? step_greedy_lds(e, team_caller != 0) : image ? fused_rollout_lds_image(e) : fused_rollout_lds(e, E);
+    const size_t lds = light ? step_greedy_lds(e, team_caller != 0) : fused_rollout_lds(e, E);
     if (lds > 160 * 1024) return fail(MATE_EINVAL, "rollout_greedy: %zu bytes of LDS per workgroup do not fit", lds);
     g.mode = MODE_STEP; g.reset_kind = -1; g.rollout_steps = steps;
     g.parity = e->dev_tick ? 0 : e->parity;

@@ -568,10 +568,6 @@ __device__ __forceinline__ const PolicyPtrs &kernarg_policy_ptrs(const PolicyPtr
 #endif
 }
 
-// Shapes whose fused Greedy rollout is ALSO compiled on the row image (engine_kernels.hpp, image_statics: the observation rows live in LDS, the lane that
-// made a visibility test writes its pair's block, image_store streams the rows out): MATE-4v8-9, the scenario of the reference's camera trainers.
-constexpr bool greedy_image_compiled(int Nc, int Nt, int No) { return Nc == 4 && Nt == 8 && No == 9; }
-
 // 16-byte row chunks per lane when a group of L lanes packs the shape's f32 row blocks (camera block / target block)
 template <typename Shape, int L>
 constexpr int sub_held_chunks(bool camera) { return ((camera ? Shape::kChunksC : Shape::kChunksT) + L - 1) / L; }

@@ -20,13 +20,6 @@ using PolicyFn = void (*)(const Params *, const Ptrs, const PolicyPtrs);
 #define MATE_SHAPES_G4(X, Y) Y(2, 4, 0) Y(2, 2, 9) Y(2, 2, 0)
 #define MATE_SHAPES_G5(X, Y) Y(1, 2, 9) Y(1, 2, 0) Y(1, 1, 9) Y(1, 1, 0)
 
-// (a template, so that the shapes without that compilation never name the kernel: its launch bounds read the shape class)
-template <int C, int T, int O>
-PolicyFn greedy_image_kernel_of() {
-    if constexpr (greedy_image_compiled(C, T, O)) return (PolicyFn)rollout_greedy_kernel<float, FixedShape<C, T, O, false, true>>;
-    else return nullptr;
-}
-
 struct KernelSet {
     StepFn step[3];            // [flow]
     StepFn split[3];           // step_split_kernel per flow, or null
@@ -38,7 +31,6 @@ struct KernelSet {
     StepFn rollout_sub[2];     // [0] generic flow, [1] FLOW_RANDOM
     PolicyFn rollout_greedy_sub;
     int sub_wave;
-    PolicyFn rollout_greedy_image;     // the fused Greedy rollout on the ROW IMAGE (greedy_image_compiled), or null
 };
 
 // true = the group holds the shape and `out` is filled (false for an f64-observation engine of a Y shape)
