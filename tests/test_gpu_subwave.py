@@ -164,3 +164,20 @@ def test_four_per_wave_census_against_the_oracle(workload, oracle_lib, monkeypat
     assert diverged == 0 and worst < 1e-9 and obs_ok and rew_ok, (diverged, worst, obs_ok, rew_ok)
     eng = Engine(read_config(workload), 8, seed=1)
     assert eng.sub_wave == 4                                   # the switch was in force (engines read it when they are created)
+
+
+@pytest.mark.parametrize('n', [1, 3, 17])
+def test_tiny_batches(n):
+    """Fewer environments than one wave's groups: the groups past the end of the batch idle, the others are what they are one per wave."""
+    sub, one = _pair('MATE-2v4-9', n, max_episode_steps=6)
+    for steps in (4, 5):
+        out = []
+        for eng in (sub, one):
+            rec = []
+            cam, tgt, sc = eng.rollout_random(steps, auto_reset=True, want_masks=True)
+            rec += [cam.clone(), tgt.clone(), sc.clone()]
+            cam, tgt, sc = eng.rollout_greedy(steps, auto_reset=True, want_masks=True)
+            rec += [cam.clone(), tgt.clone(), sc.clone(), eng.export_state().clone()]
+            out.append(rec)
+        for x, y in zip(*out):
+            assert same(x, y), (n, steps)
