@@ -672,7 +672,11 @@ __global__ __launch_bounds__(256, E == 1 ? Shape::kGreedyBlocks : MATE_SUB_BLOCK
         else if constexpr (HOLD) { if (packs_rows_f32(c)) load_pack_descriptors(c, held); }
     }
     // the lane's range-test roles held in registers, and with them the collision screen carried from step to step (NearCarry)
+#ifdef MATE_NO_GREEDY_ROLES      // (experiment: what the held lane roles and the carried collision screen are worth)
+    constexpr bool ROLES = false;
+#else
     constexpr bool ROLES = E == 1 && Shape::kGreedyRoles;
+#endif
     NearCarry near{};
     if constexpr (ROLES) {
         Ctx<ObsT> c(p, gk, smem + wave * p.lds_wave_bytes, lane, env, FLOW_GREEDY);
