@@ -21,11 +21,30 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fP
          '-mllvm', '-disable-machine-licm']
 
 
+STAMP = os.path.join(HERE, 'lib', 'build_stamp.json')
+
+
+def source_digest():
+    """sha256 over the sources and the flags the library is built from."""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for d in DEPS:
+        with open(d, 'rb') as fh:
+            h.update(os.path.basename(d).encode() + b'\0' + fh.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(OUT):
+    """True unless the library in the tree was built from exactly these sources.  By CONTENT, not by modification time: a snapshot of
+    the tree copied to another machine (gpurun, the driver's GPU tier) does not keep the order of the files' time stamps, and a
+    time-based rule rebuilt the whole library there -- 40 s in front of every smoke() -- for nothing."""
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    built = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > built for d in DEPS)
+    try:
+        with open(STAMP) as fh:
+            return json.load(fh).get('sources') != source_digest()
+    except (OSError, ValueError):
+        return True
 
 
 RESOURCES = os.path.join(HERE, 'lib', 'kernel_resources.json')
@@ -97,6 +116,8 @@ def build_engine(force=False, verbose=False):
     if bad:
         os.remove(OUT)
         raise RuntimeError('kernels with private scratch memory: ' + ', '.join(bad))
+    with open(STAMP, 'w') as f:
+        json.dump({'sources': source_digest()}, f)
     return OUT
 
 
