@@ -296,7 +296,7 @@ int mate_engine_step_versus_greedy(mate_engine *engine, int32_t team, const mate
  * whose restart group is longer than a launch): what finishes in interval i of m launches idles through i + 1 and is live again in
  * the first launch of i + 2; leaving the mode inside an interval restarts what it had listed.  (Measured on FrameSkip(5) launches of
  * MATE-4v8-9 x 4096 / 16 384: 65.5 against 66.3 us per launch and 1.3 % more idle slots -- no gain: the launch fills its registers'
- * worth of every SIMD and the restart's workgroups wait for its tail either way.  tools/frameskip_pipelined_probe.py) */
+ * worth of every SIMD and the restart's workgroups wait for its tail either way.  tools/archive/frameskip_pipelined_probe.py) */
 #define MATE_RESET_PIPELINED (-1)
 int mate_engine_rollout_greedy(mate_engine *engine, const mate_step_io *io, int32_t steps, int32_t auto_reset, void *stream);
 /* FrameSkip(frame_skip = steps) over MultiCamera / MultiTarget (examples/utils/wrappers.py:301-323: the same action for

@@ -285,7 +285,7 @@ constexpr int kClockStride = 32;      // stamps per environment in Ptrs::phase_c
 constexpr int kClockStride = 16;
 #endif
 // Sub-phase accumulators of the fused rollout (python -m mate_amd.build --variant sub -DMATE_PHASE_CLOCKS -DMATE_SUB_CLOCKS;
-// tools/rollout_subphases.py): cycles summed over a launch's steps into Ctx::sub[0..7] (sub[15]: the previous stamp), events counted
+// tools/archive/rollout_subphases.py): cycles summed over a launch's steps into Ctx::sub[0..7] (sub[15]: the previous stamp), events counted
 // in the stamp buffer itself.
 #if defined(MATE_PHASE_CLOCKS) && defined(MATE_SUB_CLOCKS)
 #define SUB_ACC(c, i) do { if ((c).sub) { const long long t_sub = (long long)__builtin_amdgcn_s_memtime(); (c).sub[i] += t_sub - (c).sub[15]; (c).sub[15] = t_sub; } } while (0)
@@ -952,7 +952,7 @@ __host__ __device__ constexpr int pivot_stride(int count) { return (count - 1 + 
 constexpr int kQuarterKnots = 4 * (kDegSlots - 1) + 1;
 // The records' cells: kCellsPerDegree per degree (round 4: two -- a cell holds the knots from the last one at or below its start on,
 // so one in 115 cells of a MATE-4v8-9 table overflows its record instead of one in 24, and the slowest waves of a launch are the
-// ones that overflow at almost every step, tools/rollout_subphases.py).  Cell starts c / kCellsPerDegree - 180 are exact in f64.
+// ones that overflow at almost every step, tools/archive/rollout_subphases.py).  Cell starts c / kCellsPerDegree - 180 are exact in f64.
 constexpr int kCellsPerDegree = 2;
 constexpr int kLutCells = 360 * kCellsPerDegree;
 __host__ __device__ __forceinline__ double cell_start(int c) { return (double)c * (1.0 / kCellsPerDegree) - 180.0; }
@@ -2621,7 +2621,7 @@ void step_kernel(const Params *__restrict__ pp, const Ptrs g) {
     PHASE_STAMP(5);
     // the state record leaves as soon as it is final (nothing behind the goals writes it): its stores' acknowledgements then pass under
     // the packer instead of standing, with the rows', between the wave's last instruction and the end of the launch
-    // (step_kernel 12.37 -> 12.17 us, step_greedy_kernel 17.93 -> 17.55 us at 4096 x MATE-4v8-9, A/B in one process: tools/step_ab.py)
+    // (step_kernel 12.37 -> 12.17 us, step_greedy_kernel 17.93 -> 17.55 us at 4096 x MATE-4v8-9, A/B in one process: tools/archive/step_ab.py)
     if (Shape::kEarlyStateStore && mode != MODE_OBSERVE) store_dynamic(c);
     if (!SKIP(64)) fill_scratch(c);
     PHASE_STAMP(6);
@@ -2807,7 +2807,7 @@ void step_split_kernel(const Params *__restrict__ pp, const Ptrs g) {
     phase_prio(g.stagger, 0);
     const Ptrs &gk = kernarg_ptrs(g);
     Ctx<ObsT> c(p, gk, smem + pair * p.lds_wave_bytes, lane, env, FLOW);
-#ifdef MATE_PHASE_CLOCKS      // per-wave stamps: slots 0-7 wave A, 8-15 wave B (tools/split_phases.py)
+#ifdef MATE_PHASE_CLOCKS      // per-wave stamps: slots 0-7 wave A, 8-15 wave B (tools/archive/split_phases.py)
 #define SPLIT_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * kClockStride + role * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SPLIT_STAMP(i) do { } while (0)
@@ -2969,7 +2969,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     const int64_t env = (int64_t)blockIdx.x * (4 * E) + slot;
     if (env >= g.N) return;               // (E > 1: the groups past the end of the batch leave; the others go on under their EXEC mask)
     const Ptrs &gk = kernarg_ptrs(g);     // launch arguments read where they are used (see step_kernel)
-#ifdef MATE_PHASE_CLOCKS      // the launch's prologue, in s_memtime ticks since the wave began: slots 8..11 (tools/rollout_prologue.py), 12 the epilogue
+#ifdef MATE_PHASE_CLOCKS      // the launch's prologue, in s_memtime ticks since the wave began: slots 8..11 (tools/archive/rollout_prologue.py), 12 the epilogue
     const long long t_wave = (long long)__builtin_amdgcn_s_memtime();
 #define PROLOGUE_STAMP(i) do { if (lane == 0 && g.phase_clocks) g.phase_clocks[env * kClockStride + (i)] = (long long)__builtin_amdgcn_s_memtime() - t_wave; } while (0)
 #else

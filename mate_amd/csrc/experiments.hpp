@@ -1,6 +1,6 @@
 // experiments.hpp -- the measurement hooks of the fused kernels.  NOT part of the product: engine_kernels.hpp includes this file
-// only when a build defines one of the switches below (python -m mate_amd.build --variant NAME -DSWITCH[=bits]; tools/ablate_rollout.sh,
-// tools/ablate_greedy.sh, tools/double_phase.sh); the shipped library is compiled without any of them, from the one-line defaults
+// only when a build defines one of the switches below (python -m mate_amd.build --variant NAME -DSWITCH[=bits]; tools/archive/ablate_rollout.sh,
+// tools/archive/ablate_greedy.sh, tools/archive/double_phase.sh); the shipped library is compiled without any of them, from the one-line defaults
 // at the top of engine_kernels.hpp, and its kernels are instruction for instruction what they were with the hooks spelled out in
 // the step loops (lib/kernel_resources.json unchanged).
 //
