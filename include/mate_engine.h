@@ -417,7 +417,8 @@ int mate_engine_block_free(void *ptr);
  * a few candidates, keeps the fastest and frees the rest -- Engine.reserve_rollout does.  The block is left filled with zeros. */
 int mate_engine_block_probe(int32_t device, void *block, int64_t bytes, int32_t rows_per_step, int32_t row_bytes, void *stream,
                             double *gbytes_per_s);
-/* Environments per wave of the fused rollouts (mate_engine_rollout_random / _rollout_greedy / _rollout_versus_greedy).  The engine maps ONE
+/* Environments per wave of the fused rollouts (mate_engine_rollout_random / _rollout_greedy / _rollout_versus_greedy) and of the one-launch
+ * forms of mate_engine_step_greedy / _step_versus_greedy (which run the same kernel with one step where the choice below says so).  The engine maps ONE
  * environment onto one 64-lane wave; the small scenarios (at most four cameras and four targets: MATE-{1v1,1v2,2v2,2v4,4v2,4v4}-{0,9}, e.g. the
  * MATE-2v4-0 of the reference's target trainers, examples/ippo/target/config.py:63-66) fill a quarter of one, so their fused rollouts
  * can step FOUR environments per wave, sixteen lanes each -- same results, bit for bit.  `enable`: 0 = one per wave; 1 = the shape's

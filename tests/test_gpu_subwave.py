@@ -181,3 +181,28 @@ def test_tiny_batches(n):
             out.append(rec)
         for x, y in zip(*out):
             assert same(x, y), (n, steps)
+
+
+@pytest.mark.parametrize('name,team', [('MATE-2v4-0', 'target'), ('MATE-4v2-9', 'camera'), ('MATE-1v2-9', 'target'), ('MATE-4v4-0', 'camera')])
+def test_per_step_greedy_flows_on_the_sub_wave_kernel(name, team):
+    """step_versus_greedy / step_greedy -- MultiTarget / MultiCamera WITHOUT a frame skip, one launch per step -- run the one-step form of the
+    four-per-wave rollout kernel where the fused flows run it (FLOW_GREEDY instead of step_greedy_kernel's FLOW_STEP_GREEDY): the caller's
+    [N][...] buffers, immediate and batched restarts that write the restarted environments' first rows, and the agents' memory, bit for bit."""
+    n = 70
+    sub, one = _pair(name, n, max_episode_steps=9)
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    k = sub.num_targets if team == 'target' else sub.num_cameras
+    for it in range(30):
+        act = (torch.rand((n, k, 2), device='cuda', generator=gen) * 2 - 1) * (25 if team == 'target' else 6)
+        out = []
+        for eng in (sub, one):
+            auto_reset = 4 if it >= 15 else True
+            if it % 3 == 2:
+                eng.step_greedy(auto_reset=auto_reset)
+            else:
+                eng.step_versus_greedy(team, act, auto_reset=auto_reset)
+            out.append([eng.camera_obs.clone(), eng.target_obs.clone(), eng.scalars.clone(), eng.export_state().clone(), eng.policy_actions()[0].clone()])
+        for x, y in zip(*out):
+            assert same(x, y), (name, it)
+    # (MATE-1v2-* has no step_greedy_kernel: its one-per-wave per-step flows run the one-step rollout form too)
+    assert sub.last_flow == 3 and one.last_flow == (3 if name.startswith('MATE-1v2') else 4) and float(sub.episode_stats[0]) >= n
