@@ -57,6 +57,10 @@
  *   MATE_PIPELINED_SERIAL=1  pipelined restarts (MATE_RESET_PIPELINED) with the resets on the caller's stream: the reference form
  *                            the tests compare the concurrent one with; MATE_PIPELINED_PRIORITY=0: the side stream at the default
  *                            priority instead of the device's lowest (both read when the mode is first entered)
+ *   MATE_SUBWAVE=0|1         environments per wave of the fused rollouts of the small scenarios (mate_engine_set_sub_wave below): 0 = always
+ *                            one, 1 = the shape's number (four; two for MATE-4v8-0's Greedy flows) in every such launch; default: where it
+ *                            measured faster.  MATE_STEP_SUBWAVE=0: the per-step mate_engine_step_greedy / _step_versus_greedy keep
+ *                            step_greedy_kernel where the fused flows run sub-wave groups (default: they follow).  Same bytes either way.
  * Read by the Python host: MATE_ENGINE_LIB=<path> (mate_amd/_native.py: another build of this library, e.g. the profiling build
  * lib/libmate_engine_prof.so); MATE_BUILD_JOBS=<n> (mate_amd/build.py: parallel hipcc processes, default one per translation
  * unit up to the CPU count); and (mate_amd/engine.py), once, when an Engine object is built -- they steer where

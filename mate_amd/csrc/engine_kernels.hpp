@@ -102,10 +102,10 @@ __host__ __device__ constexpr void fill_shape(Params &p, int Nc, int Nt, int No,
     const int obs_size = obs_f64 ? 8 : 4;
     p.desc_table_bytes = shape_round_up((p.tgt_table_off + shape_round_up(p.tgt_elems, 4)) * 4, 16);
     int off = 0;
-    p.off_st = off; off += shape_round_up(p.SW * 8, 16);
-    p.off_dy = off; off += shape_round_up(p.DW * 8, 16);
-    // (sight^2 | step vectors | the predrawn transmittance uniforms, one per camera->target pair up to 64: only where there are obstacles to see through)
-    p.off_tmp = off; off += shape_round_up((Nc + 3 * Nt + ((Nc > 0 && No > 0) ? (Nc * Nt < 64 ? Nc * Nt : 64) : 0)) * 8, 16);
+    p.off_st = off; off += p.SW * 8;                                 // (8-byte words, read as such: the dynamic record follows without padding)
+    p.off_dy = off; off = shape_round_up(off + p.DW * 8, 16);
+    // (sight^2 | step lengths | the predrawn transmittance uniforms, one per camera->target pair up to 64: only where there are obstacles to see through)
+    p.off_tmp = off; off += shape_round_up((Nc + Nt + ((Nc > 0 && No > 0) ? (Nc * Nt < 64 ? Nc * Nt : 64) : 0)) * 8, 16);
     p.off_scratch = off; off += image ? 0 : shape_round_up(p.nscratch * obs_size, 16);
     p.off_mask = off; off += shape_round_up(p.MW * 4, 16);
     p.off_misc = off; off += shape_round_up((4 * Nt + 8) * 4, 16);
@@ -472,10 +472,8 @@ struct Ctx {
     __device__ __forceinline__ int32_t &ei(int f) { return di[p.Nt * TI_STRIDE + f]; }
     // temporaries
     __device__ __forceinline__ double &sight2(int c) { return tmp[c]; }          // a camera's SQUARED sight range: area / viewing angle
-    __device__ __forceinline__ double &svx(int t) { return tmp[p.Nc + t]; }
-    __device__ __forceinline__ double &svy(int t) { return tmp[p.Nc + p.Nt + t]; }
-    __device__ __forceinline__ double &snorm(int t) { return tmp[p.Nc + 2 * p.Nt + t]; }
-    __device__ __forceinline__ double &udraw(int pair) { return tmp[p.Nc + 3 * p.Nt + pair]; }
+    __device__ __forceinline__ double &snorm(int t) { return tmp[p.Nc + t]; }
+    __device__ __forceinline__ double &udraw(int pair) { return tmp[p.Nc + p.Nt + pair]; }
     __device__ __forceinline__ int32_t &near(int t) { return misc[t]; }
     __device__ __forceinline__ int32_t &inside(int t) { return misc[2 * p.Nt + t]; }
     __device__ __forceinline__ int32_t &tracked(int t) { return misc[3 * p.Nt + t]; }
@@ -1203,7 +1201,7 @@ __device__ __forceinline__ SectorEval sector_eval_held(Ctx<ObsT> &c, const Range
     if (p.No == 0) { e.seen = true; return e; }
     if ((role >> 16) & 1) {                                                        // np_random.binomial(1, tau), entities.py:503
         double u;
-        if (predrawn && p.Nc * p.Nt <= c.predrawn_pairs()) u = lds_f64(h.sec_draw, p.off_tmp + 8 * (p.Nc + 3 * p.Nt));
+        if (predrawn && p.Nc * p.Nt <= c.predrawn_pairs()) u = lds_f64(h.sec_draw, p.off_tmp + 8 * (p.Nc + p.Nt));
         else {
             const int pair = (role & 0xff) * p.Nt + ((role >> 8) & 0xff);
             if (predrawn && pair < c.predrawn_pairs()) u = c.udraw(pair);
