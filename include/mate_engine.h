@@ -59,8 +59,9 @@
  *                            priority instead of the device's lowest (both read when the mode is first entered)
  *   MATE_SUBWAVE=0|1         environments per wave of the fused rollouts of the small scenarios (mate_engine_set_sub_wave below): 0 = always
  *                            one, 1 = the shape's number (four; two for MATE-4v8-0's Greedy flows) in every such launch; default: where it
- *                            measured faster.  MATE_STEP_SUBWAVE=0: the per-step mate_engine_step_greedy / _step_versus_greedy keep
- *                            step_greedy_kernel where the fused flows run sub-wave groups (default: they follow).  Same bytes either way.
+ *                            measured faster.  MATE_STEP_SUBWAVE=0: the per-step mate_engine_step / _step_random / _step_greedy /
+ *                            _step_versus_greedy keep the per-step kernels where the fused flows run sub-wave groups (default: they follow,
+ *                            as one-step launches of the same kernels).  Same bytes either way.
  * Read by the Python host: MATE_ENGINE_LIB=<path> (mate_amd/_native.py: another build of this library, e.g. the profiling build
  * lib/libmate_engine_prof.so); MATE_BUILD_JOBS=<n> (mate_amd/build.py: parallel hipcc processes, default one per translation
  * unit up to the CPU count); and (mate_amd/engine.py), once, when an Engine object is built -- they steer where
@@ -421,8 +422,8 @@ int mate_engine_block_free(void *ptr);
  * a few candidates, keeps the fastest and frees the rest -- Engine.reserve_rollout does.  The block is left filled with zeros. */
 int mate_engine_block_probe(int32_t device, void *block, int64_t bytes, int32_t rows_per_step, int32_t row_bytes, void *stream,
                             double *gbytes_per_s);
-/* Environments per wave of the fused rollouts (mate_engine_rollout_random / _rollout_greedy / _rollout_versus_greedy) and of the one-launch
- * forms of mate_engine_step_greedy / _step_versus_greedy (which run the same kernel with one step where the choice below says so).  The engine maps ONE
+/* Environments per wave of the fused rollouts (mate_engine_rollout_random / _rollout_greedy / _rollout_versus_greedy) and of mate_engine_step /
+ * _step_random / _step_greedy / _step_versus_greedy (which run the same kernels with one step where the choice below says so).  The engine maps ONE
  * environment onto one 64-lane wave; the small scenarios (at most four cameras and four targets: MATE-{1v1,1v2,2v2,2v4,4v2,4v4}-{0,9}, e.g. the
  * MATE-2v4-0 of the reference's target trainers, examples/ippo/target/config.py:63-66) fill a quarter of one, so their fused rollouts
  * can step FOUR environments per wave, sixteen lanes each -- same results, bit for bit.  `enable`: 0 = one per wave; 1 = the shape's

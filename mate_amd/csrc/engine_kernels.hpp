@@ -266,6 +266,10 @@ struct Ptrs {
     // parity on"; any launch of the other parity -- the one the reset runs under -- leaves such an environment alone (no step, no
     // store), so what a launch does never depends on how far the concurrent reset has come.
     int32_t pipelined;
+    // The sub-wave rollout kernel as ONE step of the per-step flows (mate_engine_step / _step_random of the small scenarios, launch_step): step()'s
+    // semantics instead of a rollout's -- a finished environment idles only under a batched restart (freeze_done), the tick and the list parity
+    // may live on the device (mate_engine_device_tick).
+    int32_t per_step;
 };
 constexpr int32_t kDoneTag = 4;
 
@@ -2959,6 +2963,13 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     const Shape shape(pp, true);
     const Params &p = shape.get();
     extern __shared__ __align__(16) unsigned char smem[];
+    if constexpr (E > 1) {          // (the per-step flows run this kernel with one step: tick and list parity may be the device's, see step_kernel)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) {
+            const int32_t parity = (int32_t)((p.dev_group + (uint32_t)g.parity) & 1u);
+            g.done_count[parity ^ 1] = 0;
+            g.ctrl[0] = parity;
+        }
+    } else
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.done_count) g.done_count[g.parity ^ 1] = 0;
     // wave-uniform by construction; readfirstlane lets the compiler keep everything derived from it in SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2979,7 +2990,8 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         load_records(c);
         wave_sync();
         build_entities(c);
-        list_finished_at_entry(c);
+        // (as one step of a per-step flow without a pending batched restart, a finished environment STEPS, as in step_kernel, and the step lists it)
+        if (!(E > 1 && g.per_step && !g.freeze_done)) list_finished_at_entry(c);
         wave_sync();
     }
     PROLOGUE_STAMP(8);
@@ -3043,7 +3055,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
     constexpr bool HELDSTATE = IMAGE && FLOW == FLOW_RANDOM;
     HeldState h{};
     int finished = 0;                // HELDSTATE: the episode is over (wave-uniform; the record's EI_DONE otherwise)
-    const uint32_t tick0 = g.tick;   // (launch arguments read once: inside the loop each read is a scalar load and a wait)
+    const uint32_t tick0 = (E > 1 ? p.dev_tick : 0u) + g.tick;   // (launch arguments read once: inside the loop each read is a scalar load and a wait)
     const uint32_t cam_low = (uint32_t)(reinterpret_cast<uintptr_t>(g.cam_obs) >> 4) & 7u, tgt_low = (uint32_t)(reinterpret_cast<uintptr_t>(g.tgt_obs) >> 4) & 7u;
     const int n_steps = g.rollout_steps;
     if constexpr (HELDSTATE) {
@@ -3078,7 +3090,8 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         c.out = (int64_t)r * g.N + env_r;
         c.statics_done = stepped;
         c.pivots = Shape::kGreedyHeld;      // (the compiled shapes; the generic kernel has no registers to spare)
-        if (HELDSTATE ? finished != 0 : c.ei(EI_DONE) != 0) {
+        // (E > 1 as one step of the per-step flows: step()'s rule -- a finished environment idles only while a batched restart is pending)
+        if (HELDSTATE ? finished != 0 : (c.ei(EI_DONE) != 0 && (E == 1 || !g.per_step || g.freeze_done))) {
             if (lane_r == 0 && g.scalars) { float *o = g.scalars + c.out * 8; o[0] = 0.f; o[1] = 0.f; o[2] = 2.f; o[3] = o[4] = o[5] = o[6] = o[7] = 0.f; }
             if (lane_r == 0 && g.idle_steps) g.idle_steps[env_r] += 1;      // a slot of the rollout, not an executed step
             continue;

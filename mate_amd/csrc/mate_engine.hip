@@ -852,6 +852,8 @@ extern "C" int mate_engine_device_tick(mate_engine *e, int32_t enable, void *str
     return MATE_OK;
 }
 
+static int sub_wave_of_launch(const mate_engine *e, bool greedy);
+
 static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int auto_reset, hipStream_t stream) {
     if (!e) return fail(MATE_EINVAL, "null engine");
     { const int rc_ = leave_pipelined(e, stream); if (rc_ != MATE_OK) return rc_; }
@@ -896,7 +898,17 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
         else if (mode == MODE_STEP) flow = FLOW_ACT_F32;      // caller-supplied real-valued actions, f32 or f64 per team
     }
     e->last_flow = flow;
-    if (e->split_on && e->split_fn[flow]) {      // two waves per environment: one 128-thread workgroup each
+    // The small scenarios' steps on the sub-wave rollout kernel with ONE step (four environments per wave; Ptrs::per_step), where their fused flows run
+    // it: from 32 environments per CU on (sub_wave_of_launch).  Not for auto_reset = 0 in the device-counted mode... every mode but observe().
+    const int E = (mode != MODE_OBSERVE && e->sw.step_sub_wave && !e->p.obs_f64) ? sub_wave_of_launch(e, false) : 1;
+    if (E > 1) {
+        g.per_step = 1; g.rollout_steps = 1; g.rotate_prio = 0;
+        const StepFn fn = e->sub.rollout_sub[flow == FLOW_RANDOM ? 1 : 0];      // (FLOW_ACT_F32's switches are FLOW_ANY's here: no folded compilation of it)
+        const unsigned sub_blocks = (unsigned)((e->N + 4 * E - 1) / (4 * E));
+        if (ev0) hipExtLaunchKernelGGL(fn, dim3(sub_blocks), dim3(256), E * e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
+        else hipLaunchKernelGGL(fn, dim3(sub_blocks), dim3(256), E * e->step_lds, stream, (const Params *)e->d_params, (const Ptrs)g);   // (capturable)
+    }
+    else if (e->split_on && e->split_fn[flow]) {      // two waves per environment: one 128-thread workgroup each
         const StepFn fn = e->split_fn[flow];
         const dim3 grid((unsigned)e->N), block(128);
         if (ev0) hipExtLaunchKernelGGL(fn, grid, block, e->step_lds / 4, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);

@@ -206,3 +206,66 @@ def test_per_step_greedy_flows_on_the_sub_wave_kernel(name, team):
             assert same(x, y), (name, it)
     # (MATE-1v2-* has no step_greedy_kernel: its one-per-wave per-step flows run the one-step rollout form too)
     assert sub.last_flow == 3 and one.last_flow == (3 if name.startswith('MATE-1v2') else 4) and float(sub.episode_stats[0]) >= n
+
+
+@pytest.mark.parametrize('name', ['MATE-2v4-0', 'MATE-4v2-9', 'MATE-2v2-9', 'MATE-1v1-0'])
+def test_per_step_flows_with_external_and_random_actions(name):
+    """step(actions) / step_random -- one launch per step, the learner-in-the-loop flows -- on the one-step form of the four-per-wave rollout
+    kernel (Ptrs::per_step): step()'s semantics, bit for bit.  f32 and f64 joint actions, immediate and batched restarts, a stretch of
+    auto_reset = 0 in which finished environments go on stepping (as in step_kernel) before a restarting call meets them, the observe() that
+    never takes this path, and a fused observation transform (the FLOW_ANY compilation)."""
+    n = 70
+    sub, one = _pair(name, n, max_episode_steps=7)
+    gen = torch.Generator(device='cuda').manual_seed(4)
+    Nc, Nt = sub.num_cameras, sub.num_targets
+    for it in range(40):
+        cam = (torch.rand((n, Nc, 2), device='cuda', generator=gen) * 2 - 1) * 6
+        tgt = (torch.rand((n, Nt, 2), device='cuda', generator=gen) * 2 - 1) * 25
+        if it % 4 == 1:
+            cam, tgt = cam.double(), tgt.double()
+        auto_reset = True if it < 12 else (0 if it < 18 else (3 if it < 30 else True))
+        out = []
+        for eng in (sub, one):
+            if it == 32:
+                eng.set_obs_transform(relative_coordinates=True, rescaled_observation=True)
+            if it % 5 == 4:
+                eng.step_random(auto_reset=auto_reset, want_masks=True)
+            else:
+                eng.step(cam, tgt, auto_reset=auto_reset)
+            out.append([eng.camera_obs.clone(), eng.target_obs.clone(), eng.scalars.clone(), eng.masks.clone(), eng.export_state().clone()])
+            if it % 7 == 6:
+                co, to = eng.observe()
+                out[-1] += [co.clone(), to.clone()]
+        for x, y in zip(*out):
+            assert same(x, y), (name, it)
+    assert float(sub.episode_stats[0]) >= 3 * n and same(sub.episode_stats, one.episode_stats) and sub.idle_steps() == one.idle_steps()
+
+
+def test_graph_replayed_external_actions_with_four_environments_per_wave():
+    """Engine.make_stepper (the device-resident step counter, K (policy kernel, step) pairs per HIP graph, one restart launch per interval) on
+    the four-per-wave kernels against direct one-per-wave launches with the host counting."""
+    cfg = read_config('MATE-2v4-0.yaml', max_episode_steps=11)
+    n, interval = 70, 4
+    outs = []
+    for sub, graph_steps in ((False, 0), (True, 2 * interval)):
+        eng = Engine(cfg, n, seed=5)
+        assert eng.set_sub_wave(sub) == (4 if sub else 1)
+        eng.reset()
+        gen = torch.Generator(device='cuda').manual_seed(9)
+        flat = (torch.rand(n * 6 * 2, device='cuda', generator=gen) * 2 - 1) * 9
+        cam, tgt = flat[:n * 2 * 2].view(n, 2, 2), flat[n * 2 * 2:].view(n, 4, 2)
+        stepper = eng.make_stepper(cam, tgt, auto_reset=interval, graph_steps=graph_steps, between=lambda f=flat: f.mul_(-1.0).add_(0.25))
+        rec = []
+        if not graph_steps:
+            stepper.run(interval)             # what the constructor's warm-up (one reset interval) did on the graph side
+        for chunk in (4 * interval, interval + 1, 2 * interval - 1):
+            stepper.run(chunk)
+            torch.cuda.synchronize()
+            rec.append([eng.camera_obs.clone(), eng.target_obs.clone(), eng.scalars.clone()])
+        stepper.close()
+        rec.append([eng.export_state().clone()])
+        outs.append(rec)
+        del stepper, eng
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            assert same(x, y)

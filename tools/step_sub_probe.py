@@ -44,3 +44,19 @@ for name, team in (('MATE-2v4-0', 'target'), ('MATE-4v2-9', 'camera')):
             line += f"   {'sub-wave' if sub else 'step_greedy'} {dt / 512 * 1e6:8.2f} us/step e2e {bb * ex / dt / 8e12:.3f}"
             st.close(); e.close(); del st, e; torch.cuda.empty_cache()
         print(line, flush=True)
+# ... and step(actions): the joint actions of both teams in caller-owned buffers that a stand-in policy kernel rewrites before every step
+for name in ('MATE-2v4-0', 'MATE-4v2-9', 'MATE-1v1-9'):
+    for n in (8192, 16384, 65536):
+        line = f'{name} step(actions) N={n}'
+        for sub in (False, True):
+            e = make(name, n, sub)
+            flat = (torch.rand(n * (e.num_cameras + e.num_targets) * 2, device='cuda') * 2 - 1) * 5
+            cam, tgt = flat[:n * e.num_cameras * 2].view(n, e.num_cameras, 2), flat[n * e.num_cameras * 2:].view(n, e.num_targets, 2)
+            st = e.make_stepper(cam, tgt, auto_reset=32, graph_steps=64, between=lambda f=flat: f.mul_(-1.0))
+            st.run(128); torch.cuda.synchronize()
+            i0, t0 = e.idle_steps(), time.perf_counter(); st.run(512); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            ex = n * 512 - (e.idle_steps() - i0)
+            bb = algorithmic_bytes(e.num_cameras, e.num_targets, e.num_obstacles)
+            line += f"   {'sub-wave' if sub else 'step_kernel'} {dt / 512 * 1e6:8.2f} us/step e2e {bb * ex / dt / 8e12:.3f}"
+            st.close(); e.close(); del st, e; torch.cuda.empty_cache()
+        print(line, flush=True)
