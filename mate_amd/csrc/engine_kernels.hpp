@@ -3116,6 +3116,7 @@ __global__ __launch_bounds__(256, 4) void rollout_kernel(const Params *__restric
         StepDraws draws{0.0, 0.0};
         pin_draw_role(draws_of_lane);
         MATE_PHASE(1, draws = step_draws(c, tick, &carry, &draws_of_lane));
+        if constexpr (FLOW == FLOW_ACT_F32) draws = prefetch_action(c);      // (the per-step flows' step(actions) on this kernel: the agents' lanes carry the caller's joint action)
         MATE_PHASE_AGAIN(1, DrawCarry again = carry; again.block = 0xffffffffu; const StepDraws d2 = step_draws(c, tick, &again); draws.a0 += 0.0 * d2.a0);
         ROLL_STAMP(0);
         if constexpr (HELDSTATE) {

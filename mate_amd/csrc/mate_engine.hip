@@ -76,7 +76,7 @@ static int fail(int code, const char *fmt, ...) {
 static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no_image, StepFn *step, StepFn *rollout, PolicyFn *policy, PolicyFn *rollout_greedy,
                          int *specialised, int *image, StepFn *split, PolicyFn *step_greedy, KernelSet *sub) {
     *specialised = 0; *image = 0;
-    sub->rollout_sub[0] = sub->rollout_sub[1] = nullptr; sub->rollout_greedy_sub = nullptr; sub->sub_wave = 1;
+    sub->rollout_sub[0] = sub->rollout_sub[1] = sub->rollout_sub[2] = nullptr; sub->rollout_greedy_sub = nullptr; sub->sub_wave = 1;
     *step_greedy = f64 ? nullptr : (PolicyFn)step_greedy_kernel<float, AnyShape>;
     for (int i = 0; i < 3; ++i) split[i] = nullptr;      // the two-wave step (step_split_kernel): f32 observations, the folded flows
     if (!generic) {
@@ -88,7 +88,7 @@ static void pick_kernels(int Nc, int Nt, int No, bool f64, bool generic, bool no
             rollout[0] = k.rollout[0]; rollout[1] = k.rollout[1];
             *policy = k.policy; *rollout_greedy = k.rollout_greedy; *step_greedy = k.step_greedy;
             *specialised = 1; *image = k.image;
-            sub->rollout_sub[0] = k.rollout_sub[0]; sub->rollout_sub[1] = k.rollout_sub[1]; sub->rollout_greedy_sub = k.rollout_greedy_sub; sub->sub_wave = k.sub_wave;
+            sub->rollout_sub[0] = k.rollout_sub[0]; sub->rollout_sub[1] = k.rollout_sub[1]; sub->rollout_sub[2] = k.rollout_sub[2]; sub->rollout_greedy_sub = k.rollout_greedy_sub; sub->sub_wave = k.sub_wave;
             return;
         }
     }
@@ -482,7 +482,7 @@ extern "C" int mate_engine_create(const mate_config *cfg, int64_t num_envs, int3
         for (int f = 0; f < 2 && err == hipSuccess; ++f)
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->rollout_fn[f]), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(f == 1 && e->image ? 4 * e->image_wave_bytes : e->step_lds));
-        for (int f = 0; f < 2 && err == hipSuccess && e->sub.rollout_sub[f]; ++f)
+        for (int f = 0; f < 3 && err == hipSuccess && e->sub.rollout_sub[f]; ++f)
             err = hipFuncSetAttribute(reinterpret_cast<const void *>(e->sub.rollout_sub[f]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(e->sub.sub_wave * e->step_lds));
         if (err != hipSuccess) {
         } else if (p.obs_f64) {
@@ -903,7 +903,7 @@ static int launch_step(mate_engine *e, const mate_step_io *io, int mode, int aut
     const int E = (mode != MODE_OBSERVE && e->sw.step_sub_wave && !e->p.obs_f64) ? sub_wave_of_launch(e, false) : 1;
     if (E > 1) {
         g.per_step = 1; g.rollout_steps = 1; g.rotate_prio = 0;
-        const StepFn fn = e->sub.rollout_sub[flow == FLOW_RANDOM ? 1 : 0];      // (FLOW_ACT_F32's switches are FLOW_ANY's here: no folded compilation of it)
+        const StepFn fn = e->sub.rollout_sub[flow];      // (FLOW_ANY / FLOW_RANDOM / FLOW_ACT_F32: the same switches folded as in step_kernel)
         const unsigned sub_blocks = (unsigned)((e->N + 4 * E - 1) / (4 * E));
         if (ev0) hipExtLaunchKernelGGL(fn, dim3(sub_blocks), dim3(256), E * e->step_lds, stream, ev0, ev1, 0, (const Params *)e->d_params, (const Ptrs)g);
         else hipLaunchKernelGGL(fn, dim3(sub_blocks), dim3(256), E * e->step_lds, stream, (const Params *)e->d_params, (const Ptrs)g);   // (capturable)

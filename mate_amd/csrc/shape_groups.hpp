@@ -28,7 +28,7 @@ struct KernelSet {
     PolicyFn step_greedy;      // step_greedy_kernel (f32 observations), or null
     int image;
     // E environments per wave (FixedShape::kSubWave, f32 observations): the fused rollouts of the small scenarios, or null / 1
-    StepFn rollout_sub[2];     // [0] generic flow, [1] FLOW_RANDOM
+    StepFn rollout_sub[3];     // [flow]: FLOW_ANY, FLOW_RANDOM, FLOW_ACT_F32 (the one-step form behind mate_engine_step)
     PolicyFn rollout_greedy_sub;
     int sub_wave;
 };
