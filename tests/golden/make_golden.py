@@ -1073,6 +1073,10 @@ def main():
         ('trace_8v8-9_greedy_s3',    'MATE-8v8-9.yaml',        3, 'greedy',  160, None, None),
         ('trace_4v8-0_greedy_s3',    'MATE-4v8-0.yaml',        3, 'greedy',  160, None, None),
         ('trace_nav_random_s3',      'MATE-Navigation.yaml',   3, 'random',  128, None, None),
+        # the small scenarios whose kernels step four environments per wave (round 6): the target trainers' MATE-2v4-0 and two more shapes
+        ('trace_2v4-0_greedy_s5',    'MATE-2v4-0.yaml',        5, 'greedy',  160, None, None),
+        ('trace_2v2-9_random_s6',    'MATE-2v2-9.yaml',        6, 'random',   96, None, None),
+        ('trace_1v1-9_greedy_s7',    'MATE-1v1-9.yaml',        7, 'greedy',  128, None, None),
     ]
     only = sys.argv[1:]
     for name, config, seed, policy, steps, overrides, tweak in plan:

@@ -269,3 +269,32 @@ def test_graph_replayed_external_actions_with_four_environments_per_wave():
     for a, b in zip(*outs):
         for x, y in zip(a, b):
             assert same(x, y)
+
+
+def _small_traces():
+    import glob
+    import os
+    import golden_util as G
+    out = []
+    for path in G.trace_files():
+        tag = os.path.basename(path)[6:].split('_')[0]
+        if tag in ('4v2-9', '2v4-0', '2v2-9', '1v1-9'):
+            out.append(path)
+    return out
+
+
+@pytest.mark.parametrize('path', _small_traces(), ids=lambda p: __import__('os').path.basename(p)[6:-4])
+def test_reference_traces_on_the_sub_wave_kernels(path):
+    """The REFERENCE's recorded traces of the small scenarios (tests/golden/trace_*: its actions, its see-through and goal draws on tapes, its
+    masks / integers / rewards / observations at every step) replayed through step() with four environments per wave forced -- the tape-driven
+    FLOW_ANY compilation of the sub-wave kernel -- not only through the one-per-wave kernels the other parity tests run at their batch sizes."""
+    import golden_util as G
+    import gpu_util as U
+    from test_gpu_parity import _check_step_against_trace, _replay
+    fx = G.load(path)
+    N = 6                                        # (two groups of the second wave idle)
+    eng = U.engine_from_fixture(fx, N, obs_dtype=torch.float32)
+    assert eng.set_sub_wave(True) == 4
+    for s in range(len(fx['step/done'])):
+        co, to, sc = _replay(eng, fx, s, N)
+        _check_step_against_trace(eng, fx, s, N, co, to, sc, torch.float32)
