@@ -298,3 +298,25 @@ def test_reference_traces_on_the_sub_wave_kernels(path):
     for s in range(len(fx['step/done'])):
         co, to, sc = _replay(eng, fx, s, N)
         _check_step_against_trace(eng, fx, s, N, co, to, sc, torch.float32)
+
+
+def test_frame_skip_on_grid_indices_is_the_sum_of_one_per_wave_steps():
+    """The target trainers' chain as tests/test_gpu_chain.py pins it to the reference (DiscreteTarget(5) -> MultiTarget(GreedyCameraAgent) ->
+    FrameSkip(10) on MATE-2v4-0): the ten-frame launch on the FOUR-per-wave kernel, joint actions as grid indices, is bit for bit ten per-step
+    calls of the one-per-wave step_greedy_kernel -- the calls that test replays against the reference's recorded chain."""
+    cfg = read_config('MATE-2v4-0.yaml')
+    n, skip = 128, 10
+    a, b = (Engine(cfg, n, seed=31) for _ in range(2))
+    assert a.set_sub_wave(True) == 4 and b.set_sub_wave(False) == 1
+    for e in (a, b):
+        e.set_action_grids(target_levels=5)
+        e.enable_policies()
+        e.reset()
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    for ls in range(6):
+        idx = torch.randint(0, 25, (n, 4), device='cuda', generator=gen, dtype=torch.int32)
+        cam_r, tgt_r, sc_r = a.rollout_versus_greedy('target', idx, skip, auto_reset=False)
+        for f in range(skip):
+            b.step_versus_greedy('target', idx, auto_reset=False)
+            assert same(sc_r[f], b.scalars) and same(cam_r[f], b.camera_obs) and same(tgt_r[f], b.target_obs), (ls, f)
+    assert same(a.export_state(), b.export_state()) and b.last_flow == 4
